@@ -1,0 +1,125 @@
+/*
+ * hh_abi.h — C ABI of the MI355X batched air-combat world (libhh_world.so).
+ *
+ * The reference has no FFI: its boundary is RLlib's Python MultiAgentEnv protocol
+ * (envs/env_hetero.py:20-63 LowLevelEnv, envs/env_hier.py:27-47 HighLevelEnv,
+ * envs/env_base.py:62-109 reset/step).  This header is what a binding for that boundary
+ * binds to; hhmarl_2d_amd/{env_hetero,env_hier}.py are the ctypes bindings that re-expose the
+ * reference's dict protocol on top of it (INTEGRATION.md shows the stub).
+ *
+ * Conventions: every function returns 0 on success or a negative HH_E_* code and never throws.
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).  Buffers marked [dev] are
+ * caller-owned device memory (e.g. torch tensors); [host] are host memory.  One host thread per
+ * world.  The world owns only its struct-of-arrays state.
+ *
+ * Units are addressed 1..A in the reference (agents 1..n_agents, opponents after); arrays here
+ * are 0-based slots in the same order.
+ */
+#ifndef HH_ABI_H
+#define HH_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HH_OK 0
+#define HH_E_ARG (-1)      /* bad argument / unsupported configuration */
+#define HH_E_HIP (-2)      /* HIP runtime error (hh_last_error() has the text) */
+#define HH_E_NODEV (-3)    /* no usable GPU */
+
+/* replaces the fields envs read from config.py's Namespace (config.py:17-54, 94-107) */
+typedef struct hh_config {
+    int32_t n_arenas;         /* arenas held by THIS world (this rank's shard) */
+    int32_t env_kind;         /* HH_ENV_LOWLEVEL | HH_ENV_HIGHLEVEL */
+    int32_t n_agents;         /* args.num_agents (2 low level, 3 high level) */
+    int32_t n_opps;           /* args.num_opps */
+    int32_t level;            /* args.level 1..5 */
+    int32_t agent_mode;       /* HH_MODE_FIGHT | HH_MODE_ESCAPE (args.agent_mode) */
+    int32_t horizon;          /* args.horizon */
+    int32_t friendly_kill;    /* args.friendly_kill */
+    int32_t friendly_punish;  /* args.friendly_punish */
+    int32_t esc_dist_rew;     /* args.esc_dist_rew */
+    int32_t hier_action_assess;   /* args.hier_action_assess */
+    int32_t hier_opp_fight_ratio; /* args.hier_opp_fight_ratio [%] */
+    int32_t auto_reset;       /* 1: a finished arena is re-sampled inside hh_step */
+    int32_t ext_opp_actions;  /* 1: opponents take actions from the caller (levels 4-5 frozen policies) */
+    double map_size;          /* args.map_size */
+    double glob_frac;         /* args.glob_frac */
+    double rew_scale;         /* args.rew_scale */
+    uint64_t seed;            /* keyed-RNG seed (hh_rng.h) */
+    uint64_t arena_offset;    /* global id of local arena 0 (rank * n_arenas when sharded) */
+} hh_config;
+
+/* World snapshot used by hh_get_state / hh_set_state (parity tests, golden injection,
+ * checkpointing).  All arrays are [host], arena-major: index = (arena * A + slot) * K + k. */
+#define HH_ACF_K 6  /* lat, lon, hdg, spd, cmd_hdg, cmd_spd                       (a1, a6) */
+#define HH_ACI_K 10 /* alive, ac_type, cannon_remain, cannon_burst, cannon_max,
+                       missile_remain, rocket_max, missile_wait, has_missile, target      */
+#define HH_RKF_K 4  /* lat, lon, hdg, cmd_hdg                                     (a10)   */
+#define HH_RKI_K 4  /* alive, target, life, seq                                           */
+#define HH_ARI_K 6  /* steps, alive_agents, alive_opps, escaping, escaping_time, episode  */
+#define HH_TGT_K 3  /* stored sorted target list per unit (high level), ids / norm. distances */
+typedef struct hh_state_view {
+    double *ac_f;   /* [N, A, HH_ACF_K] */
+    int32_t *ac_i;  /* [N, A, HH_ACI_K] */
+    double *rk_f;   /* [N, A, HH_RKF_K]  rocket slot s belongs to launcher slot s */
+    int32_t *rk_i;  /* [N, A, HH_RKI_K] */
+    int32_t *ar_i;  /* [N, HH_ARI_K] */
+    int32_t *tgt_id; /* [N, A, HH_TGT_K]  (0 = none) */
+    double *tgt_d;   /* [N, A, HH_TGT_K] */
+} hh_state_view;
+
+typedef struct hh_world hh_world;
+
+/* ctor of LowLevelEnv / HighLevelEnv (env_hetero.py:20-51, env_hier.py:31-42) for N arenas */
+int hh_world_create(const hh_config *cfg, int device, hh_world **out);
+int hh_world_destroy(hh_world *w);
+const char *hh_last_error(void);
+
+/* observation width D (floats per controlled agent, zero padded): 26 fight / 30 escape / 34 commander */
+int hh_obs_dim(const hh_world *w);
+/* number of units whose actions the caller supplies per step: n_agents, or n_agents+n_opps
+ * when ext_opp_actions */
+int hh_n_ctrl(const hh_world *w);
+
+/* reset() (env_base.py:62-77 + _reset_scenario 551-585 + state()): re-samples the arenas whose
+ * mask byte is non-zero (mask [dev] u8[N]; NULL = all), episode += 1, and refreshes the
+ * observation of those arenas into obs [dev] f32[N, n_agents, D] (may be NULL). */
+int hh_reset(hh_world *w, const uint8_t *mask, float *obs, void *stream);
+
+/* step() (env_base.py:79-109 -> env_hetero.py:105-186 _take_action -> cmano_simulator.py:138-157
+ * do_tick -> env_hetero.py:188-225 rewards -> env_hetero.py:65-103 state).
+ *   actions      [dev] i8 [N, n_ctrl, 4]   MultiDiscrete([13,9,2,2]); 4th ignored for type 2
+ *   obs          [dev] f32[N, n_agents, D] observation after the tick (all agents, zeros if dead)
+ *   reward       [dev] f32[N, n_agents]
+ *   reward_valid [dev] u8 [N, n_agents]    1 iff the reference's rewards dict has the key
+ *   done         [dev] u8 [N]              terminateds["__all__"]
+ * Arenas already done (and not auto-reset) are left untouched and report reward_valid = 0. */
+int hh_step(hh_world *w, const int8_t *actions, float *obs, float *reward, uint8_t *reward_valid,
+            uint8_t *done, void *stream);
+
+/* T consecutive steps from a pre-resident action tape in ONE launch sequence with no host
+ * round trip: actions [dev] i8[T, N, n_ctrl, 4]; outputs are [T, ...] stacked like hh_step. */
+int hh_rollout(hh_world *w, int32_t n_steps, const int8_t *actions, float *obs, float *reward,
+               uint8_t *reward_valid, uint8_t *done, void *stream);
+
+/* per-arena statistics of the most recently FINISHED episode (logging; this is what the
+ * multi-GPU all-gather moves): ret [dev] f32[N] (sum of agent rewards), len [dev] i32[N],
+ * outcome [dev] i8[N] (1 agents win, -1 opponents win, 0 draw, 2 none finished yet) */
+int hh_episode_stats(hh_world *w, float *ret, int32_t *len, int8_t *outcome, void *stream);
+
+/* host snapshot in / out (synchronises the stream) */
+int hh_get_state(hh_world *w, hh_state_view *view);
+int hh_set_state(hh_world *w, const hh_state_view *view);
+
+/* integer event masks of the last step, for bit-exact parity checks ([host] after sync):
+ * per arena u32: bits 0..7 units killed by cannon, 8..15 killed by rocket, 16..23 out of bounds,
+ * 24..31 missile launched this step (by unit slot) */
+int hh_get_event_masks(hh_world *w, uint32_t *masks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HH_ABI_H */

@@ -1,0 +1,1089 @@
+/*
+ * hh_oracle.c — TEST INFRASTRUCTURE.  Sequential CPU restatement (plain C, one arena at a time,
+ * IEEE double, reference statement order) of the reference's env-step path:
+ *
+ *   warsim/simulator/{cmano_simulator,ac1,ac2,rocket_unit}.py, warsim/utils/{angles,map_limits}.py,
+ *   envs/env_base.py, envs/env_hetero.py (LowLevelEnv), envs/env_hier.py (HighLevelEnv).
+ *
+ * Every function cites the reference lines it follows.  It is NOT part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load libhh_oracle.so,
+ * and only as the checker.  The product (hhmarl_2d_amd/csrc) is an independent, parallel
+ * formulation and never calls into this file.
+ *
+ * How this oracle is pinned (parity is NOT pinned by the reference itself: it ships no tests
+ * and its geodesic arithmetic lives in un-vendored geographiclib==2.0):
+ *   - env/simulator logic: golden step traces recorded from the REAL reference, imported
+ *     unchanged in the build container behind import stubs (oracle/ref_harness.py,
+ *     oracle/gen_env_golden.py -> tests/golden/env_*.npz); tests/test_oracle_golden.py replays
+ *     them here: integer state/masks bit-exact, floats <= 1e-9.
+ *   - geodesic: include/hh_geodesic.h (Karney 2013) against an independent mpmath ODE
+ *     integration and the paper's worked examples (tests/test_geodesic.py).
+ *   - randomness: the keyed tape of include/hh_rng.h, patched into the reference by the harness.
+ *
+ * Shared with the product on purpose: include/hh_{spec,math,rng,geodesic}.h (constants, the
+ * bit-reproducible FP64 primitives and the geodesic series) so that oracle and kernels execute
+ * the same IEEE operation sequence and can be compared bit-for-bit.
+ *
+ * Build: oracle/Makefile  (gcc -O2 -mfma -ffp-contract=off -fopenmp -shared)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "hh_abi.h"
+#include "hh_geodesic.h"
+#include "hh_math.h"
+#include "hh_rng.h"
+#include "hh_spec.h"
+
+#define MAXA HH_MAX_AIRCRAFT
+#define OBS_MAX 34
+
+typedef struct {
+    /* Position + Unit fields, cmano_simulator.py:25-32,55-63; per-type fields ac1.py:38-56, ac2.py:34-52 */
+    double lat, lon, hdg, spd, cmd_hdg, cmd_spd;
+    int alive, ac_type, cannon_remain, cannon_burst, cannon_max, missile_remain, rocket_max;
+    int has_missile;  /* actual_missile is not None (may refer to an already removed rocket) */
+    int missile_wait; /* env_base.py:72 self.missile_wait[i] */
+} o_ac;
+
+typedef struct {
+    /* rocket_unit.py:23-30; slot = launcher slot */
+    int alive, target, life, seq;
+    double lat, lon, hdg, cmd_hdg;
+} o_rk;
+
+typedef struct {
+    o_ac ac[MAXA];
+    o_rk rk[MAXA];
+    int steps, episode, escaping, escaping_time, next_seq, done;
+    int tgt_n[MAXA], tgt_id[MAXA][HH_TGT_K]; /* opp_to_attack (low level: first entry only) */
+    double tgt_d[MAXA][HH_TGT_K];
+    uint64_t akey;
+    /* outputs of the last step */
+    double reward[MAXA];
+    int reward_valid[MAXA];
+    float obs[MAXA][OBS_MAX];
+    uint32_t ev_mask;
+    /* episode statistics */
+    double ep_ret;
+    float last_ret;
+    int last_len, last_outcome;
+} o_arena;
+
+typedef struct {
+    hh_config cfg;
+    int A, D, n_ctrl;
+    double ext_lat, ext_lon, lat_hi, lon_hi, inv_diag;
+    o_arena *ar;
+} o_world;
+
+typedef struct { int origin_rocket, killer, destroyed; } o_event;
+
+/* ------------------------------------------------------------------ small helpers */
+static double rng_u(const o_arena *a, int unit, int site, int sub) {
+    return hh_rng_u01(hh_rng_tick_key(a->akey, (uint32_t)a->episode, (uint32_t)a->steps), (uint32_t)unit,
+                      (uint32_t)site, (uint32_t)sub);
+}
+
+/* warsim/utils/angles.py:10-15 */
+static double normalize_angle(double a) {
+    while (a >= 360.0) a -= 360.0;
+    while (a < 0.0) a += 360.0;
+    return a;
+}
+/* angles.py:22-29 */
+static double signed_heading_diff(double actual, double desired) {
+    double delta = desired - actual;
+    if (delta < -180.0) delta = 360.0 + delta;
+    if (delta > 180.0) delta = -360.0 + delta;
+    return delta;
+}
+
+/* cmano_simulator.py:167-174 + geodesics.py:12-19: one Inverse solution gives both */
+static void dist_bearing(double lat1, double lon1, double lat2, double lon2, double *km, double *brg) {
+    double s12, azi1;
+    hh_geo_inverse(lat1, lon1, lat2, lon2, &s12, &azi1);
+    *km = s12 / 1000.0;
+    *brg = normalize_angle(azi1);
+}
+
+/* env_base.py:424-432 _focus_angle (degrees) */
+static double focus_deg(const o_ac *a, const o_ac *b) {
+    double ang = hh_pymod(90.0 - a->hdg, 360.0) * (HH_PI / 180.0);
+    double s, c;
+    hh_sincos(ang, &s, &c);
+    double dx = b->lon - a->lon, dy = b->lat - a->lat;
+    double dot = c * dx + s * dy;
+    double n1 = hh_sqrt(c * c + s * s), n2 = hh_sqrt(dx * dx + dy * dy);
+    double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
+    return hh_acos(x) * (180.0 / HH_PI);
+}
+static double focus_norm(const o_ac *a, const o_ac *b) { return hh_clip(focus_deg(a, b) / 180.0, 0.0, 1.0); }
+/* env_base.py:441-446 _aspect_angle(norm=True) */
+static double aspect_norm(const o_ac *a, const o_ac *b) { return hh_clip((180.0 - focus_deg(a, b)) / 180.0, 0.0, 1.0); }
+/* env_base.py:448-456 _heading_diff(norm=True) */
+static double heading_diff_norm(const o_ac *a, const o_ac *b) {
+    double s1, c1, s2, c2;
+    hh_sincos(hh_pymod(90.0 - a->hdg, 360.0) * (HH_PI / 180.0), &s1, &c1);
+    hh_sincos(hh_pymod(90.0 - b->hdg, 360.0) * (HH_PI / 180.0), &s2, &c2);
+    double dot = c1 * c2 + s1 * s2;
+    double n1 = hh_sqrt(c1 * c1 + s1 * s1), n2 = hh_sqrt(c2 * c2 + s2 * s2);
+    double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
+    return hh_clip((hh_acos(x) * (180.0 / HH_PI)) / 180.0, 0.0, 1.0);
+}
+/* env_base.py:434-439 _distance */
+static double dist_raw(const o_ac *a, const o_ac *b) { return hh_hypot(b->lon - a->lon, b->lat - a->lat); }
+static double dist_norm(const o_world *w, const o_ac *a, const o_ac *b) { return w->inv_diag * dist_raw(a, b); }
+
+static int is_agent(const o_world *w, int id) { return id <= w->cfg.n_agents; }
+
+/* env_base.py:400-422 _nearby_object: ids (1-based) of live enemies (or friends) sorted by
+ * normalised distance, stable */
+static int nearby(const o_world *w, const o_arena *a, int id, int friendly, int *ids, double *dn, double *dr) {
+    int n = 0, lo, hi;
+    if (friendly) {
+        lo = is_agent(w, id) ? 1 : w->cfg.n_agents + 1;
+        hi = is_agent(w, id) ? w->cfg.n_agents : w->A;
+    } else {
+        lo = is_agent(w, id) ? w->cfg.n_agents + 1 : 1;
+        hi = is_agent(w, id) ? w->A : w->cfg.n_agents;
+    }
+    for (int j = lo; j <= hi; j++) {
+        if (j == id || !a->ac[j - 1].alive) continue;
+        ids[n] = j;
+        dn[n] = dist_norm(w, &a->ac[id - 1], &a->ac[j - 1]);
+        dr[n] = dist_raw(&a->ac[id - 1], &a->ac[j - 1]);
+        n++;
+    }
+    for (int i = 1; i < n; i++) { /* insertion sort = stable */
+        int ti = ids[i]; double tn = dn[i], tr = dr[i];
+        int k = i - 1;
+        while (k >= 0 && dn[k] > tn) { ids[k + 1] = ids[k]; dn[k + 1] = dn[k]; dr[k + 1] = dr[k]; k--; }
+        ids[k + 1] = ti; dn[k + 1] = tn; dr[k + 1] = tr;
+    }
+    return n;
+}
+
+/* map_limits.py:37-40 relative_position -> (lat_rel, lon_rel) */
+static void rel_pos(const o_world *w, const o_ac *u, double *lat_rel, double *lon_rel) {
+    *lat_rel = hh_clip((u->lat - HH_MAP_LAT0) / w->ext_lat, 0.0, 1.0);
+    *lon_rel = hh_clip((u->lon - HH_MAP_LON0) / w->ext_lon, 0.0, 1.0);
+}
+/* map_limits.py:47-48 */
+static int in_boundary(const o_world *w, const o_ac *u) {
+    return HH_MAP_LON0 <= u->lon && u->lon <= w->lon_hi && HH_MAP_LAT0 <= u->lat && u->lat <= w->lat_hi;
+}
+
+static int shot_flag(const o_ac *u) { /* env_base.py:151-154,208-211 */
+    int shot = u->cannon_burst > 0;
+    if (u->ac_type == 1) shot = shot || u->has_missile;
+    return shot;
+}
+
+/* ------------------------------------------------------------------ observations */
+/* env_base.py:185-212 opp_ac_values; mode 0 fight, 1 esc, 2 HighLevel */
+static int opp_ac_values(const o_world *w, const o_arena *a, int mode, int opp_id, int agent_id, double dist, double *st) {
+    const o_ac *o = &a->ac[opp_id - 1], *s = &a->ac[agent_id - 1];
+    int n = 0;
+    double x, y;
+    rel_pos(w, o, &x, &y);
+    st[n++] = x;
+    st[n++] = y;
+    st[n++] = hh_clip(o->spd / HH_AC_MAX_SPEED(o->ac_type), 0.0, 1.0);
+    st[n++] = hh_clip(hh_pymod(o->hdg, 359.0) / 359.0, 0.0, 1.0);
+    st[n++] = heading_diff_norm(o, s);
+    if (mode == 0) {
+        st[n++] = focus_norm(o, s);
+        st[n++] = aspect_norm(s, o);
+    } else {
+        st[n++] = focus_norm(s, o);
+        st[n++] = focus_norm(o, s);
+    }
+    if (mode == 2) {
+        st[n++] = aspect_norm(s, o);
+        st[n++] = aspect_norm(o, s);
+    }
+    st[n++] = dist;
+    if (mode != 2) st[n++] = (double)shot_flag(o);
+    return n;
+}
+
+/* env_base.py:166-183 friendly_ac_values */
+static int friendly_ac_values(const o_world *w, const o_arena *a, int agent_id, int fri_id, double *st) {
+    for (int k = 0; k < 5; k++) st[k] = 0.0;
+    if (fri_id && a->ac[fri_id - 1].alive) {
+        const o_ac *f = &a->ac[fri_id - 1], *s = &a->ac[agent_id - 1];
+        double x, y;
+        rel_pos(w, f, &x, &y);
+        st[0] = x;
+        st[1] = y;
+        st[2] = focus_norm(s, f);
+        st[3] = focus_norm(f, s);
+        st[4] = dist_norm(w, s, f);
+    }
+    return 5;
+}
+
+/* env_base.py:111-135 fight_state_values */
+static int fight_state_values(const o_world *w, const o_arena *a, int id, int opp_id, double opp_dist, int fri_id, double *st) {
+    const o_ac *u = &a->ac[id - 1], *o = &a->ac[opp_id - 1];
+    int n = 0;
+    double x, y;
+    rel_pos(w, u, &x, &y);
+    st[n++] = x;
+    st[n++] = y;
+    st[n++] = hh_clip(u->spd / HH_AC_MAX_SPEED(u->ac_type), 0.0, 1.0);
+    st[n++] = hh_clip(hh_pymod(u->hdg, 359.0) / 359.0, 0.0, 1.0);
+    st[n++] = focus_norm(u, o);
+    st[n++] = aspect_norm(o, u);
+    st[n++] = heading_diff_norm(u, o);
+    st[n++] = opp_dist;
+    st[n++] = hh_clip((double)u->cannon_remain / (double)u->cannon_max, 0.0, 1.0);
+    if (u->ac_type == 1) {
+        st[n++] = hh_clip((double)u->missile_remain / (double)u->rocket_max, 0.0, 1.0);
+        st[n++] = (double)(u->missile_wait == 0);
+        st[n++] = (double)(u->has_missile || u->cannon_burst > 0);
+    } else {
+        st[n++] = (double)(u->cannon_burst > 0);
+    }
+    n += opp_ac_values(w, a, 0, opp_id, id, opp_dist, st + n);
+    n += friendly_ac_values(w, a, id, fri_id, st + n);
+    return n;
+}
+
+/* env_base.py:137-164 esc_state_values */
+static int esc_state_values(const o_world *w, const o_arena *a, int id, int n_opps, const int *opp_ids, const double *opp_d,
+                            int fri_id, double *st) {
+    const o_ac *u = &a->ac[id - 1];
+    int n = 0;
+    double x, y;
+    rel_pos(w, u, &x, &y);
+    st[n++] = x;
+    st[n++] = y;
+    st[n++] = hh_clip(u->spd / HH_AC_MAX_SPEED(u->ac_type), 0.0, 1.0);
+    st[n++] = hh_clip(hh_pymod(u->hdg, 359.0) / 359.0, 0.0, 1.0);
+    st[n++] = hh_clip((double)u->cannon_remain / (double)u->cannon_max, 0.0, 1.0);
+    if (u->ac_type == 1) st[n++] = hh_clip((double)u->missile_remain / (double)u->rocket_max, 0.0, 1.0);
+    st[n++] = (double)shot_flag(u);
+    int m = 0;
+    double os[18];
+    for (int k = 0; k < 18; k++) os[k] = 0.0;
+    for (int k = 0; k < n_opps && m < 18; k++) m += opp_ac_values(w, a, 1, opp_ids[k], id, opp_d[k], os + m);
+    for (int k = 0; k < 18; k++) st[n++] = os[k];
+    n += friendly_ac_values(w, a, id, fri_id, st + n);
+    return n;
+}
+
+static int fri_ac_id(const o_world *w, int id) { /* env_hetero.py:71-75 */
+    if (id <= w->cfg.n_agents) return id == 2 ? 1 : 2;
+    return id == 4 ? 3 : 4;
+}
+
+static void obs_store(o_arena *a, int slot, const double *st, int n) {
+    for (int k = 0; k < OBS_MAX; k++) a->obs[slot][k] = k < n ? (float)st[k] : 0.0f;
+}
+
+/* env_hetero.py:65-103 lowlevel_state for one unit id (also refreshes opp_to_attack[id]) */
+static void lowlevel_state_one(const o_world *w, o_arena *a, int id, int mode, double *st, int *n_out) {
+    int ids[MAXA];
+    double dn[MAXA], dr[MAXA];
+    *n_out = 0;
+    a->tgt_n[id - 1] = 0;
+    a->tgt_id[id - 1][0] = 0;
+    if (a->ac[id - 1].alive) {
+        int n = nearby(w, a, id, 0, ids, dn, dr);
+        if (n > 0) {
+            if (mode == HH_MODE_FIGHT)
+                *n_out = fight_state_values(w, a, id, ids[0], dn[0], fri_ac_id(w, id), st);
+            else
+                *n_out = esc_state_values(w, a, id, n, ids, dn, fri_ac_id(w, id), st);
+            a->tgt_n[id - 1] = 1;
+            a->tgt_id[id - 1][0] = ids[0];
+            a->tgt_d[id - 1][0] = dn[0];
+        }
+    }
+}
+
+/* env_hetero.py:62-63 state() */
+static void ll_state(const o_world *w, o_arena *a) {
+    double st[OBS_MAX];
+    for (int id = 1; id <= w->cfg.n_agents; id++) {
+        int n;
+        lowlevel_state_one(w, a, id, w->cfg.agent_mode, st, &n);
+        obs_store(a, id - 1, st, n);
+    }
+}
+
+/* ------------------------------------------------------------------ simulator */
+/* ac1.py:72-79 fire_missile + 144-146 _angle_in_radar_range */
+static void fire_missile(const o_world *w, o_arena *a, int id, int opp_id) {
+    o_ac *u = &a->ac[id - 1];
+    (void)w;
+    if (!u->has_missile && u->missile_remain > 0) {
+        double km, brg;
+        const o_ac *o = &a->ac[opp_id - 1];
+        dist_bearing(u->lat, u->lon, o->lat, o->lon, &km, &brg);
+        if (km <= HH_MISSILE_RANGE_KM) {
+            double delta = hh_fabs(signed_heading_diff(normalize_angle(u->hdg + HH_MISSILE_HALF_DEG), brg));
+            if ((int)delta <= (int)HH_MISSILE_HALF_DEG) {
+                o_rk *r = &a->rk[id - 1];
+                r->alive = 1;
+                r->lat = u->lat;
+                r->lon = u->lon;
+                r->hdg = u->hdg;
+                r->cmd_hdg = u->hdg;
+                r->target = opp_id;
+                r->life = 0;
+                r->seq = ++a->next_seq;
+                u->has_missile = 1;
+                u->missile_remain = u->missile_remain - 1 > 0 ? u->missile_remain - 1 : 0;
+                a->ev_mask |= 1u << (24 + id - 1);
+            }
+        }
+    }
+}
+
+/* ac1.py:69-70 / ac2.py:65-66 */
+static void fire_cannon(o_ac *u) {
+    int b = HH_AC_BURST(u->ac_type);
+    u->cannon_burst = u->cannon_remain < b ? u->cannon_remain : b;
+}
+
+/* ac1.py:81-133 / ac2.py:68-107 update() of aircraft `id`; appends events */
+static void aircraft_update(const o_world *w, o_arena *a, int id, o_event *ev, int *nev) {
+    o_ac *u = &a->ac[id - 1];
+    int t = u->ac_type;
+    /* heading, ac1.py:83-90 */
+    if (u->hdg != u->cmd_hdg) {
+        double delta = signed_heading_diff(u->hdg, u->cmd_hdg);
+        double max_deg = HH_AC_TURN_RATE(t) * 1.0;
+        if (hh_fabs(delta) <= max_deg) {
+            u->hdg = u->cmd_hdg;
+        } else {
+            u->hdg += delta >= 0.0 ? max_deg : -max_deg;
+            u->hdg = hh_pymod(u->hdg, 360.0);
+        }
+    }
+    /* speed, ac1.py:93-99 */
+    if (u->spd != u->cmd_spd) {
+        double delta = u->cmd_spd - u->spd;
+        double max_delta = HH_AC_ACCEL(t) * 1.0;
+        if (hh_fabs(delta) <= max_delta)
+            u->spd = u->cmd_spd;
+        else
+            u->spd += delta >= 0.0 ? max_delta : -max_delta;
+    }
+    /* cannon, ac1.py:101-115 */
+    if (u->cannon_burst > 0) {
+        u->cannon_burst = u->cannon_burst - 1 > 0 ? u->cannon_burst - 1 : 0;
+        u->cannon_remain = u->cannon_remain - 1 > 0 ? u->cannon_remain - 1 : 0;
+        for (int j = 1; j <= w->A; j++) { /* list(sim.active_units.values()): currently alive, id order */
+            if (j == id || !a->ac[j - 1].alive) continue;
+            int enemy = is_agent(w, id) ? (j >= w->cfg.n_agents + 1) : (j <= w->cfg.n_agents);
+            if (!(w->cfg.friendly_kill || enemy)) continue;
+            /* _unit_in_cannon_range, ac1.py:135-142 */
+            double km, brg;
+            dist_bearing(u->lat, u->lon, a->ac[j - 1].lat, a->ac[j - 1].lon, &km, &brg);
+            int in_range = 0;
+            if (km < HH_AC_CANNON_KM(t)) {
+                double d = hh_fabs(signed_heading_diff(u->hdg, brg));
+                in_range = d <= HH_AC_CANNON_HALF(t);
+            }
+            if (in_range) {
+                if (rng_u(a, id, HH_SITE_CANNON, j) < HH_AC_HIT_PROB(t)) {
+                    a->ac[j - 1].alive = 0;
+                    ev[*nev].origin_rocket = 0;
+                    ev[*nev].killer = id;
+                    ev[*nev].destroyed = j;
+                    (*nev)++;
+                    a->ev_mask |= 1u << (j - 1);
+                }
+            }
+        }
+    }
+    /* missile bookkeeping, ac1.py:117-128 (type 2 never has actual_missile) */
+    if (u->has_missile) {
+        o_rk *r = &a->rk[id - 1];
+        if (!r->alive) {
+            u->has_missile = 0;
+        } else {
+            double h = r->hdg * hh_rng_uniform(rng_u(a, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05);
+            r->cmd_hdg = hh_clip(h, 0.0, 359.0);
+        }
+    }
+    /* Unit.update, cmano_simulator.py:65-72 */
+    if (u->spd > 0.0) hh_geo_direct(u->lat, u->lon, u->hdg, u->spd * HH_KNOTS_TO_MS * 1.0, &u->lat, &u->lon);
+}
+
+/* rocket_unit.py:37-73 */
+static void rocket_update(const o_world *w, o_arena *a, int slot, o_event *ev, int *nev) {
+    static const double speed_table[11] = HH_ROCKET_SPEED_TABLE;
+    o_rk *r = &a->rk[slot];
+    int source = slot + 1;
+    double km, brg;
+    o_ac *tg = &a->ac[r->target - 1];
+    dist_bearing(r->lat, r->lon, tg->lat, tg->lon, &km, &brg);
+    if (km < HH_ROCKET_FUSE_KM && tg->alive) {
+        r->alive = 0;
+        tg->alive = 0;
+        ev[*nev].origin_rocket = 1; ev[*nev].killer = source; ev[*nev].destroyed = r->target; (*nev)++;
+        a->ev_mask |= 1u << (8 + r->target - 1);
+        return;
+    }
+    if (w->cfg.friendly_kill) {
+        int fid = source == 2 ? 1 : 2; /* rocket_unit.py:46 */
+        o_ac *f = &a->ac[fid - 1];
+        if (f->alive) {
+            dist_bearing(r->lat, r->lon, f->lat, f->lon, &km, &brg);
+            if (km < HH_ROCKET_FUSE_KM) {
+                r->alive = 0;
+                f->alive = 0;
+                ev[*nev].origin_rocket = 1; ev[*nev].killer = source; ev[*nev].destroyed = fid; (*nev)++;
+                a->ev_mask |= 1u << (8 + fid - 1);
+                return;
+            }
+        }
+    }
+    if (r->life > HH_ROCKET_MAX_LIFE) { r->alive = 0; return; }
+    if (r->hdg != r->cmd_hdg) {
+        double delta = signed_heading_diff(r->hdg, r->cmd_hdg);
+        if (hh_fabs(delta) <= HH_ROCKET_TURN_RATE) r->hdg = r->cmd_hdg;
+        else r->hdg += delta >= 0.0 ? HH_ROCKET_TURN_RATE : -HH_ROCKET_TURN_RATE;
+    }
+    double spd = speed_table[r->life];
+    if (spd > 0.0) hh_geo_direct(r->lat, r->lon, r->hdg, spd * HH_KNOTS_TO_MS * 1.0, &r->lat, &r->lon);
+    r->life++; /* sim.utc_time advances after the tick (cmano_simulator.py:146) */
+}
+
+/* cmano_simulator.py:138-157 do_tick */
+static int do_tick(const o_world *w, o_arena *a, o_event *ev) {
+    int nev = 0;
+    int ac_snap[MAXA], rk_order[MAXA], nrk = 0;
+    for (int i = 0; i < w->A; i++) ac_snap[i] = a->ac[i].alive;
+    for (int s = 0; s < w->A; s++) if (a->rk[s].alive) rk_order[nrk++] = s;
+    for (int i = 1; i < nrk; i++) { /* launch order = unit id order */
+        int t = rk_order[i], k = i - 1;
+        while (k >= 0 && a->rk[rk_order[k]].seq > a->rk[t].seq) { rk_order[k + 1] = rk_order[k]; k--; }
+        rk_order[k + 1] = t;
+    }
+    for (int i = 1; i <= w->A; i++) if (ac_snap[i - 1]) aircraft_update(w, a, i, ev, &nev);
+    for (int k = 0; k < nrk; k++) rocket_update(w, a, rk_order[k], ev, &nev);
+    return nev;
+}
+
+/* ------------------------------------------------------------------ actions */
+/* env_base.py:214-238 _take_base_action; returns 0 or error */
+static void take_base_action(const o_world *w, o_arena *a, int hl, int id, int opp_id, const int8_t *act) {
+    o_ac *u = &a->ac[id - 1];
+    double nh = hh_pymod(u->hdg + (double)((act[0] - 6) * 15), 360.0);
+    if (nh >= 360.0 || nh < 0.0) nh = 0.0; /* ac1.py:59-60 would raise (unreachable) */
+    u->cmd_hdg = nh;
+    double mx = HH_AC_MAX_SPEED(u->ac_type);
+    u->cmd_spd = 100.0 + ((mx - 100.0) / 8.0) * (double)act[1];
+    int agent_ll = !hl && id <= w->cfg.n_agents;
+    if (act[2] && u->cannon_remain > 0) {
+        fire_cannon(u);
+        if (agent_ll && w->cfg.agent_mode == HH_MODE_ESCAPE && u->cannon_remain < 90) a->reward[id - 1] -= 0.1;
+    }
+    if (u->ac_type == 1 && act[3]) {
+        if (opp_id && u->missile_remain > 0 && !u->has_missile && u->missile_wait == 0) {
+            fire_missile(w, a, id, opp_id);
+            double uu = rng_u(a, id, HH_SITE_MISSILE_WAIT, 0);
+            u->missile_wait = hl ? hh_rng_randint(uu, 8, 12) : hh_rng_randint(uu, 7, 17);
+            if (agent_ll && w->cfg.agent_mode == HH_MODE_ESCAPE && u->missile_remain < 3) a->reward[id - 1] -= 0.1;
+        }
+    }
+    if (u->missile_wait > 0 && !u->has_missile) u->missile_wait -= 1;
+}
+
+/* env_base.py:464-487 _correct_angle_sign */
+static double correct_angle_sign(const o_ac *opp, const o_ac *ag) {
+    double x = opp->lon, y = opp->lat, h = opp->hdg;
+    double s, c;
+    hh_sincos(hh_pymod(h, 360.0) * (HH_PI / 180.0), &s, &c);
+    double x1 = x + hh_round3(s), y1 = y + hh_round3(c);
+    double xc = ag->lon, yc = ag->lat;
+    double val = (x1 - x) * (yc - y) - (xc - x) * (y1 - y);
+    return val < 0.0 ? 1.0 : -1.0;
+}
+
+static void set_speed_checked(o_ac *u, double s) { u->cmd_spd = s; }
+
+/* env_hetero.py:118-123 */
+static void opp_level1(const o_world *w, o_arena *a, int id) {
+    o_ac *u = &a->ac[id - 1];
+    if (!u->has_missile && (a->steps % 40) < 3 && hh_rng_randint(rng_u(a, id, HH_SITE_L12_COIN, 0), 0, 1) &&
+        u->missile_wait == 0 && u->ac_type == 1) {
+        int ids[MAXA]; double dn[MAXA], dr[MAXA];
+        if (nearby(w, a, id, 0, ids, dn, dr) > 0) {
+            fire_missile(w, a, id, ids[0]);
+            u->missile_wait = 5;
+        }
+    }
+}
+
+/* env_hetero.py:125-136 */
+static void opp_level2(const o_world *w, o_arena *a, int id) {
+    o_ac *u = &a->ac[id - 1];
+    fire_cannon(u);
+    int man = a->steps <= 5;
+    if (!man) man = (a->steps % hh_rng_randint(rng_u(a, id, HH_SITE_L2_PERIOD, 0), 35, 45)) <= 5;
+    if (man) {
+        int r = hh_rng_randint(rng_u(a, id, HH_SITE_L2_TURN, 0), 0, 1);
+        u->cmd_hdg = hh_pymod(u->hdg + (r ? -90.0 : 90.0), 360.0);
+        u->cmd_spd = (double)(100 + hh_rng_randint(rng_u(a, id, HH_SITE_L2_SPEED, 0), 0, 4) * 75);
+    }
+    if (!u->has_missile && (a->steps % 40) < 3 && hh_rng_randint(rng_u(a, id, HH_SITE_L12_COIN, 0), 0, 1) &&
+        u->missile_wait == 0 && u->ac_type == 1) {
+        int ids[MAXA]; double dn[MAXA], dr[MAXA];
+        if (nearby(w, a, id, 0, ids, dn, dr) > 0) {
+            fire_missile(w, a, id, ids[0]);
+            u->missile_wait = 5;
+        }
+    }
+}
+
+/* env_hetero.py:138-158 (+ _escaping_opp 227-245, _hardcoded_opp 247-271) */
+static void opp_level3(const o_world *w, o_arena *a, int id) {
+    o_ac *u = &a->ac[id - 1];
+    if (a->steps % 60 == 0 && !a->escaping) {
+        a->escaping = hh_rng_randint(rng_u(a, id, HH_SITE_L3_ESC_COIN, 0), 0, 1);
+        if (a->escaping) a->escaping_time = (int)hh_rng_uniform(rng_u(a, id, HH_SITE_L3_ESC_TIME, 0), 20.0, 30.0);
+    }
+    int opp = 0, fire = 0, fire_m = 0;
+    double heading, speed;
+    if (a->escaping) {
+        double y, x;
+        rel_pos(w, u, &y, &x);
+        double uh = rng_u(a, id, HH_SITE_ESC_HDG, 0);
+        if (y < 0.5) heading = x < 0.5 ? (double)(int)hh_rng_uniform(uh, 30.0, 60.0) : (double)(int)hh_rng_uniform(uh, 300.0, 330.0);
+        else heading = x < 0.5 ? (double)(int)hh_rng_uniform(uh, 120.0, 150.0) : (double)(int)hh_rng_uniform(uh, 210.0, 240.0);
+        speed = (double)(int)hh_rng_uniform(rng_u(a, id, HH_SITE_ESC_SPEED, 0), 300.0, 600.0);
+        fire = hh_rng_randint(rng_u(a, id, HH_SITE_ESC_FIRE, 0), 0, 1);
+        a->escaping_time -= 1;
+        if (a->escaping_time <= 0) a->escaping = 0;
+    } else {
+        int ids[MAXA]; double dn[MAXA], dr[MAXA];
+        int n = nearby(w, a, id, 0, ids, dn, dr);
+        heading = u->hdg;
+        speed = (double)(int)hh_rng_uniform(rng_u(a, id, HH_SITE_HC_SPEED1, 0), 100.0, 400.0);
+        if (n > 0) {
+            const o_ac *ag = &a->ac[ids[0] - 1];
+            double sign = correct_angle_sign(u, ag);
+            double r = hh_rng_uniform(rng_u(a, id, HH_SITE_HC_R, 0), 0.7, 1.3);
+            double focus = focus_deg(u, ag);
+            if (dn[0] > 0.008 && focus > 4.0) heading = hh_pymod(heading + r * sign * focus, 360.0);
+            if (dn[0] > 0.05) {
+                double us = rng_u(a, id, HH_SITE_HC_SPEED2, 0);
+                speed = focus < 30.0 ? (double)(int)hh_rng_uniform(us, 500.0, 800.0) : (double)(int)hh_rng_uniform(us, 100.0, 500.0);
+            }
+            fire = dn[0] < 0.03 && focus < 10.0;
+            fire_m = dn[0] < 0.09 && focus < 5.0;
+            opp = ids[0];
+        }
+        if (u->ac_type == 2) speed = hh_clip(speed, 0.0, 600.0);
+    }
+    if (heading >= 360.0 || heading < 0.0) heading = 0.0; /* set_heading would raise (Q20) */
+    u->cmd_hdg = heading;
+    set_speed_checked(u, speed);
+    if (fire) fire_cannon(u);
+    if (fire_m && opp && !u->has_missile && u->missile_wait == 0 && u->ac_type == 1) {
+        fire_missile(w, a, id, opp);
+        u->missile_wait = 10;
+    }
+}
+
+/* ------------------------------------------------------------------ rewards */
+/* env_base.py:240-310 _combat_rewards; rews[] are running sums in append order */
+static int combat_rewards(const o_world *w, o_arena *a, int hl, const o_event *ev, int nev, const double *opp_stat0,
+                          double *rews, int *destroyed) {
+    double s = w->cfg.rew_scale;
+    int kill_event = 0;
+    int nA = w->cfg.n_agents;
+    for (int i = 0; i < nA; i++) { rews[i] = 0.0; destroyed[i] = 0; }
+    for (int i = 1; i <= w->A; i++) {
+        o_ac *u = &a->ac[i - 1];
+        if (u->alive && !in_boundary(w, u)) {
+            u->alive = 0;
+            kill_event = 1;
+            a->ev_mask |= 1u << (16 + i - 1);
+            if (i <= nA) {
+                rews[i - 1] += (hl ? -2.0 : -5.0) * s;
+                destroyed[i - 1] = 1;
+            }
+        }
+    }
+    for (int e = 0; e < nev; e++) {
+        int k = ev[e].killer, d = ev[e].destroyed;
+        if (k <= nA) {
+            if (d > nA) {
+                if (!hl) {
+                    if (w->cfg.agent_mode == HH_MODE_FIGHT) {
+                        const o_ac *ku = &a->ac[k - 1];
+                        if (ev[e].origin_rocket) {
+                            rews[k - 1] += (1.0 + ((1.5 - 1.0) / (1.0 - 0.0)) * ((double)ku->missile_remain / (double)ku->rocket_max - 0.0)) * s;
+                        } else {
+                            double r1 = 0.5 + ((1.0 - 0.5) / (1.0 - 0.0)) * ((double)ku->cannon_remain / (double)ku->cannon_max - 0.0);
+                            double r2 = 0.5 + ((1.0 - 0.5) / (1.0 - 0.0)) * (opp_stat0[k - 1] - 0.0);
+                            rews[k - 1] += (r1 + r2) * s;
+                        }
+                    }
+                } else {
+                    rews[k - 1] += 1.0;
+                }
+            } else {
+                if (!hl) {
+                    rews[k - 1] += -2.0 * s;
+                    if (w->cfg.friendly_punish) {
+                        rews[d - 1] += -2.0 * s;
+                        destroyed[d - 1] = 1;
+                    }
+                }
+            }
+        } else {
+            if (d <= nA) {
+                rews[d - 1] += (hl ? -1.0 : -2.0) * s;
+                destroyed[d - 1] = 1;
+            }
+        }
+        kill_event = 1;
+    }
+    return kill_event;
+}
+
+static void count_alive(const o_world *w, const o_arena *a, int *ag, int *op) {
+    *ag = *op = 0;
+    for (int i = 1; i <= w->A; i++)
+        if (a->ac[i - 1].alive) { if (i <= w->cfg.n_agents) (*ag)++; else (*op)++; }
+}
+
+/* ------------------------------------------------------------------ reset */
+/* env_base.py:489-549 _sample_state (low level) / env_hier.py:226-250 (high level) */
+static void sample_state(const o_world *w, o_arena *a, int agent, int i, int r, double *x, double *y, int *hd) {
+    int id = agent ? i + 1 : w->cfg.n_agents + i + 1;
+    double ux = rng_u(a, id, HH_SITE_RESET_X, 0), uy = rng_u(a, id, HH_SITE_RESET_Y, 0);
+    double uh = rng_u(a, id, HH_SITE_RESET_HDG, 0);
+    int near_side = agent ? (r == 1) : (r == 2); /* which x-band this group spawns in */
+    *hd = 0;
+    if (w->cfg.env_kind == HH_ENV_HIGHLEVEL) {
+        double n = agent ? (double)w->cfg.n_agents : (double)w->cfg.n_opps;
+        *x = near_side ? hh_rng_uniform(ux, 7.07, 7.22) : hh_rng_uniform(ux, 7.28, 7.43);
+        *y = hh_rng_uniform(uy, 5.07 + i * (0.4 / n), 5.12 + i * (0.4 / n));
+        *hd = hh_rng_randint(uh, 0, 359);
+        return;
+    }
+    int lvl = w->cfg.level;
+    if (lvl == 1) {
+        *x = near_side ? hh_rng_uniform(ux, 7.12, 7.14) : hh_rng_uniform(ux, 7.16, 7.17);
+        *y = hh_rng_uniform(uy, 5.1 + i * 0.1, 5.11 + i * 0.1);
+        if (agent) *hd = r == 1 ? hh_rng_randint(uh, 30, 150) : hh_rng_randint(uh, 200, 330);
+    } else if (lvl == 2) {
+        *x = near_side ? hh_rng_uniform(ux, 7.08, 7.13) : hh_rng_uniform(ux, 7.18, 7.23);
+        *y = hh_rng_uniform(uy, 5.08 + i * 0.1, 5.13 + i * 0.1);
+        if (agent) *hd = r == 1 ? hh_rng_randint(uh, 0, 180) : hh_rng_randint(uh, 180, 359);
+        else *hd = hh_rng_randint(uh, 0, 359);
+    } else {
+        *x = near_side ? hh_rng_uniform(ux, 7.07, 7.12) : hh_rng_uniform(ux, 7.18, 7.23);
+        *y = hh_rng_uniform(uy, 5.09 + i * 0.1, 5.12 + i * 0.1);
+        if (agent) *hd = r == 1 ? hh_rng_randint(uh, 0, 270) : hh_rng_randint(uh, 90, 359);
+        else *hd = hh_rng_randint(uh, 0, 359);
+    }
+}
+
+static void hl_state(const o_world *w, o_arena *a);
+
+/* env_base.py:62-77 reset + 551-585 _reset_scenario */
+static void arena_reset(const o_world *w, o_arena *a) {
+    a->episode += 1;
+    a->steps = 0;
+    a->escaping = 0;
+    a->escaping_time = 0;
+    a->next_seq = 0;
+    a->done = 0;
+    a->ep_ret = 0.0;
+    a->ev_mask = 0;
+    int hl = w->cfg.env_kind == HH_ENV_HIGHLEVEL;
+    int r = hh_rng_randint(rng_u(a, 0, HH_SITE_RESET_SIDE, 0), 1, 2);
+    for (int g = 0; g < 2; g++) {
+        int agent = g == 0;
+        int count = agent ? w->cfg.n_agents : w->cfg.n_opps;
+        for (int i = 0; i < count; i++) {
+            int id = agent ? i + 1 : w->cfg.n_agents + i + 1;
+            double x, y;
+            int hd;
+            sample_state(w, a, agent, i, r, &x, &y, &hd);
+            int ac = i <= 1 ? i + 1 : hh_rng_randint(rng_u(a, id, HH_SITE_RESET_TYPE, 0), 1, 2);
+            o_ac *u = &a->ac[id - 1];
+            memset(u, 0, sizeof(*u));
+            u->lat = y;
+            u->lon = x;
+            u->hdg = (double)hd;
+            u->spd = (w->cfg.level <= 2 && !agent) ? 0.0 : 100.0;
+            u->cmd_hdg = u->hdg;
+            u->cmd_spd = u->spd;
+            u->alive = 1;
+            u->ac_type = ac;
+            u->cannon_remain = u->cannon_max = HH_AC_CANNON_DEFAULT;
+            u->missile_remain = u->rocket_max = ac == 1 ? HH_AC1_MISSILES_DEFAULT : 0;
+            if (!hl) {
+                if (w->cfg.level <= 4 && !agent) {
+                    u->cannon_remain = u->cannon_max = 400;
+                    if (ac == 1) u->missile_remain = u->rocket_max = 8;
+                } else if (w->cfg.level == 5) {
+                    u->cannon_remain = u->cannon_max = 300;
+                    if (ac == 1) u->missile_remain = u->rocket_max = 6;
+                }
+            } else {
+                u->cannon_remain = u->cannon_max = 300;
+                if (ac == 1) u->missile_remain = u->rocket_max = 8;
+            }
+            memset(&a->rk[id - 1], 0, sizeof(o_rk));
+            a->tgt_n[id - 1] = 0;
+            for (int k = 0; k < HH_TGT_K; k++) { a->tgt_id[id - 1][k] = 0; a->tgt_d[id - 1][k] = 0.0; }
+        }
+    }
+    for (int i = 0; i < MAXA; i++) { a->reward[i] = 0.0; a->reward_valid[i] = 0; }
+    if (hl) hl_state(w, a); else ll_state(w, a);
+}
+
+/* ------------------------------------------------------------------ LowLevelEnv.step */
+static void finish_episode(o_arena *a, int ag, int op, int horizon) {
+    a->last_ret = (float)a->ep_ret;
+    a->last_len = a->steps;
+    a->last_outcome = (op <= 0 && a->steps < horizon) ? 1 : ((ag <= 0 && a->steps < horizon) ? -1 : 0);
+}
+
+/* env_base.py:79-109 step -> env_hetero.py:105-186 _take_action -> 188-225 _get_rewards */
+static void ll_step(const o_world *w, o_arena *a, const int8_t *actions /* [n_ctrl,4] */) {
+    int nA = w->cfg.n_agents;
+    double opp_stat0[MAXA];
+    o_event ev[4 * MAXA];
+    a->ev_mask = 0;
+    for (int i = 0; i < MAXA; i++) { a->reward[i] = 0.0; a->reward_valid[i] = 0; opp_stat0[i] = 0.0; }
+    a->steps += 1;
+    for (int i = 1; i <= w->A; i++) {
+        if (!a->ac[i - 1].alive) continue;
+        if (i <= nA || w->cfg.ext_opp_actions) {
+            if (i > nA) {
+                /* env_base.py:349-398 _policy_actions: lowlevel_state(opp_mode, i) refreshes the
+                 * opponent's target; the action itself comes from the caller's frozen policy */
+                double st[OBS_MAX]; int n;
+                lowlevel_state_one(w, a, i, HH_MODE_FIGHT, st, &n);
+            } else {
+                a->reward_valid[i - 1] = 1;
+                int t = a->tgt_n[i - 1] ? a->tgt_id[i - 1][0] : 0;
+                if (t && a->ac[t - 1].alive) opp_stat0[i - 1] = focus_norm(&a->ac[t - 1], &a->ac[i - 1]);
+            }
+            int t = a->tgt_n[i - 1] ? a->tgt_id[i - 1][0] : 0;
+            take_base_action(w, a, 0, i, t, actions + 4 * (i - 1));
+        } else {
+            if (w->cfg.level == 1) opp_level1(w, a, i);
+            else if (w->cfg.level == 2) opp_level2(w, a, i);
+            else opp_level3(w, a, i);
+        }
+    }
+    int nev = do_tick(w, a, ev);
+    double rews[MAXA];
+    int destroyed[MAXA];
+    combat_rewards(w, a, 0, ev, nev, opp_stat0, rews, destroyed);
+    /* env_hetero.py:198-214 per-step escape shaping */
+    if (w->cfg.agent_mode == HH_MODE_ESCAPE && w->cfg.esc_dist_rew) {
+        for (int i = 1; i <= nA; i++) {
+            if (!a->ac[i - 1].alive) continue;
+            int ids[MAXA]; double dn[MAXA], dr[MAXA];
+            int n = nearby(w, a, i, 0, ids, dn, dr);
+            for (int j = 1; j <= n; j++) {
+                if (dr[j - 1] < 0.06) {
+                    rews[i - 1] += -0.02 / j;
+                    if (a->ac[i - 1].spd < 200.0) rews[i - 1] += -0.02 / j;
+                } else if (dr[j - 1] > 0.13) {
+                    rews[i - 1] += 0.02 / j;
+                    if (a->ac[i - 1].spd > 500.0) rews[i - 1] += 0.02 / j;
+                }
+            }
+        }
+    }
+    /* env_hetero.py:217-223 */
+    for (int i = 1; i <= nA; i++) {
+        if (a->ac[i - 1].alive || destroyed[i - 1]) {
+            if (w->cfg.glob_frac > 0.0 && w->cfg.agent_mode == HH_MODE_FIGHT)
+                a->reward[i - 1] += rews[i - 1] + w->cfg.glob_frac * rews[i % 2];
+            else
+                a->reward[i - 1] += rews[i - 1];
+        }
+    }
+    int ag, op;
+    count_alive(w, a, &ag, &op);
+    a->done = ag <= 0 || op <= 0 || a->steps >= w->cfg.horizon;
+    for (int i = 0; i < nA; i++) if (a->reward_valid[i]) a->ep_ret += a->reward[i];
+    if (a->done) finish_episode(a, ag, op, w->cfg.horizon);
+    ll_state(w, a);
+}
+
+/* ------------------------------------------------------------------ HighLevelEnv (env_hier.py) */
+/* env_hier.py:49-98 state(): commander observation + sorted target lists for every unit */
+static void hl_state(const o_world *w, o_arena *a) {
+    int nA = w->cfg.n_agents;
+    for (int id = 1; id <= w->A; id++) {
+        int ids[MAXA]; double dn[MAXA], dr[MAXA];
+        a->tgt_n[id - 1] = 0;
+        for (int k = 0; k < HH_TGT_K; k++) { a->tgt_id[id - 1][k] = 0; a->tgt_d[id - 1][k] = 0.0; }
+        if (id <= nA) {
+            double st[OBS_MAX];
+            int n = 0;
+            if (a->ac[id - 1].alive) {
+                int no = nearby(w, a, id, 0, ids, dn, dr);
+                if (no > 0) {
+                    const o_ac *u = &a->ac[id - 1];
+                    double x, y;
+                    rel_pos(w, u, &x, &y);
+                    st[n++] = x;
+                    st[n++] = y;
+                    st[n++] = hh_clip(u->spd / HH_AC_MAX_SPEED(u->ac_type), 0.0, 1.0);
+                    st[n++] = hh_clip(hh_pymod(u->hdg, 359.0) / 359.0, 0.0, 1.0);
+                    double os[20]; int m = 0;
+                    for (int k = 0; k < 20; k++) os[k] = 0.0;
+                    for (int k = 0; k < no; k++) {
+                        m += opp_ac_values(w, a, 2, ids[k], id, dn[k], os + m);
+                        a->tgt_id[id - 1][a->tgt_n[id - 1]] = ids[k];
+                        a->tgt_d[id - 1][a->tgt_n[id - 1]] = dn[k];
+                        a->tgt_n[id - 1]++;
+                        if (m == HH_N_OPP_HL * 10) break;
+                    }
+                    for (int k = 0; k < 20; k++) st[n++] = os[k];
+                    double fs[10]; m = 0;
+                    for (int k = 0; k < 10; k++) fs[k] = 0.0;
+                    int fids[MAXA]; double fdn[MAXA], fdr[MAXA];
+                    int nf = nearby(w, a, id, 1, fids, fdn, fdr);
+                    for (int k = 0; k < nf; k++) {
+                        m += friendly_ac_values(w, a, id, fids[k], fs + m);
+                        if (m == 10) break;
+                    }
+                    for (int k = 0; k < 10; k++) st[n++] = fs[k];
+                }
+            }
+            obs_store(a, id - 1, st, n);
+        } else if (a->ac[id - 1].alive) {
+            int no = nearby(w, a, id, 0, ids, dn, dr);
+            for (int k = 0; k < no && k < HH_TGT_K; k++) { a->tgt_id[id - 1][k] = ids[k]; a->tgt_d[id - 1][k] = dn[k]; }
+            a->tgt_n[id - 1] = no < HH_TGT_K ? no : HH_TGT_K;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ batch API */
+#define API __attribute__((visibility("default")))
+
+API int hho_create(const hh_config *cfg, void **out) {
+    if (!cfg || !out || cfg->n_arenas <= 0) return HH_E_ARG;
+    int A = cfg->n_agents + cfg->n_opps;
+    if (A > MAXA || cfg->n_agents < 1 || cfg->n_opps < 1) return HH_E_ARG;
+    o_world *w = (o_world *)calloc(1, sizeof(o_world));
+    w->cfg = *cfg;
+    w->A = A;
+    w->n_ctrl = cfg->ext_opp_actions ? A : cfg->n_agents;
+    if (cfg->env_kind == HH_ENV_HIGHLEVEL) w->D = HH_OBS_HL;
+    else w->D = cfg->agent_mode == HH_MODE_FIGHT ? HH_OBS_FIGHT_AC1 : HH_OBS_ESC_AC1;
+    double m = cfg->map_size;
+    w->lat_hi = HH_MAP_LAT0 + m;
+    w->lon_hi = HH_MAP_LON0 + m;
+    w->ext_lat = w->lat_hi - HH_MAP_LAT0; /* map_limits.py:19-23 */
+    w->ext_lon = w->lon_hi - HH_MAP_LON0;
+    w->inv_diag = (1.0 - 0.0) / (hh_sqrt(2.0 * (m * m)) - 0.0); /* env_base.py:439,458-462 */
+    w->ar = (o_arena *)calloc((size_t)cfg->n_arenas, sizeof(o_arena));
+    for (int n = 0; n < cfg->n_arenas; n++) {
+        w->ar[n].akey = hh_rng_arena_key(cfg->seed, cfg->arena_offset + (uint64_t)n);
+        w->ar[n].last_outcome = 2;
+        w->ar[n].done = 1; /* must be reset before stepping */
+    }
+    *out = w;
+    return HH_OK;
+}
+
+API int hho_destroy(void *h) {
+    o_world *w = (o_world *)h;
+    if (!w) return HH_E_ARG;
+    free(w->ar);
+    free(w);
+    return HH_OK;
+}
+
+API int hho_obs_dim(void *h) { return ((o_world *)h)->D; }
+API int hho_n_ctrl(void *h) { return ((o_world *)h)->n_ctrl; }
+
+static void copy_obs(const o_world *w, const o_arena *a, float *obs) {
+    for (int i = 0; i < w->cfg.n_agents; i++)
+        for (int k = 0; k < w->D; k++) obs[i * w->D + k] = a->obs[i][k];
+}
+
+API int hho_reset(void *h, const uint8_t *mask, float *obs) {
+    o_world *w = (o_world *)h;
+    int N = w->cfg.n_arenas;
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; n++) {
+        if (mask && !mask[n]) continue;
+        arena_reset(w, &w->ar[n]);
+        if (obs) copy_obs(w, &w->ar[n], obs + (size_t)n * w->cfg.n_agents * w->D);
+    }
+    return HH_OK;
+}
+
+API int hho_step(void *h, const int8_t *actions, float *obs, float *reward, uint8_t *reward_valid, uint8_t *done) {
+    o_world *w = (o_world *)h;
+    int N = w->cfg.n_arenas, nA = w->cfg.n_agents;
+    if (w->cfg.env_kind != HH_ENV_LOWLEVEL) return HH_E_ARG;
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; n++) {
+        o_arena *a = &w->ar[n];
+        if (a->done) {
+            for (int i = 0; i < nA; i++) { a->reward[i] = 0.0; a->reward_valid[i] = 0; }
+            a->ev_mask = 0;
+        } else {
+            ll_step(w, a, actions + (size_t)n * w->n_ctrl * 4);
+        }
+        if (reward) for (int i = 0; i < nA; i++) reward[(size_t)n * nA + i] = (float)a->reward[i];
+        if (reward_valid) for (int i = 0; i < nA; i++) reward_valid[(size_t)n * nA + i] = (uint8_t)a->reward_valid[i];
+        if (done) done[n] = (uint8_t)a->done;
+        if (a->done && w->cfg.auto_reset) arena_reset(w, a);
+        if (obs) copy_obs(w, a, obs + (size_t)n * nA * w->D);
+    }
+    return HH_OK;
+}
+
+API int hho_rollout(void *h, int n_steps, const int8_t *actions, float *obs, float *reward, uint8_t *reward_valid, uint8_t *done) {
+    o_world *w = (o_world *)h;
+    size_t N = (size_t)w->cfg.n_arenas, nA = (size_t)w->cfg.n_agents;
+    for (int t = 0; t < n_steps; t++) {
+        int rc = hho_step(h, actions + (size_t)t * N * w->n_ctrl * 4, obs ? obs + (size_t)t * N * nA * w->D : 0,
+                          reward ? reward + (size_t)t * N * nA : 0, reward_valid ? reward_valid + (size_t)t * N * nA : 0,
+                          done ? done + (size_t)t * N : 0);
+        if (rc) return rc;
+    }
+    return HH_OK;
+}
+
+API int hho_episode_stats(void *h, float *ret, int32_t *len, int8_t *outcome) {
+    o_world *w = (o_world *)h;
+    for (int n = 0; n < w->cfg.n_arenas; n++) {
+        if (ret) ret[n] = w->ar[n].last_ret;
+        if (len) len[n] = w->ar[n].last_len;
+        if (outcome) outcome[n] = (int8_t)w->ar[n].last_outcome;
+    }
+    return HH_OK;
+}
+
+API int hho_get_event_masks(void *h, uint32_t *masks) {
+    o_world *w = (o_world *)h;
+    for (int n = 0; n < w->cfg.n_arenas; n++) masks[n] = w->ar[n].ev_mask;
+    return HH_OK;
+}
+
+API int hho_get_state(void *h, hh_state_view *v) {
+    o_world *w = (o_world *)h;
+    int A = w->A;
+    for (int n = 0; n < w->cfg.n_arenas; n++) {
+        const o_arena *a = &w->ar[n];
+        int ag, op;
+        count_alive(w, a, &ag, &op);
+        for (int s = 0; s < A; s++) {
+            const o_ac *u = &a->ac[s];
+            const o_rk *r = &a->rk[s];
+            size_t b = (size_t)n * A + s;
+            double *f = v->ac_f + b * HH_ACF_K;
+            f[0] = u->lat; f[1] = u->lon; f[2] = u->hdg; f[3] = u->spd; f[4] = u->cmd_hdg; f[5] = u->cmd_spd;
+            int32_t *q = v->ac_i + b * HH_ACI_K;
+            q[0] = u->alive; q[1] = u->ac_type; q[2] = u->cannon_remain; q[3] = u->cannon_burst; q[4] = u->cannon_max;
+            q[5] = u->missile_remain; q[6] = u->rocket_max; q[7] = u->missile_wait; q[8] = u->has_missile;
+            q[9] = a->tgt_n[s] ? a->tgt_id[s][0] : 0;
+            double *g = v->rk_f + b * HH_RKF_K;
+            int32_t *p = v->rk_i + b * HH_RKI_K;
+            if (r->alive) { /* dead rocket slots read as zeros */
+                g[0] = r->lat; g[1] = r->lon; g[2] = r->hdg; g[3] = r->cmd_hdg;
+                p[0] = 1; p[1] = r->target; p[2] = r->life; p[3] = r->seq;
+            } else {
+                g[0] = g[1] = g[2] = g[3] = 0.0;
+                p[0] = p[1] = p[2] = p[3] = 0;
+            }
+            for (int k = 0; k < HH_TGT_K; k++) {
+                v->tgt_id[b * HH_TGT_K + k] = k < a->tgt_n[s] ? a->tgt_id[s][k] : 0;
+                v->tgt_d[b * HH_TGT_K + k] = k < a->tgt_n[s] ? a->tgt_d[s][k] : 0.0;
+            }
+        }
+        int32_t *ai = v->ar_i + (size_t)n * HH_ARI_K;
+        ai[0] = a->steps; ai[1] = ag; ai[2] = op; ai[3] = a->escaping; ai[4] = a->escaping_time; ai[5] = a->episode;
+    }
+    return HH_OK;
+}
+
+API int hho_set_state(void *h, const hh_state_view *v) {
+    o_world *w = (o_world *)h;
+    int A = w->A;
+    for (int n = 0; n < w->cfg.n_arenas; n++) {
+        o_arena *a = &w->ar[n];
+        a->next_seq = 0;
+        for (int s = 0; s < A; s++) {
+            o_ac *u = &a->ac[s];
+            o_rk *r = &a->rk[s];
+            size_t b = (size_t)n * A + s;
+            const double *f = v->ac_f + b * HH_ACF_K;
+            u->lat = f[0]; u->lon = f[1]; u->hdg = f[2]; u->spd = f[3]; u->cmd_hdg = f[4]; u->cmd_spd = f[5];
+            const int32_t *q = v->ac_i + b * HH_ACI_K;
+            u->alive = q[0]; u->ac_type = q[1]; u->cannon_remain = q[2]; u->cannon_burst = q[3]; u->cannon_max = q[4];
+            u->missile_remain = q[5]; u->rocket_max = q[6]; u->missile_wait = q[7]; u->has_missile = q[8];
+            const double *g = v->rk_f + b * HH_RKF_K;
+            r->lat = g[0]; r->lon = g[1]; r->hdg = g[2]; r->cmd_hdg = g[3];
+            const int32_t *p = v->rk_i + b * HH_RKI_K;
+            r->alive = p[0]; r->target = p[1]; r->life = p[2]; r->seq = p[3];
+            if (r->seq > a->next_seq) a->next_seq = r->seq;
+            a->tgt_n[s] = 0;
+            for (int k = 0; k < HH_TGT_K; k++) {
+                a->tgt_id[s][k] = v->tgt_id[b * HH_TGT_K + k];
+                a->tgt_d[s][k] = v->tgt_d[b * HH_TGT_K + k];
+                if (a->tgt_id[s][k]) a->tgt_n[s] = k + 1;
+            }
+        }
+        const int32_t *ai = v->ar_i + (size_t)n * HH_ARI_K;
+        a->steps = ai[0]; a->escaping = ai[3]; a->escaping_time = ai[4]; a->episode = ai[5];
+        int ag, op;
+        count_alive(w, a, &ag, &op);
+        a->done = ag <= 0 || op <= 0 || a->steps >= w->cfg.horizon;
+        if (w->cfg.env_kind == HH_ENV_HIGHLEVEL) hl_state(w, a); else ll_state(w, a);
+    }
+    return HH_OK;
+}
+
+/* current observation of every arena (after reset / set_state) */
+API int hho_get_obs(void *h, float *obs) {
+    o_world *w = (o_world *)h;
+    for (int n = 0; n < w->cfg.n_arenas; n++) copy_obs(w, &w->ar[n], obs + (size_t)n * w->cfg.n_agents * w->D);
+    return HH_OK;
+}
+
+/* probes for tests/test_math.py and tests/test_geodesic.py */
+API void hho_math_eval(int fn, int n, const double *a, const double *b, double *o0, double *o1) {
+    for (int i = 0; i < n; i++) {
+        switch (fn) {
+            case 0: hh_sincos(a[i], &o0[i], &o1[i]); break;
+            case 1: o0[i] = hh_atan2(a[i], b[i]); break;
+            case 2: o0[i] = hh_acos(a[i]); break;
+            case 3: hh_sincosd(a[i], &o0[i], &o1[i]); break;
+            case 4: o0[i] = hh_atan2d(a[i], b[i]); break;
+            case 5: o0[i] = hh_pymod(a[i], b[i]); break;
+            case 6: o0[i] = hh_remainder(a[i], b[i]); break;
+            case 7: o0[i] = hh_fmod(a[i], b[i]); break;
+            case 8: o0[i] = hh_round3(a[i]); break;
+            default: break;
+        }
+    }
+}
+API void hho_geo_direct(int n, const double *lat, const double *lon, const double *azi, const double *s, double *lat2, double *lon2) {
+    for (int i = 0; i < n; i++) hh_geo_direct(lat[i], lon[i], azi[i], s[i], &lat2[i], &lon2[i]);
+}
+API void hho_geo_inverse(int n, const double *lat1, const double *lon1, const double *lat2, const double *lon2, double *s12, double *azi1) {
+    for (int i = 0; i < n; i++) hh_geo_inverse(lat1[i], lon1[i], lat2[i], lon2[i], &s12[i], &azi1[i]);
+}
+API double hho_rng_u01(uint64_t seed, uint64_t arena, uint32_t episode, uint32_t tick, uint32_t unit, uint32_t site, uint32_t sub) {
+    return hh_rng_u01(hh_rng_tick_key(hh_rng_arena_key(seed, arena), episode, tick), unit, site, sub);
+}

@@ -1,0 +1,68 @@
+"""ctypes binding of libhh_world.so (include/hh_abi.h).  Fails loudly when the HIP library is
+missing: there is NO CPU fallback in the product path."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libhh_world.so")
+
+ENV_LOWLEVEL, ENV_HIGHLEVEL = 0, 1
+MODE_FIGHT, MODE_ESCAPE = 0, 1
+ACF_K, ACI_K, RKF_K, RKI_K, ARI_K, TGT_K = 6, 10, 4, 4, 6, 3
+
+
+class HHConfig(C.Structure):
+    """hh_config (include/hh_abi.h); field order is ABI."""
+    _fields_ = [
+        ("n_arenas", C.c_int32), ("env_kind", C.c_int32), ("n_agents", C.c_int32), ("n_opps", C.c_int32),
+        ("level", C.c_int32), ("agent_mode", C.c_int32), ("horizon", C.c_int32), ("friendly_kill", C.c_int32),
+        ("friendly_punish", C.c_int32), ("esc_dist_rew", C.c_int32), ("hier_action_assess", C.c_int32),
+        ("hier_opp_fight_ratio", C.c_int32), ("auto_reset", C.c_int32), ("ext_opp_actions", C.c_int32),
+        ("map_size", C.c_double), ("glob_frac", C.c_double), ("rew_scale", C.c_double),
+        ("seed", C.c_uint64), ("arena_offset", C.c_uint64),
+    ]
+
+
+class HHStateView(C.Structure):
+    _fields_ = [
+        ("ac_f", C.POINTER(C.c_double)), ("ac_i", C.POINTER(C.c_int32)), ("rk_f", C.POINTER(C.c_double)),
+        ("rk_i", C.POINTER(C.c_int32)), ("ar_i", C.POINTER(C.c_int32)), ("tgt_id", C.POINTER(C.c_int32)),
+        ("tgt_d", C.POINTER(C.c_double)),
+    ]
+
+
+EXPORTS = ["hh_world_create", "hh_world_destroy", "hh_last_error", "hh_obs_dim", "hh_n_ctrl", "hh_reset", "hh_step",
+           "hh_rollout", "hh_episode_stats", "hh_get_state", "hh_set_state", "hh_get_event_masks", "hh_observe"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). The MI355X world has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.hh_last_error.restype = C.c_char_p
+        vp = C.c_void_p
+        L.hh_world_create.argtypes = [C.POINTER(HHConfig), C.c_int, C.POINTER(vp)]
+        L.hh_world_destroy.argtypes = [vp]
+        L.hh_obs_dim.argtypes = [vp]
+        L.hh_n_ctrl.argtypes = [vp]
+        L.hh_reset.argtypes = [vp, vp, vp, vp]
+        L.hh_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.hh_rollout.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp]
+        L.hh_episode_stats.argtypes = [vp, vp, vp, vp, vp]
+        L.hh_get_state.argtypes = [vp, C.POINTER(HHStateView)]
+        L.hh_set_state.argtypes = [vp, C.POINTER(HHStateView)]
+        L.hh_get_event_masks.argtypes = [vp, vp]
+        L.hh_observe.argtypes = [vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f"libhh_world error {rc}: {lib().hh_last_error().decode()}")

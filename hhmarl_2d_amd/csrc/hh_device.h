@@ -1,0 +1,154 @@
+/*
+ * hh_device.h — device-side world layout and the per-lane helpers of the gfx950 kernels.
+ *
+ * Thread mapping (all kernels): ONE LANE PER AIRCRAFT SLOT.  An arena with A aircraft occupies
+ * A consecutive lanes ("group"); a 256-thread workgroup holds GPB = 256 / A arenas
+ * (64 for 2-vs-2, 42 for 3-vs-3).  Unit u = arena * A + slot, so every per-unit array is read
+ * and written with unit-stride-1 addresses: fully coalesced 8-byte (double) and 16-byte (packed
+ * ints) accesses per lane.  The rocket launched by slot s lives in rocket slot s (the reference
+ * allows at most one missile in flight per aircraft: ac1.py:73).
+ *
+ * Everything one lane needs from the other aircraft of its arena (positions before/after the
+ * move, heading unit vectors, status flags, cannon candidate masks, rocket fuse flags) is
+ * exchanged through LDS arrays indexed by thread id (stride-1 -> conflict free), separated by
+ * workgroup barriers.  The id-ordered kill semantics of cmano_simulator.py:142-144 are resolved
+ * by one lane per arena on integer masks only.
+ */
+#ifndef HH_DEVICE_H
+#define HH_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hh_abi.h"
+#include "hh_geodesic.h"
+#include "hh_math.h"
+#include "hh_rng.h"
+#include "hh_spec.h"
+
+#define HH_BLOCK 256
+
+struct DevCfg {
+    int N, env_kind, nA, nO, A, level, agent_mode, horizon;
+    int friendly_kill, friendly_punish, esc_dist_rew, hier_action_assess, hier_opp_fight_ratio;
+    int auto_reset, ext_opp, D, n_ctrl;
+    double glob_frac, rew_scale, ext_lat, ext_lon, lat_hi, lon_hi, inv_diag;
+    uint64_t seed, arena_offset;
+};
+
+/* struct-of-arrays world in HBM; U = N * A units */
+struct DevPtrs {
+    double *lat, *lon, *hdg, *spd, *cmd_hdg, *cmd_spd;   /* [U]  a1/a6 */
+    int4 *pack;                                          /* [U]  small ints, 16 B */
+    double *tgt_d;                                       /* [3][U] stored target distances */
+    double *rk_lat, *rk_lon, *rk_hdg, *rk_cmd;           /* [U]  rocket slot s <- launcher slot s */
+    int2 *rk_pack;                                       /* [U] */
+    int4 *ar_pack;                                       /* [N]  steps, episode, flags, next_seq */
+    double *ep_ret;                                      /* [N] */
+    float *last_ret;                                     /* [N] */
+    int *last_len;                                       /* [N] */
+    int8_t *last_outcome;                                /* [N] */
+    uint32_t *ev_mask;                                   /* [N] */
+};
+
+/* register-resident state of one aircraft slot (+ its rocket slot) */
+struct Unit {
+    double lat, lon, hdg, spd, cmd_hdg, cmd_spd;
+    int cannon_remain, cannon_max, burst, missile_remain, rocket_max, missile_wait;
+    int ac_type, alive, has_missile, n_tgt, tgt0, tgt1, tgt2, cmd_act;
+    double tgt_d0, tgt_d1, tgt_d2;
+    int rk_alive, rk_target, rk_life, rk_seq;
+    double rk_lat, rk_lon, rk_hdg, rk_cmd;
+};
+
+/* register-resident arena scalars, replicated on every lane of the group */
+struct Arena {
+    int steps, episode, escaping, escaping_time, done, next_seq;
+    uint64_t akey;
+};
+
+__device__ __forceinline__ void unit_load(const DevPtrs &P, size_t U, size_t u, Unit &m) {
+    m.lat = P.lat[u]; m.lon = P.lon[u]; m.hdg = P.hdg[u]; m.spd = P.spd[u];
+    m.cmd_hdg = P.cmd_hdg[u]; m.cmd_spd = P.cmd_spd[u];
+    int4 p = P.pack[u];
+    m.cannon_remain = p.x & 0xffff; m.cannon_max = (p.x >> 16) & 0xffff;
+    m.burst = p.y & 0xff; m.missile_remain = (p.y >> 8) & 0xff; m.rocket_max = (p.y >> 16) & 0xff;
+    m.missile_wait = (p.y >> 24) & 0xff;
+    m.ac_type = p.z & 0xff; m.alive = (p.z >> 8) & 0xff; m.has_missile = (p.z >> 16) & 0xff; m.n_tgt = (p.z >> 24) & 0xff;
+    m.tgt0 = p.w & 0xff; m.tgt1 = (p.w >> 8) & 0xff; m.tgt2 = (p.w >> 16) & 0xff; m.cmd_act = (int)(int8_t)((p.w >> 24) & 0xff);
+    m.tgt_d0 = P.tgt_d[u]; m.tgt_d1 = P.tgt_d[U + u]; m.tgt_d2 = P.tgt_d[2 * U + u];
+    int2 r = P.rk_pack[u];
+    m.rk_alive = r.x & 0xff; m.rk_target = (r.x >> 8) & 0xff; m.rk_life = (r.x >> 16) & 0xff; m.rk_seq = r.y;
+    m.rk_lat = P.rk_lat[u]; m.rk_lon = P.rk_lon[u]; m.rk_hdg = P.rk_hdg[u]; m.rk_cmd = P.rk_cmd[u];
+}
+
+__device__ __forceinline__ void unit_store(const DevPtrs &P, size_t U, size_t u, const Unit &m) {
+    P.lat[u] = m.lat; P.lon[u] = m.lon; P.hdg[u] = m.hdg; P.spd[u] = m.spd;
+    P.cmd_hdg[u] = m.cmd_hdg; P.cmd_spd[u] = m.cmd_spd;
+    int4 p;
+    p.x = (m.cannon_remain & 0xffff) | ((m.cannon_max & 0xffff) << 16);
+    p.y = (m.burst & 0xff) | ((m.missile_remain & 0xff) << 8) | ((m.rocket_max & 0xff) << 16) | ((m.missile_wait & 0xff) << 24);
+    p.z = (m.ac_type & 0xff) | ((m.alive & 0xff) << 8) | ((m.has_missile & 0xff) << 16) | ((m.n_tgt & 0xff) << 24);
+    p.w = (m.tgt0 & 0xff) | ((m.tgt1 & 0xff) << 8) | ((m.tgt2 & 0xff) << 16) | ((m.cmd_act & 0xff) << 24);
+    P.pack[u] = p;
+    P.tgt_d[u] = m.tgt_d0; P.tgt_d[U + u] = m.tgt_d1; P.tgt_d[2 * U + u] = m.tgt_d2;
+    int2 r;
+    r.x = (m.rk_alive & 0xff) | ((m.rk_target & 0xff) << 8) | ((m.rk_life & 0xff) << 16);
+    r.y = m.rk_seq;
+    P.rk_pack[u] = r;
+    P.rk_lat[u] = m.rk_lat; P.rk_lon[u] = m.rk_lon; P.rk_hdg[u] = m.rk_hdg; P.rk_cmd[u] = m.rk_cmd;
+}
+
+__device__ __forceinline__ void arena_load(const DevPtrs &P, const DevCfg &c, int n, Arena &a) {
+    int4 p = P.ar_pack[n];
+    a.steps = p.x; a.episode = p.y;
+    a.escaping = p.z & 0xff; a.escaping_time = (int)(int8_t)((p.z >> 8) & 0xff); a.done = (p.z >> 16) & 0xff;
+    a.next_seq = p.w;
+    a.akey = hh_rng_arena_key(c.seed, c.arena_offset + (uint64_t)n);
+}
+
+__device__ __forceinline__ void arena_store(const DevPtrs &P, int n, const Arena &a) {
+    int4 p;
+    p.x = a.steps; p.y = a.episode;
+    p.z = (a.escaping & 0xff) | ((a.escaping_time & 0xff) << 8) | ((a.done & 0xff) << 16);
+    p.w = a.next_seq;
+    P.ar_pack[n] = p;
+}
+
+/* ---- angle helpers (warsim/utils/angles.py:10-29) ---- */
+__device__ __forceinline__ double d_normalize_angle(double a) {
+    while (a >= 360.0) a -= 360.0;
+    while (a < 0.0) a += 360.0;
+    return a;
+}
+__device__ __forceinline__ double d_signed_heading_diff(double actual, double desired) {
+    double delta = desired - actual;
+    if (delta < -180.0) delta = 360.0 + delta;
+    if (delta > 180.0) delta = -360.0 + delta;
+    return delta;
+}
+
+/* cmano_simulator.py:167-174: range [km] and bearing [deg in [0,360)] from one Inverse solution */
+__device__ __forceinline__ void d_dist_bearing(double lat1, double lon1, double lat2, double lon2, double &km, double &brg) {
+    double s12, azi1;
+    hh_geo_inverse(lat1, lon1, lat2, lon2, &s12, &azi1);
+    km = s12 / 1000.0;
+    brg = d_normalize_angle(azi1);
+}
+
+/* Exactness-preserving prefilter for "geodesic range < R km" tests.  Below 25 deg latitude one
+ * degree of latitude or longitude is > 100 km on WGS84 (110.57 / >= 100.9 km), so a separation
+ * of more than R/100 degrees along either axis proves range > R: the Inverse solve is skipped
+ * and the mask bit is the same as the full computation would give. */
+__device__ __forceinline__ bool d_maybe_within_km(double lat1, double lon1, double lat2, double lon2, double r_km) {
+    double lim = r_km / 100.0;
+    bool near = hh_fabs(lat2 - lat1) <= lim && hh_fabs(lon2 - lon1) <= lim;
+    bool lowlat = hh_fabs(lat1) < 25.0 && hh_fabs(lat2) < 25.0;
+    return near || !lowlat;
+}
+
+__device__ __forceinline__ double d_rng(const Arena &a, int unit_id, int site, int sub) {
+    return hh_rng_u01(hh_rng_tick_key(a.akey, (uint32_t)a.episode, (uint32_t)a.steps), (uint32_t)unit_id, (uint32_t)site, (uint32_t)sub);
+}
+
+#endif /* HH_DEVICE_H */

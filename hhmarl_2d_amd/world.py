@@ -1,0 +1,145 @@
+"""Batched tensor API of the MI355X air-combat world (thin host layer over include/hh_abi.h).
+
+PyTorch is used for device memory and streams only; every step runs in the hand-written HIP
+kernels of hhmarl_2d_amd/csrc/hh_world.hip."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def make_config(n_arenas=1, env_kind=L.ENV_LOWLEVEL, level=1, agent_mode=L.MODE_FIGHT, n_agents=None, n_opps=None,
+                horizon=None, friendly_kill=True, friendly_punish=False, esc_dist_rew=False, hier_action_assess=True,
+                hier_opp_fight_ratio=75, auto_reset=False, ext_opp_actions=False, map_size=None, glob_frac=0.0,
+                rew_scale=1.0, seed=0, arena_offset=0):
+    """Defaults follow the reference's config.py:17-54 and horizons config.py:94-98."""
+    hl = env_kind == L.ENV_HIGHLEVEL
+    if n_agents is None:
+        n_agents = 3 if hl else 2
+    if n_opps is None:
+        n_opps = 3 if hl else 2
+    if horizon is None:
+        horizon = 500 if hl else {1: 150, 2: 200, 3: 300, 4: 350, 5: 400}[level]
+    if map_size is None:
+        map_size = 0.5 if hl else 0.3
+    return L.HHConfig(n_arenas, env_kind, n_agents, n_opps, level, agent_mode, horizon, int(friendly_kill),
+                      int(friendly_punish), int(esc_dist_rew), int(hier_action_assess), hier_opp_fight_ratio,
+                      int(auto_reset), int(ext_opp_actions), map_size, glob_frac, rew_scale, seed, arena_offset)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class World:
+    """N independent arenas resident on one GPU."""
+
+    def __init__(self, cfg, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("hhmarl_2d_amd.World needs a ROCm GPU (no CPU fallback)")
+        self.cfg = cfg
+        self.device = torch.device("cuda", device)
+        self.h = C.c_void_p()
+        L.check(L.lib().hh_world_create(C.byref(cfg), device, C.byref(self.h)))
+        self.N = cfg.n_arenas
+        self.A = cfg.n_agents + cfg.n_opps
+        self.n_agents = cfg.n_agents
+        self.D = L.lib().hh_obs_dim(self.h)
+        self.n_ctrl = L.lib().hh_n_ctrl(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            L.lib().hh_world_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def alloc_outputs(self, T=None):
+        lead = (self.N,) if T is None else (T, self.N)
+        dev = self.device
+        return (torch.zeros(lead + (self.n_agents, self.D), dtype=torch.float32, device=dev),
+                torch.zeros(lead + (self.n_agents,), dtype=torch.float32, device=dev),
+                torch.zeros(lead + (self.n_agents,), dtype=torch.uint8, device=dev),
+                torch.zeros(lead, dtype=torch.uint8, device=dev))
+
+    def reset(self, mask=None, obs=None):
+        if obs is None:
+            obs = torch.zeros((self.N, self.n_agents, self.D), dtype=torch.float32, device=self.device)
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        L.check(L.lib().hh_reset(self.h, _p(mask), _p(obs), self._stream()))
+        return obs
+
+    def observe(self, obs=None):
+        if obs is None:
+            obs = torch.zeros((self.N, self.n_agents, self.D), dtype=torch.float32, device=self.device)
+        L.check(L.lib().hh_observe(self.h, _p(obs), self._stream()))
+        return obs
+
+    def step(self, actions, out=None):
+        """actions: int8 [N, n_ctrl, 4] on the world's device -> (obs, reward, reward_valid, done)."""
+        assert actions.dtype == torch.int8 and actions.is_contiguous() and actions.device == self.device
+        assert actions.numel() == self.N * self.n_ctrl * 4
+        obs, rew, val, done = out if out is not None else self.alloc_outputs()
+        L.check(L.lib().hh_step(self.h, _p(actions), _p(obs), _p(rew), _p(val), _p(done), self._stream()))
+        return obs, rew, val, done
+
+    def rollout(self, actions, out=None, want_obs=True):
+        """actions: int8 [T, N, n_ctrl, 4] pre-resident tape -> stacked outputs [T, ...]."""
+        assert actions.dtype == torch.int8 and actions.is_contiguous() and actions.device == self.device
+        T = actions.shape[0]
+        assert actions.numel() == T * self.N * self.n_ctrl * 4
+        obs, rew, val, done = out if out is not None else self.alloc_outputs(T)
+        L.check(L.lib().hh_rollout(self.h, T, _p(actions), _p(obs) if want_obs else None, _p(rew), _p(val), _p(done),
+                                   self._stream()))
+        return obs, rew, val, done
+
+    def episode_stats(self):
+        ret = torch.zeros(self.N, dtype=torch.float32, device=self.device)
+        ln = torch.zeros(self.N, dtype=torch.int32, device=self.device)
+        oc = torch.zeros(self.N, dtype=torch.int8, device=self.device)
+        L.check(L.lib().hh_episode_stats(self.h, _p(ret), _p(ln), _p(oc), self._stream()))
+        return ret, ln, oc
+
+    # ---- host snapshots (parity tests, checkpointing) ----
+    def _alloc_state(self):
+        n, a = self.N, self.A
+        return dict(
+            ac_f=np.zeros((n, a, L.ACF_K)), ac_i=np.zeros((n, a, L.ACI_K), dtype=np.int32),
+            rk_f=np.zeros((n, a, L.RKF_K)), rk_i=np.zeros((n, a, L.RKI_K), dtype=np.int32),
+            ar_i=np.zeros((n, L.ARI_K), dtype=np.int32), tgt_id=np.zeros((n, a, L.TGT_K), dtype=np.int32),
+            tgt_d=np.zeros((n, a, L.TGT_K)))
+
+    @staticmethod
+    def _view(st):
+        def p(a, t):
+            assert a.flags.c_contiguous
+            return a.ctypes.data_as(C.POINTER(t))
+        return L.HHStateView(p(st["ac_f"], C.c_double), p(st["ac_i"], C.c_int32), p(st["rk_f"], C.c_double),
+                             p(st["rk_i"], C.c_int32), p(st["ar_i"], C.c_int32), p(st["tgt_id"], C.c_int32),
+                             p(st["tgt_d"], C.c_double))
+
+    def get_state(self):
+        st = self._alloc_state()
+        v = self._view(st)
+        L.check(L.lib().hh_get_state(self.h, C.byref(v)))
+        return st
+
+    def set_state(self, st):
+        st = {k: np.ascontiguousarray(v) for k, v in st.items()}
+        v = self._view(st)
+        L.check(L.lib().hh_set_state(self.h, C.byref(v)))
+
+    def event_masks(self):
+        m = np.zeros((self.N,), dtype=np.uint32)
+        L.check(L.lib().hh_get_event_masks(self.h, m.ctypes.data_as(C.c_void_p)))
+        return m

@@ -1,0 +1,65 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import glob
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_files():
+    return sorted(glob.glob(os.path.join(GOLDEN, "env_*.npz")))
+
+
+def load_golden(path):
+    g = np.load(path)
+    meta = json.loads(str(g["meta"]))
+    return g, meta
+
+
+def cfg_kwargs_from_meta(meta, **over):
+    a = meta["args"]
+    kw = dict(
+        n_arenas=1, env_kind=0 if meta["env"] == "low" else 1, level=a["level"],
+        agent_mode=0 if a["agent_mode"] == "fight" else 1, n_agents=a["num_agents"], n_opps=a["num_opps"],
+        horizon=a["horizon"], friendly_kill=a["friendly_kill"], friendly_punish=a["friendly_punish"],
+        esc_dist_rew=a["esc_dist_rew"], hier_action_assess=a["hier_action_assess"],
+        hier_opp_fight_ratio=a["hier_opp_fight_ratio"], map_size=a["map_size"], glob_frac=a["glob_frac"],
+        rew_scale=a["rew_scale"], seed=meta["seed"], arena_offset=meta["arena"])
+    kw.update(over)
+    return kw
+
+
+def random_actions(rng, shape_prefix, n_ctrl):
+    """uniform MultiDiscrete([13,9,2,2]) actions, int8 [..., n_ctrl, 4]"""
+    a = np.zeros(tuple(shape_prefix) + (n_ctrl, 4), dtype=np.int8)
+    a[..., 0] = rng.integers(0, 13, size=a.shape[:-1])
+    a[..., 1] = rng.integers(0, 9, size=a.shape[:-1])
+    a[..., 2] = rng.integers(0, 2, size=a.shape[:-1])
+    a[..., 3] = rng.integers(0, 2, size=a.shape[:-1])
+    return a
+
+
+def pursuit_actions(rng, state, n_agents, n_ctrl):
+    """Vectorised 'steer at the nearest opponent and shoot' policy on a host snapshot: makes
+    cannon/missile engagements (and therefore kill masks) frequent in parity runs."""
+    ac_f, ac_i = state["ac_f"], state["ac_i"]
+    N, A = ac_f.shape[:2]
+    act = np.zeros((N, n_ctrl, 4), dtype=np.int8)
+    for i in range(n_ctrl):
+        own = i < n_agents
+        lo, hi = (n_agents, A) if own else (0, n_agents)
+        dlat = ac_f[:, lo:hi, 0] - ac_f[:, i:i + 1, 0]
+        dlon = ac_f[:, lo:hi, 1] - ac_f[:, i:i + 1, 1]
+        d = np.hypot(dlat, dlon)
+        d = np.where(ac_i[:, lo:hi, 0] > 0, d, 1e9)
+        j = d.argmin(axis=1)
+        idx = np.arange(N)
+        brg = np.degrees(np.arctan2(dlon[idx, j], dlat[idx, j])) % 360
+        rel = (brg - ac_f[:, i, 2] + 180) % 360 - 180
+        act[:, i, 0] = np.clip(np.round(rel / 15.0) + 6, 0, 12)
+        act[:, i, 1] = np.where(d[idx, j] < 0.05, rng.integers(0, 4, N), rng.integers(4, 9, N))
+        act[:, i, 2] = 1
+        act[:, i, 3] = rng.random(N) < 0.5
+    return act

@@ -1,0 +1,82 @@
+"""include/hh_math.h against libm / mpmath: the bit-reproducible primitives must stay within
+2 ulp of the correctly rounded result on the ranges this workload uses, and the modulo family
+must be exact."""
+import math
+
+import mpmath as mp
+import numpy as np
+
+
+def ulps(x, ref):
+    ref = np.asarray(ref, dtype=np.float64)
+    return np.abs(x - ref) / np.spacing(np.abs(ref) + 1e-300)
+
+
+def test_sincos(oracle):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-50, 50, 50000), rng.uniform(-1e-3, 1e-3, 10000)])
+    s, c = oracle.math_eval(0, x)
+    assert ulps(s, np.sin(x)).max() <= 2 and ulps(c, np.cos(x)).max() <= 2
+
+
+def test_sincos_vs_mpmath(oracle):
+    mp.mp.dps = 40
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-7, 7, 300)
+    s, c = oracle.math_eval(0, x)
+    rs = np.array([float(mp.sin(mp.mpf(float(v)))) for v in x])
+    rc = np.array([float(mp.cos(mp.mpf(float(v)))) for v in x])
+    assert ulps(s, rs).max() <= 1 and ulps(c, rc).max() <= 1
+
+
+def test_atan2_acos(oracle):
+    rng = np.random.default_rng(2)
+    y, x = rng.normal(size=50000), rng.normal(size=50000)
+    a, _ = oracle.math_eval(1, y, x)
+    assert ulps(a, np.arctan2(y, x)).max() <= 2
+    y2 = y * 10.0 ** rng.uniform(-8, 0, y.size)
+    a, _ = oracle.math_eval(1, y2, x)
+    assert ulps(a, np.arctan2(y2, x)).max() <= 2
+    v = np.concatenate([rng.uniform(-1, 1, 50000), 1 - 10.0 ** rng.uniform(-16, -1, 20000),
+                        -(1 - 10.0 ** rng.uniform(-16, -1, 20000)), [1.0, -1.0, 0.0]])
+    a, _ = oracle.math_eval(2, v)
+    assert ulps(a, np.arccos(v)).max() <= 2
+
+
+def test_degree_helpers(oracle):
+    s, c = oracle.math_eval(3, np.array([0.0, 90, 180, 270, 360, -90, 45, 30]))
+    assert list(s[:6]) == [0, 1, 0, -1, 0, -1] and list(c[:6]) == [1, 0, -1, 0, 1, 0]
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-720, 720, 20000)
+    s, c = oracle.math_eval(3, x)
+    assert np.abs(s - np.sin(np.radians(x))).max() < 3e-15 and np.abs(c - np.cos(np.radians(x))).max() < 3e-15
+    y, xx = rng.normal(size=20000), rng.normal(size=20000)
+    a, _ = oracle.math_eval(4, y, xx)
+    assert np.abs(a - np.degrees(np.arctan2(y, xx))).max() < 1e-13
+
+
+def test_modulo_family_exact(oracle):
+    rng = np.random.default_rng(4)
+    a = np.concatenate([rng.uniform(-1000, 1000, 20000), [-1e-17, 360.0, -360.0, 0.0, -0.0, 720.5, 359.99999999999994]])
+    for m in (360.0, 359.0):
+        b = np.full(a.size, m)
+        assert np.array_equal(oracle.math_eval(5, a, b)[0], np.array([u % m for u in a]))
+        assert np.array_equal(oracle.math_eval(7, a, b)[0], np.fmod(a, m))
+    b = np.full(a.size, 360.0)
+    assert np.array_equal(oracle.math_eval(6, a, b)[0], np.array([math.remainder(u, 360.0) for u in a]))
+    t = np.array([180.0, -180, 540, 900, -540])
+    assert np.array_equal(oracle.math_eval(6, t, np.full(5, 360.0))[0], np.array([math.remainder(u, 360.0) for u in t]))
+
+
+def test_round3(oracle):
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, 20000)
+    assert np.array_equal(oracle.math_eval(8, x)[0], np.array([round(v, 3) for v in x]))
+
+
+def test_keyed_rng_matches_python_mirror(oracle):
+    import ref_harness as H  # pure-python mirror of include/hh_rng.h (no reference import needed)
+    lib = oracle.lib()
+    for seed, arena, ep, tick, unit, site, sub in [(0, 0, 1, 0, 0, 1, 0), (1234, 7, 3, 150, 4, 21, 2), (2**63 + 5, 65535, 9, 499, 6, 24, 0)]:
+        want = H.u01(H.tick_key(H.arena_key(seed, arena), ep, tick), unit, site, sub)
+        assert lib.hho_rng_u01(seed, arena, ep, tick, unit, site, sub) == want

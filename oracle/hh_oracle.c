@@ -946,7 +946,11 @@ API int hho_step(void *h, const int8_t *actions, float *obs, float *reward, uint
         if (reward) for (int i = 0; i < nA; i++) reward[(size_t)n * nA + i] = (float)a->reward[i];
         if (reward_valid) for (int i = 0; i < nA; i++) reward_valid[(size_t)n * nA + i] = (uint8_t)a->reward_valid[i];
         if (done) done[n] = (uint8_t)a->done;
-        if (a->done && w->cfg.auto_reset) arena_reset(w, a);
+        if (a->done && w->cfg.auto_reset) {
+            uint32_t em = a->ev_mask; /* masks describe the step that just ended */
+            arena_reset(w, a);
+            a->ev_mask = em;
+        }
         if (obs) copy_obs(w, a, obs + (size_t)n * nA * w->D);
     }
     return HH_OK;

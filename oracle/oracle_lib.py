@@ -113,8 +113,11 @@ class OracleWorld:
         self.n_ctrl = lib().hho_n_ctrl(self.h)
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().hho_destroy(self.h)
+        if getattr(self, "h", None) and lib is not None:
+            try:
+                lib().hho_destroy(self.h)
+            except Exception:
+                pass
             self.h = None
 
     def reset(self, mask=None):

@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""bench.py — env-steps/s of the MI355X air-combat world on BASELINE.json's configs[1]:
+4096 arenas x 2-vs-2 fight level 3 (scripted opponent), random actions, auto-reset.
+
+A "step" is one pass of the hot path over one batch: every arena takes one LowLevelEnv.step()
+(action decode, scripted opponents, do_tick, rewards, done, observation, auto-reset), with the
+action tape and all outputs resident in HBM.  Steps are issued in chunks of --chunk ticks per
+persistent-kernel launch (hh_rollout); every tick writes its obs/reward/done rows.
+
+    python bench.py                     # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM, the
+algorithmic bytes of SURVEY.md §8d over the measured kernel time) and `cpu_baseline` (the CPU
+oracle = a C port of the reference path, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_2V2_STEP = 1113   # state r/w 2*448 + actions 8 + obs 200 + reward 8 + done 1
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def cpu_baseline(n_arenas, level, seed, budget_s=12.0):
+    """The oracle (plain-C port of the reference path, OpenMP over arenas) on the host cores.
+    Test infrastructure used only as a reported baseline, never as the measured product."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle_lib as O
+    cores = len(os.sched_getaffinity(0))
+    w = O.OracleWorld(O.make_config(n_arenas=n_arenas, level=level, seed=seed, auto_reset=True))
+    w.reset()
+    rng = np.random.default_rng(seed)
+    T = 25
+    act = np.zeros((T, n_arenas, w.n_ctrl, 4), dtype=np.int8)
+    act[..., 0] = rng.integers(0, 13, act.shape[:-1]); act[..., 1] = rng.integers(0, 9, act.shape[:-1])
+    act[..., 2] = rng.integers(0, 2, act.shape[:-1]); act[..., 3] = rng.integers(0, 2, act.shape[:-1])
+    w.rollout(act[:2])  # warm
+    steps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        w.rollout(act)
+        steps += T
+    dt = time.perf_counter() - t0
+    return {"value": n_arenas * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n_arenas} arenas x {steps} ticks, same config/seed/action distribution, OpenMP over arenas"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10000)
+    ap.add_argument("--warmup", type=int, default=1000)
+    ap.add_argument("--arenas", type=int, default=4096, help="arenas per GPU (configs[1]: 4096)")
+    ap.add_argument("--level", type=int, default=3)
+    ap.add_argument("--chunk", type=int, default=250, help="ticks per persistent-kernel launch")
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from hhmarl_2d_amd.sharding import ShardedWorld
+    N = args.arenas
+    sw = ShardedWorld(dict(n_arenas=N, level=args.level, seed=args.seed, auto_reset=True), rank=rank, world_size=world,
+                      device=local_rank)
+    w = sw.world
+    w.reset()
+    chunk = max(1, min(args.chunk, args.steps))
+    # action tape resident in HBM before the timed region: i.i.d. uniform MultiDiscrete([13,9,2,2])
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(args.seed + rank)
+    n_tape = 4  # distinct chunks of actions, cycled
+    hi = torch.tensor([13, 9, 2, 2], device=dev)
+    tape = (torch.rand((n_tape, chunk, N, w.n_ctrl, 4), device=dev, generator=gen) * hi).to(torch.int8).contiguous()
+    out = w.alloc_outputs(chunk)
+
+    def run(n_steps, timed):
+        done_steps, launches, k = 0, 0, 0
+        evs = []
+        while done_steps < n_steps:
+            T = min(chunk, n_steps - done_steps)
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            w.rollout(tape[k % n_tape][:T], out=tuple(o[:T] for o in out))
+            if timed:
+                e1.record()
+                evs.append((e0, e1, T))
+            sw.log_episode_stats()   # RCCL all-gather of episode returns (logging only)
+            done_steps += T
+            launches += 1
+            k += 1
+        return evs
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup, False)
+    barrier()
+    t0 = time.perf_counter()
+    evs = run(args.steps, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel: average launch duration from HIP events on the launch stream
+    full = [(a.elapsed_time(b) * 1e-3, T) for a, b, T in evs if T == chunk] or [(a.elapsed_time(b) * 1e-3, T) for a, b, T in evs]
+    avg_launch_s = sum(x for x, _ in full) / len(full)
+    T_launch = full[0][1]
+    bytes_per_launch = ALGO_BYTES_2V2_STEP * N * T_launch
+    achieved = bytes_per_launch / avg_launch_s / 1e9
+
+    value = N * world * args.steps / dt
+    line = {
+        "metric": "env-steps/sec (2v2)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "agent_steps_per_s": value * 2,
+        "config": {"workload": f"{N} arenas/GPU x 2-vs-2 fight L{args.level} (scripted opponent), random actions, auto-reset "
+                               f"(BASELINE configs[1])", "arenas_per_gpu": N, "ticks_per_launch": chunk,
+                   "parallelism": f"arena-sharded x{world}, no data-path collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "hh_k_world<4,256>", "avg_launch_ms": avg_launch_s * 1e3,
+                     "algorithmic_bytes_per_launch": bytes_per_launch},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(N, args.level, args.seed)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

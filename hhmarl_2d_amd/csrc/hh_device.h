@@ -147,6 +147,21 @@ __device__ __forceinline__ bool d_maybe_within_km(double lat1, double lon1, doub
     return near || !lowlat;
 }
 
+/* cmano_simulator.py:65-72 position update: short-step RK4 Direct (hh_geodesic.h) with the general
+ * Karney Direct as an out-of-line fallback outside its domain (same selection as hh_geo_move) */
+__device__ __noinline__ void d_geo_direct_general(double lat1, double lon1, double azi1, double s12, double *lat2, double *lon2) {
+    hh_geo_direct(lat1, lon1, azi1, s12, lat2, lon2);
+}
+__device__ __forceinline__ void d_geo_move(double lat1, double lon1, double azi1, double s12, double &lat2, double &lon2) {
+    double a, b;
+    if (s12 <= HH_GEO_SHORT_MAX_M && hh_fabs(lat1) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon1) < 170.0)
+        hh_geo_direct_short(lat1, lon1, azi1, s12, &a, &b);
+    else
+        d_geo_direct_general(lat1, lon1, azi1, s12, &a, &b);
+    lat2 = a;
+    lon2 = b;
+}
+
 __device__ __forceinline__ double d_rng(const Arena &a, int unit_id, int site, int sub) {
     return hh_rng_u01(hh_rng_tick_key(a.akey, (uint32_t)a.episode, (uint32_t)a.steps), (uint32_t)unit_id, (uint32_t)site, (uint32_t)sub);
 }

@@ -1,0 +1,904 @@
+/*
+ * hh_kernels.h — gfx950 kernels of the batched air-combat world.
+ *
+ * Replaces, for thousands of arenas at once, the reference's per-process Python path
+ *   envs/env_base.py:79-109 step  ->  envs/env_hetero.py:105-186 _take_action
+ *   -> warsim/simulator/cmano_simulator.py:138-157 do_tick (ac1.py:81-133, ac2.py:68-107,
+ *      rocket_unit.py:37-73)  ->  env_hetero.py:188-225 rewards  ->  env_hetero.py:65-103 state
+ * and envs/env_base.py:62-77,551-585 reset.
+ *
+ * One persistent kernel, hh_k_world<A,B> (one lane per aircraft slot, see hh_device.h), keeps
+ * the state of its arenas in registers for T ticks; per tick it runs
+ *   K1 "step"    fused action decode + scripted opponents + turn/thrust kinematics + WGS84 move,
+ *                then the weapon envelopes: every geodesic range/bearing test that survives an
+ *                exactness-preserving prefilter is pushed on a workgroup-wide LDS queue and the
+ *                queue is drained densely by all lanes with ONE inlined Karney Inverse
+ *                (work compaction: ~1 solve per arena-tick instead of 6 divergent ones per lane);
+ *                id-ordered kill resolution on integer masks; rewards; done;
+ *   pair table   every lane computes distance / focus angle / heading difference from its aircraft
+ *                to the other aircraft of its arena ONCE into LDS (the "per-agent-pair" staging);
+ *                the observation, target selection, scripted opponents, reward shaping and the
+ *                next tick's pre-step statistics are all lookups into it;
+ *   K3 "reset"   finished arenas are re-sampled in place when auto_reset is set;
+ *   K2 "observe" per-agent observation rows packed into an LDS staging tile and written with
+ *                unit-stride (coalesced) stores.
+ * T = 1 is hh_step; run = RESET / OBSERVE execute only K3 / pair table / K2.
+ * No MFMA: there is no dense contraction on this path; it is FP64 VALU + HBM streaming.
+ *
+ * Arithmetic is the bit-reproducible include/hh_math.h / hh_geodesic.h set, compiled with
+ * -ffp-contract=off, so results are bit-identical to the CPU oracle (tests/test_gpu_parity.py).
+ */
+#ifndef HH_KERNELS_H
+#define HH_KERNELS_H
+
+#include "hh_device.h"
+
+/* ===================================================================== LDS exchange area */
+template <int A, int B>
+struct Shared {
+    static constexpr int GPB = B / A;
+    /* published unit state: pre-tick while a tick runs, refreshed after it */
+    double lat0[B], lon0[B], hdg[B], spd[B];
+    double uc[B], us[B], un[B]; /* heading unit vector (env_base.py:428) and its norm */
+    /* pair tables, [slot j][lane]: from the lane's aircraft towards slot j of its arena */
+    double p_dist[A][B]; /* planar distance in degrees (env_base.py:434-439, un-normalised) */
+    double p_foc[A][B];  /* focus angle [deg] at the lane's aircraft towards j (env_base.py:424-432) */
+    double p_hd[A][B];   /* normalised angle between heading vectors (env_base.py:448-456), symmetric */
+    double rew[B];
+    unsigned long long g_tkey[GPB]; /* keyed-RNG tick key per arena (cannon draws made by worker lanes) */
+    int flags[B];                   /* bit0 alive, bits1-2 ac_type, bit3 shot flag */
+    int aux[B];                     /* per-phase scratch */
+    int res[B];                     /* envelope results per requesting lane: bit0 launch ok, bits1-8 cannon hit
+                                       on slot j, bit9 rocket fuse on target, bit10 fuse on "friendly" */
+    int g_alive[GPB], g_nev[GPB], g_ev[GPB][HH_MAX_AIRCRAFT], g_rkdead[GPB];
+    union {
+        struct {
+            double lat1[B], lon1[B], hdg1[B]; /* position / heading after this tick's aircraft update */
+            double rk_lat[B], rk_lon[B];      /* rocket position before its move (speculative for a pending launch) */
+            int q_code[B * 8];                /* Inverse work queue: src lane | kind<<8 | slot<<10 */
+            int q_count;
+        } t;
+        float obs[GPB * (A / 2) * HH_OBS_HL]; /* observation staging tile (after the tick) */
+    } u;
+};
+
+#define FL_ALIVE 1
+#define FL_SHOT 8
+
+template <int A, int B>
+__device__ __forceinline__ int sh_alive(const Shared<A, B> &sh, int idx) { return sh.flags[idx] & FL_ALIVE; }
+template <int A, int B>
+__device__ __forceinline__ int sh_type(const Shared<A, B> &sh, int idx) { return (sh.flags[idx] >> 1) & 3; }
+
+/* publish the state other lanes read */
+template <int A, int B>
+__device__ __forceinline__ void publish(Shared<A, B> &sh, int tid, const Unit &m) {
+    sh.lat0[tid] = m.lat;
+    sh.lon0[tid] = m.lon;
+    sh.hdg[tid] = m.hdg;
+    sh.spd[tid] = m.spd;
+    double s, c;
+    hh_sincos(hh_pymod(90.0 - m.hdg, 360.0) * (HH_PI / 180.0), &s, &c);
+    sh.uc[tid] = c;
+    sh.us[tid] = s;
+    sh.un[tid] = hh_sqrt(c * c + s * s);
+    int shot = m.burst > 0 || (m.ac_type == 1 && m.has_missile);
+    sh.flags[tid] = (m.alive ? FL_ALIVE : 0) | ((m.ac_type & 3) << 1) | (shot ? FL_SHOT : 0);
+}
+
+/* the per-arena pair table (call between two barriers, after publish) */
+template <int A, int B>
+__device__ __forceinline__ void pair_tables(Shared<A, B> &sh, int tid, int base, int s, bool active) {
+    if (!active || !sh_alive(sh, tid)) return;
+    const double c1 = sh.uc[tid], s1 = sh.us[tid], n1 = sh.un[tid];
+    const double la = sh.lat0[tid], lo = sh.lon0[tid];
+#pragma unroll 1
+    for (int j = 0; j < A; j++) {
+        if (j == s || !sh_alive(sh, base + j)) continue;
+        double dx = sh.lon0[base + j] - lo, dy = sh.lat0[base + j] - la;
+        double n2 = hh_sqrt(dx * dx + dy * dy);
+        double dot = c1 * dx + s1 * dy;
+        double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
+        sh.p_dist[j][tid] = n2;
+        sh.p_foc[j][tid] = hh_acos(x) * (180.0 / HH_PI);
+    }
+#pragma unroll 1
+    for (int k = 1; k <= A / 2; k++) {
+        int j = s + k;
+        if (j >= A) j -= A;
+        if (!sh_alive(sh, base + j)) continue;
+        double c2 = sh.uc[base + j], s2 = sh.us[base + j], n2 = sh.un[base + j];
+        double dot = c1 * c2 + s1 * s2;
+        double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
+        double v = hh_clip((hh_acos(x) * (180.0 / HH_PI)) / 180.0, 0.0, 1.0);
+        sh.p_hd[j][tid] = v;
+        sh.p_hd[s][base + j] = v;
+    }
+}
+
+/* env_base.py:400-422 _nearby_object from the pair table: up to 3 live units of the other side
+ * (or own side), stable-sorted by normalised distance.  ids are slot indices. */
+struct Near3 {
+    int n, i0, i1, i2;
+    double d0, d1, d2, r0, r1, r2;
+};
+template <int A, int B>
+__device__ __forceinline__ void nearby(const DevCfg &c, const Shared<A, B> &sh, int tid, int base, int s, bool friendly, Near3 &o) {
+    o.n = 0; o.i0 = o.i1 = o.i2 = 0; o.d0 = o.d1 = o.d2 = 0.0; o.r0 = o.r1 = o.r2 = 0.0;
+    bool me_agent = s < c.nA;
+    int lo = (me_agent != friendly) ? c.nA : 0;
+    int hi = (me_agent != friendly) ? A : c.nA;
+#pragma unroll
+    for (int j = 0; j < A; j++) {
+        if (j < lo || j >= hi || j == s) continue;
+        if (!sh_alive(sh, base + j)) continue;
+        double dr = sh.p_dist[j][tid];
+        double dn = c.inv_diag * dr;
+        int p = (o.n >= 1 && o.d0 <= dn) + (o.n >= 2 && o.d1 <= dn) + (o.n >= 3 && o.d2 <= dn);
+        if (p <= 1) { o.i2 = o.i1; o.d2 = o.d1; o.r2 = o.r1; }
+        if (p == 0) { o.i1 = o.i0; o.d1 = o.d0; o.r1 = o.r0; o.i0 = j; o.d0 = dn; o.r0 = dr; }
+        else if (p == 1) { o.i1 = j; o.d1 = dn; o.r1 = dr; }
+        else if (p == 2) { o.i2 = j; o.d2 = dn; o.r2 = dr; }
+        if (o.n < 3) o.n++;
+    }
+}
+
+__device__ __forceinline__ double norm180(double deg) { return hh_clip(deg / 180.0, 0.0, 1.0); }          /* focus, norm=True */
+__device__ __forceinline__ double aspect(double deg) { return hh_clip((180.0 - deg) / 180.0, 0.0, 1.0); } /* env_base.py:441-446 */
+
+/* ===================================================================== K3: reset */
+/* env_base.py:489-549 / env_hier.py:226-250 _sample_state + env_base.py:551-585 _reset_scenario */
+template <int A>
+__device__ __forceinline__ void reset_unit(const DevCfg &c, int s, Unit &m, Arena &ar) {
+    bool agent = s < c.nA;
+    int i = agent ? s : s - c.nA;
+    int id = s + 1;
+    int r = hh_rng_randint(d_rng(ar, 0, HH_SITE_RESET_SIDE, 0), 1, 2);
+    double ux = d_rng(ar, id, HH_SITE_RESET_X, 0), uy = d_rng(ar, id, HH_SITE_RESET_Y, 0), uh = d_rng(ar, id, HH_SITE_RESET_HDG, 0);
+    bool near_side = agent ? (r == 1) : (r == 2);
+    double x, y;
+    int hd = 0;
+    if (c.env_kind == HH_ENV_HIGHLEVEL) {
+        double n = agent ? (double)c.nA : (double)c.nO;
+        x = near_side ? hh_rng_uniform(ux, 7.07, 7.22) : hh_rng_uniform(ux, 7.28, 7.43);
+        y = hh_rng_uniform(uy, 5.07 + i * (0.4 / n), 5.12 + i * (0.4 / n));
+        hd = hh_rng_randint(uh, 0, 359);
+    } else if (c.level == 1) {
+        x = near_side ? hh_rng_uniform(ux, 7.12, 7.14) : hh_rng_uniform(ux, 7.16, 7.17);
+        y = hh_rng_uniform(uy, 5.1 + i * 0.1, 5.11 + i * 0.1);
+        if (agent) hd = r == 1 ? hh_rng_randint(uh, 30, 150) : hh_rng_randint(uh, 200, 330);
+    } else if (c.level == 2) {
+        x = near_side ? hh_rng_uniform(ux, 7.08, 7.13) : hh_rng_uniform(ux, 7.18, 7.23);
+        y = hh_rng_uniform(uy, 5.08 + i * 0.1, 5.13 + i * 0.1);
+        if (agent) hd = r == 1 ? hh_rng_randint(uh, 0, 180) : hh_rng_randint(uh, 180, 359);
+        else hd = hh_rng_randint(uh, 0, 359);
+    } else {
+        x = near_side ? hh_rng_uniform(ux, 7.07, 7.12) : hh_rng_uniform(ux, 7.18, 7.23);
+        y = hh_rng_uniform(uy, 5.09 + i * 0.1, 5.12 + i * 0.1);
+        if (agent) hd = r == 1 ? hh_rng_randint(uh, 0, 270) : hh_rng_randint(uh, 90, 359);
+        else hd = hh_rng_randint(uh, 0, 359);
+    }
+    int ac = i <= 1 ? i + 1 : hh_rng_randint(d_rng(ar, id, HH_SITE_RESET_TYPE, 0), 1, 2);
+    m = Unit{};
+    m.lat = y; m.lon = x; m.hdg = (double)hd;
+    m.spd = (c.level <= 2 && !agent) ? 0.0 : 100.0;
+    m.cmd_hdg = m.hdg; m.cmd_spd = m.spd;
+    m.alive = 1; m.ac_type = ac;
+    m.cannon_remain = m.cannon_max = HH_AC_CANNON_DEFAULT;
+    m.missile_remain = m.rocket_max = ac == 1 ? HH_AC1_MISSILES_DEFAULT : 0;
+    if (c.env_kind == HH_ENV_LOWLEVEL) {
+        if (c.level <= 4 && !agent) {
+            m.cannon_remain = m.cannon_max = 400;
+            if (ac == 1) m.missile_remain = m.rocket_max = 8;
+        } else if (c.level == 5) {
+            m.cannon_remain = m.cannon_max = 300;
+            if (ac == 1) m.missile_remain = m.rocket_max = 6;
+        }
+    } else {
+        m.cannon_remain = m.cannon_max = 300;
+        if (ac == 1) m.missile_remain = m.rocket_max = 8;
+    }
+}
+
+__device__ __forceinline__ void reset_arena_scalars(Arena &ar) {
+    ar.episode += 1;
+    ar.steps = 0;
+    ar.escaping = 0;
+    ar.escaping_time = 0;
+    ar.next_seq = 0;
+    ar.done = 0;
+}
+
+/* ===================================================================== K2: observe */
+/* env_base.py:185-212 opp_ac_values from the pair table; mode 0 fight / 1 esc / 2 HighLevel */
+template <int A, int B>
+__device__ __forceinline__ int opp_block(const DevCfg &c, const Shared<A, B> &sh, int mode, int tid, int base, int s, int oj, double dist, float *out) {
+    const int o = base + oj;
+    const int t = sh_type(sh, o);
+    const double f_so = sh.p_foc[oj][tid], f_os = sh.p_foc[s][o];
+    int n = 0;
+    out[n++] = (float)hh_clip((sh.lat0[o] - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
+    out[n++] = (float)hh_clip((sh.lon0[o] - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
+    out[n++] = (float)hh_clip(sh.spd[o] / HH_AC_MAX_SPEED(t), 0.0, 1.0);
+    out[n++] = (float)hh_clip(hh_pymod(sh.hdg[o], 359.0) / 359.0, 0.0, 1.0);
+    out[n++] = (float)sh.p_hd[oj][tid];
+    if (mode == 0) {
+        out[n++] = (float)norm180(f_os);
+        out[n++] = (float)aspect(f_so);
+    } else {
+        out[n++] = (float)norm180(f_so);
+        out[n++] = (float)norm180(f_os);
+    }
+    if (mode == 2) {
+        out[n++] = (float)aspect(f_so);
+        out[n++] = (float)aspect(f_os);
+    }
+    out[n++] = (float)dist;
+    if (mode != 2) out[n++] = (sh.flags[o] & FL_SHOT) ? 1.0f : 0.0f;
+    return n;
+}
+
+/* env_base.py:166-183 friendly_ac_values */
+template <int A, int B>
+__device__ __forceinline__ void friend_block(const DevCfg &c, const Shared<A, B> &sh, int tid, int base, int s, int fj, float *out) {
+    const int f = base + fj;
+    if (sh_alive(sh, f)) {
+        out[0] = (float)hh_clip((sh.lat0[f] - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
+        out[1] = (float)hh_clip((sh.lon0[f] - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
+        out[2] = (float)norm180(sh.p_foc[fj][tid]);
+        out[3] = (float)norm180(sh.p_foc[s][f]);
+        out[4] = (float)(c.inv_diag * sh.p_dist[fj][tid]);
+    } else {
+        out[0] = out[1] = out[2] = out[3] = out[4] = 0.0f;
+    }
+}
+
+/* env_hetero.py:65-103 lowlevel_state for the lane's own unit (fight / escape), also refreshes
+ * opp_to_attack (m.tgt0).  Writes D floats (zero padded) to `out` (LDS staging row). */
+template <int A, int B>
+__device__ __forceinline__ void lowlevel_obs(const DevCfg &c, const Shared<A, B> &sh, int tid, int base, int s, int mode, Unit &m, float *out, int D) {
+    for (int k = 0; k < D; k++) out[k] = 0.0f;
+    m.n_tgt = 0; m.tgt0 = 0; m.tgt_d0 = 0.0;
+    if (!m.alive) return;
+    Near3 nb;
+    nearby(c, sh, tid, base, s, false, nb);
+    if (nb.n == 0) return;
+    m.n_tgt = 1; m.tgt0 = nb.i0 + 1; m.tgt_d0 = nb.d0;
+    /* env_hetero.py:71-75 fri_ac_id */
+    int fri = s < c.nA ? (s == 1 ? 0 : 1) : (s == 3 ? 2 : 3);
+    int n = 0;
+    out[n++] = (float)hh_clip((m.lat - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
+    out[n++] = (float)hh_clip((m.lon - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
+    out[n++] = (float)hh_clip(m.spd / HH_AC_MAX_SPEED(m.ac_type), 0.0, 1.0);
+    out[n++] = (float)hh_clip(hh_pymod(m.hdg, 359.0) / 359.0, 0.0, 1.0);
+    if (mode == HH_MODE_FIGHT) {
+        const int oj = nb.i0;
+        out[n++] = (float)norm180(sh.p_foc[oj][tid]);
+        out[n++] = (float)aspect(sh.p_foc[s][base + oj]);
+        out[n++] = (float)sh.p_hd[oj][tid];
+        out[n++] = (float)nb.d0;
+        out[n++] = (float)hh_clip((double)m.cannon_remain / (double)m.cannon_max, 0.0, 1.0);
+        if (m.ac_type == 1) {
+            out[n++] = (float)hh_clip((double)m.missile_remain / (double)m.rocket_max, 0.0, 1.0);
+            out[n++] = m.missile_wait == 0 ? 1.0f : 0.0f;
+            out[n++] = (m.has_missile || m.burst > 0) ? 1.0f : 0.0f;
+        } else {
+            out[n++] = m.burst > 0 ? 1.0f : 0.0f;
+        }
+        n += opp_block(c, sh, 0, tid, base, s, oj, nb.d0, out + n);
+    } else {
+        out[n++] = (float)hh_clip((double)m.cannon_remain / (double)m.cannon_max, 0.0, 1.0);
+        if (m.ac_type == 1) out[n++] = (float)hh_clip((double)m.missile_remain / (double)m.rocket_max, 0.0, 1.0);
+        out[n++] = (sh.flags[tid] & FL_SHOT) ? 1.0f : 0.0f;
+        opp_block(c, sh, 1, tid, base, s, nb.i0, nb.d0, out + n);
+        if (nb.n >= 2) opp_block(c, sh, 1, tid, base, s, nb.i1, nb.d1, out + n + 9);
+        n += 18;
+    }
+    friend_block(c, sh, tid, base, s, fri, out + n);
+}
+
+/* ===================================================================== K1: step */
+struct StepOut {
+    double reward;
+    int valid;
+};
+
+__device__ __forceinline__ void arm_cannon(Unit &m) { /* ac1.py:69-70 / ac2.py:65-66 fire_cannon */
+    int b = HH_AC_BURST(m.ac_type);
+    m.burst = m.cannon_remain < b ? m.cannon_remain : b;
+}
+
+template <int A, int B>
+__device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid, int g, int s, int base, bool active,
+                                     Unit &m, Arena &ar, const int8_t *act, StepOut &out, uint32_t &ev_mask_out) {
+    const int id = s + 1;
+    const bool running = active && !ar.done;
+    const bool agent = s < c.nA;
+    const bool hl = c.env_kind == HH_ENV_HIGHLEVEL;
+    out.reward = 0.0;
+    out.valid = 0;
+    uint32_t evm = 0;
+    if (running) ar.steps += 1;
+    const bool snap = running && m.alive; /* in do_tick's start-of-tick snapshot */
+    double opp_stat0 = 0.0;
+    int want_launch = 0, launch_tgt = 0; /* launch_tgt: slot index */
+    int wait_after = -1;                 /* scripted opponents: missile_wait value set after the attempt */
+    bool base_gate = false;              /* _take_base_action missile gate passed */
+
+    /* ---------------- phase A: commands (env_hetero.py:160-182), pair table = pre-tick state ---------------- */
+    if (snap) {
+        if (agent || c.ext_opp) {
+            int t = m.n_tgt ? m.tgt0 : 0;
+            if (!agent) {
+                /* env_base.py:349-398 _policy_actions -> lowlevel_state(opp_mode, i): refresh target */
+                Near3 nb;
+                nearby(c, sh, tid, base, s, false, nb);
+                m.n_tgt = nb.n ? 1 : 0; m.tgt0 = nb.n ? nb.i0 + 1 : 0; m.tgt_d0 = nb.n ? nb.d0 : 0.0;
+                t = m.tgt0;
+            } else {
+                out.valid = 1;
+                if (t && sh_alive(sh, base + t - 1)) opp_stat0 = norm180(sh.p_foc[s][base + t - 1]); /* env_hetero.py:169-170 */
+            }
+            /* env_base.py:214-238 _take_base_action */
+            double nh = hh_pymod(m.hdg + (double)(((int)act[0] - 6) * 15), 360.0);
+            if (nh >= 360.0 || nh < 0.0) nh = 0.0;
+            m.cmd_hdg = nh;
+            double mx = HH_AC_MAX_SPEED(m.ac_type);
+            m.cmd_spd = 100.0 + ((mx - 100.0) / 8.0) * (double)act[1];
+            bool agent_ll = agent && !hl;
+            if (act[2] && m.cannon_remain > 0) {
+                arm_cannon(m);
+                if (agent_ll && c.agent_mode == HH_MODE_ESCAPE && m.cannon_remain < 90) out.reward -= 0.1;
+            }
+            if (m.ac_type == 1 && act[3]) {
+                if (t && m.missile_remain > 0 && !m.has_missile && m.missile_wait == 0) {
+                    base_gate = true;
+                    want_launch = 1;
+                    launch_tgt = t - 1;
+                }
+            }
+        } else if (c.level <= 2) {
+            /* env_hetero.py:118-136 levels 1-2 */
+            if (c.level == 2) {
+                arm_cannon(m);
+                bool man = ar.steps <= 5;
+                if (!man) man = (ar.steps % hh_rng_randint(d_rng(ar, id, HH_SITE_L2_PERIOD, 0), 35, 45)) <= 5;
+                if (man) {
+                    int r = hh_rng_randint(d_rng(ar, id, HH_SITE_L2_TURN, 0), 0, 1);
+                    m.cmd_hdg = hh_pymod(m.hdg + (r ? -90.0 : 90.0), 360.0);
+                    m.cmd_spd = (double)(100 + hh_rng_randint(d_rng(ar, id, HH_SITE_L2_SPEED, 0), 0, 4) * 75);
+                }
+            }
+            if (!m.has_missile && (ar.steps % 40) < 3 && hh_rng_randint(d_rng(ar, id, HH_SITE_L12_COIN, 0), 0, 1) &&
+                m.missile_wait == 0 && m.ac_type == 1) {
+                Near3 nb;
+                nearby(c, sh, tid, base, s, false, nb);
+                if (nb.n) { want_launch = 1; launch_tgt = nb.i0; wait_after = 5; }
+            }
+        }
+    }
+    /* env_hetero.py:138-158 level 3: the arena-level escape flag is consumed once per live
+     * opponent in id order; every lane replays the tiny integer sequence so that
+     * each opponent lane sees the flag as it was at its turn and all lanes agree on the result */
+    if (running && !c.ext_opp && c.level >= 3 && !hl) {
+        int esc = ar.escaping, esc_t = ar.escaping_time;
+        bool my_escaping = false;
+#pragma unroll
+        for (int j = 0; j < A; j++) {
+            if (j < c.nA) continue;
+            if (!sh_alive(sh, base + j)) continue;
+            if (ar.steps % 60 == 0 && !esc) {
+                esc = hh_rng_randint(d_rng(ar, j + 1, HH_SITE_L3_ESC_COIN, 0), 0, 1);
+                if (esc) esc_t = (int)hh_rng_uniform(d_rng(ar, j + 1, HH_SITE_L3_ESC_TIME, 0), 20.0, 30.0);
+            }
+            if (j == s) my_escaping = esc != 0;
+            if (esc) {
+                esc_t -= 1;
+                if (esc_t <= 0) esc = 0;
+            }
+        }
+        ar.escaping = esc;
+        ar.escaping_time = esc_t;
+        if (snap && !agent) {
+            int opp = -1, fire = 0, fire_m = 0;
+            double heading, speed;
+            if (my_escaping) {
+                /* env_hetero.py:227-245 _escaping_opp */
+                double y = hh_clip((m.lat - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
+                double x = hh_clip((m.lon - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
+                double uh = d_rng(ar, id, HH_SITE_ESC_HDG, 0);
+                double lo_h = y < 0.5 ? (x < 0.5 ? 30.0 : 300.0) : (x < 0.5 ? 120.0 : 210.0);
+                heading = (double)(int)hh_rng_uniform(uh, lo_h, lo_h + 30.0);
+                speed = (double)(int)hh_rng_uniform(d_rng(ar, id, HH_SITE_ESC_SPEED, 0), 300.0, 600.0);
+                fire = hh_rng_randint(d_rng(ar, id, HH_SITE_ESC_FIRE, 0), 0, 1);
+            } else {
+                /* env_hetero.py:247-271 _hardcoded_opp */
+                Near3 nb;
+                nearby(c, sh, tid, base, s, false, nb);
+                heading = m.hdg;
+                speed = (double)(int)hh_rng_uniform(d_rng(ar, id, HH_SITE_HC_SPEED1, 0), 100.0, 400.0);
+                if (nb.n) {
+                    int ag = base + nb.i0;
+                    /* env_base.py:464-487 _correct_angle_sign */
+                    double sn, cs;
+                    hh_sincos(hh_pymod(m.hdg, 360.0) * (HH_PI / 180.0), &sn, &cs);
+                    double x1 = m.lon + hh_round3(sn), y1 = m.lat + hh_round3(cs);
+                    double val = (x1 - m.lon) * (sh.lat0[ag] - m.lat) - (sh.lon0[ag] - m.lon) * (y1 - m.lat);
+                    double sign = val < 0.0 ? 1.0 : -1.0;
+                    double r = hh_rng_uniform(d_rng(ar, id, HH_SITE_HC_R, 0), 0.7, 1.3);
+                    double focus = sh.p_foc[nb.i0][tid];
+                    if (nb.d0 > 0.008 && focus > 4.0) heading = hh_pymod(heading + r * sign * focus, 360.0);
+                    if (nb.d0 > 0.05) {
+                        double us = d_rng(ar, id, HH_SITE_HC_SPEED2, 0);
+                        speed = focus < 30.0 ? (double)(int)hh_rng_uniform(us, 500.0, 800.0) : (double)(int)hh_rng_uniform(us, 100.0, 500.0);
+                    }
+                    fire = nb.d0 < 0.03 && focus < 10.0;
+                    fire_m = nb.d0 < 0.09 && focus < 5.0;
+                    opp = nb.i0;
+                }
+                if (m.ac_type == 2) speed = hh_clip(speed, 0.0, 600.0);
+            }
+            if (heading >= 360.0 || heading < 0.0) heading = 0.0;
+            m.cmd_hdg = heading;
+            m.cmd_spd = speed;
+            if (fire) arm_cannon(m);
+            if (fire_m && opp >= 0 && !m.has_missile && m.missile_wait == 0 && m.ac_type == 1) {
+                want_launch = 1; launch_tgt = opp; wait_after = 10;
+            }
+        }
+    }
+
+    /* ---------------- phase B: aircraft kinematics + move (ac1.py:81-133) ---------------- */
+    const double lat_old = m.lat, lon_old = m.lon, hdg_old = m.hdg;
+    bool fired = false;
+    const int rk_pre = m.rk_alive;      /* rocket in flight at tick start (before this step's launches) */
+    const int has_missile_pre = m.has_missile; /* actual_missile as _take_base_action sees it (before the tick) */
+    const bool try_launch = want_launch && !m.has_missile && m.missile_remain > 0; /* ac1.py:73 */
+    if (snap) {
+        int t = m.ac_type;
+        if (m.hdg != m.cmd_hdg) {
+            double delta = d_signed_heading_diff(m.hdg, m.cmd_hdg);
+            double max_deg = HH_AC_TURN_RATE(t) * 1.0;
+            if (hh_fabs(delta) <= max_deg) m.hdg = m.cmd_hdg;
+            else { m.hdg += delta >= 0.0 ? max_deg : -max_deg; m.hdg = hh_pymod(m.hdg, 360.0); }
+        }
+        if (m.spd != m.cmd_spd) {
+            double delta = m.cmd_spd - m.spd;
+            double max_delta = HH_AC_ACCEL(t) * 1.0;
+            if (hh_fabs(delta) <= max_delta) m.spd = m.cmd_spd;
+            else m.spd += delta >= 0.0 ? max_delta : -max_delta;
+        }
+        if (m.burst > 0) {
+            fired = true;
+            m.burst = m.burst - 1 > 0 ? m.burst - 1 : 0;
+            m.cannon_remain = m.cannon_remain - 1 > 0 ? m.cannon_remain - 1 : 0;
+        }
+        if (m.has_missile) { /* ac1.py:117-128, rocket launched in an earlier step */
+            if (!m.rk_alive) m.has_missile = 0;
+            else m.rk_cmd = hh_clip(m.rk_hdg * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
+        }
+        if (m.spd > 0.0) d_geo_move(m.lat, m.lon, m.hdg, m.spd * HH_KNOTS_TO_MS * 1.0, m.lat, m.lon);
+    }
+    sh.u.t.lat1[tid] = m.lat;
+    sh.u.t.lon1[tid] = m.lon;
+    sh.u.t.hdg1[tid] = m.hdg;
+    sh.u.t.rk_lat[tid] = rk_pre ? m.rk_lat : lat_old;
+    sh.u.t.rk_lon[tid] = rk_pre ? m.rk_lon : lon_old;
+    sh.aux[tid] = snap ? 1 : 0;
+    sh.res[tid] = 0;
+    if (tid == 0) sh.u.t.q_count = 0;
+    if (s == 0 && active) sh.g_tkey[g] = hh_rng_tick_key(ar.akey, (uint32_t)ar.episode, (uint32_t)ar.steps);
+    __syncthreads();
+
+    /* ---------------- phase Q: enqueue every geodesic envelope test that survives the prefilter ---------------- */
+    const int rk_tgt = rk_pre ? m.rk_target - 1 : launch_tgt; /* slot the (possibly pending) rocket is aimed at */
+    const bool rk_maybe = running && (rk_pre || try_launch);
+    {
+        int nq = 0;
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
+#define HH_PUSH(code)                                                                                       \
+    do {                                                                                                    \
+        int cd_ = (code);                                                                                   \
+        switch (nq) { case 0: c0 = cd_; break; case 1: c1 = cd_; break; case 2: c2 = cd_; break; case 3: c3 = cd_; break; \
+                      case 4: c4 = cd_; break; case 5: c5 = cd_; break; case 6: c6 = cd_; break; default: c7 = cd_; break; } \
+        nq++;                                                                                               \
+    } while (0)
+        if (try_launch) HH_PUSH(tid | (0 << 8) | (launch_tgt << 10));
+        if (fired) {
+            int t = m.ac_type;
+#pragma unroll
+            for (int j = 0; j < A; j++) {
+                if (j == s) continue;
+                if (!sh.aux[base + j]) continue; /* not alive at tick start -> can never be "currently alive" */
+                bool enemy = agent ? (j >= c.nA) : (j < c.nA);
+                if (!(c.friendly_kill || enemy)) continue;
+                /* target already moved iff its id is lower (cmano_simulator.py:142) */
+                double tl = j < s ? sh.u.t.lat1[base + j] : sh.lat0[base + j];
+                double to = j < s ? sh.u.t.lon1[base + j] : sh.lon0[base + j];
+                if (d_maybe_within_km(lat_old, lon_old, tl, to, HH_AC_CANNON_KM(t))) HH_PUSH(tid | (1 << 8) | (j << 10));
+            }
+        }
+        if (rk_maybe) {
+            double rl = sh.u.t.rk_lat[tid], ro = sh.u.t.rk_lon[tid];
+            if (d_maybe_within_km(rl, ro, sh.u.t.lat1[base + rk_tgt], sh.u.t.lon1[base + rk_tgt], HH_ROCKET_FUSE_KM))
+                HH_PUSH(tid | (2 << 8) | (rk_tgt << 10));
+            if (c.friendly_kill) {
+                int fid = s == 1 ? 0 : 1; /* rocket_unit.py:46: 1 if source.id == 2 else 2 */
+                if (d_maybe_within_km(rl, ro, sh.u.t.lat1[base + fid], sh.u.t.lon1[base + fid], HH_ROCKET_FUSE_KM))
+                    HH_PUSH(tid | (3 << 8) | (fid << 10));
+            }
+        }
+#undef HH_PUSH
+        if (nq) {
+            int at = atomicAdd(&sh.u.t.q_count, nq);
+            sh.u.t.q_code[at] = c0;
+            if (nq > 1) sh.u.t.q_code[at + 1] = c1;
+            if (nq > 2) sh.u.t.q_code[at + 2] = c2;
+            if (nq > 3) sh.u.t.q_code[at + 3] = c3;
+            if (nq > 4) sh.u.t.q_code[at + 4] = c4;
+            if (nq > 5) sh.u.t.q_code[at + 5] = c5;
+            if (nq > 6) sh.u.t.q_code[at + 6] = c6;
+            if (nq > 7) sh.u.t.q_code[at + 7] = c7;
+        }
+    }
+    __syncthreads();
+
+    /* ---------------- phase I: dense pass over the queue, ONE inlined Inverse (Karney) ---------------- */
+    {
+        const int count = sh.u.t.q_count;
+#pragma unroll 1
+        for (int q = tid; q < count; q += B) {
+            int code = sh.u.t.q_code[q];
+            int src = code & 0xff, kind = (code >> 8) & 3, j = (code >> 10) & 7;
+            int ss = src % A, sb = src - ss;
+            double la1, lo1, la2, lo2;
+            if (kind <= 1) { la1 = sh.lat0[src]; lo1 = sh.lon0[src]; }
+            else { la1 = sh.u.t.rk_lat[src]; lo1 = sh.u.t.rk_lon[src]; }
+            bool moved = kind >= 2 || (kind == 1 && j < ss);
+            la2 = moved ? sh.u.t.lat1[sb + j] : sh.lat0[sb + j];
+            lo2 = moved ? sh.u.t.lon1[sb + j] : sh.lon0[sb + j];
+            double km, brg;
+            d_dist_bearing(la1, lo1, la2, lo2, km, brg);
+            int bit = 0;
+            if (kind == 0) { /* ac1.py:72-79,144-146 missile envelope */
+                if (km <= HH_MISSILE_RANGE_KM) {
+                    double delta = hh_fabs(d_signed_heading_diff(d_normalize_angle(sh.hdg[src] + HH_MISSILE_HALF_DEG), brg));
+                    if ((int)delta <= (int)HH_MISSILE_HALF_DEG) bit = 1;
+                }
+            } else if (kind == 1) { /* ac1.py:106-115,135-142 cannon cone + Bernoulli hit */
+                int t = sh_type(sh, src);
+                if (km < HH_AC_CANNON_KM(t)) {
+                    double d = hh_fabs(d_signed_heading_diff(sh.u.t.hdg1[src], brg));
+                    if (d <= HH_AC_CANNON_HALF(t)) {
+                        double u = hh_rng_u01(sh.g_tkey[src / A], (uint32_t)(ss + 1), HH_SITE_CANNON, (uint32_t)(j + 1));
+                        if (u < HH_AC_HIT_PROB(t)) bit = 2 << j;
+                    }
+                }
+            } else { /* rocket_unit.py:39,49 proximity fuse */
+                if (km < HH_ROCKET_FUSE_KM) bit = kind == 2 ? (1 << 9) : (1 << 10);
+            }
+            if (bit) atomicOr(&sh.res[src], bit);
+        }
+    }
+    __syncthreads();
+
+    /* ---------------- phase L: launch bookkeeping (env_base.py:227-236, ac1.py:76-79) ---------------- */
+    const int myres = sh.res[tid];
+    int launched = 0;
+    if (try_launch && (myres & 1)) {
+        launched = 1;
+        m.rk_alive = 1; m.rk_lat = lat_old; m.rk_lon = lon_old; m.rk_hdg = hdg_old;
+        m.rk_target = launch_tgt + 1; m.rk_life = 0;
+        m.has_missile = 1;
+        m.missile_remain = m.missile_remain - 1 > 0 ? m.missile_remain - 1 : 0;
+        evm |= 1u << (24 + s);
+        /* the launcher's own update in this tick already steers it (ac1.py:127) */
+        m.rk_cmd = hh_clip(m.rk_hdg * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
+    }
+    if (base_gate) {
+        double uu = d_rng(ar, id, HH_SITE_MISSILE_WAIT, 0);
+        m.missile_wait = hl ? hh_rng_randint(uu, 8, 12) : hh_rng_randint(uu, 7, 17);
+        if (agent && !hl && c.agent_mode == HH_MODE_ESCAPE && m.missile_remain < 3) out.reward -= 0.1;
+    }
+    if (snap && (agent || c.ext_opp)) { /* env_base.py:235-236, evaluated before do_tick */
+        if (m.missile_wait > 0 && !(launched || has_missile_pre)) m.missile_wait -= 1;
+    }
+    if (want_launch && wait_after >= 0) m.missile_wait = wait_after;
+    const int rk_at_start = m.rk_alive; /* rockets in do_tick's snapshot: in flight + launched this step */
+    sh.aux[tid] = launched | ((fired ? (myres >> 1) & 0xff : 0) << 8);
+    __syncthreads();
+    {   /* launch order = unit id order (cmano_simulator.py:104-108): seq = running id counter */
+        int before = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < A; j++) {
+            int l = active ? (sh.aux[base + j] & 1) : 0;
+            total += l;
+            if (j < s) before += l;
+        }
+        if (launched) m.rk_seq = ar.next_seq + before + 1;
+        ar.next_seq += total;
+    }
+    int rkw = 0; /* bit0 present, bit1 fuse on target, bit2 fuse on "friendly", bit3 end of life, bits4-6 target, bits 8.. seq */
+    if (running && rk_at_start) {
+        int eol = m.rk_life > HH_ROCKET_MAX_LIFE;
+        rkw = 1 | (((myres >> 9) & 1) << 1) | (((myres >> 10) & 1) << 2) | (eol << 3) | ((m.rk_target - 1) << 4) | (m.rk_seq << 8);
+    }
+    sh.res[tid] = rkw; /* res was consumed into myres above; reuse it for the rocket word */
+
+    /* ---------------- phases C + D: id-ordered resolution by one lane per arena ---------------- */
+    __syncthreads();
+    if (s == 0 && active) {
+        int alive = 0, nev = 0, dead = 0;
+#pragma unroll
+        for (int j = 0; j < A; j++) alive |= (sh_alive(sh, base + j) ? 1 : 0) << j;
+        if (running) {
+            /* aircraft phase: shooter i (alive at tick start, even if killed earlier in this tick) hits the
+             * still-alive targets in id order (ac1.py:106-115) */
+#pragma unroll
+            for (int i = 0; i < A; i++) {
+                int ci = sh.aux[base + i] >> 8;
+#pragma unroll
+                for (int j = 0; j < A; j++) {
+                    if (((ci >> j) & 1) && ((alive >> j) & 1)) {
+                        alive &= ~(1 << j);
+                        sh.g_ev[g][nev++] = i | (j << 4);
+                    }
+                }
+            }
+            /* rocket phase in launch order (rocket_unit.py:37-58) */
+            int done_mask = 0;
+            for (int k = 0; k < A; k++) {
+                int best = -1, best_seq = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < A; j++) {
+                    int w = sh.res[base + j];
+                    if ((w & 1) && !((done_mask >> j) & 1) && (w >> 8) < best_seq) { best = j; best_seq = w >> 8; }
+                }
+                if (best < 0) break;
+                done_mask |= 1 << best;
+                int w = sh.res[base + best];
+                int tg = (w >> 4) & 7;
+                int fid = best == 1 ? 0 : 1;
+                if (((w >> 1) & 1) && ((alive >> tg) & 1)) {
+                    alive &= ~(1 << tg); dead |= 1 << best;
+                    sh.g_ev[g][nev++] = best | (tg << 4) | (1 << 8);
+                } else if (c.friendly_kill && ((alive >> fid) & 1) && ((w >> 2) & 1)) {
+                    alive &= ~(1 << fid); dead |= 1 << best;
+                    sh.g_ev[g][nev++] = best | (fid << 4) | (1 << 8);
+                } else if ((w >> 3) & 1) {
+                    dead |= 1 << best;
+                }
+            }
+        }
+        sh.g_alive[g] = alive;
+        sh.g_nev[g] = nev;
+        sh.g_rkdead[g] = dead;
+    }
+    __syncthreads();
+    if (running && rk_at_start) {
+        if ((sh.g_rkdead[g] >> s) & 1) {
+            m.rk_alive = 0; m.rk_target = 0; m.rk_life = 0; m.rk_seq = 0;
+            m.rk_lat = m.rk_lon = m.rk_hdg = m.rk_cmd = 0.0;
+        } else { /* turn, speed profile, move (rocket_unit.py:61-73) */
+            const double speed_table[11] = HH_ROCKET_SPEED_TABLE;
+            if (m.rk_hdg != m.rk_cmd) {
+                double delta = d_signed_heading_diff(m.rk_hdg, m.rk_cmd);
+                if (hh_fabs(delta) <= HH_ROCKET_TURN_RATE) m.rk_hdg = m.rk_cmd;
+                else m.rk_hdg += delta >= 0.0 ? HH_ROCKET_TURN_RATE : -HH_ROCKET_TURN_RATE;
+            }
+            double spd = speed_table[m.rk_life];
+            if (spd > 0.0) d_geo_move(m.rk_lat, m.rk_lon, m.rk_hdg, spd * HH_KNOTS_TO_MS * 1.0, m.rk_lat, m.rk_lon);
+            m.rk_life += 1;
+        }
+    }
+
+    /* ---------------- phase E: out of bounds, rewards, done (env_base.py:240-310, env_hetero.py:188-225) ---------------- */
+    int oob = 0;
+    if (active) {
+        m.alive = (sh.g_alive[g] >> s) & 1;
+        if (running && m.alive) {
+            bool inb = HH_MAP_LON0 <= m.lon && m.lon <= c.lon_hi && HH_MAP_LAT0 <= m.lat && m.lat <= c.lat_hi;
+            if (!inb) { m.alive = 0; oob = 1; }
+        }
+    }
+    double rews = 0.0;
+    int destroyed = 0;
+    const int nev = active ? sh.g_nev[g] : 0;
+    if (running && agent) {
+        double sc = c.rew_scale;
+        if (oob) { rews += (hl ? -2.0 : -5.0) * sc; destroyed = 1; }
+        for (int e = 0; e < nev; e++) {
+            int w = sh.g_ev[g][e];
+            int k = w & 15, d = (w >> 4) & 15, rocket = (w >> 8) & 1;
+            if (k < c.nA) {
+                if (d >= c.nA) {
+                    if (k == s) {
+                        if (!hl) {
+                            if (c.agent_mode == HH_MODE_FIGHT) {
+                                if (rocket) {
+                                    rews += (1.0 + ((1.5 - 1.0) / (1.0 - 0.0)) * ((double)m.missile_remain / (double)m.rocket_max - 0.0)) * sc;
+                                } else {
+                                    double r1 = 0.5 + ((1.0 - 0.5) / (1.0 - 0.0)) * ((double)m.cannon_remain / (double)m.cannon_max - 0.0);
+                                    double r2 = 0.5 + ((1.0 - 0.5) / (1.0 - 0.0)) * (opp_stat0 - 0.0);
+                                    rews += (r1 + r2) * sc;
+                                }
+                            }
+                        } else {
+                            rews += 1.0;
+                        }
+                    }
+                } else if (!hl) {
+                    if (k == s) rews += -2.0 * sc;
+                    if (c.friendly_punish && d == s) { rews += -2.0 * sc; destroyed = 1; }
+                }
+            } else if (d < c.nA) {
+                if (d == s) { rews += (hl ? -1.0 : -2.0) * sc; destroyed = 1; }
+            }
+        }
+    }
+    /* event masks for parity checks */
+    for (int e = 0; e < nev; e++) {
+        int w = sh.g_ev[g][e];
+        evm |= ((w >> 8) & 1) ? (1u << (8 + ((w >> 4) & 15))) : (1u << ((w >> 4) & 15));
+    }
+    if (oob) evm |= 1u << (16 + s);
+    ev_mask_out = evm;
+    sh.aux[tid] = oob;
+    sh.rew[tid] = rews;
+    /* post-tick state + pair table: escape shaping now, observation next, pre-step lookups of the next tick */
+    publish(sh, tid, m);
+    __syncthreads();
+    pair_tables(sh, tid, base, s, active);
+    if (running) {
+        int ag = 0, op = 0;
+#pragma unroll
+        for (int j = 0; j < A; j++) {
+            int al = sh_alive(sh, base + j);
+            if (j < c.nA) ag += al; else op += al;
+        }
+        ar.done = (ag <= 0 || op <= 0 || ar.steps >= c.horizon) ? 1 : 0;
+    }
+    __syncthreads();
+    if (running && agent) {
+        if (!hl && c.agent_mode == HH_MODE_ESCAPE && c.esc_dist_rew && m.alive) {
+            /* env_hetero.py:198-214 */
+            Near3 nb;
+            nearby(c, sh, tid, base, s, false, nb);
+            double dr[3] = {nb.r0, nb.r1, nb.r2};
+#pragma unroll
+            for (int j = 1; j <= 3; j++) {
+                if (j > nb.n) break;
+                if (dr[j - 1] < 0.06) { rews += -0.02 / j; if (m.spd < 200.0) rews += -0.02 / j; }
+                else if (dr[j - 1] > 0.13) { rews += 0.02 / j; if (m.spd > 500.0) rews += 0.02 / j; }
+            }
+        }
+        if (m.alive || destroyed) {
+            if (c.glob_frac > 0.0 && !hl && c.agent_mode == HH_MODE_FIGHT) {
+                out.reward += rews + c.glob_frac * sh.rew[base + ((s + 1) % 2)];
+            } else if (c.glob_frac > 0.0 && hl) {
+                double other = 0.0;
+#pragma unroll
+                for (int j = 0; j < A; j++) if (j < c.nA && j != s) other += sh.rew[base + j];
+                out.reward += rews + c.glob_frac * other;
+            } else {
+                out.reward += rews;
+            }
+        }
+    }
+    __syncthreads(); /* all reads of rew/aux/g_* done before the caller reuses them */
+}
+
+/* ===================================================================== the kernel */
+enum { HH_RUN_ROLLOUT = 0, HH_RUN_RESET = 1, HH_RUN_OBSERVE = 2 };
+
+template <int A, int B>
+__global__ __launch_bounds__(B) void hh_k_world(DevPtrs P, DevCfg c, int run, int T, const int8_t *__restrict__ actions,
+                                                const uint8_t *__restrict__ mask, float *__restrict__ obs_out,
+                                                float *__restrict__ reward_out, uint8_t *__restrict__ valid_out,
+                                                uint8_t *__restrict__ done_out) {
+    constexpr int GPB = B / A;
+    __shared__ Shared<A, B> sh;
+    const int tid = threadIdx.x;
+    const int g = tid / A, s = tid % A;
+    const int base = g * A;
+    const int n = blockIdx.x * GPB + g;
+    const bool active = g < GPB && n < c.N;
+    const size_t U = (size_t)c.N * A;
+    const size_t u = (size_t)n * A + s;
+    const int D = c.D;
+    Unit m = Unit{};
+    Arena ar = Arena{};
+    double ep_ret = 0.0;
+    if (active) {
+        unit_load(P, U, u, m);
+        arena_load(P, c, n, ar);
+        if (s == 0) ep_ret = P.ep_ret[n];
+    } else {
+        ar.done = 1;
+    }
+    sh.aux[tid] = 0;
+    bool need_reset = run == HH_RUN_RESET && active && (mask == nullptr || mask[n]);
+    uint32_t evm_last = 0;
+    if (run == HH_RUN_ROLLOUT) { /* pair table of the pre-tick state */
+        publish(sh, tid, m);
+        __syncthreads();
+        pair_tables(sh, tid, base, s, active);
+        __syncthreads();
+    }
+    for (int t = 0; t < T; t++) {
+        if (run == HH_RUN_ROLLOUT) {
+            StepOut so;
+            int8_t act[4] = {0, 0, 0, 0};
+            if (active && s < c.n_ctrl) {
+                const int8_t *ap = actions + (((size_t)t * c.N + n) * c.n_ctrl + s) * 4;
+                int w = *reinterpret_cast<const int *>(ap);
+                act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
+            }
+            const bool was_running = active && !ar.done;
+            tick<A, B>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_last);
+            /* outputs of this tick */
+            if (active && s < c.nA) {
+                size_t o = ((size_t)t * c.N + n) * c.nA + s;
+                if (reward_out) reward_out[o] = (float)so.reward;
+                if (valid_out) valid_out[o] = (uint8_t)so.valid;
+            }
+            /* episode statistics: one lane per arena, agent order */
+            sh.rew[tid] = so.valid ? so.reward : 0.0;
+            __syncthreads();
+            if (active && s == 0 && was_running) {
+                for (int j = 0; j < c.nA; j++) ep_ret += sh.rew[base + j];
+                if (ar.done) {
+                    int ag = 0, op = 0;
+                    for (int j = 0; j < A; j++) { int al = sh_alive(sh, base + j); if (j < c.nA) ag += al; else op += al; }
+                    P.last_ret[n] = (float)ep_ret;
+                    P.last_len[n] = ar.steps;
+                    P.last_outcome[n] = (op <= 0 && ar.steps < c.horizon) ? 1 : ((ag <= 0 && ar.steps < c.horizon) ? -1 : 0);
+                }
+            }
+            if (active && s == 0 && done_out) done_out[(size_t)t * c.N + n] = (uint8_t)ar.done;
+            need_reset = active && ar.done && c.auto_reset;
+        }
+        const int any_reset = __syncthreads_or(need_reset ? 1 : 0);
+        if (need_reset) { /* K3 */
+            reset_arena_scalars(ar);
+            reset_unit<A>(c, s, m, ar);
+            ep_ret = 0.0;
+        }
+        if (run != HH_RUN_ROLLOUT || any_reset) { /* state changed (or never published) */
+            publish(sh, tid, m);
+            __syncthreads();
+            pair_tables(sh, tid, base, s, active);
+            __syncthreads();
+        }
+        need_reset = false;
+        /* K2: observation rows staged in LDS, then written with unit-stride stores */
+        if (active && s < c.nA) lowlevel_obs<A, B>(c, sh, tid, base, s, c.agent_mode, m, &sh.u.obs[(g * c.nA + s) * D], D);
+        __syncthreads();
+        if (obs_out) {
+            const int rows = min(GPB, c.N - (int)blockIdx.x * GPB);
+            const int cnt = rows * c.nA * D;
+            float *dst = obs_out + ((size_t)t * c.N + (size_t)blockIdx.x * GPB) * c.nA * D;
+            if (run == HH_RUN_RESET && mask != nullptr) {
+                for (int k = tid; k < cnt; k += B) if (mask[blockIdx.x * GPB + k / (c.nA * D)]) dst[k] = sh.u.obs[k];
+            } else {
+                for (int k = tid; k < cnt; k += B) dst[k] = sh.u.obs[k];
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        unit_store(P, U, u, m);
+        if (s == 0) {
+            arena_store(P, n, ar);
+            P.ep_ret[n] = ep_ret;
+            if (run == HH_RUN_ROLLOUT) P.ev_mask[n] = 0;
+        }
+    }
+    if (run == HH_RUN_ROLLOUT) {
+        /* OR-reduce the per-lane event bits of the last tick into the arena word */
+        __syncthreads();
+        if (active && evm_last) atomicOr(&P.ev_mask[n], evm_last);
+    }
+}
+
+#endif /* HH_KERNELS_H */

@@ -209,6 +209,74 @@ HH_HD void hh_geo_direct(double lat1, double lon1, double azi1, double s12, doub
     *lat2 = hh_atan2d(sbet2, HH_GEO_F1 * cbet2);
 }
 
+
+/* ------------------------------------------------------------------ short-step Direct */
+/* Per-tick position updates move at most 1.03 km (2000 kn rocket): s/a <= 1.7e-4.  For such
+ * steps one classical Runge-Kutta step of the geodesic equations on the ellipsoid,
+ *     dphi/dt = cos(alp) W^3 / (1-e^2),  dlam/dt = sin(alp) W / cos(phi),
+ *     dalp/dt = sin(alp) tan(phi) W,     W = sqrt(1 - e^2 sin^2 phi),  t = s/a,
+ * has a local error ~ t^5 < 2e-19 rad — below double rounding — at a fraction of the cost of the
+ * general series solution: the stage values of sin/cos(phi), sin/cos(alp), W and 1/cos(phi) are
+ * obtained from the start values by angle addition / Taylor updates in the tiny stage offsets
+ * (<= 1.7e-4 rad), so the whole step needs 2 sincosd, 1 sqrt and 2 divisions.
+ * tests/test_geodesic.py pins it to hh_geo_direct (Karney) and to the mpmath ODE vectors at
+ * <= 2e-14 deg.  Outside its domain (s > 4 km or |lat| > 70) callers fall back to hh_geo_direct. */
+#define HH_GEO_SHORT_MAX_M 4000.0
+#define HH_GEO_SHORT_MAX_LAT 70.0
+
+HH_HD void hh_geo_rk_stage(double sp0, double cp0, double sa0, double ca0, double W20, double W0, double rc0, double tp0,
+                           double dphi, double dalp, double *kphi, double *klam, double *kalp) {
+    /* sin/cos of the small offsets */
+    double p2 = dphi * dphi, a2 = dalp * dalp;
+    double sdp = dphi * (1.0 - p2 * (1.0 / 6.0 - p2 * (1.0 / 120.0)));
+    double cdp = 1.0 - p2 * (0.5 - p2 * (1.0 / 24.0));
+    double sda = dalp * (1.0 - a2 * (1.0 / 6.0));
+    double cda = 1.0 - a2 * (0.5 - a2 * (1.0 / 24.0));
+    double sp = sp0 * cdp + cp0 * sdp;
+    double sa = sa0 * cda + ca0 * sda;
+    double ca = ca0 * cda - sa0 * sda;
+    /* 1/cos(phi0+dphi) = rc0 / (cdp - tan(phi0) sdp) = rc0 / (1 - eps), eps ~ 1e-5 */
+    double eps = (1.0 - cdp) + tp0 * sdp;
+    double rc = rc0 * (1.0 + eps * (1.0 + eps * (1.0 + eps * (1.0 + eps))));
+    /* W = W0 sqrt(1 + x), x = -e2 (sp^2 - sp0^2) / W0^2 ~ 2e-7 */
+    double x = -HH_GEO_E2 * ((sp - sp0) * (sp + sp0)) / W20;
+    double W = W0 * (1.0 + x * (0.5 - x * (0.125 - x * 0.0625)));
+    double W2 = W20 * (1.0 + x);
+    *kphi = ca * W * W2 * (1.0 / (1.0 - HH_GEO_E2));
+    double q = W * rc;
+    *klam = sa * q;
+    *kalp = sa * sp * q;
+}
+
+HH_HD void hh_geo_direct_short(double lat1, double lon1, double azi1, double s12, double *lat2, double *lon2) {
+    double sp0, cp0, sa0, ca0;
+    hh_sincosd(lat1, &sp0, &cp0);
+    hh_sincosd(azi1, &sa0, &ca0);
+    double h = s12 / HH_GEO_A;
+    double W20 = 1.0 - HH_GEO_E2 * sp0 * sp0;
+    double W0 = hh_sqrt(W20);
+    double rc0 = 1.0 / cp0;
+    double tp0 = sp0 * rc0;
+    double k1p, k1l, k1a, k2p, k2l, k2a, k3p, k3l, k3a, k4p, k4l, k4a;
+    hh_geo_rk_stage(sp0, cp0, sa0, ca0, W20, W0, rc0, tp0, 0.0, 0.0, &k1p, &k1l, &k1a);
+    double hh = 0.5 * h;
+    hh_geo_rk_stage(sp0, cp0, sa0, ca0, W20, W0, rc0, tp0, hh * k1p, hh * k1a, &k2p, &k2l, &k2a);
+    hh_geo_rk_stage(sp0, cp0, sa0, ca0, W20, W0, rc0, tp0, hh * k2p, hh * k2a, &k3p, &k3l, &k3a);
+    hh_geo_rk_stage(sp0, cp0, sa0, ca0, W20, W0, rc0, tp0, h * k3p, h * k3a, &k4p, &k4l, &k4a);
+    double dphi = (h / 6.0) * ((k1p + k4p) + 2.0 * (k2p + k3p));
+    double dlam = (h / 6.0) * ((k1l + k4l) + 2.0 * (k2l + k3l));
+    *lat2 = lat1 + dphi * HH_RAD2DEG;
+    *lon2 = lon1 + dlam * HH_RAD2DEG;
+}
+
+/* position update used by the simulator tick (cmano_simulator.py:65-72) */
+HH_HD void hh_geo_move(double lat1, double lon1, double azi1, double s12, double *lat2, double *lon2) {
+    if (s12 <= HH_GEO_SHORT_MAX_M && hh_fabs(lat1) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon1) < 170.0)
+        hh_geo_direct_short(lat1, lon1, azi1, s12, lat2, lon2);
+    else
+        hh_geo_direct(lat1, lon1, azi1, s12, lat2, lon2);
+}
+
 /* ------------------------------------------------------------------ Inverse */
 HH_HD void hh_geo_lengths(double eps, double sig12, double ssig1, double csig1, double dn1, double ssig2,
                           double csig2, double dn2, double *s12b, double *m12b) {

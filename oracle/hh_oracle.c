@@ -414,7 +414,7 @@ static void aircraft_update(const o_world *w, o_arena *a, int id, o_event *ev, i
         }
     }
     /* Unit.update, cmano_simulator.py:65-72 */
-    if (u->spd > 0.0) hh_geo_direct(u->lat, u->lon, u->hdg, u->spd * HH_KNOTS_TO_MS * 1.0, &u->lat, &u->lon);
+    if (u->spd > 0.0) hh_geo_move(u->lat, u->lon, u->hdg, u->spd * HH_KNOTS_TO_MS * 1.0, &u->lat, &u->lon);
 }
 
 /* rocket_unit.py:37-73 */
@@ -453,7 +453,7 @@ static void rocket_update(const o_world *w, o_arena *a, int slot, o_event *ev, i
         else r->hdg += delta >= 0.0 ? HH_ROCKET_TURN_RATE : -HH_ROCKET_TURN_RATE;
     }
     double spd = speed_table[r->life];
-    if (spd > 0.0) hh_geo_direct(r->lat, r->lon, r->hdg, spd * HH_KNOTS_TO_MS * 1.0, &r->lat, &r->lon);
+    if (spd > 0.0) hh_geo_move(r->lat, r->lon, r->hdg, spd * HH_KNOTS_TO_MS * 1.0, &r->lat, &r->lon);
     r->life++; /* sim.utc_time advances after the tick (cmano_simulator.py:146) */
 }
 
@@ -1084,6 +1084,9 @@ API void hho_math_eval(int fn, int n, const double *a, const double *b, double *
 }
 API void hho_geo_direct(int n, const double *lat, const double *lon, const double *azi, const double *s, double *lat2, double *lon2) {
     for (int i = 0; i < n; i++) hh_geo_direct(lat[i], lon[i], azi[i], s[i], &lat2[i], &lon2[i]);
+}
+API void hho_geo_move(int n, const double *lat, const double *lon, const double *azi, const double *s, double *lat2, double *lon2) {
+    for (int i = 0; i < n; i++) hh_geo_move(lat[i], lon[i], azi[i], s[i], &lat2[i], &lon2[i]);
 }
 API void hho_geo_inverse(int n, const double *lat1, const double *lon1, const double *lat2, const double *lon2, double *s12, double *azi1) {
     for (int i = 0; i < n; i++) hh_geo_inverse(lat1[i], lon1[i], lat2[i], lon2[i], &s12[i], &azi1[i]);

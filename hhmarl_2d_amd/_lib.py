@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libhh_world.so")
+LIB_PATH = os.environ.get("HH_WORLD_LIB") or os.path.join(HERE, "lib", "libhh_world.so")  # override only for A/B experiments
 
 ENV_LOWLEVEL, ENV_HIGHLEVEL = 0, 1
 MODE_FIGHT, MODE_ESCAPE = 0, 1

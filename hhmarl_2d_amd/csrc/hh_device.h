@@ -65,7 +65,10 @@ struct Unit {
 struct Arena {
     int steps, episode, escaping, escaping_time, done, next_seq;
     uint64_t akey;
+    uint64_t tkey; /* hh_rng_tick_key(akey, episode, steps), refreshed whenever steps/episode change */
 };
+
+__device__ __forceinline__ void arena_rekey(Arena &a) { a.tkey = hh_rng_tick_key(a.akey, (uint32_t)a.episode, (uint32_t)a.steps); }
 
 __device__ __forceinline__ void unit_load(const DevPtrs &P, size_t U, size_t u, Unit &m) {
     m.lat = P.lat[u]; m.lon = P.lon[u]; m.hdg = P.hdg[u]; m.spd = P.spd[u];
@@ -105,6 +108,7 @@ __device__ __forceinline__ void arena_load(const DevPtrs &P, const DevCfg &c, in
     a.escaping = p.z & 0xff; a.escaping_time = (int)(int8_t)((p.z >> 8) & 0xff); a.done = (p.z >> 16) & 0xff;
     a.next_seq = p.w;
     a.akey = hh_rng_arena_key(c.seed, c.arena_offset + (uint64_t)n);
+    arena_rekey(a);
 }
 
 __device__ __forceinline__ void arena_store(const DevPtrs &P, int n, const Arena &a) {
@@ -136,6 +140,26 @@ __device__ __forceinline__ void d_dist_bearing(double lat1, double lon1, double 
     brg = d_normalize_angle(azi1);
 }
 
+/* The exact envelope predicates (ac1.py:72-79,135-146, rocket_unit.py:39,49) on the Karney solution.
+ * Out of line: reached only for the ~1e-5 of tests the estimate filter cannot decide.
+ * kind 0 missile launch, 1 cannon cone, 2/3 rocket fuse; returns 1 inside the envelope. */
+__device__ __noinline__ int d_envelope_exact(int kind, int ac_type, double la1, double lo1, double la2, double lo2, double hdg) {
+    double km, brg;
+    d_dist_bearing(la1, lo1, la2, lo2, km, brg);
+    if (kind == 0) {
+        if (km <= HH_MISSILE_RANGE_KM) {
+            double delta = hh_fabs(d_signed_heading_diff(d_normalize_angle(hdg + HH_MISSILE_HALF_DEG), brg));
+            return (int)delta <= (int)HH_MISSILE_HALF_DEG;
+        }
+        return 0;
+    }
+    if (kind == 1) {
+        if (km < HH_AC_CANNON_KM(ac_type)) return hh_fabs(d_signed_heading_diff(hdg, brg)) <= HH_AC_CANNON_HALF(ac_type);
+        return 0;
+    }
+    return km < HH_ROCKET_FUSE_KM;
+}
+
 /* Exactness-preserving prefilter for "geodesic range < R km" tests.  Below 25 deg latitude one
  * degree of latitude or longitude is > 100 km on WGS84 (110.57 / >= 100.9 km), so a separation
  * of more than R/100 degrees along either axis proves range > R: the Inverse solve is skipped
@@ -163,7 +187,7 @@ __device__ __forceinline__ void d_geo_move(double lat1, double lon1, double azi1
 }
 
 __device__ __forceinline__ double d_rng(const Arena &a, int unit_id, int site, int sub) {
-    return hh_rng_u01(hh_rng_tick_key(a.akey, (uint32_t)a.episode, (uint32_t)a.steps), (uint32_t)unit_id, (uint32_t)site, (uint32_t)sub);
+    return hh_rng_u01(a.tkey, (uint32_t)unit_id, (uint32_t)site, (uint32_t)sub);
 }
 
 #endif /* HH_DEVICE_H */

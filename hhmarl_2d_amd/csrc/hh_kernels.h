@@ -89,6 +89,9 @@ __device__ __forceinline__ void publish(Shared<A, B> &sh, int tid, const Unit &m
 /* the per-arena pair table (call between two barriers, after publish) */
 template <int A, int B>
 __device__ __forceinline__ void pair_tables(Shared<A, B> &sh, int tid, int base, int s, bool active) {
+#ifdef HH_ABL_NO_PAIRS
+    return;
+#endif
     if (!active || !sh_alive(sh, tid)) return;
     const double c1 = sh.uc[tid], s1 = sh.us[tid], n1 = sh.un[tid];
     const double la = sh.lat0[tid], lo = sh.lon0[tid];
@@ -207,6 +210,7 @@ __device__ __forceinline__ void reset_arena_scalars(Arena &ar) {
     ar.escaping_time = 0;
     ar.next_seq = 0;
     ar.done = 0;
+    arena_rekey(ar);
 }
 
 /* ===================================================================== K2: observe */
@@ -318,7 +322,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     out.reward = 0.0;
     out.valid = 0;
     uint32_t evm = 0;
-    if (running) ar.steps += 1;
+    if (running) { ar.steps += 1; arena_rekey(ar); }
     const bool snap = running && m.alive; /* in do_tick's start-of-tick snapshot */
     double opp_stat0 = 0.0;
     int want_launch = 0, launch_tgt = 0; /* launch_tgt: slot index */
@@ -477,7 +481,9 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
             if (!m.rk_alive) m.has_missile = 0;
             else m.rk_cmd = hh_clip(m.rk_hdg * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
         }
+#ifndef HH_ABL_NO_MOVE
         if (m.spd > 0.0) d_geo_move(m.lat, m.lon, m.hdg, m.spd * HH_KNOTS_TO_MS * 1.0, m.lat, m.lon);
+#endif
     }
     sh.u.t.lat1[tid] = m.lat;
     sh.u.t.lon1[tid] = m.lon;
@@ -487,7 +493,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     sh.aux[tid] = snap ? 1 : 0;
     sh.res[tid] = 0;
     if (tid == 0) sh.u.t.q_count = 0;
-    if (s == 0 && active) sh.g_tkey[g] = hh_rng_tick_key(ar.akey, (uint32_t)ar.episode, (uint32_t)ar.steps);
+    if (s == 0 && active) sh.g_tkey[g] = ar.tkey;
     __syncthreads();
 
     /* ---------------- phase Q: enqueue every geodesic envelope test that survives the prefilter ---------------- */
@@ -543,9 +549,13 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     }
     __syncthreads();
 
-    /* ---------------- phase I: dense pass over the queue, ONE inlined Inverse (Karney) ---------------- */
+    /* ---------------- phase I: dense pass over the queue (estimate filter + out-of-line exact Karney) ---------------- */
     {
+#ifdef HH_ABL_NO_ENVELOPE
+        const int count = 0;
+#else
         const int count = sh.u.t.q_count;
+#endif
 #pragma unroll 1
         for (int q = tid; q < count; q += B) {
             int code = sh.u.t.q_code[q];
@@ -557,25 +567,47 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
             bool moved = kind >= 2 || (kind == 1 && j < ss);
             la2 = moved ? sh.u.t.lat1[sb + j] : sh.lat0[sb + j];
             lo2 = moved ? sh.u.t.lon1[sb + j] : sh.lon0[sb + j];
-            double km, brg;
-            d_dist_bearing(la1, lo1, la2, lo2, km, brg);
-            int bit = 0;
-            if (kind == 0) { /* ac1.py:72-79,144-146 missile envelope */
-                if (km <= HH_MISSILE_RANGE_KM) {
-                    double delta = hh_fabs(d_signed_heading_diff(d_normalize_angle(sh.hdg[src] + HH_MISSILE_HALF_DEG), brg));
-                    if ((int)delta <= (int)HH_MISSILE_HALF_DEG) bit = 1;
-                }
-            } else if (kind == 1) { /* ac1.py:106-115,135-142 cannon cone + Bernoulli hit */
-                int t = sh_type(sh, src);
-                if (km < HH_AC_CANNON_KM(t)) {
-                    double d = hh_fabs(d_signed_heading_diff(sh.u.t.hdg1[src], brg));
-                    if (d <= HH_AC_CANNON_HALF(t)) {
-                        double u = hh_rng_u01(sh.g_tkey[src / A], (uint32_t)(ss + 1), HH_SITE_CANNON, (uint32_t)(j + 1));
-                        if (u < HH_AC_HIT_PROB(t)) bit = 2 << j;
+            /* filtered exact predicate: decide from the mid-latitude estimate when it is farther from every
+             * threshold than its proven error bound; otherwise redo the test with the Karney solution */
+            const int t = sh_type(sh, src);
+            const double hdg_src = kind == 0 ? sh.hdg[src] : sh.u.t.hdg1[src];
+            const double sep = hh_max(hh_fabs(la2 - la1), hh_fabs(lo2 - lo1));
+            const bool dom = hh_fabs(la1) <= HH_GEO_EST_MAX_LAT && hh_fabs(la2) <= HH_GEO_EST_MAX_LAT &&
+                             hh_fabs(lo1) < 170.0 && hh_fabs(lo2) < 170.0;
+            int verdict = -1; /* -1 undecided, 0 outside the envelope, 1 inside */
+            if (dom && sep <= (kind == 0 ? HH_GEO_EST_LONG_DEG : HH_GEO_EST_SHORT_DEG)) {
+                double s_m, az;
+                hh_geo_inverse_estimate(la1, lo1, la2, lo2, &s_m, &az);
+                if (kind == 0) {
+                    double delta = hh_fabs(d_signed_heading_diff(d_normalize_angle(hdg_src + HH_MISSILE_HALF_DEG), az));
+                    if (s_m >= HH_MISSILE_RANGE_KM * 1000.0 + HH_GEO_EST_LONG_ABS_M) verdict = 0;
+                    else if (s_m <= HH_MISSILE_RANGE_KM * 1000.0 - HH_GEO_EST_LONG_ABS_M && s_m > HH_GEO_EST_MIN_M &&
+                             hh_fabs(delta - (HH_MISSILE_HALF_DEG + 1.0)) > HH_GEO_EST_LONG_AZI)
+                        verdict = delta < HH_MISSILE_HALF_DEG + 1.0; /* int(delta) <= 60 */
+                } else {
+                    const double r_m = (kind == 1 ? HH_AC_CANNON_KM(t) : HH_ROCKET_FUSE_KM) * 1000.0;
+                    const double eps = HH_GEO_EST_SHORT_REL * s_m + HH_GEO_EST_SHORT_ABS_M;
+                    if (s_m >= r_m + eps) verdict = 0;
+                    else if (s_m < r_m - eps && s_m > HH_GEO_EST_MIN_M) {
+                        if (kind >= 2) verdict = 1;
+                        else {
+                            double d = hh_fabs(d_signed_heading_diff(hdg_src, az));
+                            if (d <= HH_AC_CANNON_HALF(t) - HH_GEO_EST_SHORT_AZI) verdict = 1;
+                            else if (d > HH_AC_CANNON_HALF(t) + HH_GEO_EST_SHORT_AZI) verdict = 0;
+                        }
                     }
                 }
-            } else { /* rocket_unit.py:39,49 proximity fuse */
-                if (km < HH_ROCKET_FUSE_KM) bit = kind == 2 ? (1 << 9) : (1 << 10);
+            }
+#ifndef HH_ABL_NO_EXACT
+            if (verdict < 0) verdict = d_envelope_exact(kind, t, la1, lo1, la2, lo2, hdg_src);
+#endif
+            int bit = 0;
+            if (verdict) {
+                if (kind == 0) bit = 1;
+                else if (kind == 1) { /* ac1.py:112-113 Bernoulli hit, drawn only when in the cone */
+                    double u = hh_rng_u01(sh.g_tkey[src / A], (uint32_t)(ss + 1), HH_SITE_CANNON, (uint32_t)(j + 1));
+                    if (u < HH_AC_HIT_PROB(t)) bit = 2 << j;
+                } else bit = kind == 2 ? (1 << 9) : (1 << 10);
             }
             if (bit) atomicOr(&sh.res[src], bit);
         }
@@ -872,7 +904,9 @@ __global__ __launch_bounds__(B) void hh_k_world(DevPtrs P, DevCfg c, int run, in
         }
         need_reset = false;
         /* K2: observation rows staged in LDS, then written with unit-stride stores */
+#ifndef HH_ABL_NO_OBS
         if (active && s < c.nA) lowlevel_obs<A, B>(c, sh, tid, base, s, c.agent_mode, m, &sh.u.obs[(g * c.nA + s) * D], D);
+#endif
         __syncthreads();
         if (obs_out) {
             const int rows = min(GPB, c.N - (int)blockIdx.x * GPB);

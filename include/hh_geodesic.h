@@ -218,13 +218,13 @@ HH_HD void hh_geo_direct(double lat1, double lon1, double azi1, double s12, doub
  * has a local error ~ t^5 < 2e-19 rad — below double rounding — at a fraction of the cost of the
  * general series solution: the stage values of sin/cos(phi), sin/cos(alp), W and 1/cos(phi) are
  * obtained from the start values by angle addition / Taylor updates in the tiny stage offsets
- * (<= 1.7e-4 rad), so the whole step needs 2 sincosd, 1 sqrt and 2 divisions.
+ * (<= 1.7e-4 rad), so the whole step needs 2 sincosd, 1 sqrt and 4 divisions.
  * tests/test_geodesic.py pins it to hh_geo_direct (Karney) and to the mpmath ODE vectors at
  * <= 2e-14 deg.  Outside its domain (s > 4 km or |lat| > 70) callers fall back to hh_geo_direct. */
 #define HH_GEO_SHORT_MAX_M 4000.0
 #define HH_GEO_SHORT_MAX_LAT 70.0
 
-HH_HD void hh_geo_rk_stage(double sp0, double cp0, double sa0, double ca0, double W20, double W0, double rc0, double tp0,
+HH_HD void hh_geo_rk_stage(double sp0, double cp0, double sa0, double ca0, double W20, double rW20, double W0, double rc0, double tp0,
                            double dphi, double dalp, double *kphi, double *klam, double *kalp) {
     /* sin/cos of the small offsets */
     double p2 = dphi * dphi, a2 = dalp * dalp;
@@ -239,7 +239,7 @@ HH_HD void hh_geo_rk_stage(double sp0, double cp0, double sa0, double ca0, doubl
     double eps = (1.0 - cdp) + tp0 * sdp;
     double rc = rc0 * (1.0 + eps * (1.0 + eps * (1.0 + eps * (1.0 + eps))));
     /* W = W0 sqrt(1 + x), x = -e2 (sp^2 - sp0^2) / W0^2 ~ 2e-7 */
-    double x = -HH_GEO_E2 * ((sp - sp0) * (sp + sp0)) / W20;
+    double x = -HH_GEO_E2 * ((sp - sp0) * (sp + sp0)) * rW20;
     double W = W0 * (1.0 + x * (0.5 - x * (0.125 - x * 0.0625)));
     double W2 = W20 * (1.0 + x);
     *kphi = ca * W * W2 * (1.0 / (1.0 - HH_GEO_E2));
@@ -256,15 +256,17 @@ HH_HD void hh_geo_direct_short(double lat1, double lon1, double azi1, double s12
     double W20 = 1.0 - HH_GEO_E2 * sp0 * sp0;
     double W0 = hh_sqrt(W20);
     double rc0 = 1.0 / cp0;
+    double rW20 = 1.0 / W20;
     double tp0 = sp0 * rc0;
     double k1p, k1l, k1a, k2p, k2l, k2a, k3p, k3l, k3a, k4p, k4l, k4a;
-    hh_geo_rk_stage(sp0, cp0, sa0, ca0, W20, W0, rc0, tp0, 0.0, 0.0, &k1p, &k1l, &k1a);
+    hh_geo_rk_stage(sp0, cp0, sa0, ca0, W20, rW20, W0, rc0, tp0, 0.0, 0.0, &k1p, &k1l, &k1a);
     double hh = 0.5 * h;
-    hh_geo_rk_stage(sp0, cp0, sa0, ca0, W20, W0, rc0, tp0, hh * k1p, hh * k1a, &k2p, &k2l, &k2a);
-    hh_geo_rk_stage(sp0, cp0, sa0, ca0, W20, W0, rc0, tp0, hh * k2p, hh * k2a, &k3p, &k3l, &k3a);
-    hh_geo_rk_stage(sp0, cp0, sa0, ca0, W20, W0, rc0, tp0, h * k3p, h * k3a, &k4p, &k4l, &k4a);
-    double dphi = (h / 6.0) * ((k1p + k4p) + 2.0 * (k2p + k3p));
-    double dlam = (h / 6.0) * ((k1l + k4l) + 2.0 * (k2l + k3l));
+    hh_geo_rk_stage(sp0, cp0, sa0, ca0, W20, rW20, W0, rc0, tp0, hh * k1p, hh * k1a, &k2p, &k2l, &k2a);
+    hh_geo_rk_stage(sp0, cp0, sa0, ca0, W20, rW20, W0, rc0, tp0, hh * k2p, hh * k2a, &k3p, &k3l, &k3a);
+    hh_geo_rk_stage(sp0, cp0, sa0, ca0, W20, rW20, W0, rc0, tp0, h * k3p, h * k3a, &k4p, &k4l, &k4a);
+    double h6 = h / 6.0;
+    double dphi = h6 * ((k1p + k4p) + 2.0 * (k2p + k3p));
+    double dlam = h6 * ((k1l + k4l) + 2.0 * (k2l + k3l));
     *lat2 = lat1 + dphi * HH_RAD2DEG;
     *lon2 = lon1 + dlam * HH_RAD2DEG;
 }
@@ -275,6 +277,47 @@ HH_HD void hh_geo_move(double lat1, double lon1, double azi1, double s12, double
         hh_geo_direct_short(lat1, lon1, azi1, s12, lat2, lon2);
     else
         hh_geo_direct(lat1, lon1, azi1, s12, lat2, lon2);
+}
+
+
+/* ------------------------------------------------------------------ filter estimate for Inverse */
+/* Mid-latitude (Gauss) estimate of range and initial bearing:
+ *     x = N(phi_m) cos(phi_m) dlam,  y = M(phi_m) dphi,  s ~ hypot(x, y),
+ *     azi1 ~ atan2(x, y) - dlam sin(phi_m) / 2          (half the meridian convergence).
+ * It is NOT used for results.  The kernels use it as the cheap stage of a filtered exact predicate:
+ * a weapon-envelope test (range < R, |bearing - heading| <= w) is decided from the estimate only
+ * when the estimate is farther from the threshold than the error bound below; otherwise the
+ * test is redone with hh_geo_inverse.  Either way the mask bit equals the exact predicate.
+ * Error bounds (tests/test_geodesic.py measures them against hh_geo_inverse over the domain
+ * |lat| <= 10 deg and asserts a >= 10x margin to the bounds used here):
+ *     |dlat|,|dlon| <= 0.06 deg (<= 9.4 km), s > 1 m:  |ds| <= 2.3e-4 m, |dazi| <= 3.9e-6 deg -> bounds 1e-6*s + 1e-3 m, 1e-4 deg
+ *     |dlat|,|dlon| <= 0.85 deg (<= 133 km):           |ds| <= 0.65 m,   |dazi| <= 7.8e-4 deg -> bounds 10 m, 1e-2 deg
+ * Separations below 1 m are always treated as undecided (the bearing of a near-zero vector). */
+#define HH_GEO_EST_MAX_LAT 10.0
+#define HH_GEO_EST_SHORT_DEG 0.06
+#define HH_GEO_EST_LONG_DEG 0.85
+#define HH_GEO_EST_SHORT_REL 1e-6
+#define HH_GEO_EST_SHORT_ABS_M 1e-3
+#define HH_GEO_EST_SHORT_AZI 1e-4
+#define HH_GEO_EST_LONG_ABS_M 10.0
+#define HH_GEO_EST_LONG_AZI 1e-2
+#define HH_GEO_EST_MIN_M 1.0
+
+HH_HD void hh_geo_inverse_estimate(double lat1, double lon1, double lat2, double lon2, double *s12, double *azi1) {
+    double pm = (0.5 * (lat1 + lat2)) * HH_DEG2RAD;
+    double dp = (lat2 - lat1) * HH_DEG2RAD, dl = (lon2 - lon1) * HH_DEG2RAD;
+    double sm, cm;
+    hh_sincos(pm, &sm, &cm);
+    double W2 = 1.0 - HH_GEO_E2 * sm * sm;
+    double W = hh_sqrt(W2);
+    double N = HH_GEO_A / W;
+    double M = N * (1.0 - HH_GEO_E2) / W2;
+    double x = N * cm * dl, y = M * dp;
+    *s12 = hh_sqrt(x * x + y * y);
+    double a = (hh_atan2(x, y) - 0.5 * dl * sm) * HH_RAD2DEG;
+    if (a < 0.0) a += 360.0;
+    if (a >= 360.0) a -= 360.0;
+    *azi1 = a; /* [0, 360) */
 }
 
 /* ------------------------------------------------------------------ Inverse */

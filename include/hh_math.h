@@ -143,30 +143,24 @@ HH_HD double hh_atan_pos(double x) /* x >= 0 */ {
                  aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02,
                  aT8 = 4.97687799461593236017e-02, aT9 = -3.65315727442169155270e-02,
                  aT10 = 1.62858201153657823623e-02;
-    double hi, lo, t;
-    int id;
     if (x > 1e300) return 1.57079632679489655800e+00 + 6.12323399573676603587e-17;
-    if (x < 0.4375) {
-        id = -1; t = x; hi = 0.0; lo = 0.0;
-    } else if (x < 0.6875) {
-        id = 0; t = (2.0 * x - 1.0) / (2.0 + x);
-        hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17;
-    } else if (x < 1.1875) {
-        id = 1; t = (x - 1.0) / (x + 1.0);
-        hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17;
-    } else if (x < 2.4375) {
-        id = 2; t = (x - 1.5) / (1.0 + 1.5 * x);
-        hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17;
-    } else {
-        id = 3; t = -1.0 / x;
-        hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17;
-    }
+    /* argument reduction t = num/den on five intervals; written with selects and a single
+     * division so that a 64-lane wave does not serialise five divergent paths */
+    double num, den, hi, lo;
+    int low = x < 0.4375;
+    if (x < 0.6875) { num = 2.0 * x - 1.0; den = 2.0 + x; hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; }
+    else if (x < 1.1875) { num = x - 1.0; den = x + 1.0; hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; }
+    else if (x < 2.4375) { num = x - 1.5; den = 1.0 + 1.5 * x; hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; }
+    else { num = -1.0; den = x; hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; }
+    if (low) { num = x; den = 1.0; } /* x / 1 is exact: t = x */
+    double t = num / den;
     double z = t * t;
     double w = z * z;
     double s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
     double s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
-    if (id < 0) return t - t * (s1 + s2);
-    return hi - ((t * (s1 + s2) - lo) - t);
+    double r_low = t - t * (s1 + s2);
+    double r_hi = hi - ((t * (s1 + s2) - lo) - t);
+    return low ? r_low : r_hi;
 }
 
 HH_HD double hh_atan2(double y, double x) {
@@ -199,26 +193,25 @@ HH_HD double hh_acos(double x) /* |x| <= 1 */ {
     const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
     double ax = hh_fabs(x);
     if (ax >= 1.0) return x > 0.0 ? 0.0 : HH_PI + 2.0 * PIO2_LO;
-    if (ax < 0.5) {
-        if (ax < 0x1p-57) return PIO2_HI + PIO2_LO;
-        return PIO2_HI - (x - (PIO2_LO - x * hh_acos_R(x * x)));
-    }
-    if (x < 0.0) {
-        double z = (1.0 + x) * 0.5;
-        double s = hh_sqrt(z);
-        double w = hh_acos_R(z) * s - PIO2_LO;
-        return HH_PI - 2.0 * (s + w);
-    }
-    double z = (1.0 - x) * 0.5;
+    /* the three classic ranges (|x| < 0.5, x <= -0.5, x >= 0.5) share one evaluation of the rational
+     * R and one square root; only the final assembly differs, so lanes of a wave do not diverge */
+    int small = ax < 0.5;
+    double z = small ? x * x : (1.0 - ax) * 0.5;
+    double r = hh_acos_R(z);
     double s = hh_sqrt(z);
-    /* df = s with the low 32 bits cleared */
+    /* |x| < 0.5 */
+    double res_small = PIO2_HI - (x - (PIO2_LO - x * r));
+    if (ax < 0x1p-57) res_small = PIO2_HI + PIO2_LO;
+    /* x <= -0.5 */
+    double res_neg = HH_PI - 2.0 * (s + (r * s - PIO2_LO));
+    /* x >= 0.5: df = s with the low 32 bits cleared */
     union { double d; uint64_t u; } cv;
     cv.d = s;
     cv.u &= 0xffffffff00000000ULL;
     double df = cv.d;
     double c = (z - df * df) / (s + df);
-    double w = hh_acos_R(z) * s + c;
-    return 2.0 * (df + w);
+    double res_pos = 2.0 * (df + (r * s + c));
+    return small ? res_small : (x < 0.0 ? res_neg : res_pos);
 }
 
 /* ---- degree helpers used by the geodesic layer (Karney 2013, Sec. 6 implementation notes:

@@ -1088,6 +1088,9 @@ API void hho_geo_direct(int n, const double *lat, const double *lon, const doubl
 API void hho_geo_move(int n, const double *lat, const double *lon, const double *azi, const double *s, double *lat2, double *lon2) {
     for (int i = 0; i < n; i++) hh_geo_move(lat[i], lon[i], azi[i], s[i], &lat2[i], &lon2[i]);
 }
+API void hho_geo_inverse_estimate(int n, const double *lat1, const double *lon1, const double *lat2, const double *lon2, double *s12, double *azi1) {
+    for (int i = 0; i < n; i++) hh_geo_inverse_estimate(lat1[i], lon1[i], lat2[i], lon2[i], &s12[i], &azi1[i]);
+}
 API void hho_geo_inverse(int n, const double *lat1, const double *lon1, const double *lat2, const double *lon2, double *s12, double *azi1) {
     for (int i = 0; i < n; i++) hh_geo_inverse(lat1[i], lon1[i], lat2[i], lon2[i], &s12[i], &azi1[i]);
 }

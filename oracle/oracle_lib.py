@@ -216,3 +216,12 @@ def geo_inverse(lat1, lon1, lat2, lon2):
     D = C.c_double
     lib().hho_geo_inverse(len(o0), *[_ptr(x, D) for x in arrs], _ptr(o0, D), _ptr(o1, D))
     return o0, o1
+
+
+def geo_inverse_estimate(lat1, lon1, lat2, lon2):
+    arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (lat1, lon1, lat2, lon2)]
+    o0 = np.empty_like(arrs[0])
+    o1 = np.empty_like(arrs[0])
+    D = C.c_double
+    lib().hho_geo_inverse_estimate(len(o0), *[_ptr(x, D) for x in arrs], _ptr(o0, D), _ptr(o1, D))
+    return o0, o1

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 sqlite outputs (rocpd) into text: per-kernel duration stats and, when
-present, per-kernel PMC counter averages.  Usage: rocpd_summary.py <results.db> [...]"""
+present, per-kernel PMC counter averages.
+Usage: rocpd_summary.py [--kernel SUBSTR] [--min-us X] <results.db> [...]
+--min-us drops short dispatches (e.g. the reset launch) from duration and counter averages."""
 import sqlite3
 import sys
 
@@ -10,32 +12,37 @@ def cols(db, t):
 
 
 def main():
-    for path in sys.argv[1:]:
+    args = sys.argv[1:]
+    filt, min_us = None, 0.0
+    while args and args[0].startswith("--"):
+        if args[0] == "--kernel":
+            filt = args[1]
+        elif args[0] == "--min-us":
+            min_us = float(args[1])
+        args = args[2:]
+    for path in args:
         db = sqlite3.connect(path)
-        print(f"== {path}")
-        kc = cols(db, "kernels")
-        name = "name" if "name" in kc else kc[0]
-        q = (f"select {name}, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start) from kernels "
-             f"group by {name} order by sum(end-start) desc")
-        print(f"{'kernel':60s} {'calls':>7s} {'avg_us':>12s} {'min_us':>12s} {'max_us':>12s} {'total_ms':>12s}")
+        print(f"== {path.split('gpurun_out/')[-1]}")
+        q = ("select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start) from kernels "
+             f"where (end-start) >= {min_us * 1e3} group by name order by sum(end-start) desc")
+        print(f"{'kernel':56s} {'calls':>6s} {'avg_us':>11s} {'min_us':>11s} {'max_us':>11s} {'total_ms':>10s}")
         for n, c, a, mn, mx, s in db.execute(q):
-            print(f"{str(n)[:60]:60s} {c:7d} {a/1e3:12.2f} {mn/1e3:12.2f} {mx/1e3:12.2f} {s/1e6:12.3f}")
-        try:
-            pc = cols(db, "counters_collection")
-            if pc:
-                kn = "kernel_name" if "kernel_name" in pc else ("name" if "name" in pc else None)
-                cn = "counter_name" if "counter_name" in pc else None
-                vn = "value" if "value" in pc else ("counter_value" if "counter_value" in pc else None)
-                if kn and cn and vn:
-                    rows = list(db.execute(f"select {kn}, {cn}, count(*), avg({vn}), sum({vn}) from counters_collection group by {kn}, {cn}"))
-                    if rows:
-                        print(f"{'kernel':44s} {'counter':24s} {'dispatches':>10s} {'avg/dispatch':>18s}")
-                        for k, cname, n, a, s in rows:
-                            print(f"{str(k)[:44]:44s} {cname:24s} {n:10d} {a:18.1f}")
-                else:
-                    print("counters_collection columns:", pc)
-        except sqlite3.Error as e:
-            print("pmc query failed:", e)
+            if filt and filt not in str(n):
+                continue
+            print(f"{str(n)[:56]:56s} {c:6d} {a/1e3:11.2f} {mn/1e3:11.2f} {mx/1e3:11.2f} {s/1e6:10.3f}")
+        pc = cols(db, "counters_collection")
+        if pc and "counter_name" in pc:
+            dur = "(end-start)" if "end" in pc and "start" in pc else None
+            where = f"where {dur} >= {min_us * 1e3}" if dur and min_us else ""
+            try:
+                rows = list(db.execute(f"select kernel_name, counter_name, count(*), avg(value), max(value) from counters_collection {where} group by kernel_name, counter_name"))
+            except sqlite3.Error:
+                rows = list(db.execute("select kernel_name, counter_name, count(*), avg(value), max(value) from counters_collection group by kernel_name, counter_name"))
+            rows = [r for r in rows if not filt or filt in str(r[0])]
+            if rows:
+                print(f"{'kernel':40s} {'counter':22s} {'dispatches':>10s} {'avg/dispatch':>18s} {'max/dispatch':>18s}")
+                for k, cname, n, a, mx in rows:
+                    print(f"{str(k)[:40]:40s} {cname:22s} {n:10d} {a:18.1f} {mx:18.1f}")
 
 
 if __name__ == "__main__":

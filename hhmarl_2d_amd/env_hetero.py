@@ -1,0 +1,135 @@
+"""Drop-in for envs/env_hetero.py LowLevelEnv (reference boundary: envs/env_hetero.py:20-63,
+envs/env_base.py:62-109) on top of the MI355X world.
+
+Same constructor (`LowLevelEnv(env_config)` with env_config["args"] = the reference's argparse
+Namespace), same attributes (observation_space, action_space, _agent_ids, the *_preferred_format
+flags, _skip_env_checking), same `reset(*, seed=None, options=None) -> (obs, {})` and
+`step(action_dict) -> (obs, rewards, terminateds, truncateds, infos)` dict protocol:
+obs has every agent id (zeros when dead), rewards only the ids alive at step start,
+`terminateds is truncateds == {"__all__": done}`.
+
+Extra keys of env_config (all optional, none changes the reference semantics):
+  num_envs   number of arenas held on the GPU (default 1).  With num_envs > 1 the dict values
+             carry a leading arena axis; RLlib-style single-env callers leave it at 1.
+  seed       keyed-RNG seed (the reference is unseeded: env_base.py:62-77 ignores `seed`)
+  device     GPU index
+The batched tensor API for native rollout drivers is `self.world` (hhmarl_2d_amd.world.World).
+"""
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import spaces
+from .world import World, make_config
+
+ACTION_DIM_AC1, ACTION_DIM_AC2 = 4, 3
+OBS_AC1, OBS_AC2, OBS_ESC_AC1, OBS_ESC_AC2 = 26, 24, 30, 29
+
+try:  # subclass RLlib's base class only when ray is importable (it is not in the build image)
+    from ray.rllib.env.multi_agent_env import MultiAgentEnv as _Base  # pragma: no cover
+except Exception:  # noqa: BLE001
+    class _Base:
+        def __init__(self):
+            pass
+
+
+def config_from_args(args, env_kind, num_envs, seed, auto_reset=False, arena_offset=0):
+    return make_config(
+        n_arenas=num_envs, env_kind=env_kind, level=args.level,
+        agent_mode=L.MODE_FIGHT if args.agent_mode == "fight" else L.MODE_ESCAPE,
+        n_agents=args.num_agents, n_opps=args.num_opps, horizon=args.horizon,
+        friendly_kill=args.friendly_kill, friendly_punish=args.friendly_punish, esc_dist_rew=args.esc_dist_rew,
+        hier_action_assess=getattr(args, "hier_action_assess", True),
+        hier_opp_fight_ratio=getattr(args, "hier_opp_fight_ratio", 75), auto_reset=auto_reset,
+        ext_opp_actions=(env_kind == L.ENV_LOWLEVEL and args.level >= 4), map_size=args.map_size,
+        glob_frac=args.glob_frac, rew_scale=float(args.rew_scale), seed=seed, arena_offset=arena_offset)
+
+
+class LowLevelEnv(_Base):
+    """Low-Level Environment for Aircombat Maneuvering (2-vs-2), MI355X-resident."""
+
+    def __init__(self, env_config):
+        self.args = env_config.get("args", None)
+        self.agent_mode = self.args.agent_mode
+        self.obs_fight = {1: OBS_AC1, 2: OBS_AC2, 3: OBS_AC1, 4: OBS_AC2}
+        self.obs_esc = {1: OBS_ESC_AC1, 2: OBS_ESC_AC2, 3: OBS_ESC_AC1, 4: OBS_ESC_AC2}
+        self.obs_dim_map = self.obs_fight if self.agent_mode == "fight" else self.obs_esc
+        self._obs_space_in_preferred_format = True
+        self.observation_space = spaces.Dict({
+            i: spaces.Box(low=np.zeros(self.obs_dim_map[i]), high=np.ones(self.obs_dim_map[i]), dtype=np.float32)
+            for i in range(1, 5)})
+        self._action_space_in_preferred_format = True
+        self.action_space = spaces.Dict({
+            1: spaces.MultiDiscrete([13, 9, 2, 2]), 2: spaces.MultiDiscrete([13, 9, 2]),
+            3: spaces.MultiDiscrete([13, 9, 2, 2]), 4: spaces.MultiDiscrete([13, 9, 2])})
+        self._agent_ids = set(range(1, self.args.num_agents + 1))
+        self._skip_env_checking = True
+        self.map_size = self.args.map_size
+        self.num_envs = int(env_config.get("num_envs", 1))
+        self.opponent_policy = env_config.get("opponent_policy", None)
+        if self.args.level >= 4 and self.opponent_policy is None:
+            raise ValueError("levels 4-5 fly frozen opponent policies (envs/env_base.py:312-398); pass "
+                             "env_config['opponent_policy'] = callable(world) -> int8 actions [N, 2, 4] for units 3,4")
+        cfg = config_from_args(self.args, L.ENV_LOWLEVEL, self.num_envs, int(env_config.get("seed", 0)))
+        self.world = World(cfg, device=int(env_config.get("device", 0)))
+        self._act = torch.zeros((self.num_envs, self.world.n_ctrl, 4), dtype=torch.int8, device=self.world.device)
+        self._act_host = np.zeros((self.num_envs, self.world.n_ctrl, 4), dtype=np.int8)
+        self._out = self.world.alloc_outputs()
+        self.steps = 0
+        self.rewards = {}
+        super().__init__()
+
+    # -- helpers
+    def _obs_dict(self, obs):
+        o = obs.cpu().numpy()
+        if self.num_envs == 1:
+            return {i: o[0, i - 1, : self.obs_dim_map[i]].copy() for i in sorted(self._agent_ids)}
+        return {i: o[:, i - 1, : self.obs_dim_map[i]].copy() for i in sorted(self._agent_ids)}
+
+    def reset(self, *, seed=None, options=None):
+        self.steps = 0
+        obs = self.world.reset()
+        return self._obs_dict(obs), {}
+
+    def state(self):
+        return self._obs_dict(self.world.observe())
+
+    def step(self, action):
+        self.rewards = {}
+        n_ag = self.args.num_agents
+        if action:
+            a = self._act_host
+            a[:] = 0
+            for k, v in action.items():
+                v = np.asarray(v)
+                if self.num_envs == 1:
+                    a[0, k - 1, : v.shape[-1]] = v
+                else:
+                    a[:, k - 1, : v.shape[-1]] = v
+            self._act.copy_(torch.from_numpy(a))
+            if self.opponent_policy is not None:
+                self._act[:, n_ag:] = self.opponent_policy(self.world)
+            obs, rew, val, done = self.world.step(self._act, out=self._out)
+            self.steps += 1
+            rew, val, done = rew.cpu().numpy(), val.cpu().numpy(), done.cpu().numpy()
+            if self.num_envs == 1:
+                self.rewards = {i: float(rew[0, i - 1]) for i in range(1, n_ag + 1) if val[0, i - 1]}
+                d = bool(done[0])
+            else:
+                self.rewards = {i: np.where(val[:, i - 1] > 0, rew[:, i - 1], 0.0) for i in range(1, n_ag + 1)}
+                d = done.astype(bool)
+            obs_d = self._obs_dict(obs)
+        else:  # the reference skips _take_action for an empty action dict (env_base.py:87-88)
+            obs_d = self.state()
+            st = self.world.get_state()["ar_i"]
+            dn = (st[:, 1] <= 0) | (st[:, 2] <= 0) | (st[:, 0] >= self.args.horizon)
+            d = bool(dn[0]) if self.num_envs == 1 else dn
+        terminateds = truncateds = {"__all__": d}
+        return obs_d, self.rewards, terminateds, truncateds, {}
+
+    def plot(self, out_file=None, paths=True):
+        """rendering (warsim/scenplotter) is out of scope for the GPU path"""
+        return None
+
+    def close(self):
+        self.world.close()

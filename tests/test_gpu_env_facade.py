@@ -1,0 +1,75 @@
+"""The drop-in boundary: hhmarl_2d_amd.env_hetero.LowLevelEnv driven exactly like RLlib drives the
+reference's LowLevelEnv (dict in / dict out), checked against the golden traces recorded from the
+reference: same keys, same shapes/dtypes, same values."""
+import numpy as np
+import pytest
+
+from helpers import golden_files, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _env_from_meta(meta, **extra):
+    from hhmarl_2d_amd.config import make_args
+    from hhmarl_2d_amd.env_hetero import LowLevelEnv
+    a = meta["args"]
+    args = make_args(0, **{k: a[k] for k in ("level", "agent_mode", "horizon", "map_size", "glob_frac", "rew_scale",
+                                              "esc_dist_rew", "friendly_kill", "friendly_punish")})
+    cfg = {"args": args, "seed": meta["seed"]}
+    cfg.update(extra)
+    env = LowLevelEnv(cfg)
+    return env, args
+
+
+@pytest.mark.parametrize("path", golden_files()[:4], ids=lambda p: p.split("env_")[-1][:-4])
+def test_dict_protocol_matches_reference_trace(path):
+    g, meta = load_golden(path)
+    # the facade numbers arenas from 0; the trace was recorded for global arena id meta["arena"]
+    from hhmarl_2d_amd import env_hetero
+    orig = env_hetero.config_from_args
+    env_hetero.config_from_args = lambda *a, **k: orig(*a, **{**k, "arena_offset": meta["arena"]})
+    try:
+        env, args = _env_from_meta(meta)
+    finally:
+        env_hetero.config_from_args = orig
+    dims = env.obs_dim_map
+    assert env._agent_ids == {1, 2} and env._skip_env_checking
+    assert env.observation_space[1].shape == (dims[1],) and env.action_space[2].nvec.tolist() == [13, 9, 2]
+    for r in range(len(g["kind"])):
+        if g["kind"][r] == 0:
+            obs, info = env.reset()
+            assert info == {}
+        else:
+            act = {1: g["actions"][r][0, :4].tolist(), 2: g["actions"][r][1, :3].tolist()}
+            obs, rew, term, trunc, info = env.step(act)
+            assert term is trunc and set(term) == {"__all__"} and info == {}
+            assert term["__all__"] == bool(g["done"][r])
+            assert set(rew) == {i + 1 for i in range(2) if g["valid"][r][i]}
+            for i in rew:
+                assert abs(rew[i] - g["reward"][r][i - 1]) <= 1e-6 * max(1.0, abs(g["reward"][r][i - 1]))
+        assert set(obs) == {1, 2}
+        for i in (1, 2):
+            assert obs[i].dtype == np.float32 and obs[i].shape == (dims[i],)
+            assert np.abs(obs[i] - g["obs"][r][i - 1, : dims[i]]).max() <= 1e-6
+    env.close()
+
+
+def test_vector_facade_and_empty_action():
+    from hhmarl_2d_amd.config import make_args
+    from hhmarl_2d_amd.env_hetero import LowLevelEnv
+    env = LowLevelEnv({"args": make_args(0, level=3), "num_envs": 32, "seed": 9})
+    obs, _ = env.reset()
+    assert obs[1].shape == (32, 26) and obs[2].shape == (32, 24)
+    o2, rew, term, trunc, _ = env.step({})
+    assert rew == {} and np.array_equal(o2[1], obs[1]) and not term["__all__"].any()
+    act = {1: np.tile([6, 4, 1, 1], (32, 1)), 2: np.tile([6, 4, 1], (32, 1))}
+    o3, rew, term, _, _ = env.step(act)
+    assert o3[1].shape == (32, 26) and rew[1].shape == (32,)
+    env.close()
+
+
+def test_level4_requires_opponent_policy():
+    from hhmarl_2d_amd.config import make_args
+    from hhmarl_2d_amd.env_hetero import LowLevelEnv
+    with pytest.raises(ValueError):
+        LowLevelEnv({"args": make_args(0, level=4)})

@@ -1,0 +1,83 @@
+"""Multi-GPU path on CPU: arena sharding is bit-invariant (a 2-rank sharded run equals one big
+world) and the logging all-gather returns the per-arena statistics in global arena order.
+Runs world_size-2 `gloo` process groups; the per-rank world is backed by the CPU oracle through
+ShardedWorld's world_factory hook (tests may use the oracle; the product path never does)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import random_actions
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _OracleBackedWorld:
+    """adapter: the World call surface on top of oracle_lib.OracleWorld with torch tensors"""
+
+    def __init__(self, kw):
+        import oracle_lib as O
+        self.o = O.OracleWorld(O.make_config(**kw))
+        self.N, self.n_ctrl = self.o.N, self.o.n_ctrl
+
+    def reset(self):
+        return torch.from_numpy(self.o.reset())
+
+    def rollout(self, act):
+        return [torch.from_numpy(x) for x in self.o.rollout(act.numpy())]
+
+    def episode_stats(self):
+        return [torch.from_numpy(x) for x in self.o.episode_stats()]
+
+
+def _worker(rank, world_size, port, n_per_rank, T, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from hhmarl_2d_amd.sharding import ShardedWorld, summarize
+    kw = dict(n_arenas=n_per_rank, level=3, seed=42, auto_reset=True, horizon=40)
+    sw = ShardedWorld(kw, rank=rank, world_size=world_size, world_factory=_OracleBackedWorld)
+    sw.world.reset()
+    act_all = random_actions(np.random.default_rng(0), (T, n_per_rank * world_size), 2)
+    act = torch.from_numpy(np.ascontiguousarray(act_all[:, rank * n_per_rank:(rank + 1) * n_per_rank]))
+    obs, rew, val, done = sw.world.rollout(act)
+    stats = sw.log_episode_stats()
+    assert stats.shape == (n_per_rank * world_size, 3)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), obs=obs.numpy(), rew=rew.numpy(), done=done.numpy(), stats=stats.numpy())
+    s = summarize(stats)
+    assert s["episodes"] > 0 and s["agents_win"] + s["opps_win"] + s["draw"] == s["episodes"]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_equals_one_world(tmp_path, oracle):
+    n_per_rank, T, ws = 24, 60, 2
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(ws, port, n_per_rank, T, str(tmp_path)), nprocs=ws, join=True)
+    # single world with all arenas
+    o = oracle.OracleWorld(oracle.make_config(n_arenas=n_per_rank * ws, level=3, seed=42, auto_reset=True, horizon=40))
+    o.reset()
+    act_all = random_actions(np.random.default_rng(0), (T, n_per_rank * ws), 2)
+    obs, rew, val, done = o.rollout(act_all)
+    ret, ln, oc = o.episode_stats()
+    r = [np.load(os.path.join(tmp_path, f"rank{k}.npz")) for k in range(ws)]
+    assert np.array_equal(np.concatenate([x["obs"] for x in r], axis=1), obs)
+    assert np.array_equal(np.concatenate([x["rew"] for x in r], axis=1), rew)
+    assert np.array_equal(np.concatenate([x["done"] for x in r], axis=1), done)
+    want = np.stack([ret, ln.astype(np.float32), oc.astype(np.float32)], axis=1)
+    for x in r:  # every rank holds the full gathered table, in global arena order
+        assert np.array_equal(x["stats"], want)
+
+
+def test_shard_kwargs_offsets():
+    from hhmarl_2d_amd.sharding import shard_kwargs
+    kw = dict(n_arenas=8192, seed=1, arena_offset=100)
+    assert [shard_kwargs(kw, r, 8)["arena_offset"] for r in range(8)] == [100 + 8192 * r for r in range(8)]
+    assert shard_kwargs(kw, 3, 8)["seed"] == 1 and kw["arena_offset"] == 100

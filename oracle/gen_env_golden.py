@@ -128,6 +128,100 @@ def record(name, kind, kw, policy, episodes, max_rows, seed=20240917, arena=7):
           f"rocket_rows={int(out['rk_i'][:, :, 0].any(axis=1).sum())} size={os.path.getsize(path)}")
 
 
+# ---------------------------------------------------------------- HighLevelEnv (3-vs-3 commander)
+HL_SCENARIOS = [
+    # name, args kwargs, pilot style, episodes, max commander steps
+    ("hl_random_pilots", dict(mode=1), "random", 2, 70),
+    ("hl_pursuit_pilots", dict(mode=1), "pursuit", 4, 90),
+    ("hl_pursuit_share", dict(mode=1, glob_frac=0.3, hier_opp_fight_ratio=50, hier_action_assess=False), "pursuit", 3, 70),
+]
+
+
+def record_hl(name, kw, style, episodes, max_rows, seed=20240917, arena=11):
+    """HighLevelEnv.step = _action_assess + <=16 x {pilot policy -> _take_base_action -> do_tick}.
+    The frozen pilot networks are not shipped (.gitignore:5), so `_policy_actions` is replaced by a
+    tape: it still evaluates the reference's own lowlevel_state (recorded = expected pilot
+    observation) and returns a scripted action (recorded = input)."""
+    args = H.make_args(**kw)
+    env = H.RefEnv("high", args, seed=seed, arena=arena)
+    A, nA = args.total_num, args.num_agents
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    cls = type(env.env)
+    sub = dict(obs=[], mode=[], act=[])
+    cur = {"last": 99}
+
+    def policy_actions(self_, policy_type, agent_id, unit):
+        st = self_.lowlevel_state(policy_type, agent_id, unit=unit)[agent_id]
+        if agent_id <= cur["last"]:  # first live unit of a new sub-step
+            sub["obs"].append(np.zeros((A, 30), dtype=np.float32))
+            sub["mode"].append(np.zeros(A, dtype=np.uint8))
+            sub["act"].append(np.zeros((A, 4), dtype=np.int8))
+        cur["last"] = agent_id
+        a = [int(rng.integers(13)), int(rng.integers(9)), int(rng.integers(2)), int(rng.integers(2))]
+        if style == "pursuit" and policy_type == "fight":
+            tgt = self_.opp_to_attack[agent_id][self_.commander_actions[agent_id] - 1][0]
+            o = self_.sim.get_unit(tgt)
+            brg = math.degrees(math.atan2(o.position.lon - unit.position.lon, o.position.lat - unit.position.lat)) % 360
+            rel = (brg - unit.heading + 180) % 360 - 180
+            a = [int(np.clip(round(rel / 15.0) + 6, 0, 12)), int(rng.integers(3, 9)), 1, int(rng.random() < 0.5)]
+        sub["obs"][-1][agent_id - 1, : len(st)] = st
+        sub["mode"][-1][agent_id - 1] = 1 if policy_type == "fight" else 2
+        sub["act"][-1][agent_id - 1] = a
+        return {agent_id: np.array(a)}
+
+    cls._policy_actions = policy_actions
+    rows = dict(kind=[], cmd=[], nsub=[], ac_f=[], ac_i=[], rk_f=[], rk_i=[], ar_i=[], tgt_id=[], tgt_d=[], obs=[],
+                reward=[], valid=[], done=[], cmd_all=[])
+
+    def push(k, cmd, nsub, obs, rew, done, cmd_all):
+        st = env.state()
+        rows["kind"].append(k)
+        rows["cmd"].append(cmd)
+        rows["nsub"].append(nsub)
+        for key in ("ac_f", "ac_i", "rk_i", "ar_i", "tgt_id", "tgt_d"):
+            rows[key].append(st[key])
+        rows["rk_f"].append(st["rk_f"][:, :4])
+        rows["obs"].append(env.obs_array(obs, 34))
+        r = np.zeros(nA)
+        v = np.zeros(nA, dtype=np.uint8)
+        for i, x in (rew or {}).items():
+            r[i - 1] = x
+            v[i - 1] = 1
+        rows["reward"].append(r)
+        rows["valid"].append(v)
+        rows["done"].append(int(done))
+        rows["cmd_all"].append(cmd_all)
+
+    for ep in range(episodes):
+        obs = env.reset()
+        push(0, np.zeros(nA, dtype=np.int8), 0, obs, None, False, np.zeros(A, dtype=np.int8))
+        done = False
+        while not done and len(rows["kind"]) < max_rows:
+            cmd = rng.integers(0, 3, nA).astype(np.int8)
+            n0 = len(sub["obs"])
+            cur["last"] = 99
+            cd = {i + 1: int(cmd[i]) for i in range(nA)}
+            obs, rew, term, trunc, info = env.step(cd)
+            done = term["__all__"]
+            ca = np.array([(cd.get(i) or 0) for i in range(1, A + 1)], dtype=np.int8)  # env expanded it in place
+            push(1, cmd, len(sub["obs"]) - n0, obs, rew, done, ca)
+        if len(rows["kind"]) >= max_rows:
+            break
+    meta = dict(name=name, env="high", args={k: v for k, v in vars(args).items()}, seed=seed, arena=arena, obs_dim=34,
+                draws=len(env.tape.log))
+    assert len(set(env.tape.log)) == len(env.tape.log), "keyed-RNG key collision"
+    out = {k: np.asarray(v) for k, v in rows.items()}
+    out["sub_obs"] = np.asarray(sub["obs"])
+    out["sub_mode"] = np.asarray(sub["mode"])
+    out["sub_act"] = np.asarray(sub["act"])
+    out["meta"] = np.array(json.dumps(meta))
+    path = os.path.join(OUT, f"env_{name}.npz")
+    np.savez_compressed(path, **out)
+    deaths = int((np.diff(out["ac_i"][:, :, 0].astype(int), axis=0) < 0).sum())
+    print(f"{name}: rows={len(out['kind'])} substeps={len(sub['obs'])} mean_sub={out['nsub'][out['kind'] == 1].mean():.1f} "
+          f"draws={meta['draws']} deaths={deaths} size={os.path.getsize(path)}")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
@@ -135,3 +229,7 @@ if __name__ == "__main__":
         if only and sc[0] not in only:
             continue
         record(*sc)
+    for sc in HL_SCENARIOS:
+        if only and sc[0] not in only:
+            continue
+        record_hl(*sc)

@@ -66,6 +66,9 @@ typedef struct {
     int reward_valid[MAXA];
     float obs[MAXA][OBS_MAX];
     uint32_t ev_mask;
+    /* HighLevelEnv macro step (env_hier.py:114-140) */
+    int hl_s, hl_running, hl_kill, hl_situ;
+    int cmd_act[MAXA]; /* self.commander_actions[i]: 0 escape, k>0 fight stored target k (agents and opponents) */
     /* episode statistics */
     double ep_ret;
     float last_ret;
@@ -873,6 +876,7 @@ static void hl_state(const o_world *w, o_arena *a) {
     }
 }
 
+
 /* ------------------------------------------------------------------ batch API */
 #define API __attribute__((visibility("default")))
 
@@ -1064,6 +1068,231 @@ API int hho_get_obs(void *h, float *obs) {
     for (int n = 0; n < w->cfg.n_arenas; n++) copy_obs(w, &w->ar[n], obs + (size_t)n * w->cfg.n_agents * w->D);
     return HH_OK;
 }
+
+/* ------------------------------------------------------------------ HighLevelEnv macro step */
+static int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+/* env_hier.py:142-190 _action_assess */
+static void hl_action_assess(const o_world *w, o_arena *a, const int8_t *cmd /* [n_agents] */) {
+    int nA = w->cfg.n_agents;
+    for (int i = 1; i <= w->A; i++) {
+        const o_ac *u = &a->ac[i - 1];
+        if (u->alive) {
+            if (i <= nA) {
+                a->reward[i - 1] = 0.0;
+                int c = cmd[i - 1];
+                if (c > 0) {
+                    int opp_id = 0;
+                    if (c - 1 < a->tgt_n[i - 1]) opp_id = a->tgt_id[i - 1][c - 1];
+                    else c = 1; /* try/except IndexError -> opp_id None, action forced to 1 */
+                    if (!opp_id) a->reward[i - 1] = -0.1;
+                    if (w->cfg.hier_action_assess && opp_id) {
+                        const o_ac *o = &a->ac[opp_id - 1];
+                        if (dist_raw(u, o) < 0.1 && focus_deg(u, o) < 15.0 && focus_deg(o, u) > 40.0) a->reward[i - 1] = 0.1;
+                        else a->reward[i - 1] = 0.0;
+                    }
+                } else if (w->cfg.hier_action_assess) {
+                    const o_ac *o = &a->ac[a->tgt_id[i - 1][0] - 1];
+                    if (dist_raw(o, u) < 0.1 && focus_deg(o, u) < 15.0 && focus_deg(u, o) > 40.0) a->reward[i - 1] = 0.1;
+                }
+                a->cmd_act[i - 1] = c;
+            } else {
+                /* Fraction(ratio, 100).limit_denominator().as_integer_ratio() -> weights [den-num, num] */
+                int g = gcd_i(w->cfg.hier_opp_fight_ratio, 100);
+                int num = w->cfg.hier_opp_fight_ratio / (g ? g : 1), den = 100 / (g ? g : 1);
+                double total = (double)den + 0.0;
+                int fight = rng_u(a, i, HH_SITE_HL_FIGHT, 0) * total >= (double)(den - num); /* bisect(cum, u*total, 0, 1) */
+                int ag_id;
+                if (fight) {
+                    int possible = a->tgt_n[i - 1];
+                    if (possible > 1 && (rng_u(a, i, HH_SITE_HL_OTHER, 0) * 4.0 >= 1.0))
+                        ag_id = hh_rng_randint(rng_u(a, i, HH_SITE_HL_PICK, 0), 2, possible);
+                    else
+                        ag_id = 1;
+                } else {
+                    ag_id = 0;
+                }
+                a->cmd_act[i - 1] = ag_id;
+            }
+        } else {
+            if (i <= nA) a->reward[i - 1] = 0.0;
+            a->cmd_act[i - 1] = 0;
+        }
+    }
+    for (int i = 0; i < nA; i++) a->reward_valid[i] = 1; /* every agent id gets a key (env_hier.py:154,188) */
+}
+
+/* index into the stored target list the way Python does: commander_actions[i]-1, -1 = last */
+static int hl_target_index(const o_arena *a, int id) {
+    int c = a->cmd_act[id - 1];
+    return c > 0 ? c - 1 : a->tgt_n[id - 1] - 1;
+}
+
+/* env_hier.py:100-112 lowlevel_state for one unit; returns policy mode 1 fight / 2 escape */
+static int hl_pilot_obs_one(const o_world *w, const o_arena *a, int id, float *out /* [30] */) {
+    double st[OBS_MAX];
+    int ids[MAXA]; double dn[MAXA], dr[MAXA];
+    int nf = nearby(w, a, id, 1, ids, dn, dr);
+    int fri = nf ? ids[0] : 0;
+    int n, mode;
+    if (a->cmd_act[id - 1] != 0) {
+        int k = a->cmd_act[id - 1] - 1;
+        n = fight_state_values(w, a, id, a->tgt_id[id - 1][k], a->tgt_d[id - 1][k], fri, st);
+        mode = 1;
+    } else {
+        n = esc_state_values(w, a, id, a->tgt_n[id - 1], a->tgt_id[id - 1], a->tgt_d[id - 1], fri, st);
+        mode = 2;
+    }
+    for (int k = 0; k < 30; k++) out[k] = k < n ? (float)st[k] : 0.0f;
+    return mode;
+}
+
+/* env_hier.py:192-208 _surrounding_event */
+static int hl_surrounding_event(const o_world *w, const o_arena *a) {
+    for (int i = 1; i <= w->cfg.n_agents; i++)
+        for (int j = w->cfg.n_agents + 1; j <= w->A; j++)
+            if (a->ac[i - 1].alive && a->ac[j - 1].alive) {
+                const o_ac *x = &a->ac[i - 1], *y = &a->ac[j - 1];
+                if (dist_raw(x, y) < 0.1 && (focus_deg(x, y) < 15.0 || focus_deg(y, x) < 15.0)) return 1;
+            }
+    return 0;
+}
+
+/* one sub-step of env_hier.py:125-138 for one arena */
+static void hl_substep(const o_world *w, o_arena *a, const int8_t *actions /* [A,4] */) {
+    int nA = w->cfg.n_agents;
+    o_event ev[4 * MAXA];
+    for (int i = nA + 1; i <= w->A; i++) { /* agents already acted in hl_side_act (same id order as env_hier.py:126-130) */
+        if (!a->ac[i - 1].alive) continue;
+        int k = hl_target_index(a, i);
+        int tgt = k >= 0 ? a->tgt_id[i - 1][k] : 0;
+        take_base_action(w, a, 1, i, tgt, actions + 4 * (i - 1));
+    }
+    int nev = do_tick(w, a, ev);
+    double rews[MAXA];
+    int destroyed[MAXA];
+    double dummy[MAXA] = {0};
+    int kill_event = combat_rewards(w, a, 1, ev, nev, dummy, rews, destroyed);
+    /* env_hier.py:210-224 _get_rewards */
+    for (int i = 1; i <= nA; i++) {
+        if (a->ac[i - 1].alive || destroyed[i - 1]) {
+            if (w->cfg.glob_frac > 0.0) {
+                double other = 0.0;
+                for (int j = 1; j <= nA; j++) if (j != i) other += rews[j - 1];
+                a->reward[i - 1] += rews[i - 1] + w->cfg.glob_frac * other;
+            } else {
+                a->reward[i - 1] += rews[i - 1];
+            }
+        }
+    }
+    a->hl_kill = kill_event;
+    if (a->hl_s > 10) a->hl_situ = hl_surrounding_event(w, a); /* s > self.min_sub_steps (10) */
+    a->hl_s += 1;
+    a->steps += 1;
+    a->hl_running = a->hl_s <= 15 && !a->hl_kill && !a->hl_situ; /* while s <= n_sub_steps(15) and not ... */
+}
+
+API int hho_hl_begin(void *h, const int8_t *cmd /* [N, n_agents] */) {
+    o_world *w = (o_world *)h;
+    if (w->cfg.env_kind != HH_ENV_HIGHLEVEL) return HH_E_ARG;
+    for (int n = 0; n < w->cfg.n_arenas; n++) {
+        o_arena *a = &w->ar[n];
+        for (int i = 0; i < MAXA; i++) { a->reward[i] = 0.0; a->reward_valid[i] = 0; }
+        a->hl_s = 0; a->hl_kill = 0; a->hl_situ = 0;
+        a->hl_running = !a->done;
+        if (a->hl_running) hl_action_assess(w, a, cmd + (size_t)n * w->cfg.n_agents);
+    }
+    return HH_OK;
+}
+
+/* The reference walks the units in id order and lets each one observe and act before the next one
+ * observes (env_hier.py:126-130), so the opponents' observations already contain the agents'
+ * same-sub-step cannon / missile flags.  Batched restatement with identical results:
+ *   side 0: observations of the agents -> (pilot inference) -> hho_hl_agents_act
+ *   side 1: observations of the opponents -> (pilot inference) -> hho_hl_tick
+ * (within a side nobody observes a same-side unit's weapon flags, so the order inside a side is free). */
+API int hho_hl_agents_act(void *h, const int8_t *actions /* [N, A, 4], agent rows used */) {
+    o_world *w = (o_world *)h;
+    for (int n = 0; n < w->cfg.n_arenas; n++) {
+        o_arena *a = &w->ar[n];
+        if (!a->hl_running) continue;
+        a->ev_mask = 0;
+        for (int i = 1; i <= w->cfg.n_agents; i++) {
+            if (!a->ac[i - 1].alive) continue;
+            int k = hl_target_index(a, i);
+            int tgt = k >= 0 ? a->tgt_id[i - 1][k] : 0;
+            take_base_action(w, a, 1, i, tgt, actions + ((size_t)n * w->A + (i - 1)) * 4);
+        }
+    }
+    return HH_OK;
+}
+
+API int hho_hl_pilot_obs(void *h, int side, float *obs /* [N, A, 30] */, uint8_t *mode /* [N, A] */) {
+    o_world *w = (o_world *)h;
+    int A = w->A;
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < w->cfg.n_arenas; n++) {
+        o_arena *a = &w->ar[n];
+        for (int i = 1; i <= A; i++) {
+            float *o = obs + ((size_t)n * A + (i - 1)) * 30;
+            int md = 0;
+            int mine = side == 0 ? i <= w->cfg.n_agents : i > w->cfg.n_agents;
+            if (a->hl_running && a->ac[i - 1].alive && mine) md = hl_pilot_obs_one(w, a, i, o);
+            else for (int k = 0; k < 30; k++) o[k] = 0.0f;
+            mode[(size_t)n * A + (i - 1)] = (uint8_t)md;
+        }
+    }
+    return HH_OK;
+}
+
+API int hho_hl_tick(void *h, const int8_t *actions /* [N, A, 4] */) {
+    o_world *w = (o_world *)h;
+    int running = 0;
+#pragma omp parallel for schedule(static) reduction(+ : running)
+    for (int n = 0; n < w->cfg.n_arenas; n++) {
+        o_arena *a = &w->ar[n];
+        if (a->hl_running) hl_substep(w, a, actions + (size_t)n * w->A * 4);
+        running += a->hl_running;
+    }
+    return running;
+}
+
+API int hho_hl_end(void *h, float *obs /* [N, n_agents, 34] */, float *reward, uint8_t *reward_valid, uint8_t *done) {
+    o_world *w = (o_world *)h;
+    int nA = w->cfg.n_agents;
+    for (int n = 0; n < w->cfg.n_arenas; n++) {
+        o_arena *a = &w->ar[n];
+        if (!a->done) {
+            int ag, op;
+            count_alive(w, a, &ag, &op);
+            a->done = ag <= 0 || op <= 0 || a->steps >= w->cfg.horizon;
+            for (int i = 0; i < nA; i++) if (a->reward_valid[i]) a->ep_ret += a->reward[i];
+            if (a->done) finish_episode(a, ag, op, w->cfg.horizon);
+            hl_state(w, a);
+        }
+        a->hl_running = 0;
+        if (reward) for (int i = 0; i < nA; i++) reward[(size_t)n * nA + i] = (float)a->reward[i];
+        if (reward_valid) for (int i = 0; i < nA; i++) reward_valid[(size_t)n * nA + i] = (uint8_t)a->reward_valid[i];
+        if (done) done[n] = (uint8_t)a->done;
+        if (a->done && w->cfg.auto_reset) {
+            uint32_t em = a->ev_mask;
+            arena_reset(w, a);
+            a->ev_mask = em;
+        }
+        if (obs) copy_obs(w, a, obs + (size_t)n * nA * w->D);
+    }
+    return HH_OK;
+}
+
+API int hho_hl_get_cmd(void *h, int32_t *cmd /* [N, A] */, int32_t *sub /* [N] */) {
+    o_world *w = (o_world *)h;
+    for (int n = 0; n < w->cfg.n_arenas; n++) {
+        for (int i = 0; i < w->A; i++) cmd[(size_t)n * w->A + i] = w->ar[n].cmd_act[i];
+        if (sub) sub[n] = w->ar[n].hl_s;
+    }
+    return HH_OK;
+}
+
 
 /* probes for tests/test_math.py and tests/test_geodesic.py */
 API void hho_math_eval(int fn, int n, const double *a, const double *b, double *o0, double *o1) {

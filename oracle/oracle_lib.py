@@ -173,6 +173,41 @@ class OracleWorld:
         lib().hho_get_event_masks(self.h, _ptr(m, C.c_uint32))
         return m
 
+    # ---- HighLevelEnv macro step (env_hier.py:114-140), split so that pilot inference runs between ticks
+    def hl_begin(self, cmd):
+        cmd = np.ascontiguousarray(cmd, dtype=np.int8).reshape(self.N, self.n_agents)
+        rc = lib().hho_hl_begin(self.h, _ptr(cmd, C.c_int8))
+        assert rc == 0, rc
+
+    def hl_pilot_obs(self, side):
+        """side 0: agents (before anybody acted); side 1: opponents (after hl_agents_act)"""
+        obs = np.zeros((self.N, self.A, 30), dtype=np.float32)
+        mode = np.zeros((self.N, self.A), dtype=np.uint8)
+        lib().hho_hl_pilot_obs(self.h, side, _ptr(obs, C.c_float), _ptr(mode, C.c_uint8))
+        return obs, mode
+
+    def hl_agents_act(self, actions):
+        actions = np.ascontiguousarray(actions, dtype=np.int8).reshape(self.N, self.A, 4)
+        lib().hho_hl_agents_act(self.h, _ptr(actions, C.c_int8))
+
+    def hl_tick(self, actions):
+        actions = np.ascontiguousarray(actions, dtype=np.int8).reshape(self.N, self.A, 4)
+        return lib().hho_hl_tick(self.h, _ptr(actions, C.c_int8))
+
+    def hl_end(self):
+        obs = np.zeros((self.N, self.n_agents, self.D), dtype=np.float32)
+        rew = np.zeros((self.N, self.n_agents), dtype=np.float32)
+        val = np.zeros((self.N, self.n_agents), dtype=np.uint8)
+        done = np.zeros((self.N,), dtype=np.uint8)
+        lib().hho_hl_end(self.h, _ptr(obs, C.c_float), _ptr(rew, C.c_float), _ptr(val, C.c_uint8), _ptr(done, C.c_uint8))
+        return obs, rew, val, done
+
+    def hl_cmd(self):
+        cmd = np.zeros((self.N, self.A), dtype=np.int32)
+        sub = np.zeros((self.N,), dtype=np.int32)
+        lib().hho_hl_get_cmd(self.h, _ptr(cmd, C.c_int32), _ptr(sub, C.c_int32))
+        return cmd, sub
+
     def episode_stats(self):
         ret = np.zeros((self.N,), dtype=np.float32)
         ln = np.zeros((self.N,), dtype=np.int32)

@@ -340,7 +340,17 @@ def dump_state(env, n_units):
             rk_i[s] = (1, r.target.id, (sim.utc_time - r.firing_time).seconds, uid - n_units)
     ar_i = np.array([env.steps, env.alive_agents, env.alive_opps, int(env.hardcoded_opps_escaping),
                      env.opps_escaping_time], dtype=np.int32)
-    return dict(ac_f=ac_f, ac_i=ac_i, rk_f=rk_f, rk_i=rk_i, ar_i=ar_i)
+    tgt_id = np.zeros((n_units, 3), dtype=np.int32)
+    tgt_d = np.zeros((n_units, 3))
+    for i in range(1, n_units + 1):
+        t = env.opp_to_attack.get(i)
+        if isinstance(t, list):
+            for k, e in enumerate(t[:3]):
+                tgt_id[i - 1, k] = e[0]
+                tgt_d[i - 1, k] = e[1]
+        elif t:
+            tgt_id[i - 1, 0] = t
+    return dict(ac_f=ac_f, ac_i=ac_i, rk_f=rk_f, rk_i=rk_i, ar_i=ar_i, tgt_id=tgt_id, tgt_d=tgt_d)
 
 
 class RefEnv:

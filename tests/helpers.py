@@ -8,8 +8,11 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def golden_files():
-    return sorted(glob.glob(os.path.join(GOLDEN, "env_*.npz")))
+def golden_files(kind="low"):
+    """low: LowLevelEnv traces (env_l*.npz); high: HighLevelEnv traces (env_hl_*.npz)"""
+    allf = sorted(glob.glob(os.path.join(GOLDEN, "env_*.npz")))
+    hl = [f for f in allf if os.path.basename(f).startswith("env_hl_")]
+    return hl if kind == "high" else [f for f in allf if f not in hl]
 
 
 def load_golden(path):

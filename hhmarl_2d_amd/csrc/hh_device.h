@@ -49,6 +49,7 @@ struct DevPtrs {
     int *last_len;                                       /* [N] */
     int8_t *last_outcome;                                /* [N] */
     uint32_t *ev_mask;                                   /* [N] */
+    double *acc_rew;                                     /* [U] rewards accumulated over a HighLevelEnv macro step */
 };
 
 /* register-resident state of one aircraft slot (+ its rocket slot) */
@@ -64,6 +65,7 @@ struct Unit {
 /* register-resident arena scalars, replicated on every lane of the group */
 struct Arena {
     int steps, episode, escaping, escaping_time, done, next_seq;
+    int hl_s, hl_run; /* HighLevelEnv macro step: sub-step counter, still running (env_hier.py:125) */
     uint64_t akey;
     uint64_t tkey; /* hh_rng_tick_key(akey, episode, steps), refreshed whenever steps/episode change */
 };
@@ -106,6 +108,7 @@ __device__ __forceinline__ void arena_load(const DevPtrs &P, const DevCfg &c, in
     int4 p = P.ar_pack[n];
     a.steps = p.x; a.episode = p.y;
     a.escaping = p.z & 0xff; a.escaping_time = (int)(int8_t)((p.z >> 8) & 0xff); a.done = (p.z >> 16) & 0xff;
+    a.hl_s = (p.z >> 24) & 0x1f; a.hl_run = (p.z >> 29) & 1;
     a.next_seq = p.w;
     a.akey = hh_rng_arena_key(c.seed, c.arena_offset + (uint64_t)n);
     arena_rekey(a);
@@ -114,7 +117,7 @@ __device__ __forceinline__ void arena_load(const DevPtrs &P, const DevCfg &c, in
 __device__ __forceinline__ void arena_store(const DevPtrs &P, int n, const Arena &a) {
     int4 p;
     p.x = a.steps; p.y = a.episode;
-    p.z = (a.escaping & 0xff) | ((a.escaping_time & 0xff) << 8) | ((a.done & 0xff) << 16);
+    p.z = (a.escaping & 0xff) | ((a.escaping_time & 0xff) << 8) | ((a.done & 0xff) << 16) | ((a.hl_s & 0x1f) << 24) | ((a.hl_run & 1) << 29);
     p.w = a.next_seq;
     P.ar_pack[n] = p;
 }

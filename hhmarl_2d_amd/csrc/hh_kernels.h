@@ -305,7 +305,75 @@ __device__ __forceinline__ void lowlevel_obs(const DevCfg &c, const Shared<A, B>
 struct StepOut {
     double reward;
     int valid;
+    int kill_event; /* any aircraft removed this tick (env_base.py:248,256,308) */
 };
+
+/* phase I of the tick: dense pass over the workgroup's envelope queue.  Every entry is decided by the
+ * filtered exact predicate (mid-latitude estimate with proven error bounds; the Karney solution for
+ * the undecided sliver) and its verdict is OR-ed into the requesting lane's result word. */
+template <int A, int B>
+__device__ __forceinline__ void drain_envelope_queue(Shared<A, B> &sh, int tid) {
+#ifdef HH_ABL_NO_ENVELOPE
+    const int count = 0;
+#else
+    const int count = sh.u.t.q_count;
+#endif
+#pragma unroll 1
+    for (int q = tid; q < count; q += B) {
+        int code = sh.u.t.q_code[q];
+        int src = code & 0xff, kind = (code >> 8) & 3, j = (code >> 10) & 7;
+        int ss = src % A, sb = src - ss;
+        double la1, lo1, la2, lo2;
+        if (kind <= 1) { la1 = sh.lat0[src]; lo1 = sh.lon0[src]; }
+        else { la1 = sh.u.t.rk_lat[src]; lo1 = sh.u.t.rk_lon[src]; }
+        bool moved = kind >= 2 || (kind == 1 && j < ss);
+        la2 = moved ? sh.u.t.lat1[sb + j] : sh.lat0[sb + j];
+        lo2 = moved ? sh.u.t.lon1[sb + j] : sh.lon0[sb + j];
+        /* filtered exact predicate: decide from the mid-latitude estimate when it is farther from every
+         * threshold than its proven error bound; otherwise redo the test with the Karney solution */
+        const int t = sh_type(sh, src);
+        const double hdg_src = kind == 0 ? sh.hdg[src] : sh.u.t.hdg1[src];
+        const double sep = hh_max(hh_fabs(la2 - la1), hh_fabs(lo2 - lo1));
+        const bool dom = hh_fabs(la1) <= HH_GEO_EST_MAX_LAT && hh_fabs(la2) <= HH_GEO_EST_MAX_LAT &&
+                         hh_fabs(lo1) < 170.0 && hh_fabs(lo2) < 170.0;
+        int verdict = -1; /* -1 undecided, 0 outside the envelope, 1 inside */
+        if (dom && sep <= (kind == 0 ? HH_GEO_EST_LONG_DEG : HH_GEO_EST_SHORT_DEG)) {
+            double s_m, az;
+            hh_geo_inverse_estimate(la1, lo1, la2, lo2, &s_m, &az);
+            if (kind == 0) {
+                double delta = hh_fabs(d_signed_heading_diff(d_normalize_angle(hdg_src + HH_MISSILE_HALF_DEG), az));
+                if (s_m >= HH_MISSILE_RANGE_KM * 1000.0 + HH_GEO_EST_LONG_ABS_M) verdict = 0;
+                else if (s_m <= HH_MISSILE_RANGE_KM * 1000.0 - HH_GEO_EST_LONG_ABS_M && s_m > HH_GEO_EST_MIN_M &&
+                         hh_fabs(delta - (HH_MISSILE_HALF_DEG + 1.0)) > HH_GEO_EST_LONG_AZI)
+                    verdict = delta < HH_MISSILE_HALF_DEG + 1.0; /* int(delta) <= 60 */
+            } else {
+                const double r_m = (kind == 1 ? HH_AC_CANNON_KM(t) : HH_ROCKET_FUSE_KM) * 1000.0;
+                const double eps = HH_GEO_EST_SHORT_REL * s_m + HH_GEO_EST_SHORT_ABS_M;
+                if (s_m >= r_m + eps) verdict = 0;
+                else if (s_m < r_m - eps && s_m > HH_GEO_EST_MIN_M) {
+                    if (kind >= 2) verdict = 1;
+                    else {
+                        double d = hh_fabs(d_signed_heading_diff(hdg_src, az));
+                        if (d <= HH_AC_CANNON_HALF(t) - HH_GEO_EST_SHORT_AZI) verdict = 1;
+                        else if (d > HH_AC_CANNON_HALF(t) + HH_GEO_EST_SHORT_AZI) verdict = 0;
+                    }
+                }
+            }
+        }
+#ifndef HH_ABL_NO_EXACT
+        if (verdict < 0) verdict = d_envelope_exact(kind, t, la1, lo1, la2, lo2, hdg_src);
+#endif
+        int bit = 0;
+        if (verdict) {
+            if (kind == 0) bit = 1;
+            else if (kind == 1) { /* ac1.py:112-113 Bernoulli hit, drawn only when in the cone */
+                double u = hh_rng_u01(sh.g_tkey[src / A], (uint32_t)(ss + 1), HH_SITE_CANNON, (uint32_t)(j + 1));
+                if (u < HH_AC_HIT_PROB(t)) bit = 2 << j;
+            } else bit = kind == 2 ? (1 << 9) : (1 << 10);
+        }
+        if (bit) atomicOr(&sh.res[src], bit);
+    }
+}
 
 __device__ __forceinline__ void arm_cannon(Unit &m) { /* ac1.py:69-70 / ac2.py:65-66 fire_cannon */
     int b = HH_AC_BURST(m.ac_type);
@@ -314,15 +382,19 @@ __device__ __forceinline__ void arm_cannon(Unit &m) { /* ac1.py:69-70 / ac2.py:6
 
 template <int A, int B>
 __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid, int g, int s, int base, bool active,
-                                     Unit &m, Arena &ar, const int8_t *act, StepOut &out, uint32_t &ev_mask_out) {
+                                     Unit &m, Arena &ar, const int8_t *act, StepOut &out, uint32_t &ev_mask_out,
+                                     const int tmode = 0, const bool run_arena = true) {
+    /* tmode 0: fused LowLevelEnv step (commands + tick).  tmode 1: tick only — commands and launches were
+     * already applied per side by act_phase (HighLevelEnv sub-steps; steps is advanced by the caller) */
     const int id = s + 1;
-    const bool running = active && !ar.done;
+    const bool running = tmode == 0 ? (active && !ar.done) : (active && run_arena);
     const bool agent = s < c.nA;
     const bool hl = c.env_kind == HH_ENV_HIGHLEVEL;
     out.reward = 0.0;
     out.valid = 0;
     uint32_t evm = 0;
-    if (running) { ar.steps += 1; arena_rekey(ar); }
+    out.kill_event = 0;
+    if (running && tmode == 0) { ar.steps += 1; arena_rekey(ar); }
     const bool snap = running && m.alive; /* in do_tick's start-of-tick snapshot */
     double opp_stat0 = 0.0;
     int want_launch = 0, launch_tgt = 0; /* launch_tgt: slot index */
@@ -330,7 +402,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     bool base_gate = false;              /* _take_base_action missile gate passed */
 
     /* ---------------- phase A: commands (env_hetero.py:160-182), pair table = pre-tick state ---------------- */
-    if (snap) {
+    if (snap && tmode == 0) {
         if (agent || c.ext_opp) {
             int t = m.n_tgt ? m.tgt0 : 0;
             if (!agent) {
@@ -384,7 +456,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     /* env_hetero.py:138-158 level 3: the arena-level escape flag is consumed once per live
      * opponent in id order; every lane replays the tiny integer sequence so that
      * each opponent lane sees the flag as it was at its turn and all lanes agree on the result */
-    if (running && !c.ext_opp && c.level >= 3 && !hl) {
+    if (running && tmode == 0 && !c.ext_opp && c.level >= 3 && !hl) {
         int esc = ar.escaping, esc_t = ar.escaping_time;
         bool my_escaping = false;
 #pragma unroll
@@ -550,68 +622,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     __syncthreads();
 
     /* ---------------- phase I: dense pass over the queue (estimate filter + out-of-line exact Karney) ---------------- */
-    {
-#ifdef HH_ABL_NO_ENVELOPE
-        const int count = 0;
-#else
-        const int count = sh.u.t.q_count;
-#endif
-#pragma unroll 1
-        for (int q = tid; q < count; q += B) {
-            int code = sh.u.t.q_code[q];
-            int src = code & 0xff, kind = (code >> 8) & 3, j = (code >> 10) & 7;
-            int ss = src % A, sb = src - ss;
-            double la1, lo1, la2, lo2;
-            if (kind <= 1) { la1 = sh.lat0[src]; lo1 = sh.lon0[src]; }
-            else { la1 = sh.u.t.rk_lat[src]; lo1 = sh.u.t.rk_lon[src]; }
-            bool moved = kind >= 2 || (kind == 1 && j < ss);
-            la2 = moved ? sh.u.t.lat1[sb + j] : sh.lat0[sb + j];
-            lo2 = moved ? sh.u.t.lon1[sb + j] : sh.lon0[sb + j];
-            /* filtered exact predicate: decide from the mid-latitude estimate when it is farther from every
-             * threshold than its proven error bound; otherwise redo the test with the Karney solution */
-            const int t = sh_type(sh, src);
-            const double hdg_src = kind == 0 ? sh.hdg[src] : sh.u.t.hdg1[src];
-            const double sep = hh_max(hh_fabs(la2 - la1), hh_fabs(lo2 - lo1));
-            const bool dom = hh_fabs(la1) <= HH_GEO_EST_MAX_LAT && hh_fabs(la2) <= HH_GEO_EST_MAX_LAT &&
-                             hh_fabs(lo1) < 170.0 && hh_fabs(lo2) < 170.0;
-            int verdict = -1; /* -1 undecided, 0 outside the envelope, 1 inside */
-            if (dom && sep <= (kind == 0 ? HH_GEO_EST_LONG_DEG : HH_GEO_EST_SHORT_DEG)) {
-                double s_m, az;
-                hh_geo_inverse_estimate(la1, lo1, la2, lo2, &s_m, &az);
-                if (kind == 0) {
-                    double delta = hh_fabs(d_signed_heading_diff(d_normalize_angle(hdg_src + HH_MISSILE_HALF_DEG), az));
-                    if (s_m >= HH_MISSILE_RANGE_KM * 1000.0 + HH_GEO_EST_LONG_ABS_M) verdict = 0;
-                    else if (s_m <= HH_MISSILE_RANGE_KM * 1000.0 - HH_GEO_EST_LONG_ABS_M && s_m > HH_GEO_EST_MIN_M &&
-                             hh_fabs(delta - (HH_MISSILE_HALF_DEG + 1.0)) > HH_GEO_EST_LONG_AZI)
-                        verdict = delta < HH_MISSILE_HALF_DEG + 1.0; /* int(delta) <= 60 */
-                } else {
-                    const double r_m = (kind == 1 ? HH_AC_CANNON_KM(t) : HH_ROCKET_FUSE_KM) * 1000.0;
-                    const double eps = HH_GEO_EST_SHORT_REL * s_m + HH_GEO_EST_SHORT_ABS_M;
-                    if (s_m >= r_m + eps) verdict = 0;
-                    else if (s_m < r_m - eps && s_m > HH_GEO_EST_MIN_M) {
-                        if (kind >= 2) verdict = 1;
-                        else {
-                            double d = hh_fabs(d_signed_heading_diff(hdg_src, az));
-                            if (d <= HH_AC_CANNON_HALF(t) - HH_GEO_EST_SHORT_AZI) verdict = 1;
-                            else if (d > HH_AC_CANNON_HALF(t) + HH_GEO_EST_SHORT_AZI) verdict = 0;
-                        }
-                    }
-                }
-            }
-#ifndef HH_ABL_NO_EXACT
-            if (verdict < 0) verdict = d_envelope_exact(kind, t, la1, lo1, la2, lo2, hdg_src);
-#endif
-            int bit = 0;
-            if (verdict) {
-                if (kind == 0) bit = 1;
-                else if (kind == 1) { /* ac1.py:112-113 Bernoulli hit, drawn only when in the cone */
-                    double u = hh_rng_u01(sh.g_tkey[src / A], (uint32_t)(ss + 1), HH_SITE_CANNON, (uint32_t)(j + 1));
-                    if (u < HH_AC_HIT_PROB(t)) bit = 2 << j;
-                } else bit = kind == 2 ? (1 << 9) : (1 << 10);
-            }
-            if (bit) atomicOr(&sh.res[src], bit);
-        }
-    }
+    drain_envelope_queue(sh, tid);
     __syncthreads();
 
     /* ---------------- phase L: launch bookkeeping (env_base.py:227-236, ac1.py:76-79) ---------------- */
@@ -632,7 +643,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
         m.missile_wait = hl ? hh_rng_randint(uu, 8, 12) : hh_rng_randint(uu, 7, 17);
         if (agent && !hl && c.agent_mode == HH_MODE_ESCAPE && m.missile_remain < 3) out.reward -= 0.1;
     }
-    if (snap && (agent || c.ext_opp)) { /* env_base.py:235-236, evaluated before do_tick */
+    if (snap && tmode == 0 && (agent || c.ext_opp)) { /* env_base.py:235-236, evaluated before do_tick */
         if (m.missile_wait > 0 && !(launched || has_missile_pre)) m.missile_wait -= 1;
     }
     if (want_launch && wait_after >= 0) m.missile_wait = wait_after;
@@ -782,13 +793,15 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     __syncthreads();
     pair_tables(sh, tid, base, s, active);
     if (running) {
-        int ag = 0, op = 0;
+        int ag = 0, op = 0, kill = nev > 0;
 #pragma unroll
         for (int j = 0; j < A; j++) {
             int al = sh_alive(sh, base + j);
             if (j < c.nA) ag += al; else op += al;
+            kill |= sh.aux[base + j]; /* out-of-bounds removals */
         }
-        ar.done = (ag <= 0 || op <= 0 || ar.steps >= c.horizon) ? 1 : 0;
+        out.kill_event = kill;
+        if (tmode == 0) ar.done = (ag <= 0 || op <= 0 || ar.steps >= c.horizon) ? 1 : 0;
     }
     __syncthreads();
     if (running && agent) {

@@ -1,0 +1,394 @@
+/*
+ * hh_kernels_hier.h — HighLevelEnv (3-vs-3 commander, envs/env_hier.py) on the same world.
+ *
+ * One commander step of the reference = _action_assess (env_hier.py:142-190) + up to 16 sub-steps of
+ * { every live unit: frozen pilot policy on lowlevel_state -> _take_base_action } -> do_tick -> rewards
+ * (env_hier.py:125-138), then state() (49-98).  The pilot networks run in PyTorch BETWEEN kernels, and
+ * the reference lets units observe and act in id order, so the opponents' observations contain the
+ * agents' same-sub-step weapon flags.  The macro step is therefore split into phases, one launch each:
+ *
+ *   HL_BEGIN       action assessment, opponents' fight/escape draws     -> agents' pilot observations
+ *   HL_AGENTS_ACT  agents' _take_base_action (incl. missile envelope)   -> opponents' pilot observations
+ *   HL_TICK        opponents' _take_base_action, do_tick, rewards, kill / surrounding events, s += 1
+ *                                                                       -> agents' observations of the next sub-step
+ *   HL_END         done, commander observation + stored target lists, episode statistics, auto-reset
+ *   HL_REFRESH / HL_RESET   commander observation + lists only (hh_observe, hh_set_state) / masked reset first
+ *
+ * Arenas whose macro step ended early (kill or surrounding event) idle until HL_END; the host loops
+ * a fixed 16 sub-steps or until the running counter reaches zero.
+ */
+#ifndef HH_KERNELS_HIER_H
+#define HH_KERNELS_HIER_H
+
+#include "hh_kernels.h"
+
+enum { HH_HL_BEGIN = 0, HH_HL_AGENTS_ACT = 1, HH_HL_TICK = 2, HH_HL_END = 3, HH_HL_REFRESH = 4, HH_HL_RESET = 5 };
+
+/* index into the stored target list like Python: commander_actions[i]-1, with -1 = last */
+__device__ __forceinline__ int hl_target_slot(const Unit &m, double &dist) {
+    int k = m.cmd_act > 0 ? m.cmd_act - 1 : m.n_tgt - 1;
+    int t = 0;
+    dist = 0.0;
+    if (k == 0 && m.n_tgt > 0) { t = m.tgt0; dist = m.tgt_d0; }
+    else if (k == 1 && m.n_tgt > 1) { t = m.tgt1; dist = m.tgt_d1; }
+    else if (k == 2 && m.n_tgt > 2) { t = m.tgt2; dist = m.tgt_d2; }
+    return t; /* 1-based unit id, 0 = none */
+}
+
+/* env_base.py:214-238 _take_base_action("HighLevel") for the lanes selected by `acts`, including the
+ * missile envelope test (one pass over the workgroup queue) and launch bookkeeping. */
+template <int A, int B>
+__device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int tid, int s, int base, bool active,
+                                          Unit &m, Arena &ar, const int8_t *act, bool acts, uint32_t &evm) {
+    const int id = s + 1;
+    const bool snap = active && ar.hl_run && m.alive && acts;
+    int want_launch = 0, launch_tgt = 0;
+    bool base_gate = false;
+    if (snap) {
+        double dd;
+        int t = hl_target_slot(m, dd);
+        double nh = hh_pymod(m.hdg + (double)(((int)act[0] - 6) * 15), 360.0);
+        if (nh >= 360.0 || nh < 0.0) nh = 0.0;
+        m.cmd_hdg = nh;
+        double mx = HH_AC_MAX_SPEED(m.ac_type);
+        m.cmd_spd = 100.0 + ((mx - 100.0) / 8.0) * (double)act[1];
+        if (act[2] && m.cannon_remain > 0) arm_cannon(m);
+        if (m.ac_type == 1 && act[3]) {
+            if (t && m.missile_remain > 0 && !m.has_missile && m.missile_wait == 0) {
+                base_gate = true;
+                want_launch = 1;
+                launch_tgt = t - 1;
+            }
+        }
+    }
+    const bool try_launch = want_launch && !m.has_missile && m.missile_remain > 0;
+    sh.res[tid] = 0;
+    if (tid == 0) sh.u.t.q_count = 0;
+    __syncthreads();
+    if (try_launch) {
+        int at = atomicAdd(&sh.u.t.q_count, 1);
+        sh.u.t.q_code[at] = tid | (0 << 8) | (launch_tgt << 10);
+    }
+    __syncthreads();
+    drain_envelope_queue(sh, tid);
+    __syncthreads();
+    int launched = 0;
+    if (try_launch && (sh.res[tid] & 1)) { /* ac1.py:76-79 */
+        launched = 1;
+        m.rk_alive = 1; m.rk_lat = m.lat; m.rk_lon = m.lon; m.rk_hdg = m.hdg; m.rk_cmd = m.hdg;
+        m.rk_target = launch_tgt + 1; m.rk_life = 0;
+        m.has_missile = 1;
+        m.missile_remain = m.missile_remain - 1 > 0 ? m.missile_remain - 1 : 0;
+        evm |= 1u << (24 + s);
+    }
+    if (base_gate) m.missile_wait = hh_rng_randint(d_rng(ar, id, HH_SITE_MISSILE_WAIT, 0), 8, 12);
+    if (snap) {
+        if (m.missile_wait > 0 && !m.has_missile) m.missile_wait -= 1;
+    }
+    sh.aux[tid] = launched;
+    __syncthreads();
+    {   /* rocket ids in unit id order (cmano_simulator.py:104-108) */
+        int before = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < A; j++) {
+            int l = active ? sh.aux[base + j] : 0;
+            total += l;
+            if (j < s) before += l;
+        }
+        if (launched) m.rk_seq = ar.next_seq + before + 1;
+        ar.next_seq += total;
+    }
+    /* weapon flags other lanes observe (env_base.py:208-211) */
+    int shot = m.burst > 0 || (m.ac_type == 1 && m.has_missile);
+    sh.flags[tid] = (m.alive ? FL_ALIVE : 0) | ((m.ac_type & 3) << 1) | (shot ? FL_SHOT : 0);
+    __syncthreads();
+}
+
+/* env_hier.py:100-112 lowlevel_state of the lane's unit -> 30 floats (zero padded) + policy type */
+template <int A, int B>
+__device__ __forceinline__ int hl_pilot_obs(const DevCfg &c, const Shared<A, B> &sh, int tid, int base, int s, const Unit &m, float *out) {
+    for (int k = 0; k < 30; k++) out[k] = 0.0f;
+    Near3 fr;
+    nearby(c, sh, tid, base, s, true, fr);
+    int n = 0;
+    out[n++] = (float)hh_clip((m.lat - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
+    out[n++] = (float)hh_clip((m.lon - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
+    out[n++] = (float)hh_clip(m.spd / HH_AC_MAX_SPEED(m.ac_type), 0.0, 1.0);
+    out[n++] = (float)hh_clip(hh_pymod(m.hdg, 359.0) / 359.0, 0.0, 1.0);
+    int mode;
+    if (m.cmd_act != 0) { /* fight the commander-chosen target, with the stale stored distance */
+        mode = 1;
+        double dist = m.tgt_d0;
+        int oj = m.tgt0 - 1;
+        if (m.cmd_act == 2) { dist = m.tgt_d1; oj = m.tgt1 - 1; }
+        else if (m.cmd_act >= 3) { dist = m.tgt_d2; oj = m.tgt2 - 1; }
+        out[n++] = (float)norm180(sh.p_foc[oj][tid]);
+        out[n++] = (float)aspect(sh.p_foc[s][base + oj]);
+        out[n++] = (float)sh.p_hd[oj][tid];
+        out[n++] = (float)dist;
+        out[n++] = (float)hh_clip((double)m.cannon_remain / (double)m.cannon_max, 0.0, 1.0);
+        if (m.ac_type == 1) {
+            out[n++] = (float)hh_clip((double)m.missile_remain / (double)m.rocket_max, 0.0, 1.0);
+            out[n++] = m.missile_wait == 0 ? 1.0f : 0.0f;
+            out[n++] = (m.has_missile || m.burst > 0) ? 1.0f : 0.0f;
+        } else {
+            out[n++] = m.burst > 0 ? 1.0f : 0.0f;
+        }
+        n += opp_block(c, sh, 0, tid, base, s, oj, dist, out + n);
+    } else {
+        mode = 2;
+        out[n++] = (float)hh_clip((double)m.cannon_remain / (double)m.cannon_max, 0.0, 1.0);
+        if (m.ac_type == 1) out[n++] = (float)hh_clip((double)m.missile_remain / (double)m.rocket_max, 0.0, 1.0);
+        out[n++] = (sh.flags[tid] & FL_SHOT) ? 1.0f : 0.0f;
+        if (m.n_tgt >= 1) opp_block(c, sh, 1, tid, base, s, m.tgt0 - 1, m.tgt_d0, out + n);
+        if (m.n_tgt >= 2) opp_block(c, sh, 1, tid, base, s, m.tgt1 - 1, m.tgt_d1, out + n + 9);
+        n += 18;
+    }
+    if (fr.n) friend_block(c, sh, tid, base, s, fr.i0, out + n);
+    return mode;
+}
+
+/* env_hier.py:49-98 state(): commander observation (agents) and the stored sorted target lists (all units) */
+template <int A, int B>
+__device__ __forceinline__ void hl_commander_obs(const DevCfg &c, const Shared<A, B> &sh, int tid, int base, int s, Unit &m, float *out) {
+    const bool agent = s < c.nA;
+    if (agent) for (int k = 0; k < HH_OBS_HL; k++) out[k] = 0.0f;
+    m.n_tgt = 0; m.tgt0 = m.tgt1 = m.tgt2 = 0; m.tgt_d0 = m.tgt_d1 = m.tgt_d2 = 0.0;
+    if (!m.alive) return;
+    Near3 nb;
+    nearby(c, sh, tid, base, s, false, nb);
+    if (agent) {
+        if (nb.n == 0) return;
+        int n = 0;
+        out[n++] = (float)hh_clip((m.lat - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
+        out[n++] = (float)hh_clip((m.lon - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
+        out[n++] = (float)hh_clip(m.spd / HH_AC_MAX_SPEED(m.ac_type), 0.0, 1.0);
+        out[n++] = (float)hh_clip(hh_pymod(m.hdg, 359.0) / 359.0, 0.0, 1.0);
+        opp_block(c, sh, 2, tid, base, s, nb.i0, nb.d0, out + n);
+        m.n_tgt = 1; m.tgt0 = nb.i0 + 1; m.tgt_d0 = nb.d0;
+        if (nb.n >= 2) {
+            opp_block(c, sh, 2, tid, base, s, nb.i1, nb.d1, out + n + 10);
+            m.n_tgt = 2; m.tgt1 = nb.i1 + 1; m.tgt_d1 = nb.d1;
+        }
+        n += HH_N_OPP_HL * 10;
+        Near3 fr;
+        nearby(c, sh, tid, base, s, true, fr);
+        if (fr.n >= 1) friend_block(c, sh, tid, base, s, fr.i0, out + n);
+        if (fr.n >= 2) friend_block(c, sh, tid, base, s, fr.i1, out + n + 5);
+    } else { /* opponents keep the full sorted list of agents (env_hier.py:97) */
+        m.n_tgt = nb.n;
+        if (nb.n >= 1) { m.tgt0 = nb.i0 + 1; m.tgt_d0 = nb.d0; }
+        if (nb.n >= 2) { m.tgt1 = nb.i1 + 1; m.tgt_d1 = nb.d1; }
+        if (nb.n >= 3) { m.tgt2 = nb.i2 + 1; m.tgt_d2 = nb.d2; }
+    }
+}
+
+__device__ __forceinline__ int hl_gcd(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+/* env_hier.py:142-190 _action_assess for the lane's unit; returns the shaping reward of an agent */
+template <int A, int B>
+__device__ __forceinline__ double hl_action_assess(const DevCfg &c, const Shared<A, B> &sh, int tid, int base, int s, Unit &m,
+                                                   const Arena &ar, int cmd) {
+    const int id = s + 1;
+    double rew = 0.0;
+    if (!m.alive) { m.cmd_act = 0; return 0.0; }
+    if (s < c.nA) {
+        int cc = cmd;
+        if (cc > 0) {
+            int opp = 0;
+            if (cc - 1 < m.n_tgt) opp = cc == 1 ? m.tgt0 : (cc == 2 ? m.tgt1 : m.tgt2);
+            else cc = 1;
+            if (!opp) rew = -0.1;
+            if (c.hier_action_assess && opp) {
+                int oj = opp - 1;
+                rew = (sh.p_dist[oj][tid] < 0.1 && sh.p_foc[oj][tid] < 15.0 && sh.p_foc[s][base + oj] > 40.0) ? 0.1 : 0.0;
+            }
+        } else if (c.hier_action_assess) {
+            int oj = m.tgt0 - 1;
+            if (sh.p_dist[s][base + oj] < 0.1 && sh.p_foc[s][base + oj] < 15.0 && sh.p_foc[oj][tid] > 40.0) rew = 0.1;
+        }
+        m.cmd_act = cc;
+    } else {
+        int g = hl_gcd(c.hier_opp_fight_ratio, 100);
+        int num = c.hier_opp_fight_ratio / (g ? g : 1), den = 100 / (g ? g : 1);
+        double total = (double)den + 0.0;
+        int fight = d_rng(ar, id, HH_SITE_HL_FIGHT, 0) * total >= (double)(den - num);
+        int ag = 0;
+        if (fight) {
+            int possible = m.n_tgt;
+            if (possible > 1 && (d_rng(ar, id, HH_SITE_HL_OTHER, 0) * 4.0 >= 1.0))
+                ag = hh_rng_randint(d_rng(ar, id, HH_SITE_HL_PICK, 0), 2, possible);
+            else
+                ag = 1;
+        }
+        m.cmd_act = ag;
+    }
+    return rew;
+}
+
+template <int A, int B>
+__global__ __launch_bounds__(B) void hh_k_hier(DevPtrs P, DevCfg c, int phase, const int8_t *__restrict__ cmd,
+                                               const int8_t *__restrict__ actions, float *__restrict__ pilot_obs,
+                                               uint8_t *__restrict__ pilot_mode, float *__restrict__ obs_out,
+                                               float *__restrict__ reward_out, uint8_t *__restrict__ valid_out,
+                                               uint8_t *__restrict__ done_out, int *__restrict__ running_count,
+                                               const uint8_t *__restrict__ mask) {
+    constexpr int GPB = B / A;
+    __shared__ Shared<A, B> sh;
+    const int tid = threadIdx.x;
+    const int g = tid / A, s = tid % A;
+    const int base = g * A;
+    const int n = blockIdx.x * GPB + g;
+    const bool active = g < GPB && n < c.N;
+    const size_t U = (size_t)c.N * A;
+    const size_t u = (size_t)n * A + s;
+    const bool agent = s < c.nA;
+    Unit m = Unit{};
+    Arena ar = Arena{};
+    double acc = 0.0, ep_ret = 0.0;
+    if (active) {
+        unit_load(P, U, u, m);
+        arena_load(P, c, n, ar);
+        acc = P.acc_rew[u];
+        if (s == 0) ep_ret = P.ep_ret[n];
+    } else {
+        ar.done = 1;
+    }
+    sh.aux[tid] = 0;
+    uint32_t evm = 0;
+    publish(sh, tid, m);
+    __syncthreads();
+    pair_tables(sh, tid, base, s, active);
+    __syncthreads();
+    int obs_side = -1; /* which side's pilot observations this launch emits */
+
+    if (phase == HH_HL_BEGIN) {
+        ar.hl_s = 0;
+        ar.hl_run = active && !ar.done;
+        acc = 0.0;
+        if (ar.hl_run) {
+            int cc = agent ? (int)cmd[(size_t)n * c.nA + s] : 0;
+            double r = hl_action_assess(c, sh, tid, base, s, m, ar, cc);
+            if (agent) acc = r;
+        }
+        obs_side = 0;
+    } else if (phase == HH_HL_AGENTS_ACT) {
+        int8_t act[4] = {0, 0, 0, 0};
+        if (active) {
+            int w = *reinterpret_cast<const int *>(actions + u * 4);
+            act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
+        }
+        act_phase(c, sh, tid, s, base, active, m, ar, act, agent, evm);
+        obs_side = 1;
+    } else if (phase == HH_HL_TICK) {
+        int8_t act[4] = {0, 0, 0, 0};
+        if (active) {
+            int w = *reinterpret_cast<const int *>(actions + u * 4);
+            act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
+        }
+        act_phase(c, sh, tid, s, base, active, m, ar, act, !agent, evm);
+        StepOut so;
+        const bool was_running = active && ar.hl_run;
+        uint32_t evm_tick = 0;
+        tick<A, B>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_tick, 1, ar.hl_run != 0);
+        evm |= evm_tick;
+        if (was_running) {
+            if (agent) acc += so.reward;
+            /* env_hier.py:133-138: surrounding event only after min_sub_steps, then s += 1, steps += 1 */
+            int situ = 0;
+            if (ar.hl_s > 10) {
+#pragma unroll
+                for (int i = 0; i < A; i++) {
+                    if (i >= c.nA || !sh_alive(sh, base + i)) continue;
+#pragma unroll
+                    for (int j = 0; j < A; j++) {
+                        if (j < c.nA || !sh_alive(sh, base + j)) continue;
+                        if (sh.p_dist[j][base + i] < 0.1 && (sh.p_foc[j][base + i] < 15.0 || sh.p_foc[i][base + j] < 15.0)) situ = 1;
+                    }
+                }
+            }
+            ar.hl_s += 1;
+            ar.steps += 1;
+            arena_rekey(ar);
+            ar.hl_run = (ar.hl_s <= 15 && !so.kill_event && !situ) ? 1 : 0;
+            if (s == 0 && ar.hl_run && running_count) atomicAdd(running_count, 1);
+        }
+        obs_side = 0;
+    } else { /* HH_HL_END, HH_HL_REFRESH, HH_HL_RESET */
+        const bool ending = phase == HH_HL_END && active && !ar.done; /* arena took part in this macro step */
+        int ag = 0, op = 0;
+#pragma unroll
+        for (int j = 0; j < A; j++) { int al = sh_alive(sh, base + j); if (j < c.nA) ag += al; else op += al; }
+        if (ending) ar.done = (ag <= 0 || op <= 0 || ar.steps >= c.horizon) ? 1 : 0;
+        sh.rew[tid] = (ending && agent) ? acc : 0.0;
+        __syncthreads();
+        if (ending && s == 0) {
+            for (int j = 0; j < c.nA; j++) ep_ret += sh.rew[base + j];
+            if (ar.done) {
+                P.last_ret[n] = (float)ep_ret;
+                P.last_len[n] = ar.steps;
+                P.last_outcome[n] = (op <= 0 && ar.steps < c.horizon) ? 1 : ((ag <= 0 && ar.steps < c.horizon) ? -1 : 0);
+            }
+        }
+        if (phase == HH_HL_END) {
+            ar.hl_run = 0;
+            if (active && agent) {
+                size_t o = (size_t)n * c.nA + s;
+                if (reward_out) reward_out[o] = ending ? (float)acc : 0.0f;
+                if (valid_out) valid_out[o] = ending ? 1 : 0; /* every agent id has a reward key (env_hier.py:154,188) */
+            }
+            if (active && s == 0 && done_out) done_out[n] = (uint8_t)ar.done;
+        }
+        bool need_reset = phase == HH_HL_END ? (active && ar.done && c.auto_reset)
+                                             : (phase == HH_HL_RESET && active && (mask == nullptr || mask[n]));
+        const int any_reset = __syncthreads_or(need_reset ? 1 : 0);
+        if (need_reset) {
+            reset_arena_scalars(ar);
+            reset_unit<A>(c, s, m, ar);
+            ar.hl_s = 0; ar.hl_run = 0;
+            ep_ret = 0.0;
+            acc = 0.0;
+        }
+        if (any_reset) {
+            publish(sh, tid, m);
+            __syncthreads();
+            pair_tables(sh, tid, base, s, active);
+            __syncthreads();
+        }
+        if (active) {
+            float row[HH_OBS_HL];
+            hl_commander_obs(c, sh, tid, base, s, m, row);
+            const bool wr = phase != HH_HL_RESET || mask == nullptr || mask[n];
+            if (agent && obs_out && wr) {
+                float *dst = obs_out + ((size_t)n * c.nA + s) * HH_OBS_HL;
+                for (int k = 0; k < HH_OBS_HL; k++) dst[k] = row[k];
+            }
+        }
+    }
+    /* RESET / set_state style refresh of the stored lists is done by HL_END; pilot observations: */
+    if (obs_side >= 0 && active && pilot_obs) {
+        float row[30];
+        int mode = 0;
+        bool mine = obs_side == 0 ? agent : !agent;
+        if (ar.hl_run && m.alive && mine) mode = hl_pilot_obs(c, sh, tid, base, s, m, row);
+        else for (int k = 0; k < 30; k++) row[k] = 0.0f;
+        float *dst = pilot_obs + u * 30;
+        for (int k = 0; k < 30; k++) dst[k] = row[k];
+        if (pilot_mode) pilot_mode[u] = (uint8_t)mode;
+    }
+    if (active) {
+        unit_store(P, U, u, m);
+        P.acc_rew[u] = acc;
+        if (s == 0) {
+            arena_store(P, n, ar);
+            P.ep_ret[n] = ep_ret;
+        }
+    }
+    if (phase == HH_HL_AGENTS_ACT || phase == HH_HL_TICK) {
+        if (active && s == 0 && phase == HH_HL_AGENTS_ACT && ar.hl_run) P.ev_mask[n] = 0;
+        __syncthreads();
+        if (active && evm) atomicOr(&P.ev_mask[n], evm);
+    }
+}
+
+#endif /* HH_KERNELS_HIER_H */

@@ -10,7 +10,7 @@
 #include <string>
 #include <vector>
 
-#include "hh_kernels.h"
+#include "hh_kernels_hier.h"
 
 /* ===================================================================== host side */
 static thread_local std::string g_err;
@@ -33,6 +33,7 @@ struct hh_world {
     int block; /* threads per workgroup */
     void *slab;
     size_t slab_bytes;
+    int *counter; /* device word: arenas still inside their macro step */
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -82,7 +83,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     size_t o_pack = take(U * 16), o_tgt = take(3 * U * 8);
     size_t o_rk[4]; for (int k = 0; k < 4; k++) o_rk[k] = take(U * 8);
     size_t o_rkp = take(U * 8), o_ar = take(N * 16), o_ep = take(N * 8), o_lr = take(N * 4), o_ll = take(N * 4);
-    size_t o_lo = take(N), o_ev = take(N * 4);
+    size_t o_lo = take(N), o_ev = take(N * 4), o_acc = take(U * 8), o_cnt = take(256);
     w->slab_bytes = off;
     HIPCHK(hipMalloc(&w->slab, off));
     HIPCHK(hipMemset(w->slab, 0, off));
@@ -95,6 +96,8 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     P.rk_pack = (int2 *)(b + o_rkp); P.ar_pack = (int4 *)(b + o_ar); P.ep_ret = (double *)(b + o_ep);
     P.last_ret = (float *)(b + o_lr); P.last_len = (int *)(b + o_ll); P.last_outcome = (int8_t *)(b + o_lo);
     P.ev_mask = (uint32_t *)(b + o_ev);
+    P.acc_rew = (double *)(b + o_acc);
+    w->counter = (int *)(b + o_cnt);
     /* arenas start "done" (must be reset first); outcome 2 = no finished episode yet */
     {
         std::vector<int4> ar(N);
@@ -117,10 +120,25 @@ extern "C" int hh_world_destroy(hh_world *w) {
 extern "C" int hh_obs_dim(const hh_world *w) { return w ? w->dc.D : HH_E_ARG; }
 extern "C" int hh_n_ctrl(const hh_world *w) { return w ? w->dc.n_ctrl : HH_E_ARG; }
 
+static int launch_hier(hh_world *w, int phase, const int8_t *cmd, const int8_t *actions, float *pilot_obs, uint8_t *pilot_mode,
+                       float *obs, float *reward, uint8_t *valid, uint8_t *done, const uint8_t *mask, hipStream_t st) {
+    const DevCfg &c = w->dc;
+    if (w->cfg.env_kind != HH_ENV_HIGHLEVEL || c.A != 6) { g_err = "not a HighLevelEnv (3-vs-3) world"; return HH_E_ARG; }
+    constexpr int B = HH_BLOCK, GPB = B / 6;
+    int grid = (c.N + GPB - 1) / GPB;
+    hipLaunchKernelGGL((hh_k_hier<6, B>), dim3(grid), dim3(B), 0, st, w->P, c, phase, cmd, actions, pilot_obs, pilot_mode, obs, reward,
+                       valid, done, w->counter, mask);
+    HIPCHK(hipGetLastError());
+    return HH_OK;
+}
+
 static int launch(hh_world *w, int run, int T, const int8_t *actions, const uint8_t *mask, float *obs, float *reward,
                   uint8_t *valid, uint8_t *done, hipStream_t st) {
-    if (w->cfg.env_kind != HH_ENV_LOWLEVEL) { g_err = "HighLevelEnv stepping goes through hh_hl_* (not built in this round)"; return HH_E_ARG; }
     const DevCfg &c = w->dc;
+    if (w->cfg.env_kind != HH_ENV_LOWLEVEL) {
+        if (run == HH_RUN_ROLLOUT) { g_err = "HighLevelEnv steps through hh_hl_begin / hh_hl_agents_act / hh_hl_tick / hh_hl_end"; return HH_E_ARG; }
+        return launch_hier(w, run == HH_RUN_RESET ? HH_HL_RESET : HH_HL_REFRESH, nullptr, nullptr, nullptr, nullptr, obs, nullptr, nullptr, nullptr, mask, st);
+    }
     if (c.A == 4) {
         constexpr int B = HH_BLOCK, GPB = B / 4;
         int grid = (c.N + GPB - 1) / GPB;
@@ -282,4 +300,33 @@ extern "C" int hh_set_state(hh_world *w, const hh_state_view *v) {
 extern "C" int hh_observe(hh_world *w, float *obs, void *stream) {
     if (!w) return HH_E_ARG;
     return launch(w, HH_RUN_OBSERVE, 1, nullptr, nullptr, obs, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+/* ---- HighLevelEnv macro step (envs/env_hier.py:114-140), split so that pilot inference runs between launches ---- */
+extern "C" int hh_hl_begin(hh_world *w, const int8_t *commander_actions, float *pilot_obs, uint8_t *pilot_mode, void *stream) {
+    if (!w || !commander_actions) { g_err = "null argument"; return HH_E_ARG; }
+    return launch_hier(w, HH_HL_BEGIN, commander_actions, nullptr, pilot_obs, pilot_mode, nullptr, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int hh_hl_agents_act(hh_world *w, const int8_t *actions, float *pilot_obs, uint8_t *pilot_mode, void *stream) {
+    if (!w || !actions) { g_err = "null argument"; return HH_E_ARG; }
+    return launch_hier(w, HH_HL_AGENTS_ACT, nullptr, actions, pilot_obs, pilot_mode, nullptr, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int hh_hl_tick(hh_world *w, const int8_t *actions, float *pilot_obs, uint8_t *pilot_mode, int32_t *running, void *stream) {
+    if (!w || !actions) { g_err = "null argument"; return HH_E_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    if (running) HIPCHK(hipMemsetAsync(w->counter, 0, 4, st));
+    int rc = launch_hier(w, HH_HL_TICK, nullptr, actions, pilot_obs, pilot_mode, nullptr, nullptr, nullptr, nullptr, nullptr, st);
+    if (rc) return rc;
+    if (running) { /* host-visible count of arenas still inside the macro step (synchronises the stream) */
+        HIPCHK(hipMemcpyAsync(running, w->counter, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return HH_OK;
+}
+
+extern "C" int hh_hl_end(hh_world *w, float *obs, float *reward, uint8_t *reward_valid, uint8_t *done, void *stream) {
+    if (!w) return HH_E_ARG;
+    return launch_hier(w, HH_HL_END, nullptr, nullptr, nullptr, nullptr, obs, reward, reward_valid, done, nullptr, (hipStream_t)stream);
 }

@@ -103,6 +103,40 @@ class World:
                                    self._stream()))
         return obs, rew, val, done
 
+    # ---- HighLevelEnv macro step (envs/env_hier.py:114-140); pilot inference runs between the calls
+    def alloc_pilot(self):
+        return (torch.zeros((self.N, self.A, 30), dtype=torch.float32, device=self.device),
+                torch.zeros((self.N, self.A), dtype=torch.uint8, device=self.device))
+
+    def hl_begin(self, commander_actions, pilot=None):
+        """commander_actions int8 [N, n_agents] in {0,1,2} -> (pilot_obs [N,A,30], pilot_mode [N,A]) of the agents"""
+        assert commander_actions.dtype == torch.int8 and commander_actions.is_contiguous()
+        po, pm = pilot if pilot is not None else self.alloc_pilot()
+        L.check(L.lib().hh_hl_begin(self.h, _p(commander_actions), _p(po), _p(pm), self._stream()))
+        return po, pm
+
+    def hl_agents_act(self, actions, pilot=None):
+        """actions int8 [N, A, 4] (agent rows used) -> pilot observations of the opponents"""
+        assert actions.dtype == torch.int8 and actions.is_contiguous() and actions.numel() == self.N * self.A * 4
+        po, pm = pilot if pilot is not None else self.alloc_pilot()
+        L.check(L.lib().hh_hl_agents_act(self.h, _p(actions), _p(po), _p(pm), self._stream()))
+        return po, pm
+
+    def hl_tick(self, actions, pilot=None, count_running=True):
+        """actions int8 [N, A, 4] (opponent rows used) -> agents' pilot observations of the next sub-step and
+        the number of arenas still inside their macro step (None when count_running=False: no host sync)"""
+        assert actions.dtype == torch.int8 and actions.is_contiguous() and actions.numel() == self.N * self.A * 4
+        po, pm = pilot if pilot is not None else self.alloc_pilot()
+        running = C.c_int32(0)
+        L.check(L.lib().hh_hl_tick(self.h, _p(actions), _p(po), _p(pm), C.byref(running) if count_running else None,
+                                   self._stream()))
+        return po, pm, (running.value if count_running else None)
+
+    def hl_end(self, out=None):
+        obs, rew, val, done = out if out is not None else self.alloc_outputs()
+        L.check(L.lib().hh_hl_end(self.h, _p(obs), _p(rew), _p(val), _p(done), self._stream()))
+        return obs, rew, val, done
+
     def episode_stats(self):
         ret = torch.zeros(self.N, dtype=torch.float32, device=self.device)
         ln = torch.zeros(self.N, dtype=torch.int32, device=self.device)

@@ -105,6 +105,24 @@ int hh_step(hh_world *w, const int8_t *actions, float *obs, float *reward, uint8
 int hh_rollout(hh_world *w, int32_t n_steps, const int8_t *actions, float *obs, float *reward,
                uint8_t *reward_valid, uint8_t *done, void *stream);
 
+/* current observation of every arena without stepping (state(): env_hetero.py:62-63 / env_hier.py:49-98) */
+int hh_observe(hh_world *w, float *obs, void *stream);
+
+/* HighLevelEnv.step (envs/env_hier.py:114-140) for 3-vs-3 worlds.  One commander step =
+ *   hh_hl_begin(commander actions)            _action_assess + opponents' draws (142-190)
+ *   up to 16 x { pilots(agents) -> hh_hl_agents_act -> pilots(opponents) -> hh_hl_tick }
+ *   hh_hl_end                                 done, rewards, commander observation (49-98)
+ * The frozen pilot policies (env_base.py:349-398) run in the caller between the launches on the
+ * observations these calls emit: pilot_obs [dev] f32 [N, 6, 30] = lowlevel_state (env_hier.py:100-112)
+ * of the side that acts next (agents after begin/tick, opponents after agents_act), zero elsewhere;
+ * pilot_mode [dev] u8 [N, 6]: 0 = no action needed, 1 = fight policy, 2 = escape policy.
+ * actions [dev] i8 [N, 6, 4] (rows of the side that acts).  commander_actions [dev] i8 [N, 3] in {0,1,2}.
+ * `running` (host, nullable): number of arenas still inside their macro step after this tick. */
+int hh_hl_begin(hh_world *w, const int8_t *commander_actions, float *pilot_obs, uint8_t *pilot_mode, void *stream);
+int hh_hl_agents_act(hh_world *w, const int8_t *actions, float *pilot_obs, uint8_t *pilot_mode, void *stream);
+int hh_hl_tick(hh_world *w, const int8_t *actions, float *pilot_obs, uint8_t *pilot_mode, int32_t *running, void *stream);
+int hh_hl_end(hh_world *w, float *obs, float *reward, uint8_t *reward_valid, uint8_t *done, void *stream);
+
 /* per-arena statistics of the most recently FINISHED episode (logging; this is what the
  * multi-GPU all-gather moves): ret [dev] f32[N] (sum of agent rewards), len [dev] i32[N],
  * outcome [dev] i8[N] (1 agents win, -1 opponents win, 0 draw, 2 none finished yet) */

@@ -1,0 +1,95 @@
+"""HighLevelEnv (3-vs-3 commander, envs/env_hier.py) on the GPU: bit-exact against the CPU oracle with
+random commander/pilot actions, and against the golden traces recorded from the real reference."""
+import numpy as np
+import pytest
+
+from helpers import cfg_kwargs_from_meta, golden_files, load_golden, random_actions
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_state(a, b, what):
+    for k in ("ac_i", "rk_i", "ar_i", "tgt_id"):
+        assert np.array_equal(a[k], b[k]), f"{what}: {k} differs at {np.argwhere(a[k] != b[k])[:5].tolist()}"
+    for k in ("ac_f", "rk_f", "tgt_d"):
+        assert np.array_equal(a[k], b[k]), f"{what}: {k} max diff {np.abs(a[k] - b[k]).max()}"
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(glob_frac=0.3, hier_opp_fight_ratio=50, hier_action_assess=False),
+                                dict(friendly_kill=False, horizon=120)], ids=["default", "share", "nofriendly"])
+def test_macro_step_parity(oracle, kw):
+    import torch
+    from hhmarl_2d_amd.world import World, make_config
+    N = 170  # 42 arenas per workgroup: 4 full + 1 partial
+    base = dict(n_arenas=N, env_kind=1, seed=21, arena_offset=500, auto_reset=True)
+    base.update(kw)
+    g = World(make_config(**base))
+    o = oracle.OracleWorld(oracle.make_config(**base))
+    assert np.array_equal(g.reset().cpu().numpy(), o.reset())
+    _same_state(g.get_state(), o.get_state(), "reset")
+    rng = np.random.default_rng(4)
+    dones = kills = 0
+    for step in range(45):
+        cmd = rng.integers(0, 3, (N, 3)).astype(np.int8)
+        po, pm = g.hl_begin(torch.from_numpy(cmd).cuda())
+        o.hl_begin(cmd)
+        for sub in range(16):
+            po_o, pm_o = o.hl_pilot_obs(0)
+            assert np.array_equal(pm.cpu().numpy(), pm_o) and np.array_equal(po.cpu().numpy(), po_o), f"{step}/{sub}: agent pilot obs"
+            act = random_actions(rng, (N,), 6)
+            if step % 3 == 0:  # engage: everybody keeps the trigger pulled
+                act[..., 2] = 1
+            ta = torch.from_numpy(act).cuda()
+            po, pm = g.hl_agents_act(ta)
+            o.hl_agents_act(act)
+            po_o, pm_o = o.hl_pilot_obs(1)
+            assert np.array_equal(pm.cpu().numpy(), pm_o) and np.array_equal(po.cpu().numpy(), po_o), f"{step}/{sub}: opp pilot obs"
+            po, pm, running = g.hl_tick(ta)
+            running_o = o.hl_tick(act)
+            assert running == running_o, f"{step}/{sub}: running {running} vs {running_o}"
+            assert np.array_equal(g.event_masks(), o.event_masks()), f"{step}/{sub}: event masks"
+            kills += int(np.count_nonzero(o.event_masks() & 0xFFFF))
+            if running == 0:
+                break
+        outs = [x.cpu().numpy() for x in g.hl_end()]
+        outs_o = o.hl_end()
+        for a, b, name in zip(outs, outs_o, ("obs", "reward", "valid", "done")):
+            assert np.array_equal(a, b), f"step {step}: {name}"
+        dones += int(outs[3].sum())
+        _same_state(g.get_state(), o.get_state(), f"step {step}")
+    for a, b in zip([x.cpu().numpy() for x in g.episode_stats()], o.episode_stats()):
+        assert np.array_equal(a, b)
+    assert dones > 0 and kills > 0
+
+
+@pytest.mark.parametrize("path", golden_files("high"), ids=lambda p: p.split("env_")[-1][:-4])
+def test_reference_traces_on_gpu(path):
+    import torch
+    from hhmarl_2d_amd.world import World, make_config
+    g, meta = load_golden(path)
+    w = World(make_config(**cfg_kwargs_from_meta(meta)))
+    nA, ptr = w.n_agents, 0
+    for r in range(len(g["kind"])):
+        if g["kind"][r] == 0:
+            obs = w.reset().cpu().numpy()[0]
+            rew, val, done = np.zeros(nA), np.zeros(nA, dtype=np.uint8), 0
+        else:
+            po, pm = w.hl_begin(torch.from_numpy(np.ascontiguousarray(g["cmd"][r][None])).cuda())
+            for k in range(g["nsub"][r]):
+                act = torch.from_numpy(np.ascontiguousarray(g["sub_act"][ptr][None])).cuda()
+                po1, pm1 = w.hl_agents_act(act)
+                mode = (pm + pm1).cpu().numpy()[0]
+                pobs = (po + po1).cpu().numpy()[0]
+                assert np.array_equal(mode, g["sub_mode"][ptr]), f"row {r} sub {k}"
+                assert np.abs(pobs - g["sub_obs"][ptr]).max() <= 1e-6, f"row {r} sub {k}"
+                po, pm, running = w.hl_tick(act)
+                ptr += 1
+                assert running == (1 if k < g["nsub"][r] - 1 else 0), f"row {r}: macro step length"
+            o, rw, v, d = [x.cpu().numpy() for x in w.hl_end()]
+            obs, rew, val, done = o[0], rw[0], v[0], d[0]
+        st = w.get_state()
+        assert np.array_equal(st["tgt_id"][0], g["tgt_id"][r]) and np.array_equal(st["rk_i"][0], g["rk_i"][r]), f"row {r}"
+        assert np.array_equal(st["ac_i"][0][:, :9], g["ac_i"][r][:, :9]), f"row {r}"
+        assert np.array_equal(val, g["valid"][r]) and done == g["done"][r], f"row {r}"
+        assert np.abs(st["ac_f"][0] - g["ac_f"][r]).max() <= 1e-9 and np.abs(obs - g["obs"][r]).max() <= 1e-6, f"row {r}"
+        assert np.abs(rew - g["reward"][r]).max() <= 1e-6, f"row {r}"

@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_2V2_STEP = 1113   # state r/w 2*448 + actions 8 + obs 200 + reward 8 + done 1
+ALGO_BYTES_3V3_CMD_STEP = 27600  # 13.2 ticks x 2056 B + commander obs 408 + actions/rewards/done
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -65,7 +66,13 @@ def main():
     ap.add_argument("--chunk", type=int, default=250, help="ticks per persistent-kernel launch")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["low", "hier"], default="low",
+                    help="low: BASELINE configs[1] (default, the headline).  hier: configs[3], 3-vs-3 HighLevelEnv commander "
+                         "steps (use --arenas 8192); a step is one commander step = 16 sub-steps with pilot actions")
+    ap.add_argument("--pilot", choices=["random", "mlp"], default="random", help="hier: uniform action tape or random-init MLP pilots")
     args = ap.parse_args()
+    if args.workload == "hier":
+        return main_hier(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -149,6 +156,78 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(N, args.level, args.seed)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def main_hier(args):
+    """BASELINE configs[3]/[4]: N arenas x 3-vs-3 HighLevelEnv (map 0.5, horizon 500, N_OPP_HL=2), commander
+    actions uniform {0,1,2}; pilots = uniform actions (default) or random-init MLPs evaluated on the same GPU."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from hhmarl_2d_amd.env_hier import macro_step
+    from hhmarl_2d_amd.pilots import MLPPilot, RandomPilot
+    from hhmarl_2d_amd.sharding import ShardedWorld
+    N = args.arenas
+    sw = ShardedWorld(dict(n_arenas=N, env_kind=1, seed=args.seed, auto_reset=True), rank=rank, world_size=world, device=local_rank)
+    w = sw.world
+    w.reset()
+    pilot = RandomPilot(dev, args.seed + rank) if args.pilot == "random" else MLPPilot(dev, seed=args.seed)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(args.seed + 17 + rank)
+    steps, warm = args.steps, args.warmup
+    cmds = (torch.rand((64, N, 3), device=dev, generator=gen) * 3).to(torch.int8).contiguous()
+    out, pbuf = w.alloc_outputs(), w.alloc_pilot()
+
+    def run(n):
+        for k in range(n):
+            macro_step(w, cmds[k % 64], pilot, out=out, pilot_buf=pbuf)
+            if k % 16 == 15:
+                sw.log_episode_stats()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(warm)
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    run(steps)
+    e1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    gpu_s = e0.elapsed_time(e1) * 1e-3
+    value = N * world * steps / dt
+    achieved = ALGO_BYTES_3V3_CMD_STEP * N * steps / gpu_s / 1e9
+    line = {
+        "metric": "commander-steps/sec (3v3 HighLevelEnv)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": steps,
+        "warmup": warm, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic", "agent_steps_per_s": value * 3, "sim_ticks_per_s": value * 16,
+        "config": {"workload": f"{N} arenas/GPU x 3-vs-3 HighLevelEnv commander steps (16 sub-steps each), uniform commander actions, "
+                               f"pilots = {'uniform action tape' if args.pilot == 'random' else 'random-init MLP fight/escape nets'}, "
+                               f"auto-reset (BASELINE configs[3])", "arenas_per_gpu": N,
+                   "parallelism": f"arena-sharded x{world}, no data-path collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "hh_k_hier<6,256> (all phases of the macro step, incl. pilot action generation)",
+                     "algorithmic_bytes_per_step": ALGO_BYTES_3V3_CMD_STEP * N},
+    }
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

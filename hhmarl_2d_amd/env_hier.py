@@ -1,0 +1,106 @@
+"""Drop-in for envs/env_hier.py HighLevelEnv (3-vs-3 commander) on top of the MI355X world.
+
+Same surface as the reference (envs/env_hier.py:27-47): `HighLevelEnv(env_config)`,
+`observation_space = Box(0,1,(34,))`, `action_space = Discrete(3)`, `_agent_ids = {1,2,3}`,
+`reset() -> (obs, {})`, `step({1:a1, 2:a2, 3:a3}) -> (obs, rewards, terminateds, truncateds, {})`.
+The frozen low-level pilots the reference loads inside the env (env_base.py:312-398, not shipped) are
+supplied as `env_config["pilot"]` (see hhmarl_2d_amd/pilots.py); they run in PyTorch between the
+phase kernels of the macro step (csrc/hh_kernels_hier.h)."""
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import spaces
+from .env_hetero import _Base, config_from_args
+from .world import World
+
+N_OPP_HL = 2
+OBS_HL = 14 + N_OPP_HL * 10
+N_SUB_STEPS = 16  # while s <= self.n_sub_steps (15)
+
+
+def macro_step(world, commander_actions, pilot, out=None, pilot_buf=None, early_exit=False):
+    """One HighLevelEnv.step for every arena of `world` (env_hier.py:114-140).
+    commander_actions: int8 [N, n_agents] on the world's device."""
+    nA = world.n_agents
+    po, pm = world.hl_begin(commander_actions, pilot_buf)
+    for sub in range(N_SUB_STEPS):
+        act = pilot(po, pm).contiguous()
+        po, pm = world.hl_agents_act(act, pilot_buf)
+        act_o = pilot(po, pm)
+        act[:, nA:] = act_o[:, nA:]
+        po, pm, running = world.hl_tick(act, pilot_buf, count_running=early_exit)
+        if early_exit and running == 0:
+            break
+    return world.hl_end(out)
+
+
+class HighLevelEnv(_Base):
+    """High-Level Environment for Aircombat Maneuvering (commander), MI355X-resident."""
+
+    def __init__(self, env_config):
+        self.args = env_config.get("args", None)
+        self.n_sub_steps = 15
+        self.min_sub_steps = 10
+        self.observation_space = spaces.Box(low=np.zeros(OBS_HL), high=np.ones(OBS_HL), dtype=np.float32)
+        self.action_space = spaces.Discrete(N_OPP_HL + 1)
+        self._agent_ids = set(range(1, self.args.num_agents + 1))
+        self._skip_env_checking = True
+        self.map_size = self.args.map_size
+        self.num_envs = int(env_config.get("num_envs", 1))
+        self.pilot = env_config.get("pilot", None)
+        if self.pilot is None:
+            raise ValueError("HighLevelEnv flies frozen low-level pilot policies (envs/env_base.py:312-398); pass "
+                             "env_config['pilot'] = callable(pilot_obs, pilot_mode) -> int8 actions [N, 6, 4]")
+        cfg = config_from_args(self.args, L.ENV_HIGHLEVEL, self.num_envs, int(env_config.get("seed", 0)))
+        self.world = World(cfg, device=int(env_config.get("device", 0)))
+        self._cmd = torch.zeros((self.num_envs, self.args.num_agents), dtype=torch.int8, device=self.world.device)
+        self.commander_actions = None
+        self.rewards = {}
+        super().__init__()
+
+    def _obs_dict(self, obs):
+        o = obs.cpu().numpy()
+        if self.num_envs == 1:
+            return {i: o[0, i - 1].copy() for i in sorted(self._agent_ids)}
+        return {i: o[:, i - 1].copy() for i in sorted(self._agent_ids)}
+
+    def reset(self, *, seed=None, options=None):
+        self.commander_actions = None
+        return self._obs_dict(self.world.reset()), {}
+
+    def state(self):
+        return self._obs_dict(self.world.observe())
+
+    def step(self, action):
+        self.rewards = {}
+        nA = self.args.num_agents
+        if action:
+            self.commander_actions = action
+            c = np.zeros((self.num_envs, nA), dtype=np.int8)
+            for k, v in action.items():
+                if k <= nA:
+                    c[:, k - 1] = np.asarray(v)
+            self._cmd.copy_(torch.from_numpy(c))
+            obs, rew, val, done = macro_step(self.world, self._cmd, self.pilot, early_exit=True)
+            rew, val, done = rew.cpu().numpy(), val.cpu().numpy(), done.cpu().numpy()
+            if self.num_envs == 1:
+                self.rewards = {i: float(rew[0, i - 1]) for i in range(1, nA + 1) if val[0, i - 1]}
+                d = bool(done[0])
+            else:
+                self.rewards = {i: rew[:, i - 1] for i in range(1, nA + 1)}
+                d = done.astype(bool)
+            obs_d = self._obs_dict(obs)
+        else:
+            obs_d = self.state()
+            st = self.world.get_state()["ar_i"]
+            dn = (st[:, 1] <= 0) | (st[:, 2] <= 0) | (st[:, 0] >= self.args.horizon)
+            d = bool(dn[0]) if self.num_envs == 1 else dn
+        terminateds = truncateds = {"__all__": d}
+        return obs_d, self.rewards, terminateds, truncateds, {}
+
+    def plot(self, out_file=None, paths=True):
+        return None
+
+    def close(self):
+        self.world.close()

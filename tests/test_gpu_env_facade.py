@@ -73,3 +73,43 @@ def test_level4_requires_opponent_policy():
     from hhmarl_2d_amd.env_hetero import LowLevelEnv
     with pytest.raises(ValueError):
         LowLevelEnv({"args": make_args(0, level=4)})
+
+
+def test_highlevel_dict_protocol_matches_reference_trace():
+    """HighLevelEnv facade driven like RLlib drives the reference, with the trace's taped pilot actions"""
+    import torch
+    from hhmarl_2d_amd import env_hetero
+    from hhmarl_2d_amd.config import make_args
+    from hhmarl_2d_amd.env_hier import HighLevelEnv
+    g, meta = load_golden(golden_files("high")[0])
+    a = meta["args"]
+    args = make_args(1, **{k: a[k] for k in ("horizon", "map_size", "glob_frac", "rew_scale", "friendly_kill",
+                                              "hier_action_assess", "hier_opp_fight_ratio", "level")})
+    tape = {"ptr": 0}
+
+    def pilot(po, pm):  # replays the recorded pilot actions; called for agents then opponents in each sub-step
+        k = tape["ptr"] // 2
+        tape["ptr"] += 1
+        return torch.from_numpy(np.ascontiguousarray(g["sub_act"][min(k, len(g["sub_act"]) - 1)][None])).to(po.device)
+
+    orig = env_hetero.config_from_args
+    import hhmarl_2d_amd.env_hier as eh
+    eh.config_from_args = lambda *x, **k: orig(*x, **{**k, "arena_offset": meta["arena"]})
+    try:
+        env = HighLevelEnv({"args": args, "seed": meta["seed"], "pilot": pilot})
+    finally:
+        eh.config_from_args = orig
+    assert env._agent_ids == {1, 2, 3} and env.observation_space.shape == (34,) and env.action_space.n == 3
+    for r in range(len(g["kind"])):
+        if g["kind"][r] == 0:
+            obs, info = env.reset()
+        else:
+            obs, rew, term, trunc, info = env.step({i + 1: int(g["cmd"][r][i]) for i in range(3)})
+            assert term is trunc and term["__all__"] == bool(g["done"][r]) and set(rew) == {1, 2, 3}
+            for i in rew:
+                assert abs(rew[i] - g["reward"][r][i - 1]) <= 1e-6
+        for i in (1, 2, 3):
+            assert obs[i].dtype == np.float32 and obs[i].shape == (34,)
+            assert np.abs(obs[i] - g["obs"][r][i - 1]).max() <= 1e-6
+    assert tape["ptr"] == 2 * len(g["sub_act"])
+    env.close()

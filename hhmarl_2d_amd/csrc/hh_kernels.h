@@ -836,8 +836,11 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
 /* ===================================================================== the kernel */
 enum { HH_RUN_ROLLOUT = 0, HH_RUN_RESET = 1, HH_RUN_OBSERVE = 2 };
 
-template <int A, int B>
-__global__ __launch_bounds__(B) void hh_k_world(DevPtrs P, DevCfg c, int run, int T, const int8_t *__restrict__ actions,
+/* W = waves per SIMD the register allocation is held to: 1 = no spills, lowest per-tick latency (few arenas);
+ * 2 = 256 registers per lane, spills to scratch but two resident waves per SIMD: +35 % throughput once there
+ * are more than ~2 waves per SIMD to run (>= 32768 arenas).  Same source, same results. */
+template <int A, int B, int W>
+__global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run, int T, const int8_t *__restrict__ actions,
                                                 const uint8_t *__restrict__ mask, float *__restrict__ obs_out,
                                                 float *__restrict__ reward_out, uint8_t *__restrict__ valid_out,
                                                 uint8_t *__restrict__ done_out) {

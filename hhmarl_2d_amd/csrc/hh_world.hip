@@ -34,6 +34,7 @@ struct hh_world {
     void *slab;
     size_t slab_bytes;
     int *counter; /* device word: arenas still inside their macro step */
+    int force_w;  /* 0 = choose the kernel variant by arena count, 1 / 2 = force (HH_FORCE_W, experiments/tests) */
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -75,6 +76,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     d.inv_diag = (1.0 - 0.0) / (__builtin_sqrt(2.0 * (ms * ms)) - 0.0);
     d.seed = cfg->seed; d.arena_offset = cfg->arena_offset;
     w->block = HH_BLOCK;
+    { const char *fw = getenv("HH_FORCE_W"); w->force_w = fw ? atoi(fw) : 0; }
     /* one slab, 256-byte aligned sub-arrays */
     size_t U = (size_t)d.N * A, N = (size_t)d.N;
     size_t off = 0;
@@ -139,15 +141,14 @@ static int launch(hh_world *w, int run, int T, const int8_t *actions, const uint
         if (run == HH_RUN_ROLLOUT) { g_err = "HighLevelEnv steps through hh_hl_begin / hh_hl_agents_act / hh_hl_tick / hh_hl_end"; return HH_E_ARG; }
         return launch_hier(w, run == HH_RUN_RESET ? HH_HL_RESET : HH_HL_REFRESH, nullptr, nullptr, nullptr, nullptr, obs, nullptr, nullptr, nullptr, mask, st);
     }
-    if (c.A == 4) {
-        constexpr int B = HH_BLOCK, GPB = B / 4;
-        int grid = (c.N + GPB - 1) / GPB;
-        hipLaunchKernelGGL((hh_k_world<4, B>), dim3(grid), dim3(B), 0, st, w->P, c, run, T, actions, mask, obs, reward, valid, done);
-    } else {
-        constexpr int B = HH_BLOCK, GPB = B / 6;
-        int grid = (c.N + GPB - 1) / GPB;
-        hipLaunchKernelGGL((hh_k_world<6, B>), dim3(grid), dim3(B), 0, st, w->P, c, run, T, actions, mask, obs, reward, valid, done);
-    }
+    if (c.A != 4) { g_err = "LowLevelEnv worlds are 2-vs-2"; return HH_E_ARG; }
+    constexpr int B = HH_BLOCK, GPB = B / 4;
+    const int grid = (c.N + GPB - 1) / GPB;
+    const int waves = grid * (B / 64);
+    if (w->force_w == 2 || (w->force_w == 0 && waves >= 2048))
+        hipLaunchKernelGGL((hh_k_world<4, B, 2>), dim3(grid), dim3(B), 0, st, w->P, c, run, T, actions, mask, obs, reward, valid, done);
+    else
+        hipLaunchKernelGGL((hh_k_world<4, B, 1>), dim3(grid), dim3(B), 0, st, w->P, c, run, T, actions, mask, obs, reward, valid, done);
     HIPCHK(hipGetLastError());
     return HH_OK;
 }

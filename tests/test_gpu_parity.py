@@ -167,3 +167,29 @@ def test_set_state_round_trip_and_edge_cases(oracle):
         _assert_same_state(g.get_state(), o.get_state(), f"t={t}")
     assert (o.get_state()["ac_i"][:, 1, 0] == 0).any()      # somebody left the map
     assert (o.get_state()["ac_i"][:, [0, 2], 0] == 0).any()  # cannon kills happened
+
+
+@pytest.mark.parametrize("N,T,force_w", [(4096, 300, "1"), (16384, 60, "1"), (4096, 120, "2"), (40000, 40, "0")],
+                         ids=["configs1-4096x300", "configs2-16384x60", "spill-variant-4096x120", "auto-variant-40000x40"])
+def test_full_size_rollout_parity(oracle, monkeypatch, N, T, force_w):
+    """BASELINE.json sizes (4096 / 16384 arenas, level-3 horizon 300) through hh_rollout, both kernel
+    variants (W=1 no-spill, W=2 two waves per SIMD), bit-exact against the oracle incl. final state,
+    episode statistics and the size-independent bookkeeping (every arena's step counter <= horizon)."""
+    import torch
+    monkeypatch.setenv("HH_FORCE_W", force_w)
+    kw = dict(n_arenas=N, level=3, seed=1234, auto_reset=True)
+    g, o = _worlds(oracle, **kw)
+    assert np.array_equal(g.reset().cpu().numpy(), o.reset())
+    rng = np.random.default_rng(77)
+    chunk = 60
+    for t0 in range(0, T, chunk):
+        act = random_actions(rng, (min(chunk, T - t0), N), g.n_ctrl)
+        outs = [x.cpu().numpy() for x in g.rollout(torch.from_numpy(act).cuda())]
+        outs_o = o.rollout(act)
+        for a, b, name in zip(outs, outs_o, ("obs", "reward", "valid", "done")):
+            assert np.array_equal(a, b), f"{name} @ t0={t0}"
+    sg, so = g.get_state(), o.get_state()
+    _assert_same_state(sg, so, "final")
+    assert (sg["ar_i"][:, 0] <= 300).all() and (sg["ar_i"][:, 5] >= 1).all()
+    for a, b in zip([x.cpu().numpy() for x in g.episode_stats()], o.episode_stats()):
+        assert np.array_equal(a, b)

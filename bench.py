@@ -56,6 +56,18 @@ def cpu_baseline(n_arenas, level, seed, budget_s=12.0):
             "sample": f"{n_arenas} arenas x {steps} ticks, same config/seed/action distribution, OpenMP over arenas"}
 
 
+def init_dist(rank, local_rank, world):
+    """one process per GPU over RCCL (backend "nccl" is RCCL on ROCm) whenever launched by torch.distributed.run"""
+    if "RANK" not in os.environ:
+        return None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    return dist
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,11 +89,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dist = init_dist(rank, local_rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -168,11 +176,7 @@ def main_hier(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dist = init_dist(rank, local_rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from hhmarl_2d_amd.env_hier import macro_step

@@ -33,6 +33,23 @@
 
 #include "hh_device.h"
 
+/* phase timers for tuning builds only (-DHH_PROFILE_PHASES): s_memtime deltas per phase, summed per wave
+ * into hh_prof_cycles[]; compiled out of the product */
+#ifdef HH_PROFILE_PHASES
+__device__ unsigned long long hh_prof_cycles[16];
+#define HH_PROF_DECL unsigned long long prof_t0_ = __builtin_readcyclecounter(), prof_acc_[12] = {0}
+#define HH_PROF(k) do { unsigned long long t_ = __builtin_readcyclecounter(); prof_acc_[k] += t_ - prof_t0_; prof_t0_ = t_; } while (0)
+#define HH_PROF_ARGS , unsigned long long &prof_t0_, unsigned long long *prof_acc_
+#define HH_PROF_PASS , prof_t0_, prof_acc_
+#define HH_PROF_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 12; k_++) atomicAdd(&hh_prof_cycles[k_], prof_acc_[k_]); } while (0)
+#else
+#define HH_PROF_DECL
+#define HH_PROF(k)
+#define HH_PROF_ARGS
+#define HH_PROF_PASS
+#define HH_PROF_FLUSH
+#endif
+
 /* ===================================================================== LDS exchange area */
 template <int A, int B>
 struct Shared {
@@ -86,36 +103,51 @@ __device__ __forceinline__ void publish(Shared<A, B> &sh, int tid, const Unit &m
     sh.flags[tid] = (m.alive ? FL_ALIVE : 0) | ((m.ac_type & 3) << 1) | (shot ? FL_SHOT : 0);
 }
 
-/* the per-arena pair table (call between two barriers, after publish) */
+/* the per-arena pair table (call between two barriers, after publish).  Branch-free and fully unrolled on
+ * purpose: the kernel runs at one or two waves per SIMD, so the 2(A-1)+A/2 independent acos chains must
+ * overlap inside the lane (ILP); entries involving a dead aircraft are computed but never read. */
 template <int A, int B>
 __device__ __forceinline__ void pair_tables(Shared<A, B> &sh, int tid, int base, int s, bool active) {
 #ifdef HH_ABL_NO_PAIRS
     return;
 #endif
-    if (!active || !sh_alive(sh, tid)) return;
     const double c1 = sh.uc[tid], s1 = sh.us[tid], n1 = sh.un[tid];
     const double la = sh.lat0[tid], lo = sh.lon0[tid];
-#pragma unroll 1
-    for (int j = 0; j < A; j++) {
-        if (j == s || !sh_alive(sh, base + j)) continue;
+    double dist[A - 1], foc[A - 1], hd[A / 2];
+#pragma unroll
+    for (int k = 1; k < A; k++) {
+        int j = s + k;
+        if (j >= A) j -= A;
         double dx = sh.lon0[base + j] - lo, dy = sh.lat0[base + j] - la;
         double n2 = hh_sqrt(dx * dx + dy * dy);
         double dot = c1 * dx + s1 * dy;
         double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
-        sh.p_dist[j][tid] = n2;
-        sh.p_foc[j][tid] = hh_acos(x) * (180.0 / HH_PI);
+        dist[k - 1] = n2;
+        foc[k - 1] = hh_acos(x) * (180.0 / HH_PI);
     }
-#pragma unroll 1
+#pragma unroll
     for (int k = 1; k <= A / 2; k++) {
         int j = s + k;
         if (j >= A) j -= A;
-        if (!sh_alive(sh, base + j)) continue;
         double c2 = sh.uc[base + j], s2 = sh.us[base + j], n2 = sh.un[base + j];
         double dot = c1 * c2 + s1 * s2;
         double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
-        double v = hh_clip((hh_acos(x) * (180.0 / HH_PI)) / 180.0, 0.0, 1.0);
-        sh.p_hd[j][tid] = v;
-        sh.p_hd[s][base + j] = v;
+        hd[k - 1] = hh_clip((hh_acos(x) * (180.0 / HH_PI)) / 180.0, 0.0, 1.0);
+    }
+    if (!active) return;
+#pragma unroll
+    for (int k = 1; k < A; k++) {
+        int j = s + k;
+        if (j >= A) j -= A;
+        sh.p_dist[j][tid] = dist[k - 1];
+        sh.p_foc[j][tid] = foc[k - 1];
+    }
+#pragma unroll
+    for (int k = 1; k <= A / 2; k++) {
+        int j = s + k;
+        if (j >= A) j -= A;
+        sh.p_hd[j][tid] = hd[k - 1];
+        sh.p_hd[s][base + j] = hd[k - 1];
     }
 }
 
@@ -383,7 +415,7 @@ __device__ __forceinline__ void arm_cannon(Unit &m) { /* ac1.py:69-70 / ac2.py:6
 template <int A, int B>
 __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid, int g, int s, int base, bool active,
                                      Unit &m, Arena &ar, const int8_t *act, StepOut &out, uint32_t &ev_mask_out,
-                                     const int tmode = 0, const bool run_arena = true) {
+                                     const int tmode, const bool run_arena HH_PROF_ARGS) {
     /* tmode 0: fused LowLevelEnv step (commands + tick).  tmode 1: tick only — commands and launches were
      * already applied per side by act_phase (HighLevelEnv sub-steps; steps is advanced by the caller) */
     const int id = s + 1;
@@ -524,6 +556,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
         }
     }
 
+    HH_PROF(0);
     /* ---------------- phase B: aircraft kinematics + move (ac1.py:81-133) ---------------- */
     const double lat_old = m.lat, lon_old = m.lon, hdg_old = m.hdg;
     bool fired = false;
@@ -568,6 +601,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     if (s == 0 && active) sh.g_tkey[g] = ar.tkey;
     __syncthreads();
 
+    HH_PROF(1);
     /* ---------------- phase Q: enqueue every geodesic envelope test that survives the prefilter ---------------- */
     const int rk_tgt = rk_pre ? m.rk_target - 1 : launch_tgt; /* slot the (possibly pending) rocket is aimed at */
     const bool rk_maybe = running && (rk_pre || try_launch);
@@ -621,10 +655,12 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     }
     __syncthreads();
 
+    HH_PROF(2);
     /* ---------------- phase I: dense pass over the queue (estimate filter + out-of-line exact Karney) ---------------- */
     drain_envelope_queue(sh, tid);
     __syncthreads();
 
+    HH_PROF(3);
     /* ---------------- phase L: launch bookkeeping (env_base.py:227-236, ac1.py:76-79) ---------------- */
     const int myres = sh.res[tid];
     int launched = 0;
@@ -735,6 +771,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
         }
     }
 
+    HH_PROF(4);
     /* ---------------- phase E: out of bounds, rewards, done (env_base.py:240-310, env_hetero.py:188-225) ---------------- */
     int oob = 0;
     if (active) {
@@ -789,9 +826,12 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     sh.aux[tid] = oob;
     sh.rew[tid] = rews;
     /* post-tick state + pair table: escape shaping now, observation next, pre-step lookups of the next tick */
+    HH_PROF(5);
     publish(sh, tid, m);
     __syncthreads();
+    HH_PROF(6);
     pair_tables(sh, tid, base, s, active);
+    HH_PROF(7);
     if (running) {
         int ag = 0, op = 0, kill = nev > 0;
 #pragma unroll
@@ -831,6 +871,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
         }
     }
     __syncthreads(); /* all reads of rew/aux/g_* done before the caller reuses them */
+    HH_PROF(8);
 }
 
 /* ===================================================================== the kernel */
@@ -854,6 +895,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
     const size_t U = (size_t)c.N * A;
     const size_t u = (size_t)n * A + s;
     const int D = c.D;
+    HH_PROF_DECL;
     Unit m = Unit{};
     Arena ar = Arena{};
     double ep_ret = 0.0;
@@ -883,7 +925,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
                 act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
             }
             const bool was_running = active && !ar.done;
-            tick<A, B>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_last);
+            tick<A, B>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_last, 0, true HH_PROF_PASS);
             /* outputs of this tick */
             if (active && s < c.nA) {
                 size_t o = ((size_t)t * c.N + n) * c.nA + s;
@@ -919,6 +961,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
             __syncthreads();
         }
         need_reset = false;
+        HH_PROF(9);
         /* K2: observation rows staged in LDS, then written with unit-stride stores */
 #ifndef HH_ABL_NO_OBS
         if (active && s < c.nA) lowlevel_obs<A, B>(c, sh, tid, base, s, c.agent_mode, m, &sh.u.obs[(g * c.nA + s) * D], D);
@@ -935,7 +978,9 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
             }
         }
         __syncthreads();
+        HH_PROF(10);
     }
+    HH_PROF_FLUSH;
     if (active) {
         unit_store(P, U, u, m);
         if (s == 0) {

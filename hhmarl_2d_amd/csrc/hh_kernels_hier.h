@@ -290,7 +290,10 @@ __global__ __launch_bounds__(B) void hh_k_hier(DevPtrs P, DevCfg c, int phase, c
         StepOut so;
         const bool was_running = active && ar.hl_run;
         uint32_t evm_tick = 0;
-        tick<A, B>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_tick, 1, ar.hl_run != 0);
+#ifdef HH_PROFILE_PHASES
+        unsigned long long prof_t0_ = 0, prof_acc_[12] = {0};
+#endif
+        tick<A, B>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_tick, 1, ar.hl_run != 0 HH_PROF_PASS);
         evm |= evm_tick;
         if (was_running) {
             if (agent) acc += so.reward;

@@ -331,3 +331,12 @@ extern "C" int hh_hl_end(hh_world *w, float *obs, float *reward, uint8_t *reward
     if (!w) return HH_E_ARG;
     return launch_hier(w, HH_HL_END, nullptr, nullptr, nullptr, nullptr, obs, reward, reward_valid, done, nullptr, (hipStream_t)stream);
 }
+
+#ifdef HH_PROFILE_PHASES
+extern "C" int hh_prof_read(unsigned long long *out16, int reset) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(hh_prof_cycles), 16 * 8));
+    if (reset) { unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(hh_prof_cycles), z, 16 * 8)); }
+    return HH_OK;
+}
+#endif

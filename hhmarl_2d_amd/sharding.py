@@ -23,9 +23,9 @@ def pack_stats(ret, length, outcome):
 
 def gather_stats(block, world_size, group=None):
     """all-gather the per-rank [N,3] blocks -> [world_size*N, 3] in global arena order."""
-    if world_size == 1:
-        return block
     import torch.distributed as dist
+    if world_size == 1 and not (dist.is_available() and dist.is_initialized()):
+        return block
     out = torch.empty((world_size * block.shape[0], block.shape[1]), dtype=block.dtype, device=block.device)
     dist.all_gather_into_tensor(out, block, group=group)
     return out

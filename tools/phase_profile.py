@@ -1,0 +1,25 @@
+"""Per-phase cycle breakdown of the tick (tuning tool; needs lib/prof_phases.so built with -DHH_PROFILE_PHASES)."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["HH_WORLD_LIB"] = os.path.join(ROOT, "hhmarl_2d_amd", "lib", "prof_phases.so")
+import torch
+from hhmarl_2d_amd import _lib
+from hhmarl_2d_amd.world import World, make_config
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+T = 250
+w = World(make_config(n_arenas=N, level=3, seed=1234, auto_reset=True)); w.reset()
+hi = torch.tensor([13, 9, 2, 2], device="cuda")
+act = (torch.rand((T, N, 2, 4), device="cuda") * hi).to(torch.int8)
+out = w.alloc_outputs(T)
+w.rollout(act, out=out)
+buf = (C.c_ulonglong * 16)()
+L = _lib.lib(); L.hh_prof_read(buf, 1)
+for _ in range(4): w.rollout(act, out=out)
+L.hh_prof_read(buf, 0)
+names = ["A commands/scripts", "B kinematics+move", "Q enqueue", "I drain (estimate)", "L+C+D launch/resolve/rocket move", "E rewards", "publish", "pair tables", "finish (shaping, done)", "stats/outputs/reset", "K2 observe+store"]
+waves = (N + 15) // 16
+tot = sum(buf[:11])
+for k, nm in enumerate(names):
+    print(f"{nm:36s} {buf[k] / (waves * 4 * T):9.0f} cycles/wave-tick  {100.0 * buf[k] / tot:5.1f} %")
+print(f"{'total':36s} {tot / (waves * 4 * T):9.0f} cycles/wave-tick")

@@ -193,6 +193,23 @@ __device__ __forceinline__ void d_geo_move(double lat1, double lon1, double azi1
     lon2 = b;
 }
 
+/* two independent short-step moves in one basic block so that their RK4 chains interleave (ILP); each
+ * result is bit-identical to d_geo_move of the same arguments */
+__device__ __forceinline__ void d_geo_move2(double lat_a, double lon_a, double azi_a, double s_a, double &lat2_a, double &lon2_a,
+                                            double lat_b, double lon_b, double azi_b, double s_b, double &lat2_b, double &lon2_b) {
+    bool ok_a = s_a <= HH_GEO_SHORT_MAX_M && hh_fabs(lat_a) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon_a) < 170.0;
+    bool ok_b = s_b <= HH_GEO_SHORT_MAX_M && hh_fabs(lat_b) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon_b) < 170.0;
+    if (ok_a && ok_b) {
+        double a0, a1, b0, b1;
+        hh_geo_direct_short(lat_a, lon_a, azi_a, s_a, &a0, &a1);
+        hh_geo_direct_short(lat_b, lon_b, azi_b, s_b, &b0, &b1);
+        lat2_a = a0; lon2_a = a1; lat2_b = b0; lon2_b = b1;
+    } else {
+        d_geo_move(lat_a, lon_a, azi_a, s_a, lat2_a, lon2_a);
+        d_geo_move(lat_b, lon_b, azi_b, s_b, lat2_b, lon2_b);
+    }
+}
+
 __device__ __forceinline__ double d_rng(const Arena &a, int unit_id, int site, int sub) {
     return hh_rng_u01(a.tkey, (uint32_t)unit_id, (uint32_t)site, (uint32_t)sub);
 }

@@ -61,6 +61,8 @@ struct Shared {
     double p_dist[A][B]; /* planar distance in degrees (env_base.py:434-439, un-normalised) */
     double p_foc[A][B];  /* focus angle [deg] at the lane's aircraft towards j (env_base.py:424-432) */
     double p_hd[A][B];   /* normalised angle between heading vectors (env_base.py:448-456), symmetric */
+    float nlat[B], nlon[B], nspd[B], nhdg[B]; /* observation entries every observer of this aircraft shares:
+                                                 relative position, speed and heading normalised (env_base.py:117-121) */
     double rew[B];
     unsigned long long g_tkey[GPB]; /* keyed-RNG tick key per arena (cannon draws made by worker lanes) */
     int flags[B];                   /* bit0 alive, bits1-2 ac_type, bit3 shot flag */
@@ -101,6 +103,16 @@ __device__ __forceinline__ void publish(Shared<A, B> &sh, int tid, const Unit &m
     sh.un[tid] = hh_sqrt(c * c + s * s);
     int shot = m.burst > 0 || (m.ac_type == 1 && m.has_missile);
     sh.flags[tid] = (m.alive ? FL_ALIVE : 0) | ((m.ac_type & 3) << 1) | (shot ? FL_SHOT : 0);
+}
+
+/* publish + the normalised entries of the observation (needs the map extents) */
+template <int A, int B>
+__device__ __forceinline__ void publish_obs(const DevCfg &c, Shared<A, B> &sh, int tid, const Unit &m) {
+    publish(sh, tid, m);
+    sh.nlat[tid] = (float)hh_clip((m.lat - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
+    sh.nlon[tid] = (float)hh_clip((m.lon - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
+    sh.nspd[tid] = (float)hh_clip(m.spd / HH_AC_MAX_SPEED(m.ac_type), 0.0, 1.0);
+    sh.nhdg[tid] = (float)hh_clip(hh_pymod(m.hdg, 359.0) / 359.0, 0.0, 1.0);
 }
 
 /* the per-arena pair table (call between two barriers, after publish).  Branch-free and fully unrolled on
@@ -253,10 +265,11 @@ __device__ __forceinline__ int opp_block(const DevCfg &c, const Shared<A, B> &sh
     const int t = sh_type(sh, o);
     const double f_so = sh.p_foc[oj][tid], f_os = sh.p_foc[s][o];
     int n = 0;
-    out[n++] = (float)hh_clip((sh.lat0[o] - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
-    out[n++] = (float)hh_clip((sh.lon0[o] - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
-    out[n++] = (float)hh_clip(sh.spd[o] / HH_AC_MAX_SPEED(t), 0.0, 1.0);
-    out[n++] = (float)hh_clip(hh_pymod(sh.hdg[o], 359.0) / 359.0, 0.0, 1.0);
+    (void)t;
+    out[n++] = sh.nlat[o];
+    out[n++] = sh.nlon[o];
+    out[n++] = sh.nspd[o];
+    out[n++] = sh.nhdg[o];
     out[n++] = (float)sh.p_hd[oj][tid];
     if (mode == 0) {
         out[n++] = (float)norm180(f_os);
@@ -279,8 +292,8 @@ template <int A, int B>
 __device__ __forceinline__ void friend_block(const DevCfg &c, const Shared<A, B> &sh, int tid, int base, int s, int fj, float *out) {
     const int f = base + fj;
     if (sh_alive(sh, f)) {
-        out[0] = (float)hh_clip((sh.lat0[f] - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
-        out[1] = (float)hh_clip((sh.lon0[f] - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
+        out[0] = sh.nlat[f];
+        out[1] = sh.nlon[f];
         out[2] = (float)norm180(sh.p_foc[fj][tid]);
         out[3] = (float)norm180(sh.p_foc[s][f]);
         out[4] = (float)(c.inv_diag * sh.p_dist[fj][tid]);
@@ -303,10 +316,10 @@ __device__ __forceinline__ void lowlevel_obs(const DevCfg &c, const Shared<A, B>
     /* env_hetero.py:71-75 fri_ac_id */
     int fri = s < c.nA ? (s == 1 ? 0 : 1) : (s == 3 ? 2 : 3);
     int n = 0;
-    out[n++] = (float)hh_clip((m.lat - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
-    out[n++] = (float)hh_clip((m.lon - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
-    out[n++] = (float)hh_clip(m.spd / HH_AC_MAX_SPEED(m.ac_type), 0.0, 1.0);
-    out[n++] = (float)hh_clip(hh_pymod(m.hdg, 359.0) / 359.0, 0.0, 1.0);
+    out[n++] = sh.nlat[tid];
+    out[n++] = sh.nlon[tid];
+    out[n++] = sh.nspd[tid];
+    out[n++] = sh.nhdg[tid];
     if (mode == HH_MODE_FIGHT) {
         const int oj = nb.i0;
         out[n++] = (float)norm180(sh.p_foc[oj][tid]);
@@ -586,9 +599,43 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
             if (!m.rk_alive) m.has_missile = 0;
             else m.rk_cmd = hh_clip(m.rk_hdg * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
         }
-#ifndef HH_ABL_NO_MOVE
-        if (m.spd > 0.0) d_geo_move(m.lat, m.lon, m.hdg, m.spd * HH_KNOTS_TO_MS * 1.0, m.lat, m.lon);
+    }
+    /* Moves.  The rocket of this slot — in flight, or the one a pending launch would create (position and
+     * heading of the launcher before its update, steered by this tick's noise draw: ac1.py:76-79,127) — is
+     * moved speculatively together with the aircraft so that the two RK4 chains overlap; the result is
+     * committed after the kill resolution only if the rocket exists and survives (rocket_unit.py:61-73). */
+    const bool rk_spec = running && (rk_pre ? m.rk_life <= HH_ROCKET_MAX_LIFE : try_launch);
+    double rk_nlat = 0.0, rk_nlon = 0.0, rk_nhdg = 0.0, rk_ncmd = 0.0;
+    {
+        const bool mv_a = snap && m.spd > 0.0;
+#ifdef HH_ABL_NO_MOVE
+        const bool any_rk = false;
+#else
+        const bool any_rk = __ballot(rk_spec) != 0ULL;
 #endif
+        if (any_rk) {
+            const double speed_table[11] = HH_ROCKET_SPEED_TABLE;
+            double r_lat = rk_pre ? m.rk_lat : lat_old, r_lon = rk_pre ? m.rk_lon : lon_old;
+            double r_hdg = rk_pre ? m.rk_hdg : hdg_old;
+            rk_ncmd = rk_pre ? m.rk_cmd
+                             : hh_clip(hdg_old * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
+            if (r_hdg != rk_ncmd) {
+                double delta = d_signed_heading_diff(r_hdg, rk_ncmd);
+                if (hh_fabs(delta) <= HH_ROCKET_TURN_RATE) r_hdg = rk_ncmd;
+                else r_hdg += delta >= 0.0 ? HH_ROCKET_TURN_RATE : -HH_ROCKET_TURN_RATE;
+            }
+            rk_nhdg = r_hdg;
+            int life = rk_pre ? m.rk_life : 0;
+            double r_spd = speed_table[rk_spec ? life : 0];
+            double a_lat, a_lon;
+            d_geo_move2(m.lat, m.lon, m.hdg, mv_a ? m.spd * HH_KNOTS_TO_MS * 1.0 : 0.0, a_lat, a_lon,
+                        rk_spec ? r_lat : 5.0, rk_spec ? r_lon : 7.0, r_hdg, r_spd * HH_KNOTS_TO_MS * 1.0, rk_nlat, rk_nlon);
+            if (mv_a) { m.lat = a_lat; m.lon = a_lon; }
+        } else {
+#ifndef HH_ABL_NO_MOVE
+            if (mv_a) d_geo_move(m.lat, m.lon, m.hdg, m.spd * HH_KNOTS_TO_MS * 1.0, m.lat, m.lon);
+#endif
+        }
     }
     sh.u.t.lat1[tid] = m.lat;
     sh.u.t.lon1[tid] = m.lon;
@@ -672,7 +719,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
         m.missile_remain = m.missile_remain - 1 > 0 ? m.missile_remain - 1 : 0;
         evm |= 1u << (24 + s);
         /* the launcher's own update in this tick already steers it (ac1.py:127) */
-        m.rk_cmd = hh_clip(m.rk_hdg * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
+        m.rk_cmd = rk_ncmd;
     }
     if (base_gate) {
         double uu = d_rng(ar, id, HH_SITE_MISSILE_WAIT, 0);
@@ -758,15 +805,8 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
         if ((sh.g_rkdead[g] >> s) & 1) {
             m.rk_alive = 0; m.rk_target = 0; m.rk_life = 0; m.rk_seq = 0;
             m.rk_lat = m.rk_lon = m.rk_hdg = m.rk_cmd = 0.0;
-        } else { /* turn, speed profile, move (rocket_unit.py:61-73) */
-            const double speed_table[11] = HH_ROCKET_SPEED_TABLE;
-            if (m.rk_hdg != m.rk_cmd) {
-                double delta = d_signed_heading_diff(m.rk_hdg, m.rk_cmd);
-                if (hh_fabs(delta) <= HH_ROCKET_TURN_RATE) m.rk_hdg = m.rk_cmd;
-                else m.rk_hdg += delta >= 0.0 ? HH_ROCKET_TURN_RATE : -HH_ROCKET_TURN_RATE;
-            }
-            double spd = speed_table[m.rk_life];
-            if (spd > 0.0) d_geo_move(m.rk_lat, m.rk_lon, m.rk_hdg, spd * HH_KNOTS_TO_MS * 1.0, m.rk_lat, m.rk_lon);
+        } else { /* commit the speculative turn + move (rocket_unit.py:61-73) */
+            m.rk_hdg = rk_nhdg; m.rk_lat = rk_nlat; m.rk_lon = rk_nlon;
             m.rk_life += 1;
         }
     }
@@ -827,7 +867,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     sh.rew[tid] = rews;
     /* post-tick state + pair table: escape shaping now, observation next, pre-step lookups of the next tick */
     HH_PROF(5);
-    publish(sh, tid, m);
+    publish_obs(c, sh, tid, m);
     __syncthreads();
     HH_PROF(6);
     pair_tables(sh, tid, base, s, active);
@@ -955,7 +995,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
             ep_ret = 0.0;
         }
         if (run != HH_RUN_ROLLOUT || any_reset) { /* state changed (or never published) */
-            publish(sh, tid, m);
+            publish_obs(c, sh, tid, m);
             __syncthreads();
             pair_tables(sh, tid, base, s, active);
             __syncthreads();

@@ -111,10 +111,10 @@ __device__ __forceinline__ int hl_pilot_obs(const DevCfg &c, const Shared<A, B> 
     Near3 fr;
     nearby(c, sh, tid, base, s, true, fr);
     int n = 0;
-    out[n++] = (float)hh_clip((m.lat - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
-    out[n++] = (float)hh_clip((m.lon - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
-    out[n++] = (float)hh_clip(m.spd / HH_AC_MAX_SPEED(m.ac_type), 0.0, 1.0);
-    out[n++] = (float)hh_clip(hh_pymod(m.hdg, 359.0) / 359.0, 0.0, 1.0);
+    out[n++] = sh.nlat[tid];
+    out[n++] = sh.nlon[tid];
+    out[n++] = sh.nspd[tid];
+    out[n++] = sh.nhdg[tid];
     int mode;
     if (m.cmd_act != 0) { /* fight the commander-chosen target, with the stale stored distance */
         mode = 1;
@@ -160,10 +160,10 @@ __device__ __forceinline__ void hl_commander_obs(const DevCfg &c, const Shared<A
     if (agent) {
         if (nb.n == 0) return;
         int n = 0;
-        out[n++] = (float)hh_clip((m.lat - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
-        out[n++] = (float)hh_clip((m.lon - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
-        out[n++] = (float)hh_clip(m.spd / HH_AC_MAX_SPEED(m.ac_type), 0.0, 1.0);
-        out[n++] = (float)hh_clip(hh_pymod(m.hdg, 359.0) / 359.0, 0.0, 1.0);
+        out[n++] = sh.nlat[tid];
+        out[n++] = sh.nlon[tid];
+        out[n++] = sh.nspd[tid];
+        out[n++] = sh.nhdg[tid];
         opp_block(c, sh, 2, tid, base, s, nb.i0, nb.d0, out + n);
         m.n_tgt = 1; m.tgt0 = nb.i0 + 1; m.tgt_d0 = nb.d0;
         if (nb.n >= 2) {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(B) void hh_k_hier(DevPtrs P, DevCfg c, int phase, c
     }
     sh.aux[tid] = 0;
     uint32_t evm = 0;
-    publish(sh, tid, m);
+    publish_obs(c, sh, tid, m);
     __syncthreads();
     pair_tables(sh, tid, base, s, active);
     __syncthreads();
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(B) void hh_k_hier(DevPtrs P, DevCfg c, int phase, c
             acc = 0.0;
         }
         if (any_reset) {
-            publish(sh, tid, m);
+            publish_obs(c, sh, tid, m);
             __syncthreads();
             pair_tables(sh, tid, base, s, active);
             __syncthreads();

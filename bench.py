@@ -149,7 +149,18 @@ def main():
     bytes_per_launch = ALGO_BYTES_2V2_STEP * N * T_launch
     achieved = bytes_per_launch / avg_launch_s / 1e9
 
+    # HBM bytes per launch from the PMC counters of a separate rocprofv3 run of this same command
+    # (tools/prof_pmc.sh -> profiles/*_traffic.json; counters cannot be read from inside the process)
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
+        if tj.get("arenas") == N and tj.get("ticks_per_launch") == T_launch:
+            traffic = tj["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     value = N * world * args.steps / dt
+    variant = "W=2 (2 waves/SIMD)" if (N + 15) // 16 >= 2048 else "W=1"
     line = {
         "metric": "env-steps/sec (2v2)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -159,7 +170,7 @@ def main():
                                f"(BASELINE configs[1])", "arenas_per_gpu": N, "ticks_per_launch": chunk,
                    "parallelism": f"arena-sharded x{world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "hh_k_world<4,256>", "avg_launch_ms": avg_launch_s * 1e3,
+                     "traffic": traffic, "kernel": f"hh_k_world<4,64,{variant}>", "avg_launch_ms": avg_launch_s * 1e3,
                      "algorithmic_bytes_per_launch": bytes_per_launch},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

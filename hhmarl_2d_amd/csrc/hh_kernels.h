@@ -351,6 +351,7 @@ struct StepOut {
     double reward;
     int valid;
     int kill_event; /* any aircraft removed this tick (env_base.py:248,256,308) */
+    double opp_stat0; /* tmode 1 input: env_hetero.py:169-170 statistic taken when the agent acted */
 };
 
 /* phase I of the tick: dense pass over the workgroup's envelope queue.  Every entry is decided by the
@@ -435,13 +436,12 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     const bool running = tmode == 0 ? (active && !ar.done) : (active && run_arena);
     const bool agent = s < c.nA;
     const bool hl = c.env_kind == HH_ENV_HIGHLEVEL;
-    out.reward = 0.0;
-    out.valid = 0;
+    if (tmode == 0) { out.reward = 0.0; out.valid = 0; } /* tmode 1: the caller passes what act_phase produced */
     uint32_t evm = 0;
     out.kill_event = 0;
     if (running && tmode == 0) { ar.steps += 1; arena_rekey(ar); }
     const bool snap = running && m.alive; /* in do_tick's start-of-tick snapshot */
-    double opp_stat0 = 0.0;
+    double opp_stat0 = tmode == 0 ? 0.0 : out.opp_stat0;
     int want_launch = 0, launch_tgt = 0; /* launch_tgt: slot index */
     int wait_after = -1;                 /* scripted opponents: missile_wait value set after the attempt */
     bool base_gate = false;              /* _take_base_action missile gate passed */
@@ -914,13 +914,112 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     HH_PROF(8);
 }
 
+/* index into the stored target list like Python: commander_actions[i]-1, with -1 = last */
+__device__ __forceinline__ int hl_target_slot(const Unit &m, double &dist) {
+    int k = m.cmd_act > 0 ? m.cmd_act - 1 : m.n_tgt - 1;
+    int t = 0;
+    dist = 0.0;
+    if (k == 0 && m.n_tgt > 0) { t = m.tgt0; dist = m.tgt_d0; }
+    else if (k == 1 && m.n_tgt > 1) { t = m.tgt1; dist = m.tgt_d1; }
+    else if (k == 2 && m.n_tgt > 2) { t = m.tgt2; dist = m.tgt_d2; }
+    return t; /* 1-based unit id, 0 = none */
+}
+
+/* env_base.py:214-238 _take_base_action for the lanes selected by `acts` (one side), including the missile
+ * envelope test (one pass over the workgroup queue) and launch bookkeeping.  Used where pilot / frozen-policy
+ * inference runs between the two sides' actions: HighLevelEnv sub-steps (hl) and LowLevelEnv levels 4-5. */
+template <int A, int B>
+__device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int tid, int s, int base, bool active, bool running,
+                                          Unit &m, Arena &ar, const int8_t *act, bool acts, bool hl, double &pre_reward,
+                                          double &opp_stat0, int &valid, uint32_t &evm) {
+    const int id = s + 1;
+    const bool agent = s < c.nA;
+    const bool snap = active && running && m.alive && acts;
+    int want_launch = 0, launch_tgt = 0;
+    bool base_gate = false;
+    if (snap) {
+        double dd;
+        int t = hl ? hl_target_slot(m, dd) : (m.n_tgt ? m.tgt0 : 0);
+        if (!hl && agent) { /* env_hetero.py:168-170 */
+            valid = 1;
+            if (t && sh_alive(sh, base + t - 1)) opp_stat0 = norm180(sh.p_foc[s][base + t - 1]);
+        }
+        double nh = hh_pymod(m.hdg + (double)(((int)act[0] - 6) * 15), 360.0);
+        if (nh >= 360.0 || nh < 0.0) nh = 0.0;
+        m.cmd_hdg = nh;
+        double mx = HH_AC_MAX_SPEED(m.ac_type);
+        m.cmd_spd = 100.0 + ((mx - 100.0) / 8.0) * (double)act[1];
+        const bool agent_ll = agent && !hl;
+        if (act[2] && m.cannon_remain > 0) {
+            arm_cannon(m);
+            if (agent_ll && c.agent_mode == HH_MODE_ESCAPE && m.cannon_remain < 90) pre_reward -= 0.1;
+        }
+        if (m.ac_type == 1 && act[3]) {
+            if (t && m.missile_remain > 0 && !m.has_missile && m.missile_wait == 0) {
+                base_gate = true;
+                want_launch = 1;
+                launch_tgt = t - 1;
+            }
+        }
+    }
+    const bool try_launch = want_launch && !m.has_missile && m.missile_remain > 0;
+    sh.res[tid] = 0;
+    if (tid == 0) sh.u.t.q_count = 0;
+    __syncthreads();
+    if (try_launch) {
+        int at = atomicAdd(&sh.u.t.q_count, 1);
+        sh.u.t.q_code[at] = tid | (0 << 8) | (launch_tgt << 10);
+    }
+    __syncthreads();
+    drain_envelope_queue(sh, tid);
+    __syncthreads();
+    int launched = 0;
+    if (try_launch && (sh.res[tid] & 1)) { /* ac1.py:76-79 */
+        launched = 1;
+        m.rk_alive = 1; m.rk_lat = m.lat; m.rk_lon = m.lon; m.rk_hdg = m.hdg; m.rk_cmd = m.hdg;
+        m.rk_target = launch_tgt + 1; m.rk_life = 0;
+        m.has_missile = 1;
+        m.missile_remain = m.missile_remain - 1 > 0 ? m.missile_remain - 1 : 0;
+        evm |= 1u << (24 + s);
+    }
+    if (base_gate) {
+        double uu = d_rng(ar, id, HH_SITE_MISSILE_WAIT, 0);
+        m.missile_wait = hl ? hh_rng_randint(uu, 8, 12) : hh_rng_randint(uu, 7, 17);
+        if (agent && !hl && c.agent_mode == HH_MODE_ESCAPE && m.missile_remain < 3) pre_reward -= 0.1;
+    }
+    if (snap) {
+        if (m.missile_wait > 0 && !m.has_missile) m.missile_wait -= 1;
+    }
+    sh.aux[tid] = launched;
+    __syncthreads();
+    {   /* rocket ids in unit id order (cmano_simulator.py:104-108) */
+        int before = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < A; j++) {
+            int l = active ? sh.aux[base + j] : 0;
+            total += l;
+            if (j < s) before += l;
+        }
+        if (launched) m.rk_seq = ar.next_seq + before + 1;
+        ar.next_seq += total;
+    }
+    /* weapon flags other lanes observe (env_base.py:208-211) */
+    int shot = m.burst > 0 || (m.ac_type == 1 && m.has_missile);
+    sh.flags[tid] = (m.alive ? FL_ALIVE : 0) | ((m.ac_type & 3) << 1) | (shot ? FL_SHOT : 0);
+    __syncthreads();
+}
+
 /* ===================================================================== the kernel */
-enum { HH_RUN_ROLLOUT = 0, HH_RUN_RESET = 1, HH_RUN_OBSERVE = 2 };
+enum { HH_RUN_ROLLOUT = 0, HH_RUN_RESET = 1, HH_RUN_OBSERVE = 2, HH_RUN_LL_BEGIN = 3, HH_RUN_LL_FINISH = 4 };
 
 /* W = waves per SIMD the register allocation is held to: 1 = no spills, lowest per-tick latency (few arenas);
  * 2 = 256 registers per lane, spills to scratch but two resident waves per SIMD: +35 % throughput once there
  * are more than ~2 waves per SIMD to run (>= 32768 arenas).  Same source, same results. */
-template <int A, int B, int W>
+/* SPLIT adds the two half-step run modes of LowLevelEnv levels 4-5 (frozen opponent policies, env_hetero.py:160-172):
+ *   LL_BEGIN   steps += 1, agents' _take_base_action          -> observations of the opponents [N, n_opps, 30] in obs_out
+ *   LL_FINISH  opponents' _take_base_action, then the tick, rewards, done, reset, agents' observation like ROLLOUT (T = 1)
+ * `actions` holds the acting side's rows only; `mask` carries nothing; opp_mode (fight 0 / escape 1) arrives in T for LL_BEGIN. */
+template <int A, int B, int W, bool SPLIT>
 __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run, int T, const int8_t *__restrict__ actions,
                                                 const uint8_t *__restrict__ mask, float *__restrict__ obs_out,
                                                 float *__restrict__ reward_out, uint8_t *__restrict__ valid_out,
@@ -949,23 +1048,84 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
     sh.aux[tid] = 0;
     bool need_reset = run == HH_RUN_RESET && active && (mask == nullptr || mask[n]);
     uint32_t evm_last = 0;
-    if (run == HH_RUN_ROLLOUT) { /* pair table of the pre-tick state */
-        publish(sh, tid, m);
+    if (run == HH_RUN_ROLLOUT || run >= HH_RUN_LL_BEGIN) { /* pair table of the pre-tick state */
+        publish_obs(c, sh, tid, m);
         __syncthreads();
         pair_tables(sh, tid, base, s, active);
         __syncthreads();
     }
+    if constexpr (SPLIT) {
+        if (run == HH_RUN_LL_BEGIN) {
+            const int opp_mode = T;
+            const bool running = active && !ar.done;
+            if (running) { ar.steps += 1; arena_rekey(ar); }
+            int8_t act[4] = {0, 0, 0, 0};
+            if (active && s < c.nA) {
+                int w = *reinterpret_cast<const int *>(actions + ((size_t)n * c.nA + s) * 4);
+                act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
+            }
+            double pre = 0.0, os0 = 0.0;
+            int valid = 0;
+            act_phase(c, sh, tid, s, base, active, running, m, ar, act, s < c.nA, false, pre, os0, valid, evm_last);
+            if (active) {
+                m.cmd_act = valid;          /* reward key present (agents alive at step start) */
+                P.acc_rew[u] = pre;         /* escape-mode ammunition penalties (env_base.py:223-233) */
+                m.tgt_d1 = os0;             /* tgt_d1 is unused by LowLevelEnv: carries opp_stats[i][0] to LL_FINISH */
+            }
+            /* observation of the frozen-policy opponents, after the agents acted (shot flags refreshed by act_phase) */
+            if (active && s >= c.nA) {
+                float row[30];
+                if (running && m.alive) lowlevel_obs<A, B>(c, sh, tid, base, s, opp_mode, m, row, 30);
+                else for (int q = 0; q < 30; q++) row[q] = 0.0f;
+                if (obs_out) {
+                    float *dst = obs_out + ((size_t)n * c.nO + (s - c.nA)) * 30;
+                    for (int q = 0; q < 30; q++) dst[q] = row[q];
+                }
+            }
+            T = 0; /* no tick in this launch */
+        } else if (run == HH_RUN_LL_FINISH) {
+            T = 1;
+        }
+    }
     for (int t = 0; t < T; t++) {
-        if (run == HH_RUN_ROLLOUT) {
+        if (run == HH_RUN_ROLLOUT || (SPLIT && run == HH_RUN_LL_FINISH)) {
             StepOut so;
             int8_t act[4] = {0, 0, 0, 0};
-            if (active && s < c.n_ctrl) {
+            if (active && s < c.n_ctrl && run == HH_RUN_ROLLOUT) {
                 const int8_t *ap = actions + (((size_t)t * c.N + n) * c.n_ctrl + s) * 4;
                 int w = *reinterpret_cast<const int *>(ap);
                 act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
             }
             const bool was_running = active && !ar.done;
-            tick<A, B>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_last, 0, true HH_PROF_PASS);
+            if constexpr (SPLIT) {
+                if (run == HH_RUN_LL_FINISH) {
+                    if (active && s >= c.nA) {
+                        int w = *reinterpret_cast<const int *>(actions + ((size_t)n * c.nO + (s - c.nA)) * 4);
+                        act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
+                    }
+                    double pre = 0.0, os0 = 0.0;
+                    int vl = 0;
+                    uint32_t evm_act = 0;
+                    act_phase(c, sh, tid, s, base, active, was_running, m, ar, act, s >= c.nA, false, pre, os0, vl, evm_act);
+                    so.reward = (active && s < c.nA) ? P.acc_rew[u] : 0.0;
+                    so.valid = (active && s < c.nA) ? m.cmd_act : 0;
+                    so.opp_stat0 = m.tgt_d1;
+                    uint32_t evm_tick = 0;
+                    tick<A, B>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_tick, 1, was_running HH_PROF_PASS);
+                    evm_last |= evm_act | evm_tick;
+                    if (was_running) {
+                        int ag = 0, op = 0;
+#pragma unroll
+                        for (int j = 0; j < A; j++) { int al = sh_alive(sh, base + j); if (j < c.nA) ag += al; else op += al; }
+                        ar.done = (ag <= 0 || op <= 0 || ar.steps >= c.horizon) ? 1 : 0;
+                    }
+                    if (active) { m.cmd_act = 0; m.tgt_d1 = 0.0; }
+                } else {
+                    tick<A, B>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_last, 0, true HH_PROF_PASS);
+                }
+            } else {
+                tick<A, B>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_last, 0, true HH_PROF_PASS);
+            }
             /* outputs of this tick */
             if (active && s < c.nA) {
                 size_t o = ((size_t)t * c.N + n) * c.nA + s;
@@ -1026,10 +1186,10 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
         if (s == 0) {
             arena_store(P, n, ar);
             P.ep_ret[n] = ep_ret;
-            if (run == HH_RUN_ROLLOUT) P.ev_mask[n] = 0;
+            if (run == HH_RUN_ROLLOUT || run == HH_RUN_LL_BEGIN) P.ev_mask[n] = 0;
         }
     }
-    if (run == HH_RUN_ROLLOUT) {
+    if (run == HH_RUN_ROLLOUT || run >= HH_RUN_LL_BEGIN) {
         /* OR-reduce the per-lane event bits of the last tick into the arena word */
         __syncthreads();
         if (active && evm_last) atomicOr(&P.ev_mask[n], evm_last);

@@ -24,86 +24,6 @@
 
 enum { HH_HL_BEGIN = 0, HH_HL_AGENTS_ACT = 1, HH_HL_TICK = 2, HH_HL_END = 3, HH_HL_REFRESH = 4, HH_HL_RESET = 5 };
 
-/* index into the stored target list like Python: commander_actions[i]-1, with -1 = last */
-__device__ __forceinline__ int hl_target_slot(const Unit &m, double &dist) {
-    int k = m.cmd_act > 0 ? m.cmd_act - 1 : m.n_tgt - 1;
-    int t = 0;
-    dist = 0.0;
-    if (k == 0 && m.n_tgt > 0) { t = m.tgt0; dist = m.tgt_d0; }
-    else if (k == 1 && m.n_tgt > 1) { t = m.tgt1; dist = m.tgt_d1; }
-    else if (k == 2 && m.n_tgt > 2) { t = m.tgt2; dist = m.tgt_d2; }
-    return t; /* 1-based unit id, 0 = none */
-}
-
-/* env_base.py:214-238 _take_base_action("HighLevel") for the lanes selected by `acts`, including the
- * missile envelope test (one pass over the workgroup queue) and launch bookkeeping. */
-template <int A, int B>
-__device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int tid, int s, int base, bool active,
-                                          Unit &m, Arena &ar, const int8_t *act, bool acts, uint32_t &evm) {
-    const int id = s + 1;
-    const bool snap = active && ar.hl_run && m.alive && acts;
-    int want_launch = 0, launch_tgt = 0;
-    bool base_gate = false;
-    if (snap) {
-        double dd;
-        int t = hl_target_slot(m, dd);
-        double nh = hh_pymod(m.hdg + (double)(((int)act[0] - 6) * 15), 360.0);
-        if (nh >= 360.0 || nh < 0.0) nh = 0.0;
-        m.cmd_hdg = nh;
-        double mx = HH_AC_MAX_SPEED(m.ac_type);
-        m.cmd_spd = 100.0 + ((mx - 100.0) / 8.0) * (double)act[1];
-        if (act[2] && m.cannon_remain > 0) arm_cannon(m);
-        if (m.ac_type == 1 && act[3]) {
-            if (t && m.missile_remain > 0 && !m.has_missile && m.missile_wait == 0) {
-                base_gate = true;
-                want_launch = 1;
-                launch_tgt = t - 1;
-            }
-        }
-    }
-    const bool try_launch = want_launch && !m.has_missile && m.missile_remain > 0;
-    sh.res[tid] = 0;
-    if (tid == 0) sh.u.t.q_count = 0;
-    __syncthreads();
-    if (try_launch) {
-        int at = atomicAdd(&sh.u.t.q_count, 1);
-        sh.u.t.q_code[at] = tid | (0 << 8) | (launch_tgt << 10);
-    }
-    __syncthreads();
-    drain_envelope_queue(sh, tid);
-    __syncthreads();
-    int launched = 0;
-    if (try_launch && (sh.res[tid] & 1)) { /* ac1.py:76-79 */
-        launched = 1;
-        m.rk_alive = 1; m.rk_lat = m.lat; m.rk_lon = m.lon; m.rk_hdg = m.hdg; m.rk_cmd = m.hdg;
-        m.rk_target = launch_tgt + 1; m.rk_life = 0;
-        m.has_missile = 1;
-        m.missile_remain = m.missile_remain - 1 > 0 ? m.missile_remain - 1 : 0;
-        evm |= 1u << (24 + s);
-    }
-    if (base_gate) m.missile_wait = hh_rng_randint(d_rng(ar, id, HH_SITE_MISSILE_WAIT, 0), 8, 12);
-    if (snap) {
-        if (m.missile_wait > 0 && !m.has_missile) m.missile_wait -= 1;
-    }
-    sh.aux[tid] = launched;
-    __syncthreads();
-    {   /* rocket ids in unit id order (cmano_simulator.py:104-108) */
-        int before = 0, total = 0;
-#pragma unroll
-        for (int j = 0; j < A; j++) {
-            int l = active ? sh.aux[base + j] : 0;
-            total += l;
-            if (j < s) before += l;
-        }
-        if (launched) m.rk_seq = ar.next_seq + before + 1;
-        ar.next_seq += total;
-    }
-    /* weapon flags other lanes observe (env_base.py:208-211) */
-    int shot = m.burst > 0 || (m.ac_type == 1 && m.has_missile);
-    sh.flags[tid] = (m.alive ? FL_ALIVE : 0) | ((m.ac_type & 3) << 1) | (shot ? FL_SHOT : 0);
-    __syncthreads();
-}
-
 /* env_hier.py:100-112 lowlevel_state of the lane's unit -> 30 floats (zero padded) + policy type */
 template <int A, int B>
 __device__ __forceinline__ int hl_pilot_obs(const DevCfg &c, const Shared<A, B> &sh, int tid, int base, int s, const Unit &m, float *out) {
@@ -278,7 +198,7 @@ __global__ __launch_bounds__(B) void hh_k_hier(DevPtrs P, DevCfg c, int phase, c
             int w = *reinterpret_cast<const int *>(actions + u * 4);
             act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
         }
-        act_phase(c, sh, tid, s, base, active, m, ar, act, agent, evm);
+        { double pr = 0.0, os0 = 0.0; int vl = 0; act_phase(c, sh, tid, s, base, active, ar.hl_run != 0, m, ar, act, agent, true, pr, os0, vl, evm); }
         obs_side = 1;
     } else if (phase == HH_HL_TICK) {
         int8_t act[4] = {0, 0, 0, 0};
@@ -286,8 +206,9 @@ __global__ __launch_bounds__(B) void hh_k_hier(DevPtrs P, DevCfg c, int phase, c
             int w = *reinterpret_cast<const int *>(actions + u * 4);
             act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
         }
-        act_phase(c, sh, tid, s, base, active, m, ar, act, !agent, evm);
+        { double pr = 0.0, os0 = 0.0; int vl = 0; act_phase(c, sh, tid, s, base, active, ar.hl_run != 0, m, ar, act, !agent, true, pr, os0, vl, evm); }
         StepOut so;
+        so.reward = 0.0; so.valid = 0; so.opp_stat0 = 0.0;
         const bool was_running = active && ar.hl_run;
         uint32_t evm_tick = 0;
 #ifdef HH_PROFILE_PHASES

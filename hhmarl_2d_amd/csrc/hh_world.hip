@@ -145,10 +145,12 @@ static int launch(hh_world *w, int run, int T, const int8_t *actions, const uint
     constexpr int B = HH_BLOCK, GPB = B / 4;
     const int grid = (c.N + GPB - 1) / GPB;
     const int waves = grid * (B / 64);
-    if (w->force_w == 2 || (w->force_w == 0 && waves >= 2048))
-        hipLaunchKernelGGL((hh_k_world<4, B, 2>), dim3(grid), dim3(B), 0, st, w->P, c, run, T, actions, mask, obs, reward, valid, done);
+    if (run >= HH_RUN_LL_BEGIN)
+        hipLaunchKernelGGL((hh_k_world<4, B, 1, true>), dim3(grid), dim3(B), 0, st, w->P, c, run, T, actions, mask, obs, reward, valid, done);
+    else if (w->force_w == 2 || (w->force_w == 0 && waves >= 2048))
+        hipLaunchKernelGGL((hh_k_world<4, B, 2, false>), dim3(grid), dim3(B), 0, st, w->P, c, run, T, actions, mask, obs, reward, valid, done);
     else
-        hipLaunchKernelGGL((hh_k_world<4, B, 1>), dim3(grid), dim3(B), 0, st, w->P, c, run, T, actions, mask, obs, reward, valid, done);
+        hipLaunchKernelGGL((hh_k_world<4, B, 1, false>), dim3(grid), dim3(B), 0, st, w->P, c, run, T, actions, mask, obs, reward, valid, done);
     HIPCHK(hipGetLastError());
     return HH_OK;
 }
@@ -340,3 +342,16 @@ extern "C" int hh_prof_read(unsigned long long *out16, int reset) {
     return HH_OK;
 }
 #endif
+
+/* ---- LowLevelEnv levels 4-5: the step split around the frozen opponent policy (env_hetero.py:160-172) ---- */
+extern "C" int hh_step_begin(hh_world *w, const int8_t *agent_actions, int32_t opp_mode, float *opp_obs, void *stream) {
+    if (!w || !agent_actions) { g_err = "null argument"; return HH_E_ARG; }
+    if (!w->cfg.ext_opp_actions) { g_err = "hh_step_begin needs ext_opp_actions (levels 4-5)"; return HH_E_ARG; }
+    return launch(w, HH_RUN_LL_BEGIN, opp_mode, agent_actions, nullptr, opp_obs, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int hh_step_finish(hh_world *w, const int8_t *opp_actions, float *obs, float *reward, uint8_t *reward_valid, uint8_t *done, void *stream) {
+    if (!w || !opp_actions) { g_err = "null argument"; return HH_E_ARG; }
+    if (!w->cfg.ext_opp_actions) { g_err = "hh_step_finish needs ext_opp_actions (levels 4-5)"; return HH_E_ARG; }
+    return launch(w, HH_RUN_LL_FINISH, 1, opp_actions, nullptr, obs, reward, reward_valid, done, (hipStream_t)stream);
+}

@@ -67,9 +67,10 @@ class LowLevelEnv(_Base):
         self.map_size = self.args.map_size
         self.num_envs = int(env_config.get("num_envs", 1))
         self.opponent_policy = env_config.get("opponent_policy", None)
+        self.opp_mode = "fight"  # env_hetero.py:23; level-5 callers switch it per episode (env_hetero.py:55-59)
         if self.args.level >= 4 and self.opponent_policy is None:
-            raise ValueError("levels 4-5 fly frozen opponent policies (envs/env_base.py:312-398); pass "
-                             "env_config['opponent_policy'] = callable(world) -> int8 actions [N, 2, 4] for units 3,4")
+            raise ValueError("levels 4-5 fly frozen opponent policies (envs/env_base.py:312-398); pass env_config["
+                             "'opponent_policy'] = callable(opp_obs f32 [N,2,30], env) -> int8 actions [N,2,4] for units 3,4")
         cfg = config_from_args(self.args, L.ENV_LOWLEVEL, self.num_envs, int(env_config.get("seed", 0)))
         self.world = World(cfg, device=int(env_config.get("device", 0)))
         self._act = torch.zeros((self.num_envs, self.world.n_ctrl, 4), dtype=torch.int8, device=self.world.device)
@@ -108,8 +109,12 @@ class LowLevelEnv(_Base):
                     a[:, k - 1, : v.shape[-1]] = v
             self._act.copy_(torch.from_numpy(a))
             if self.opponent_policy is not None:
-                self._act[:, n_ag:] = self.opponent_policy(self.world)
-            obs, rew, val, done = self.world.step(self._act, out=self._out)
+                # env_hetero.py:160-172: agents act, then each frozen-policy opponent observes and acts
+                opp_obs = self.world.step_begin(self._act[:, :n_ag].contiguous(), 0 if self.opp_mode == "fight" else 1)
+                opp_act = self.opponent_policy(opp_obs, self).to(torch.int8).contiguous()
+                obs, rew, val, done = self.world.step_finish(opp_act, out=self._out)
+            else:
+                obs, rew, val, done = self.world.step(self._act, out=self._out)
             self.steps += 1
             rew, val, done = rew.cpu().numpy(), val.cpu().numpy(), done.cpu().numpy()
             if self.num_envs == 1:

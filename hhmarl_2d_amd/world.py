@@ -93,6 +93,22 @@ class World:
         L.check(L.lib().hh_step(self.h, _p(actions), _p(obs), _p(rew), _p(val), _p(done), self._stream()))
         return obs, rew, val, done
 
+    def step_begin(self, agent_actions, opp_mode=0, opp_obs=None):
+        """levels 4-5: agents act; returns the frozen-policy opponents' observations f32 [N, n_opps, 30]"""
+        assert agent_actions.dtype == torch.int8 and agent_actions.is_contiguous()
+        assert agent_actions.numel() == self.N * self.n_agents * 4
+        if opp_obs is None:
+            opp_obs = torch.zeros((self.N, self.A - self.n_agents, 30), dtype=torch.float32, device=self.device)
+        L.check(L.lib().hh_step_begin(self.h, _p(agent_actions), int(opp_mode), _p(opp_obs), self._stream()))
+        return opp_obs
+
+    def step_finish(self, opp_actions, out=None):
+        assert opp_actions.dtype == torch.int8 and opp_actions.is_contiguous()
+        assert opp_actions.numel() == self.N * (self.A - self.n_agents) * 4
+        obs, rew, val, done = out if out is not None else self.alloc_outputs()
+        L.check(L.lib().hh_step_finish(self.h, _p(opp_actions), _p(obs), _p(rew), _p(val), _p(done), self._stream()))
+        return obs, rew, val, done
+
     def rollout(self, actions, out=None, want_obs=True):
         """actions: int8 [T, N, n_ctrl, 4] pre-resident tape -> stacked outputs [T, ...]."""
         assert actions.dtype == torch.int8 and actions.is_contiguous() and actions.device == self.device

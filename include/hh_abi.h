@@ -105,6 +105,17 @@ int hh_step(hh_world *w, const int8_t *actions, float *obs, float *reward, uint8
 int hh_rollout(hh_world *w, int32_t n_steps, const int8_t *actions, float *obs, float *reward,
                uint8_t *reward_valid, uint8_t *done, void *stream);
 
+/* Levels 4-5 (ext_opp_actions): the opponents fly frozen policies that the reference evaluates INSIDE step(),
+ * in unit id order after the agents acted (env_hetero.py:160-172, env_base.py:349-398).  Faithful split:
+ *   hh_step_begin(agent_actions [dev] i8[N, n_agents, 4], opp_mode 0 fight / 1 escape)
+ *       -> opp_obs [dev] f32[N, n_opps, 30]: lowlevel_state(opp_mode, i) of each live opponent (zeros if dead)
+ *   (caller runs its frozen policies)
+ *   hh_step_finish(opp_actions [dev] i8[N, n_opps, 4]) -> outputs exactly like hh_step.
+ * hh_step with n_ctrl = n_agents + n_opps remains for callers that do not need the opponents' observations. */
+int hh_step_begin(hh_world *w, const int8_t *agent_actions, int32_t opp_mode, float *opp_obs, void *stream);
+int hh_step_finish(hh_world *w, const int8_t *opp_actions, float *obs, float *reward, uint8_t *reward_valid,
+                   uint8_t *done, void *stream);
+
 /* current observation of every arena without stepping (state(): env_hetero.py:62-63 / env_hier.py:49-98) */
 int hh_observe(hh_world *w, float *obs, void *stream);
 

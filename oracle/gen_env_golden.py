@@ -72,16 +72,49 @@ SCENARIOS = [
     ("l3_fight_pursuit_share", "low", dict(level=3, glob_frac=0.5, friendly_punish=True, rew_scale=2), pursuit_actions, 4, 420),
     ("l3_escape_shaping", "low", dict(level=3, agent_mode="escape", esc_dist_rew=True), pursuit_actions, 3, 360),
     ("l3_fight_nofriendly", "low", dict(level=3, friendly_kill=False), pursuit_actions, 3, 320),
+    # levels 4-5: opponents fly frozen policies (env_base.py:312-398, files not shipped): taped actions, and the
+    # opponents' own observations (the reference's lowlevel_state, evaluated after the agents acted) are recorded
+    ("l4_fight_frozen_opps", "low", dict(level=4), pursuit_actions, 3, 300),
+    ("l5_fight_frozen_opps", "low", dict(level=5), pursuit_actions, 4, 360),
 ]
 
 
 def record(name, kind, kw, policy, episodes, max_rows, seed=20240917, arena=7):
     args = H.make_args(**kw)
+    ext = kind == "low" and args.level >= 4
+    opp_tape = {}
+    if ext:
+        ref = H.load_reference()
+        cls = ref["env_hetero"].LowLevelEnv
+
+        def get_policies(self_, mode):
+            self_.policy = None
+            self_.policies = {3: None, 4: None, 5: None}
+
+        def policy_actions(self_, policy_type, agent_id, unit):
+            st = self_.lowlevel_state(policy_type, agent_id, unit=unit)[agent_id]
+            u = self_.sim.get_unit(agent_id)
+            a = [int(opp_tape["rng"].integers(13)), int(opp_tape["rng"].integers(9)), 1, int(opp_tape["rng"].random() < 0.5)]
+            tgt = self_.opp_to_attack[agent_id]
+            if tgt and opp_tape["rng"].random() < 0.8:
+                o = self_.sim.get_unit(tgt)
+                brg = math.degrees(math.atan2(o.position.lon - u.position.lon, o.position.lat - u.position.lat)) % 360
+                rel = (brg - u.heading + 180) % 360 - 180
+                a[0] = int(np.clip(round(rel / 15.0) + 6, 0, 12))
+            opp_tape["obs"][agent_id] = np.asarray(st, dtype=np.float32)
+            opp_tape["act"][agent_id] = a
+            opp_tape["mode"] = 0 if policy_type == "fight" else 1
+            return {agent_id: np.array(a)}
+
+        cls._get_policies = get_policies
+        cls._policy_actions = policy_actions
     env = H.RefEnv(kind, args, seed=seed, arena=arena)
     A, nA = args.total_num, args.num_agents
     D = (26 if args.agent_mode == "fight" else 30) if kind == "low" else 34
     rng = np.random.default_rng(zlib.crc32(name.encode()))
-    rows = dict(kind=[], actions=[], ac_f=[], ac_i=[], rk_f=[], rk_i=[], ar_i=[], obs=[], reward=[], valid=[], done=[])
+    rows = dict(kind=[], actions=[], ac_f=[], ac_i=[], rk_f=[], rk_i=[], ar_i=[], obs=[], reward=[], valid=[], done=[],
+                opp_obs=[], opp_mode=[])
+    opp_tape.update(rng=np.random.default_rng(zlib.crc32((name + "/opp").encode())), obs={}, act={}, mode=0)
 
     def push(k, act, obs, rew, done):
         st = env.state()
@@ -89,6 +122,15 @@ def record(name, kind, kw, policy, episodes, max_rows, seed=20240917, arena=7):
         a = np.zeros((A, 4), dtype=np.int8)
         for i, v in (act or {}).items():
             a[i - 1, : len(v)] = v
+        oo = np.zeros((A - nA, 30), dtype=np.float32)
+        if k == 1:
+            for i, v in opp_tape["act"].items():
+                a[i - 1, : len(v)] = v
+            for i, v in opp_tape["obs"].items():
+                oo[i - nA - 1, : len(v)] = v
+        rows["opp_obs"].append(oo)
+        rows["opp_mode"].append(opp_tape["mode"])
+        opp_tape["obs"], opp_tape["act"] = {}, {}
         rows["actions"].append(a)
         for key in ("ac_f", "ac_i", "rk_i", "ar_i"):
             rows[key].append(st[key])

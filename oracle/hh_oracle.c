@@ -69,6 +69,7 @@ typedef struct {
     /* HighLevelEnv macro step (env_hier.py:114-140) */
     int hl_s, hl_running, hl_kill, hl_situ;
     int cmd_act[MAXA]; /* self.commander_actions[i]: 0 escape, k>0 fight stored target k (agents and opponents) */
+    double opp_stat0[MAXA]; /* env_hetero.py:169-170 opp_stats[i][0], kept between the two halves of a split step */
     /* episode statistics */
     double ep_ret;
     float last_ret;
@@ -758,39 +759,47 @@ static void finish_episode(o_arena *a, int ag, int op, int horizon) {
     a->last_outcome = (op <= 0 && a->steps < horizon) ? 1 : ((ag <= 0 && a->steps < horizon) ? -1 : 0);
 }
 
-/* env_base.py:79-109 step -> env_hetero.py:105-186 _take_action -> 188-225 _get_rewards */
-static void ll_step(const o_world *w, o_arena *a, const int8_t *actions /* [n_ctrl,4] */) {
+/* env_hetero.py:160-172: the units flown by actions (agents; opponents at levels 4-5) in id order.
+ * first = 1 / last = n_agents for the agents' half, n_agents+1 / A for the frozen-policy opponents. */
+static void ll_act_range(const o_world *w, o_arena *a, int first, int last, const int8_t *actions /* rows by unit id */) {
     int nA = w->cfg.n_agents;
-    double opp_stat0[MAXA];
-    o_event ev[4 * MAXA];
-    a->ev_mask = 0;
-    for (int i = 0; i < MAXA; i++) { a->reward[i] = 0.0; a->reward_valid[i] = 0; opp_stat0[i] = 0.0; }
-    a->steps += 1;
-    for (int i = 1; i <= w->A; i++) {
+    for (int i = first; i <= last; i++) {
         if (!a->ac[i - 1].alive) continue;
-        if (i <= nA || w->cfg.ext_opp_actions) {
-            if (i > nA) {
-                /* env_base.py:349-398 _policy_actions: lowlevel_state(opp_mode, i) refreshes the
-                 * opponent's target; the action itself comes from the caller's frozen policy */
-                double st[OBS_MAX]; int n;
-                lowlevel_state_one(w, a, i, HH_MODE_FIGHT, st, &n);
-            } else {
-                a->reward_valid[i - 1] = 1;
-                int t = a->tgt_n[i - 1] ? a->tgt_id[i - 1][0] : 0;
-                if (t && a->ac[t - 1].alive) opp_stat0[i - 1] = focus_norm(&a->ac[t - 1], &a->ac[i - 1]);
-            }
+        if (i <= nA) {
+            a->reward_valid[i - 1] = 1;
             int t = a->tgt_n[i - 1] ? a->tgt_id[i - 1][0] : 0;
-            take_base_action(w, a, 0, i, t, actions + 4 * (i - 1));
-        } else {
-            if (w->cfg.level == 1) opp_level1(w, a, i);
-            else if (w->cfg.level == 2) opp_level2(w, a, i);
-            else opp_level3(w, a, i);
+            if (t && a->ac[t - 1].alive) a->opp_stat0[i - 1] = focus_norm(&a->ac[t - 1], &a->ac[i - 1]);
         }
+        int t = a->tgt_n[i - 1] ? a->tgt_id[i - 1][0] : 0;
+        take_base_action(w, a, 0, i, t, actions + 4 * (i - 1));
     }
+}
+
+/* env_base.py:349-398 _policy_actions -> lowlevel_state(opp_mode, i): observation of a frozen-policy
+ * opponent (also refreshes its target).  Evaluated after the agents acted (id order, env_hetero.py:160-172). */
+static void ll_opp_obs(const o_world *w, o_arena *a, int opp_mode, float *obs /* [n_opps, 30] */) {
+    double st[OBS_MAX];
+    for (int i = w->cfg.n_agents + 1; i <= w->A; i++) {
+        int n = 0;
+        if (a->ac[i - 1].alive) lowlevel_state_one(w, a, i, opp_mode, st, &n); /* dead units are skipped (env_hetero.py:161) */
+        if (obs) for (int k = 0; k < 30; k++) obs[(i - w->cfg.n_agents - 1) * 30 + k] = k < n ? (float)st[k] : 0.0f;
+    }
+}
+
+static void ll_begin(o_arena *a) {
+    a->ev_mask = 0;
+    for (int i = 0; i < MAXA; i++) { a->reward[i] = 0.0; a->reward_valid[i] = 0; a->opp_stat0[i] = 0.0; }
+    a->steps += 1;
+}
+
+/* do_tick + rewards + done + state (env_hetero.py:184-225, env_base.py:89-90) */
+static void ll_tick_and_rewards(const o_world *w, o_arena *a) {
+    int nA = w->cfg.n_agents;
+    o_event ev[4 * MAXA];
     int nev = do_tick(w, a, ev);
     double rews[MAXA];
     int destroyed[MAXA];
-    combat_rewards(w, a, 0, ev, nev, opp_stat0, rews, destroyed);
+    combat_rewards(w, a, 0, ev, nev, a->opp_stat0, rews, destroyed);
     /* env_hetero.py:198-214 per-step escape shaping */
     if (w->cfg.agent_mode == HH_MODE_ESCAPE && w->cfg.esc_dist_rew) {
         for (int i = 1; i <= nA; i++) {
@@ -823,6 +832,25 @@ static void ll_step(const o_world *w, o_arena *a, const int8_t *actions /* [n_ct
     for (int i = 0; i < nA; i++) if (a->reward_valid[i]) a->ep_ret += a->reward[i];
     if (a->done) finish_episode(a, ag, op, w->cfg.horizon);
     ll_state(w, a);
+}
+
+/* env_base.py:79-109 step -> env_hetero.py:105-186 _take_action -> 188-225 _get_rewards */
+static void ll_step(const o_world *w, o_arena *a, const int8_t *actions /* [n_ctrl,4] */) {
+    int nA = w->cfg.n_agents;
+    ll_begin(a);
+    ll_act_range(w, a, 1, nA, actions);
+    if (w->cfg.ext_opp_actions) {
+        ll_opp_obs(w, a, HH_MODE_FIGHT, 0);
+        ll_act_range(w, a, nA + 1, w->A, actions);
+    } else {
+        for (int i = nA + 1; i <= w->A; i++) {
+            if (!a->ac[i - 1].alive) continue;
+            if (w->cfg.level == 1) opp_level1(w, a, i);
+            else if (w->cfg.level == 2) opp_level2(w, a, i);
+            else opp_level3(w, a, i);
+        }
+    }
+    ll_tick_and_rewards(w, a);
 }
 
 /* ------------------------------------------------------------------ HighLevelEnv (env_hier.py) */
@@ -952,6 +980,56 @@ API int hho_step(void *h, const int8_t *actions, float *obs, float *reward, uint
         if (done) done[n] = (uint8_t)a->done;
         if (a->done && w->cfg.auto_reset) {
             uint32_t em = a->ev_mask; /* masks describe the step that just ended */
+            arena_reset(w, a);
+            a->ev_mask = em;
+        }
+        if (obs) copy_obs(w, a, obs + (size_t)n * nA * w->D);
+    }
+    return HH_OK;
+}
+
+/* levels 4-5: the step split around the frozen opponent policy (env_hetero.py:160-172):
+ *   hho_step_begin(agent actions) -> observations of the opponents (after the agents acted)
+ *   hho_step_finish(opponent actions) -> like hho_step */
+API int hho_step_begin(void *h, const int8_t *agent_actions /* [N, n_agents, 4] */, int opp_mode, float *opp_obs /* [N, n_opps, 30] */) {
+    o_world *w = (o_world *)h;
+    int N = w->cfg.n_arenas, nA = w->cfg.n_agents, nO = w->cfg.n_opps;
+    if (w->cfg.env_kind != HH_ENV_LOWLEVEL || !w->cfg.ext_opp_actions) return HH_E_ARG;
+    for (int n = 0; n < N; n++) {
+        o_arena *a = &w->ar[n];
+        float *oo = opp_obs ? opp_obs + (size_t)n * nO * 30 : 0;
+        if (a->done) {
+            for (int i = 0; i < nA; i++) { a->reward[i] = 0.0; a->reward_valid[i] = 0; }
+            a->ev_mask = 0;
+            if (oo) for (int k = 0; k < nO * 30; k++) oo[k] = 0.0f;
+            continue;
+        }
+        int8_t act[MAXA * 4] = {0};
+        for (int i = 0; i < nA * 4; i++) act[i] = agent_actions[(size_t)n * nA * 4 + i];
+        ll_begin(a);
+        ll_act_range(w, a, 1, nA, act);
+        ll_opp_obs(w, a, opp_mode, oo);
+    }
+    return HH_OK;
+}
+
+API int hho_step_finish(void *h, const int8_t *opp_actions /* [N, n_opps, 4] */, float *obs, float *reward, uint8_t *reward_valid, uint8_t *done) {
+    o_world *w = (o_world *)h;
+    int N = w->cfg.n_arenas, nA = w->cfg.n_agents, nO = w->cfg.n_opps;
+    if (w->cfg.env_kind != HH_ENV_LOWLEVEL || !w->cfg.ext_opp_actions) return HH_E_ARG;
+    for (int n = 0; n < N; n++) {
+        o_arena *a = &w->ar[n];
+        if (!a->done) {
+            int8_t act[MAXA * 4] = {0};
+            for (int i = 0; i < nO * 4; i++) act[nA * 4 + i] = opp_actions[(size_t)n * nO * 4 + i];
+            ll_act_range(w, a, nA + 1, w->A, act);
+            ll_tick_and_rewards(w, a);
+        }
+        if (reward) for (int i = 0; i < nA; i++) reward[(size_t)n * nA + i] = (float)a->reward[i];
+        if (reward_valid) for (int i = 0; i < nA; i++) reward_valid[(size_t)n * nA + i] = (uint8_t)a->reward_valid[i];
+        if (done) done[n] = (uint8_t)a->done;
+        if (a->done && w->cfg.auto_reset) {
+            uint32_t em = a->ev_mask;
             arena_reset(w, a);
             a->ev_mask = em;
         }

@@ -140,6 +140,24 @@ class OracleWorld:
         assert rc == 0, rc
         return obs, rew, val, done
 
+    def step_begin(self, agent_actions, opp_mode=0):
+        a = np.ascontiguousarray(agent_actions, dtype=np.int8).reshape(self.N, self.n_agents, 4)
+        oo = np.zeros((self.N, self.A - self.n_agents, 30), dtype=np.float32)
+        rc = lib().hho_step_begin(self.h, _ptr(a, C.c_int8), opp_mode, _ptr(oo, C.c_float))
+        assert rc == 0, rc
+        return oo
+
+    def step_finish(self, opp_actions):
+        a = np.ascontiguousarray(opp_actions, dtype=np.int8).reshape(self.N, self.A - self.n_agents, 4)
+        obs = np.zeros((self.N, self.n_agents, self.D), dtype=np.float32)
+        rew = np.zeros((self.N, self.n_agents), dtype=np.float32)
+        val = np.zeros((self.N, self.n_agents), dtype=np.uint8)
+        done = np.zeros((self.N,), dtype=np.uint8)
+        rc = lib().hho_step_finish(self.h, _ptr(a, C.c_int8), _ptr(obs, C.c_float), _ptr(rew, C.c_float),
+                                   _ptr(val, C.c_uint8), _ptr(done, C.c_uint8))
+        assert rc == 0, rc
+        return obs, rew, val, done
+
     def rollout(self, actions):
         T = actions.shape[0]
         actions = np.ascontiguousarray(actions, dtype=np.int8).reshape(T, self.N, self.n_ctrl, 4)

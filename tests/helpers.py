@@ -29,7 +29,8 @@ def cfg_kwargs_from_meta(meta, **over):
         horizon=a["horizon"], friendly_kill=a["friendly_kill"], friendly_punish=a["friendly_punish"],
         esc_dist_rew=a["esc_dist_rew"], hier_action_assess=a["hier_action_assess"],
         hier_opp_fight_ratio=a["hier_opp_fight_ratio"], map_size=a["map_size"], glob_frac=a["glob_frac"],
-        rew_scale=a["rew_scale"], seed=meta["seed"], arena_offset=meta["arena"])
+        rew_scale=a["rew_scale"], seed=meta["seed"], arena_offset=meta["arena"],
+        ext_opp_actions=(meta["env"] == "low" and a["level"] >= 4))
     kw.update(over)
     return kw
 

@@ -104,7 +104,7 @@ def test_no_auto_reset_freezes_done_arenas_and_masked_reset(oracle):
     _assert_same_state(g.get_state(), o.get_state(), "after masked reset")
 
 
-@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("env_")[-1][:-4])
+@pytest.mark.parametrize("path", [p for p in golden_files() if "frozen" not in p], ids=lambda p: p.split("env_")[-1][:-4])
 def test_golden_traces_on_gpu(path):
     """the committed reference traces replayed directly on the HIP world"""
     import torch
@@ -193,3 +193,51 @@ def test_full_size_rollout_parity(oracle, monkeypatch, N, T, force_w):
     assert (sg["ar_i"][:, 0] <= 300).all() and (sg["ar_i"][:, 5] >= 1).all()
     for a, b in zip([x.cpu().numpy() for x in g.episode_stats()], o.episode_stats()):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("level,opp_mode", [(4, 0), (5, 1)], ids=["L4-fight-opps", "L5-escape-opps"])
+def test_split_step_parity_levels_4_5(oracle, level, opp_mode):
+    """frozen-policy opponents: hh_step_begin (agents act, opponents observe) / hh_step_finish"""
+    import torch
+    N = 200
+    g, o = _worlds(oracle, n_arenas=N, level=level, seed=13, auto_reset=True, ext_opp_actions=True)
+    assert np.array_equal(g.reset().cpu().numpy(), o.reset())
+    rng = np.random.default_rng(9)
+    dones = 0
+    for t in range(150):
+        st = o.get_state()
+        act = pursuit_actions(rng, st, 2, 4) if t % 2 else random_actions(rng, (N,), 4)
+        a_ag, a_op = np.ascontiguousarray(act[:, :2]), np.ascontiguousarray(act[:, 2:])
+        oo = g.step_begin(torch.from_numpy(a_ag).cuda(), opp_mode).cpu().numpy()
+        oo_o = o.step_begin(a_ag, opp_mode)
+        assert np.array_equal(oo, oo_o), f"t={t}: opponents' observations"
+        outs = [x.cpu().numpy() for x in g.step_finish(torch.from_numpy(a_op).cuda())]
+        outs_o = o.step_finish(a_op)
+        for a, b, name in zip(outs, outs_o, ("obs", "reward", "valid", "done")):
+            assert np.array_equal(a, b), f"t={t}: {name}"
+        assert np.array_equal(g.event_masks(), o.event_masks()), f"t={t}: masks"
+        dones += int(outs[3].sum())
+        if t % 25 == 0:
+            _assert_same_state(g.get_state(), o.get_state(), f"t={t}")
+    assert dones > 0
+
+
+@pytest.mark.parametrize("path", [p for p in golden_files() if "frozen" in p], ids=lambda p: p.split("env_")[-1][:-4])
+def test_frozen_opponent_traces_on_gpu(path):
+    import torch
+    from hhmarl_2d_amd.world import World, make_config
+    g, meta = load_golden(path)
+    w = World(make_config(**cfg_kwargs_from_meta(meta)))
+    for r in range(len(g["kind"])):
+        if g["kind"][r] == 0:
+            obs = w.reset().cpu().numpy()[0]
+            continue
+        a = g["actions"][r]
+        oo = w.step_begin(torch.from_numpy(np.ascontiguousarray(a[None, :2])).cuda(), int(g["opp_mode"][r])).cpu().numpy()[0]
+        assert np.abs(oo - g["opp_obs"][r]).max() <= 1e-6, f"row {r}: opponents' policy observation"
+        o, rw, v, d = [x.cpu().numpy() for x in w.step_finish(torch.from_numpy(np.ascontiguousarray(a[None, 2:])).cuda())]
+        st = w.get_state()
+        assert np.array_equal(st["ac_i"][0], g["ac_i"][r]) and np.array_equal(st["rk_i"][0], g["rk_i"][r]), f"row {r}"
+        assert np.array_equal(v[0], g["valid"][r]) and d[0] == g["done"][r], f"row {r}"
+        assert np.abs(st["ac_f"][0] - g["ac_f"][r]).max() <= 1e-9 and np.abs(o[0] - g["obs"][r]).max() <= 1e-6, f"row {r}"
+        assert np.abs(rw[0] - g["reward"][r]).max() <= 1e-6 * max(1.0, np.abs(g["reward"][r]).max()), f"row {r}"

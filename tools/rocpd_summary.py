@@ -45,5 +45,22 @@ def main():
                     print(f"{str(k)[:40]:40s} {cname:22s} {n:10d} {a:18.1f} {mx:18.1f}")
 
 
+def traffic_json(fetch_db, write_db, kernel, min_us, arenas, ticks):
+    """HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KB; gfx950 FETCH_SIZE counts half of wide reads)"""
+    import json
+    vals = {}
+    for name, path in (("FETCH_SIZE", fetch_db), ("WRITE_SIZE", write_db)):
+        db = sqlite3.connect(path)
+        rows = list(db.execute("select kernel_name, avg(value), max(value) from counters_collection where counter_name=? group by kernel_name", (name,)))
+        rows = [r for r in rows if kernel in str(r[0])]
+        vals[name] = rows[0][2] if rows else None   # max over dispatches = a full-length launch
+    b = None if None in vals.values() else int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+    print(json.dumps({"arenas": arenas, "ticks_per_launch": ticks, "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
+                      "hbm_bytes_per_launch": b, "note": "2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate passes"}))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--traffic":
+        traffic_json(sys.argv[2], sys.argv[3], sys.argv[4], 0, int(sys.argv[5]), int(sys.argv[6]))
+    else:
+        main()

@@ -192,7 +192,8 @@ HH_HD double hh_acos_R(double z) {
 HH_HD double hh_acos(double x) /* |x| <= 1 */ {
     const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
     double ax = hh_fabs(x);
-    if (ax >= 1.0) return x > 0.0 ? 0.0 : HH_PI + 2.0 * PIO2_LO;
+    const int edge = ax >= 1.0; /* |x| = 1 (callers clip): handled by a select so the routine stays straight-line */
+    if (edge) ax = 1.0;
     /* the three classic ranges (|x| < 0.5, x <= -0.5, x >= 0.5) share one evaluation of the rational
      * R and one square root; only the final assembly differs, so lanes of a wave do not diverge */
     int small = ax < 0.5;
@@ -201,7 +202,7 @@ HH_HD double hh_acos(double x) /* |x| <= 1 */ {
     double s = hh_sqrt(z);
     /* |x| < 0.5 */
     double res_small = PIO2_HI - (x - (PIO2_LO - x * r));
-    if (ax < 0x1p-57) res_small = PIO2_HI + PIO2_LO;
+    res_small = ax < 0x1p-57 ? PIO2_HI + PIO2_LO : res_small;
     /* x <= -0.5 */
     double res_neg = HH_PI - 2.0 * (s + (r * s - PIO2_LO));
     /* x >= 0.5: df = s with the low 32 bits cleared */
@@ -211,7 +212,8 @@ HH_HD double hh_acos(double x) /* |x| <= 1 */ {
     double df = cv.d;
     double c = (z - df * df) / (s + df);
     double res_pos = 2.0 * (df + (r * s + c));
-    return small ? res_small : (x < 0.0 ? res_neg : res_pos);
+    double res = small ? res_small : (x < 0.0 ? res_neg : res_pos);
+    return edge ? (x > 0.0 ? 0.0 : HH_PI + 2.0 * PIO2_LO) : res;
 }
 
 /* ---- degree helpers used by the geodesic layer (Karney 2013, Sec. 6 implementation notes:

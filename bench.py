@@ -82,6 +82,7 @@ def main():
                     help="low: BASELINE configs[1] (default, the headline).  hier: configs[3], 3-vs-3 HighLevelEnv commander "
                          "steps (use --arenas 8192); a step is one commander step = 16 sub-steps with pilot actions")
     ap.add_argument("--pilot", choices=["random", "mlp"], default="random", help="hier: uniform action tape or random-init MLP pilots")
+    ap.add_argument("--no-graph", action="store_true", help="hier: launch the macro step eagerly instead of replaying a HIP graph")
     args = ap.parse_args()
     if args.workload == "hier":
         return main_hier(args)
@@ -204,9 +205,28 @@ def main_hier(args):
     cmds = (torch.rand((64, N, 3), device=dev, generator=gen) * 3).to(torch.int8).contiguous()
     out, pbuf = w.alloc_outputs(), w.alloc_pilot()
 
+    # the macro step is ~34 world launches + the pilots' torch kernels: capture it once into a HIP graph
+    # (launch-bound inner loop; no host synchronisation inside) and replay it per commander step
+    cmd_static = cmds[0].clone()
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                macro_step(w, cmd_static, pilot, out=out, pilot_buf=pbuf)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            macro_step(w, cmd_static, pilot, out=out, pilot_buf=pbuf)
+
     def run(n):
         for k in range(n):
-            macro_step(w, cmds[k % 64], pilot, out=out, pilot_buf=pbuf)
+            if graph is not None:
+                cmd_static.copy_(cmds[k % 64])
+                graph.replay()
+            else:
+                macro_step(w, cmds[k % 64], pilot, out=out, pilot_buf=pbuf)
             if k % 16 == 15:
                 sw.log_episode_stats()
 

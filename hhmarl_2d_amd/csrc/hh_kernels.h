@@ -175,11 +175,15 @@ __device__ __forceinline__ void nearby(const DevCfg &c, const Shared<A, B> &sh, 
     bool me_agent = s < c.nA;
     int lo = (me_agent != friendly) ? c.nA : 0;
     int hi = (me_agent != friendly) ? A : c.nA;
+    /* all LDS reads first (independent, one wait), then the tiny insertion sort on registers */
+    double dr_[A];
+    int al_[A];
+#pragma unroll
+    for (int j = 0; j < A; j++) { dr_[j] = sh.p_dist[j][tid]; al_[j] = sh.flags[base + j] & FL_ALIVE; }
 #pragma unroll
     for (int j = 0; j < A; j++) {
-        if (j < lo || j >= hi || j == s) continue;
-        if (!sh_alive(sh, base + j)) continue;
-        double dr = sh.p_dist[j][tid];
+        if (j < lo || j >= hi || j == s || !al_[j]) continue;
+        double dr = dr_[j];
         double dn = c.inv_diag * dr;
         int p = (o.n >= 1 && o.d0 <= dn) + (o.n >= 2 && o.d1 <= dn) + (o.n >= 3 && o.d2 <= dn);
         if (p <= 1) { o.i2 = o.i1; o.d2 = o.d1; o.r2 = o.r1; }
@@ -755,14 +759,15 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     __syncthreads();
     if (s == 0 && active) {
         int alive = 0, nev = 0, dead = 0;
+        int aux_[A], res_[A];
 #pragma unroll
-        for (int j = 0; j < A; j++) alive |= (sh_alive(sh, base + j) ? 1 : 0) << j;
+        for (int j = 0; j < A; j++) { aux_[j] = sh.aux[base + j]; res_[j] = sh.res[base + j]; alive |= (sh_alive(sh, base + j) ? 1 : 0) << j; }
         if (running) {
             /* aircraft phase: shooter i (alive at tick start, even if killed earlier in this tick) hits the
              * still-alive targets in id order (ac1.py:106-115) */
 #pragma unroll
             for (int i = 0; i < A; i++) {
-                int ci = sh.aux[base + i] >> 8;
+                int ci = aux_[i] >> 8;
 #pragma unroll
                 for (int j = 0; j < A; j++) {
                     if (((ci >> j) & 1) && ((alive >> j) & 1)) {
@@ -775,14 +780,14 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
             int done_mask = 0;
             for (int k = 0; k < A; k++) {
                 int best = -1, best_seq = 0x7fffffff;
+                int w = 0;
 #pragma unroll
                 for (int j = 0; j < A; j++) {
-                    int w = sh.res[base + j];
-                    if ((w & 1) && !((done_mask >> j) & 1) && (w >> 8) < best_seq) { best = j; best_seq = w >> 8; }
+                    int wj = res_[j];
+                    if ((wj & 1) && !((done_mask >> j) & 1) && (wj >> 8) < best_seq) { best = j; best_seq = wj >> 8; w = wj; }
                 }
                 if (best < 0) break;
                 done_mask |= 1 << best;
-                int w = sh.res[base + best];
                 int tg = (w >> 4) & 7;
                 int fid = best == 1 ? 0 : 1;
                 if (((w >> 1) & 1) && ((alive >> tg) & 1)) {
@@ -1087,13 +1092,18 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
             T = 1;
         }
     }
+    /* the action word of tick t+1 is requested while tick t computes (one wave per SIMD cannot hide a ~1 us
+     * HBM round trip at the top of every tick) */
+    const bool has_act = active && s < c.n_ctrl && run == HH_RUN_ROLLOUT;
+    int act_next = 0;
+    if (has_act && T > 0) act_next = *reinterpret_cast<const int *>(actions + (((size_t)0 * c.N + n) * c.n_ctrl + s) * 4);
     for (int t = 0; t < T; t++) {
         if (run == HH_RUN_ROLLOUT || (SPLIT && run == HH_RUN_LL_FINISH)) {
             StepOut so;
             int8_t act[4] = {0, 0, 0, 0};
-            if (active && s < c.n_ctrl && run == HH_RUN_ROLLOUT) {
-                const int8_t *ap = actions + (((size_t)t * c.N + n) * c.n_ctrl + s) * 4;
-                int w = *reinterpret_cast<const int *>(ap);
+            if (has_act) {
+                int w = act_next;
+                if (t + 1 < T) act_next = *reinterpret_cast<const int *>(actions + (((size_t)(t + 1) * c.N + n) * c.n_ctrl + s) * 4);
                 act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
             }
             const bool was_running = active && !ar.done;

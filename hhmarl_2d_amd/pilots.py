@@ -12,13 +12,12 @@ class RandomPilot:
     """uniform actions from a device generator (env-only throughput measurements)"""
 
     def __init__(self, device, seed=0):
-        self.gen = torch.Generator(device=device)
-        self.gen.manual_seed(seed)
+        torch.manual_seed(seed)  # default generator: usable inside a captured HIP graph
         self.hi = torch.tensor([13, 9, 2, 2], device=device)
 
     def __call__(self, pilot_obs, pilot_mode):
         n, a = pilot_mode.shape
-        return (torch.rand((n, a, 4), device=pilot_obs.device, generator=self.gen) * self.hi).to(torch.int8)
+        return (torch.rand((n, a, 4), device=pilot_obs.device) * self.hi).to(torch.int8)
 
 
 class MLPPilot(torch.nn.Module):

@@ -185,7 +185,7 @@ __device__ __noinline__ void d_geo_direct_general(double lat1, double lon1, doub
 }
 __device__ __forceinline__ void d_geo_move(double lat1, double lon1, double azi1, double s12, double &lat2, double &lon2) {
     double a, b;
-    if (s12 <= HH_GEO_SHORT_MAX_M && hh_fabs(lat1) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon1) < 170.0)
+    if (s12 <= HH_GEO_SHORT_MAX_M && hh_fabs(lat1) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon1) < 170.0 && hh_fabs(azi1) <= 360.0)
         hh_geo_direct_short(lat1, lon1, azi1, s12, &a, &b);
     else
         d_geo_direct_general(lat1, lon1, azi1, s12, &a, &b);
@@ -197,8 +197,8 @@ __device__ __forceinline__ void d_geo_move(double lat1, double lon1, double azi1
  * result is bit-identical to d_geo_move of the same arguments */
 __device__ __forceinline__ void d_geo_move2(double lat_a, double lon_a, double azi_a, double s_a, double &lat2_a, double &lon2_a,
                                             double lat_b, double lon_b, double azi_b, double s_b, double &lat2_b, double &lon2_b) {
-    bool ok_a = s_a <= HH_GEO_SHORT_MAX_M && hh_fabs(lat_a) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon_a) < 170.0;
-    bool ok_b = s_b <= HH_GEO_SHORT_MAX_M && hh_fabs(lat_b) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon_b) < 170.0;
+    bool ok_a = s_a <= HH_GEO_SHORT_MAX_M && hh_fabs(lat_a) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon_a) < 170.0 && hh_fabs(azi_a) <= 360.0;
+    bool ok_b = s_b <= HH_GEO_SHORT_MAX_M && hh_fabs(lat_b) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon_b) < 170.0 && hh_fabs(azi_b) <= 360.0;
     if (ok_a && ok_b) {
         double a0, a1, b0, b1;
         hh_geo_direct_short(lat_a, lon_a, azi_a, s_a, &a0, &a1);

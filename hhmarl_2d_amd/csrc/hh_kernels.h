@@ -502,6 +502,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
             }
         }
     }
+    HH_PROF(11);
     /* env_hetero.py:138-158 level 3: the arena-level escape flag is consumed once per live
      * opponent in id order; every lane replays the tiny integer sequence so that
      * each opponent lane sees the flag as it was at its turn and all lanes agree on the result */

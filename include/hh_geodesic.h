@@ -211,69 +211,79 @@ HH_HD void hh_geo_direct(double lat1, double lon1, double azi1, double s12, doub
 
 
 /* ------------------------------------------------------------------ short-step Direct */
-/* Per-tick position updates move at most 1.03 km (2000 kn rocket): s/a <= 1.7e-4.  For such
- * steps one classical Runge-Kutta step of the geodesic equations on the ellipsoid,
- *     dphi/dt = cos(alp) W^3 / (1-e^2),  dlam/dt = sin(alp) W / cos(phi),
- *     dalp/dt = sin(alp) tan(phi) W,     W = sqrt(1 - e^2 sin^2 phi),  t = s/a,
- * has a local error ~ t^5 < 2e-19 rad — below double rounding — at a fraction of the cost of the
- * general series solution: the stage values of sin/cos(phi), sin/cos(alp), W and 1/cos(phi) are
- * obtained from the start values by angle addition / Taylor updates in the tiny stage offsets
- * (<= 1.7e-4 rad), so the whole step needs 2 sincosd, 1 sqrt and 4 divisions.
- * tests/test_geodesic.py pins it to hh_geo_direct (Karney) and to the mpmath ODE vectors at
- * <= 2e-14 deg.  Outside its domain (s > 4 km or |lat| > 70) callers fall back to hh_geo_direct. */
+/* Per-tick position updates move at most 1.03 km (2000 kn rocket): t = s/a <= 1.7e-4.  For such steps the
+ * geodesic equations on the ellipsoid,
+ *     dphi/dt = cos(alp) W^3 / (1-e^2),  dlam/dt = sin(alp) W / cos(phi),  dalp/dt = sin(alp) tan(phi) W,
+ *     W = sqrt(1 - e^2 sin^2 phi),
+ * are solved by their TAYLOR SERIES in t to 4th order.  The coefficients come from the standard
+ * power-series recurrences of the auxiliary functions S = sin phi, C = cos phi, Sa = sin alp, Ca = cos alp,
+ * U = 1 - e^2 S^2, W = sqrt(U), Q = W/C, P = W U/(1-e^2)   (S' = C phi', C' = -S phi', W_k from W^2 = U,
+ * Q_k from Q C = W, products by Cauchy sums), all evaluated at the start point only.  The truncation
+ * error is ~ t^5 < 2e-19 rad (< 1e-16 rad at the 4 km domain limit) — below double rounding — and the
+ * dependency chain is ~30 operations deep instead of the ~160 of a Runge-Kutta step or the several
+ * hundred of the general series solution: this is the per-tick latency that matters at one wave per
+ * SIMD.  Cost: 2 division-free sincosd, 1 sqrt, 2 divisions, ~170 multiply-adds.
+ * tests/test_geodesic.py pins it to hh_geo_direct (Karney) and to the mpmath ODE vectors at <= 2e-14 deg.
+ * Outside its domain (s > 4 km or |lat| > 70) callers fall back to hh_geo_direct. */
 #define HH_GEO_SHORT_MAX_M 4000.0
 #define HH_GEO_SHORT_MAX_LAT 70.0
 
-HH_HD void hh_geo_rk_stage(double sp0, double cp0, double sa0, double ca0, double W20, double rW20, double W0, double rc0, double tp0,
-                           double dphi, double dalp, double *kphi, double *klam, double *kalp) {
-    /* sin/cos of the small offsets */
-    double p2 = dphi * dphi, a2 = dalp * dalp;
-    double sdp = dphi * (1.0 - p2 * (1.0 / 6.0 - p2 * (1.0 / 120.0)));
-    double cdp = 1.0 - p2 * (0.5 - p2 * (1.0 / 24.0));
-    double sda = dalp * (1.0 - a2 * (1.0 / 6.0));
-    double cda = 1.0 - a2 * (0.5 - a2 * (1.0 / 24.0));
-    double sp = sp0 * cdp + cp0 * sdp;
-    double sa = sa0 * cda + ca0 * sda;
-    double ca = ca0 * cda - sa0 * sda;
-    /* 1/cos(phi0+dphi) = rc0 / (cdp - tan(phi0) sdp) = rc0 / (1 - eps), eps ~ 1e-5 */
-    double eps = (1.0 - cdp) + tp0 * sdp;
-    double rc = rc0 * (1.0 + eps * (1.0 + eps * (1.0 + eps * (1.0 + eps))));
-    /* W = W0 sqrt(1 + x), x = -e2 (sp^2 - sp0^2) / W0^2 ~ 2e-7 */
-    double x = -HH_GEO_E2 * ((sp - sp0) * (sp + sp0)) * rW20;
-    double W = W0 * (1.0 + x * (0.5 - x * (0.125 - x * 0.0625)));
-    double W2 = W20 * (1.0 + x);
-    *kphi = ca * W * W2 * (1.0 / (1.0 - HH_GEO_E2));
-    double q = W * rc;
-    *klam = sa * q;
-    *kalp = sa * sp * q;
-}
-
 HH_HD void hh_geo_direct_short(double lat1, double lon1, double azi1, double s12, double *lat2, double *lon2) {
-    double sp0, cp0, sa0, ca0;
-    hh_sincosd(lat1, &sp0, &cp0);
-    hh_sincosd(azi1, &sa0, &ca0);
-    double h = s12 / HH_GEO_A;
-    double W20 = 1.0 - HH_GEO_E2 * sp0 * sp0;
-    double W0 = hh_sqrt(W20);
-    double rc0 = 1.0 / cp0;
-    double rW20 = 1.0 / W20;
-    double tp0 = sp0 * rc0;
-    double k1p, k1l, k1a, k2p, k2l, k2a, k3p, k3l, k3a, k4p, k4l, k4a;
-    hh_geo_rk_stage(sp0, cp0, sa0, ca0, W20, rW20, W0, rc0, tp0, 0.0, 0.0, &k1p, &k1l, &k1a);
-    double hh = 0.5 * h;
-    hh_geo_rk_stage(sp0, cp0, sa0, ca0, W20, rW20, W0, rc0, tp0, hh * k1p, hh * k1a, &k2p, &k2l, &k2a);
-    hh_geo_rk_stage(sp0, cp0, sa0, ca0, W20, rW20, W0, rc0, tp0, hh * k2p, hh * k2a, &k3p, &k3l, &k3a);
-    hh_geo_rk_stage(sp0, cp0, sa0, ca0, W20, rW20, W0, rc0, tp0, h * k3p, h * k3a, &k4p, &k4l, &k4a);
-    double h6 = h / 6.0;
-    double dphi = h6 * ((k1p + k4p) + 2.0 * (k2p + k3p));
-    double dlam = h6 * ((k1l + k4l) + 2.0 * (k2l + k3l));
+    const double E2 = HH_GEO_E2, K1 = 1.0 / (1.0 - HH_GEO_E2), TH = 1.0 / 3.0;
+    double S0, C0, Sa0, Ca0;
+    hh_sincosd_small(lat1, &S0, &C0);
+    hh_sincosd_small(azi1, &Sa0, &Ca0);
+    const double h = s12 * (1.0 / HH_GEO_A);
+    const double U0 = 1.0 - E2 * S0 * S0;
+    const double W0 = hh_sqrt(U0);
+    const double iC = 1.0 / C0, hW = 0.5 / W0;
+    const double Q0 = W0 * iC, P0 = W0 * U0 * K1;
+    /* order 1 */
+    const double f1 = Ca0 * P0;
+    const double SS0 = Sa0 * S0;
+    const double a1 = SS0 * Q0;
+    const double l1 = Sa0 * Q0;
+    const double S1 = C0 * f1, C1 = -S0 * f1, Sa1 = Ca0 * a1, Ca1 = -Sa0 * a1;
+    const double U1 = -E2 * (2.0 * S0 * S1);
+    const double W1 = U1 * hW;
+    const double Q1 = (W1 - C1 * Q0) * iC;
+    const double P1 = (W0 * U1 + W1 * U0) * K1;
+    /* order 2 */
+    const double f2 = 0.5 * (Ca0 * P1 + Ca1 * P0);
+    const double SS1 = Sa0 * S1 + Sa1 * S0;
+    const double a2 = 0.5 * (SS0 * Q1 + SS1 * Q0);
+    const double l2 = 0.5 * (Sa0 * Q1 + Sa1 * Q0);
+    const double S2 = 0.5 * (C0 * (2.0 * f2) + C1 * f1), C2 = -0.5 * (S0 * (2.0 * f2) + S1 * f1);
+    const double Sa2 = 0.5 * (Ca0 * (2.0 * a2) + Ca1 * a1), Ca2 = -0.5 * (Sa0 * (2.0 * a2) + Sa1 * a1);
+    const double U2 = -E2 * (2.0 * S0 * S2 + S1 * S1);
+    const double W2 = (U2 - W1 * W1) * hW;
+    const double Q2 = (W2 - C1 * Q1 - C2 * Q0) * iC;
+    const double P2 = (W0 * U2 + W1 * U1 + W2 * U0) * K1;
+    /* order 3 */
+    const double f3 = TH * (Ca0 * P2 + Ca1 * P1 + Ca2 * P0);
+    const double SS2 = Sa0 * S2 + Sa1 * S1 + Sa2 * S0;
+    const double a3 = TH * (SS0 * Q2 + SS1 * Q1 + SS2 * Q0);
+    const double l3 = TH * (Sa0 * Q2 + Sa1 * Q1 + Sa2 * Q0);
+    const double S3 = TH * (C0 * (3.0 * f3) + C1 * (2.0 * f2) + C2 * f1);
+    const double C3 = -TH * (S0 * (3.0 * f3) + S1 * (2.0 * f2) + S2 * f1);
+    const double Sa3 = TH * (Ca0 * (3.0 * a3) + Ca1 * (2.0 * a2) + Ca2 * a1);
+    const double Ca3 = -TH * (Sa0 * (3.0 * a3) + Sa1 * (2.0 * a2) + Sa2 * a1);
+    const double U3 = -E2 * (2.0 * S0 * S3 + 2.0 * S1 * S2);
+    const double W3 = (U3 - 2.0 * W1 * W2) * hW;
+    const double Q3 = (W3 - C1 * Q2 - C2 * Q1 - C3 * Q0) * iC;
+    const double P3 = (W0 * U3 + W1 * U2 + W2 * U1 + W3 * U0) * K1;
+    /* order 4 */
+    const double f4 = 0.25 * (Ca0 * P3 + Ca1 * P2 + Ca2 * P1 + Ca3 * P0);
+    const double l4 = 0.25 * (Sa0 * Q3 + Sa1 * Q2 + Sa2 * Q1 + Sa3 * Q0);
+    const double dphi = h * (f1 + h * (f2 + h * (f3 + h * f4)));
+    const double dlam = h * (l1 + h * (l2 + h * (l3 + h * l4)));
     *lat2 = lat1 + dphi * HH_RAD2DEG;
     *lon2 = lon1 + dlam * HH_RAD2DEG;
 }
 
 /* position update used by the simulator tick (cmano_simulator.py:65-72) */
 HH_HD void hh_geo_move(double lat1, double lon1, double azi1, double s12, double *lat2, double *lon2) {
-    if (s12 <= HH_GEO_SHORT_MAX_M && hh_fabs(lat1) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon1) < 170.0)
+    if (s12 <= HH_GEO_SHORT_MAX_M && hh_fabs(lat1) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon1) < 170.0 && hh_fabs(azi1) <= 360.0)
         hh_geo_direct_short(lat1, lon1, azi1, s12, lat2, lon2);
     else
         hh_geo_direct(lat1, lon1, azi1, s12, lat2, lon2);

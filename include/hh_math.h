@@ -249,6 +249,21 @@ HH_HD void hh_sincosd(double x, double *sinx, double *cosx) {
     *cosx = cc;
 }
 
+/* sin, cos of x degrees for |x| <= 360 without divisions (used by the short-step move, where the result
+ * only has to be accurate, not identical to the Karney helper above): q = nearest multiple of 90 */
+HH_HD void hh_sincosd_small(double x, double *sinx, double *cosx) {
+    double qf = hh_rint(x * (1.0 / 90.0));
+    int q = (int)qf;
+    double r = hh_fma(-90.0, qf, x) * HH_DEG2RAD; /* exact remainder in [-45.0000001, 45.0000001] */
+    double s = hh_ksin(r, 0.0), c = hh_kcos(r, 0.0);
+    double ss = (q & 1) ? c : s;
+    double cc = (q & 1) ? s : c;
+    if (((q + 1) & 2) != 0) cc = -cc; /* q mod 4 in {1, 2} */
+    if ((q & 2) != 0) ss = -ss;       /* q mod 4 in {2, 3} */
+    *sinx = ss;
+    *cosx = cc;
+}
+
 /* sin, cos of (x + t) degrees where t is a small correction (AngDiff's error term) */
 HH_HD void hh_sincosde(double x, double t, double *sinx, double *cosx) {
     double qf = hh_rint(x / 90.0);

@@ -17,9 +17,9 @@ buf = (C.c_ulonglong * 16)()
 L = _lib.lib(); L.hh_prof_read(buf, 1)
 for _ in range(4): w.rollout(act, out=out)
 L.hh_prof_read(buf, 0)
-names = ["A commands/scripts", "B kinematics+move", "Q enqueue", "I drain (estimate)", "L+C+D launch/resolve/rocket move", "E rewards", "publish", "pair tables", "finish (shaping, done)", "stats/outputs/reset", "K2 observe+store"]
+names = ["A2 level-3 script (opponents)", "B kinematics+move", "Q enqueue", "I drain (estimate)", "L+C+D launch/resolve/rocket move", "E rewards", "publish", "pair tables", "finish (shaping, done)", "stats/outputs/reset", "K2 observe+store", "A1 rekey + agents' action decode"]
 waves = (N + 15) // 16
-tot = sum(buf[:11])
+tot = sum(buf[:12])
 for k, nm in enumerate(names):
     print(f"{nm:36s} {buf[k] / (waves * 4 * T):9.0f} cycles/wave-tick  {100.0 * buf[k] / tot:5.1f} %")
 print(f"{'total':36s} {tot / (waves * 4 * T):9.0f} cycles/wave-tick")

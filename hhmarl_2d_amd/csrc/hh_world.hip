@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "hh_kernels_hier.h"
+#include "hh_gae.h"
 
 /* ===================================================================== host side */
 static thread_local std::string g_err;
@@ -354,4 +355,15 @@ extern "C" int hh_step_finish(hh_world *w, const int8_t *opp_actions, float *obs
     if (!w || !opp_actions) { g_err = "null argument"; return HH_E_ARG; }
     if (!w->cfg.ext_opp_actions) { g_err = "hh_step_finish needs ext_opp_actions (levels 4-5)"; return HH_E_ARG; }
     return launch(w, HH_RUN_LL_FINISH, 1, opp_actions, nullptr, obs, reward, reward_valid, done, (hipStream_t)stream);
+}
+
+/* ---- rollout post-processing: GAE over the [T, N, n_agents] tensors of hh_rollout ---- */
+extern "C" int hh_gae(int32_t T, int32_t N, int32_t n_agents, const float *reward, const float *value, const uint8_t *valid,
+                      const uint8_t *done, float gamma, float lam, float *adv, float *ret, void *stream) {
+    if (T <= 0 || N <= 0 || n_agents <= 0 || !reward || !value || !valid || !done || !adv || !ret) { g_err = "bad argument"; return HH_E_ARG; }
+    size_t cols = (size_t)N * n_agents;
+    int grid = (int)((cols + 255) / 256);
+    hipLaunchKernelGGL(hh_k_gae, dim3(grid), dim3(256), 0, (hipStream_t)stream, T, N, n_agents, reward, value, valid, done, gamma, lam, adv, ret);
+    HIPCHK(hipGetLastError());
+    return HH_OK;
 }

@@ -1,0 +1,43 @@
+"""Rollout post-processing next to the environment: the centralised-critic input
+packing of train_hetero.py:113-181 and GAE (train_hetero.py:216) on device tensors."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+ACTION_DIM_AC1, ACTION_DIM_AC2 = 4, 3
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def gae(reward, value, valid, done, gamma=0.99, lam=0.95):
+    """reward, valid [T,N,nA]; value [T+1,N,nA]; done [T,N] (device tensors) -> (advantages, returns)"""
+    T, N, nA = reward.shape
+    assert value.shape == (T + 1, N, nA) and valid.shape == reward.shape and done.shape == (T, N)
+    reward, value = reward.contiguous().float(), value.contiguous().float()
+    valid, done = valid.contiguous().to(torch.uint8), done.contiguous().to(torch.uint8)
+    adv, ret = torch.empty_like(reward), torch.empty_like(reward)
+    st = C.c_void_p(torch.cuda.current_stream(reward.device).cuda_stream)
+    L.check(L.lib().hh_gae(T, N, nA, _p(reward), _p(value), _p(valid), _p(done), float(gamma), float(lam), _p(adv), _p(ret), st))
+    return adv, ret
+
+
+def central_critic_inputs(obs, actions):
+    """The four blocks the reference's centralised critic sees per agent (central_critic_observer +
+    on_postprocess_trajectory, train_hetero.py:113-181), for the 2-vs-2 low-level setting:
+      agent 1: obs_1_own = obs[1] (26|30), obs_2 = obs[2] (24|29), act_1_own = own action (4), act_2 = friend's (3)
+      agent 2: obs_1_own = obs[2],         obs_2 = obs[1],          act_1_own = own (3),        act_2 = friend's (4)
+    with the heading / speed components scaled by 1/12 and 1/8 (train_hetero.py:143-160).
+    obs [..., 2, D] (zero padded rows as the world emits them), actions int8 [..., 2, 4].
+    Returns a dict per agent of float32 tensors with the reference's widths."""
+    d1 = obs.shape[-1]
+    d2 = d1 - 2 if d1 == 26 else d1 - 1          # 26/24 fight, 30/29 escape
+    a = actions.float()
+    scaled = torch.stack([a[..., 0] / 12.0, a[..., 1] / 8.0, a[..., 2], a[..., 3]], dim=-1)
+    o1, o2 = obs[..., 0, :d1], obs[..., 1, :d2]
+    a1, a2 = scaled[..., 0, :ACTION_DIM_AC1], scaled[..., 1, :ACTION_DIM_AC2]
+    return {1: {"obs_1_own": o1, "obs_2": o2, "act_1_own": a1, "act_2": a2},
+            2: {"obs_1_own": o2, "obs_2": o1, "act_1_own": a2, "act_2": a1}}

@@ -139,6 +139,12 @@ int hh_hl_end(hh_world *w, float *obs, float *reward, uint8_t *reward_valid, uin
  * outcome [dev] i8[N] (1 agents win, -1 opponents win, 0 draw, 2 none finished yet) */
 int hh_episode_stats(hh_world *w, float *ret, int32_t *len, int8_t *outcome, void *stream);
 
+/* Generalised advantage estimation on the stacked outputs of hh_rollout (what RLlib's postprocessing does
+ * for the reference: train_hetero.py:216 gamma=0.99, lambda_=0.95, complete episodes).  All [dev]:
+ * reward, valid, adv, ret [T, N, n_agents]; value [T+1, N, n_agents] (critic incl. bootstrap row); done [T, N]. */
+int hh_gae(int32_t T, int32_t N, int32_t n_agents, const float *reward, const float *value, const uint8_t *valid,
+           const uint8_t *done, float gamma, float lam, float *adv, float *ret, void *stream);
+
 /* host snapshot in / out (synchronises the stream) */
 int hh_get_state(hh_world *w, hh_state_view *view);
 int hh_set_state(hh_world *w, const hh_state_view *view);

@@ -33,7 +33,7 @@ class HHStateView(C.Structure):
 
 EXPORTS = ["hh_world_create", "hh_world_destroy", "hh_last_error", "hh_obs_dim", "hh_n_ctrl", "hh_reset", "hh_step",
            "hh_rollout", "hh_episode_stats", "hh_get_state", "hh_set_state", "hh_get_event_masks", "hh_observe",
-           "hh_hl_begin", "hh_hl_agents_act", "hh_hl_tick", "hh_hl_end", "hh_step_begin", "hh_step_finish", "hh_gae"]
+           "hh_hl_begin", "hh_hl_agents_act", "hh_hl_tick", "hh_hl_end", "hh_step_begin", "hh_step_finish", "hh_gae", "hh_hl_commands"]
 
 _lib = None
 
@@ -66,6 +66,7 @@ def lib():
         L.hh_hl_end.argtypes = [vp, vp, vp, vp, vp, vp]
         L.hh_step_begin.argtypes = [vp, vp, C.c_int32, vp, vp]
         L.hh_step_finish.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.hh_hl_commands.argtypes = [vp, vp]
         L.hh_gae.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
         _lib = L
     return _lib

@@ -367,3 +367,16 @@ extern "C" int hh_gae(int32_t T, int32_t N, int32_t n_agents, const float *rewar
     HIPCHK(hipGetLastError());
     return HH_OK;
 }
+
+/* commander_actions after _action_assess expanded them (agents: validated action, opponents: drawn fight target /
+ * escape; env_hier.py:142-190) — what evaluation.py's eval_info counters read (env_base.py:91-107) */
+extern "C" int hh_hl_commands(hh_world *w, int8_t *out /* [host] [N, A] */) {
+    if (!w || !out) return HH_E_ARG;
+    HIPCHK(hipSetDevice(w->device));
+    HIPCHK(hipDeviceSynchronize());
+    size_t U = (size_t)w->dc.N * w->dc.A;
+    std::vector<int4> pack(U);
+    HIPCHK(hipMemcpy(pack.data(), w->P.pack, U * 16, hipMemcpyDeviceToHost));
+    for (size_t u = 0; u < U; u++) out[u] = (int8_t)((pack[u].w >> 24) & 0xff);
+    return HH_OK;
+}

@@ -72,8 +72,40 @@ class HighLevelEnv(_Base):
     def state(self):
         return self._obs_dict(self.world.observe())
 
+    def _eval_info(self):
+        """env_base.py:91-107: win/lose/draw flags and fight / escape counters over the units that still exist
+        after the step (eval mode of evaluation.py).  Only meaningful without auto-reset (facade worlds)."""
+        nA = self.args.num_agents
+        st = self.world.get_state()
+        alive = st["ac_i"][0, :, 0]
+        steps, ag, op = int(st["ar_i"][0, 0]), int(st["ar_i"][0, 1]), int(st["ar_i"][0, 2])
+        cmd = self.world.hl_commands()[0]
+        af = ae = of = oe = ast = ost = 0
+        sel = {"opp1": 0, "opp2": 0, "opp3": 0}
+        for k in range(1, self.args.total_num + 1):
+            if not alive[k - 1]:
+                continue
+            v = int(cmd[k - 1])
+            if v:
+                if k <= nA:
+                    af += 1; ast += 1; sel[f"opp{v}"] += 1
+                else:
+                    of += 1; ost += 1
+            else:
+                if k <= nA:
+                    ae += 1; ast += 1
+                else:
+                    oe += 1; ost += 1
+        h = self.args.horizon
+        info = {"agents_win": int(op <= 0 and steps < h), "opps_win": int(ag <= 0 and steps < h),
+                "draw": int(steps >= h and ag > 0 and op > 0), "agent_fight": af, "agent_escape": ae, "opp_fight": of,
+                "opp_escape": oe, "agent_steps": ast, "opp_steps": ost}
+        info.update(sel)
+        return info
+
     def step(self, action):
         self.rewards = {}
+        info = {}
         nA = self.args.num_agents
         if action:
             self.commander_actions = action
@@ -84,6 +116,8 @@ class HighLevelEnv(_Base):
             self._cmd.copy_(torch.from_numpy(c))
             obs, rew, val, done = macro_step(self.world, self._cmd, self.pilot, early_exit=True)
             rew, val, done = rew.cpu().numpy(), val.cpu().numpy(), done.cpu().numpy()
+            if getattr(self.args, "eval_info", False) and self.num_envs == 1:
+                info = self._eval_info()
             if self.num_envs == 1:
                 self.rewards = {i: float(rew[0, i - 1]) for i in range(1, nA + 1) if val[0, i - 1]}
                 d = bool(done[0])
@@ -97,7 +131,7 @@ class HighLevelEnv(_Base):
             dn = (st[:, 1] <= 0) | (st[:, 2] <= 0) | (st[:, 0] >= self.args.horizon)
             d = bool(dn[0]) if self.num_envs == 1 else dn
         terminateds = truncateds = {"__all__": d}
-        return obs_d, self.rewards, terminateds, truncateds, {}
+        return obs_d, self.rewards, terminateds, truncateds, info
 
     def plot(self, out_file=None, paths=True):
         return None

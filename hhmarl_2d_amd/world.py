@@ -153,6 +153,12 @@ class World:
         L.check(L.lib().hh_hl_end(self.h, _p(obs), _p(rew), _p(val), _p(done), self._stream()))
         return obs, rew, val, done
 
+    def hl_commands(self):
+        """host int8 [N, A]: commander_actions after _action_assess (opponents' draws included)"""
+        out = np.zeros((self.N, self.A), dtype=np.int8)
+        L.check(L.lib().hh_hl_commands(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def episode_stats(self):
         ret = torch.zeros(self.N, dtype=torch.float32, device=self.device)
         ln = torch.zeros(self.N, dtype=torch.int32, device=self.device)

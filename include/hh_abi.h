@@ -134,6 +134,10 @@ int hh_hl_agents_act(hh_world *w, const int8_t *actions, float *pilot_obs, uint8
 int hh_hl_tick(hh_world *w, const int8_t *actions, float *pilot_obs, uint8_t *pilot_mode, int32_t *running, void *stream);
 int hh_hl_end(hh_world *w, float *obs, float *reward, uint8_t *reward_valid, uint8_t *done, void *stream);
 
+/* commander_actions of the current macro step after _action_assess (env_hier.py:142-190): agents' validated
+ * actions and the opponents' drawn ones, [host] i8 [N, 6]; read by the eval_info counters (env_base.py:91-107) */
+int hh_hl_commands(hh_world *w, int8_t *out);
+
 /* per-arena statistics of the most recently FINISHED episode (logging; this is what the
  * multi-GPU all-gather moves): ret [dev] f32[N] (sum of agent rewards), len [dev] i32[N],
  * outcome [dev] i8[N] (1 agents win, -1 opponents win, 0 draw, 2 none finished yet) */

@@ -176,6 +176,7 @@ HL_SCENARIOS = [
     ("hl_random_pilots", dict(mode=1), "random", 2, 70),
     ("hl_pursuit_pilots", dict(mode=1), "pursuit", 4, 90),
     ("hl_pursuit_share", dict(mode=1, glob_frac=0.3, hier_opp_fight_ratio=50, hier_action_assess=False), "pursuit", 3, 70),
+    ("hl_eval_info", dict(mode=1, eval_info=True), "pursuit", 3, 60),   # evaluation.py mode: info dict of env_base.py:91-107
 ]
 
 
@@ -214,6 +215,7 @@ def record_hl(name, kw, style, episodes, max_rows, seed=20240917, arena=11):
     cls._policy_actions = policy_actions
     rows = dict(kind=[], cmd=[], nsub=[], ac_f=[], ac_i=[], rk_f=[], rk_i=[], ar_i=[], tgt_id=[], tgt_d=[], obs=[],
                 reward=[], valid=[], done=[], cmd_all=[])
+    infos = []
 
     def push(k, cmd, nsub, obs, rew, done, cmd_all):
         st = env.state()
@@ -237,6 +239,7 @@ def record_hl(name, kw, style, episodes, max_rows, seed=20240917, arena=11):
     for ep in range(episodes):
         obs = env.reset()
         push(0, np.zeros(nA, dtype=np.int8), 0, obs, None, False, np.zeros(A, dtype=np.int8))
+        infos.append({})
         done = False
         while not done and len(rows["kind"]) < max_rows:
             cmd = rng.integers(0, 3, nA).astype(np.int8)
@@ -247,6 +250,7 @@ def record_hl(name, kw, style, episodes, max_rows, seed=20240917, arena=11):
             done = term["__all__"]
             ca = np.array([(cd.get(i) or 0) for i in range(1, A + 1)], dtype=np.int8)  # env expanded it in place
             push(1, cmd, len(sub["obs"]) - n0, obs, rew, done, ca)
+            infos.append({k: int(v) for k, v in info.items()})
         if len(rows["kind"]) >= max_rows:
             break
     meta = dict(name=name, env="high", args={k: v for k, v in vars(args).items()}, seed=seed, arena=arena, obs_dim=34,
@@ -256,6 +260,7 @@ def record_hl(name, kw, style, episodes, max_rows, seed=20240917, arena=11):
     out["sub_obs"] = np.asarray(sub["obs"])
     out["sub_mode"] = np.asarray(sub["mode"])
     out["sub_act"] = np.asarray(sub["act"])
+    out["infos"] = np.array(json.dumps(infos))
     out["meta"] = np.array(json.dumps(meta))
     path = os.path.join(OUT, f"env_{name}.npz")
     np.savez_compressed(path, **out)

@@ -102,16 +102,20 @@ def test_level4_requires_opponent_policy_and_replays_reference_trace():
     env.close()
 
 
-def test_highlevel_dict_protocol_matches_reference_trace():
-    """HighLevelEnv facade driven like RLlib drives the reference, with the trace's taped pilot actions"""
+@pytest.mark.parametrize("which", ["hl_random_pilots", "hl_eval_info"])
+def test_highlevel_dict_protocol_matches_reference_trace(which):
+    """HighLevelEnv facade driven like RLlib / evaluation.py drive the reference, with the trace's taped pilot
+    actions; with eval_info the info dict (env_base.py:91-107) must equal the reference's"""
+    import json
     import torch
     from hhmarl_2d_amd import env_hetero
     from hhmarl_2d_amd.config import make_args
     from hhmarl_2d_amd.env_hier import HighLevelEnv
-    g, meta = load_golden(golden_files("high")[0])
+    g, meta = load_golden([p for p in golden_files("high") if which in p][0])
+    infos = json.loads(str(g["infos"])) if "infos" in g.files else None
     a = meta["args"]
     args = make_args(1, **{k: a[k] for k in ("horizon", "map_size", "glob_frac", "rew_scale", "friendly_kill",
-                                              "hier_action_assess", "hier_opp_fight_ratio", "level")})
+                                              "hier_action_assess", "hier_opp_fight_ratio", "level", "eval_info")})
     tape = {"ptr": 0}
 
     def pilot(po, pm):  # replays the recorded pilot actions; called for agents then opponents in each sub-step
@@ -133,6 +137,8 @@ def test_highlevel_dict_protocol_matches_reference_trace():
         else:
             obs, rew, term, trunc, info = env.step({i + 1: int(g["cmd"][r][i]) for i in range(3)})
             assert term is trunc and term["__all__"] == bool(g["done"][r]) and set(rew) == {1, 2, 3}
+            if infos is not None:
+                assert info == infos[r], f"row {r}: eval info {info} != {infos[r]}"
             for i in rew:
                 assert abs(rew[i] - g["reward"][r][i - 1]) <= 1e-6
         for i in (1, 2, 3):

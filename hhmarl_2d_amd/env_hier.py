@@ -11,7 +11,7 @@ import torch
 
 from . import _lib as L
 from . import spaces
-from .env_hetero import _Base, config_from_args
+from .env_hetero import _Base, _snapshot, config_from_args, plot_trace
 from .world import World
 
 N_OPP_HL = 2
@@ -57,6 +57,8 @@ class HighLevelEnv(_Base):
         self._cmd = torch.zeros((self.num_envs, self.args.num_agents), dtype=torch.int8, device=self.world.device)
         self.commander_actions = None
         self.rewards = {}
+        self.record_trace = bool(env_config.get("record_trace", False))
+        self.trace = []
         super().__init__()
 
     def _obs_dict(self, obs):
@@ -67,7 +69,10 @@ class HighLevelEnv(_Base):
 
     def reset(self, *, seed=None, options=None):
         self.commander_actions = None
-        return self._obs_dict(self.world.reset()), {}
+        obs = self.world.reset()
+        self.trace = []
+        _snapshot(self)
+        return self._obs_dict(obs), {}
 
     def state(self):
         return self._obs_dict(self.world.observe())
@@ -125,6 +130,7 @@ class HighLevelEnv(_Base):
                 self.rewards = {i: rew[:, i - 1] for i in range(1, nA + 1)}
                 d = done.astype(bool)
             obs_d = self._obs_dict(obs)
+            _snapshot(self)
         else:
             obs_d = self.state()
             st = self.world.get_state()["ar_i"]
@@ -134,7 +140,7 @@ class HighLevelEnv(_Base):
         return obs_d, self.rewards, terminateds, truncateds, info
 
     def plot(self, out_file=None, paths=True):
-        return None
+        return plot_trace(self, out_file, paths)
 
     def close(self):
         self.world.close()

@@ -146,3 +146,16 @@ def test_highlevel_dict_protocol_matches_reference_trace(which):
             assert np.abs(obs[i] - g["obs"][r][i - 1]).max() <= 1e-6
     assert tape["ptr"] == 2 * len(g["sub_act"])
     env.close()
+
+
+def test_plot_writes_a_png(tmp_path):
+    from hhmarl_2d_amd.config import make_args
+    from hhmarl_2d_amd.env_hetero import LowLevelEnv
+    env = LowLevelEnv({"args": make_args(0, level=3), "seed": 2, "record_trace": True})
+    env.reset()
+    for _ in range(30):
+        env.step({1: [6, 5, 1, 1], 2: [7, 5, 1]})
+    out = tmp_path / "arena.png"
+    env.plot(out)
+    assert out.exists() and out.stat().st_size > 5000
+    env.close()

@@ -88,8 +88,16 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     size_t o_rkp = take(U * 8), o_ar = take(N * 16), o_ep = take(N * 8), o_lr = take(N * 4), o_ll = take(N * 4);
     size_t o_lo = take(N), o_ev = take(N * 4), o_acc = take(U * 8), o_cnt = take(256);
     w->slab_bytes = off;
-    HIPCHK(hipMalloc(&w->slab, off));
-    HIPCHK(hipMemset(w->slab, 0, off));
+    {
+        hipError_t e = hipMalloc(&w->slab, off);
+        if (e == hipSuccess) e = hipMemset(w->slab, 0, off);
+        if (e != hipSuccess) {
+            g_err = std::string("hipMalloc/hipMemset of the world slab: ") + hipGetErrorString(e);
+            if (w->slab) (void)hipFree(w->slab);
+            delete w;
+            return HH_E_HIP;
+        }
+    }
     char *b = (char *)w->slab;
     DevPtrs &P = w->P;
     P.lat = (double *)(b + o_f[0]); P.lon = (double *)(b + o_f[1]); P.hdg = (double *)(b + o_f[2]);
@@ -114,8 +122,8 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
 
 extern "C" int hh_world_destroy(hh_world *w) {
     if (!w) return HH_E_ARG;
-    hipSetDevice(w->device);
-    hipFree(w->slab);
+    (void)hipSetDevice(w->device);
+    (void)hipFree(w->slab);
     delete w;
     return HH_OK;
 }

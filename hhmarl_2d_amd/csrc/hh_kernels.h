@@ -70,7 +70,7 @@ struct Shared {
     int res[B];                     /* envelope results per requesting lane: bit0 launch ok, bits1-8 cannon hit
                                        on slot j, bit9 rocket fuse on target, bit10 fuse on "friendly" */
     int g_alive[GPB], g_nev[GPB], g_ev[GPB][HH_MAX_AIRCRAFT], g_rkdead[GPB];
-    union {
+    union alignas(16) {
         struct {
             double lat1[B], lon1[B], hdg1[B]; /* position / heading after this tick's aircraft update */
             double rk_lat[B], rk_lon[B];      /* rocket position before its move (speculative for a pending launch) */
@@ -362,11 +362,9 @@ struct StepOut {
  * filtered exact predicate (mid-latitude estimate with proven error bounds; the Karney solution for
  * the undecided sliver) and its verdict is OR-ed into the requesting lane's result word. */
 template <int A, int B>
-__device__ __forceinline__ void drain_envelope_queue(Shared<A, B> &sh, int tid) {
+__device__ __forceinline__ void drain_envelope_queue(Shared<A, B> &sh, int tid, int count) {
 #ifdef HH_ABL_NO_ENVELOPE
-    const int count = 0;
-#else
-    const int count = sh.u.t.q_count;
+    count = 0;
 #endif
 #pragma unroll 1
     for (int q = tid; q < count; q += B) {
@@ -709,7 +707,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
 
     HH_PROF(2);
     /* ---------------- phase I: dense pass over the queue (estimate filter + out-of-line exact Karney) ---------------- */
-    drain_envelope_queue(sh, tid);
+    drain_envelope_queue(sh, tid, sh.u.t.q_count);
     __syncthreads();
 
     HH_PROF(3);
@@ -977,7 +975,7 @@ __device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int
         sh.u.t.q_code[at] = tid | (0 << 8) | (launch_tgt << 10);
     }
     __syncthreads();
-    drain_envelope_queue(sh, tid);
+    drain_envelope_queue(sh, tid, sh.u.t.q_count);
     __syncthreads();
     int launched = 0;
     if (try_launch && (sh.res[tid] & 1)) { /* ac1.py:76-79 */

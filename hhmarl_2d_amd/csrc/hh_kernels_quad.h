@@ -1,0 +1,776 @@
+/*
+ * hh_kernels_quad.h — the 2-vs-2 (LowLevelEnv) rollout kernel with REGISTER exchange.
+ *
+ * Same path, same arithmetic and same results as hh_k_world<4, 64, W, false> run in ROLLOUT mode (hh_kernels.h):
+ *   envs/env_base.py:79-109 step -> envs/env_hetero.py:105-186 _take_action -> cmano_simulator.py:138-157 do_tick
+ *   -> env_hetero.py:188-225 rewards -> env_hetero.py:65-103 state, plus env_base.py:62-77 reset on done.
+ *
+ * What differs is how the four aircraft of an arena see each other.  An arena is one aligned QUAD of lanes, so
+ * every cross-aircraft read is a DPP quad permute (v_mov_b32_dpp quad_perm, a VALU modifier: no memory, no
+ * wait) instead of an LDS write + s_waitcnt + read.  At one wave per SIMD there is nothing to hide an LDS
+ * round trip behind; the generic kernel spends ~37 % of its wave cycles in s_waitcnt (profiles/README.md).
+ *   - the per-arena pair table (distance, focus both ways, heading difference, normalised observation
+ *     entries, flags, positions) lives in registers, indexed by RELATIVE slot k = (j - s) & 3;
+ *   - the id-ordered kill resolution runs redundantly on all four lanes from quad-broadcast words (SIMT: the
+ *     same cost as one lane doing it) so its result needs no broadcast back;
+ *   - the envelope tests keep the workgroup-wide LDS queue (work compaction across arenas is what LDS is for),
+ *     but slots are assigned with wave ballots, so the count is a scalar and an empty queue costs nothing.
+ * DPP reads are only made from wave-uniform control flow (a disabled source lane would read as 0).
+ *
+ * The generic kernel remains the implementation of RESET / OBSERVE / the split step and of 3-vs-3.
+ */
+#ifndef HH_KERNELS_QUAD_H
+#define HH_KERNELS_QUAD_H
+
+#include "hh_kernels.h"
+
+#define HH_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+
+template <int CTRL>
+__device__ __forceinline__ int q_perm_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ float q_perm_f(float v) { return __int_as_float(q_perm_i<CTRL>(__float_as_int(v))); }
+template <int CTRL>
+__device__ __forceinline__ double q_perm_d(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = q_perm_i<CTRL>(lo);
+    hi = q_perm_i<CTRL>(hi);
+    return __hiloint2double(hi, lo);
+}
+/* value held by slot (s + K) & 3 of the lane's arena */
+#define HH_QROT(K) HH_QP((K) & 3, ((K) + 1) & 3, ((K) + 2) & 3, ((K) + 3) & 3)
+template <int K> __device__ __forceinline__ int q_rot_i(int v) { return q_perm_i<HH_QROT(K)>(v); }
+template <int K> __device__ __forceinline__ float q_rot_f(float v) { return q_perm_f<HH_QROT(K)>(v); }
+template <int K> __device__ __forceinline__ double q_rot_d(double v) { return q_perm_d<HH_QROT(K)>(v); }
+/* value held by absolute slot J */
+template <int J> __device__ __forceinline__ int q_bc_i(int v) { return q_perm_i<HH_QP(J, J, J, J)>(v); }
+template <int J> __device__ __forceinline__ double q_bc_d(double v) { return q_perm_d<HH_QP(J, J, J, J)>(v); }
+/* the other aircraft of the same side (slot s ^ 1) */
+__device__ __forceinline__ double q_mate_d(double v) { return q_perm_d<HH_QP(1, 0, 3, 2)>(v); }
+
+/* table lookup by relative slot k in 1..3 (k outside -> entry 3).  Operands by VALUE: a select between array
+ * addresses would pin the table in scratch memory. */
+template <class T>
+__device__ __forceinline__ T q_sel3(T a1, T a2, T a3, int k) {
+    T r = a3;
+    if (k == 2) r = a2;
+    if (k == 1) r = a1;
+    return r;
+}
+#define q_sel(arr, k) q_sel3((arr)[0], (arr)[1], (arr)[2], (k))
+
+/* what the other lanes read from this aircraft */
+struct QPub {
+    double uc, us, un;             /* heading unit vector and its norm (env_base.py:428) */
+    float nlat, nlon, nspd, nhdg;  /* normalised observation entries (env_base.py:117-121) */
+    int flags;                     /* FL_ALIVE | type << 1 | FL_SHOT */
+};
+
+/* the arena as seen from this lane, entry k-1 = slot (s + k) & 3 */
+struct QTab {
+    double lat[3], lon[3];                    /* position */
+    double dist[3], foc[3], focr[3], hd[3];   /* planar distance [deg], focus me->k, focus k->me, heading difference */
+    float nlat[3], nlon[3], nspd[3], nhdg[3];
+    int fl[3];
+    int amask;                                /* alive bits by ABSOLUTE slot, own bit included */
+};
+
+__device__ __forceinline__ void quad_publish(const DevCfg &c, const Unit &m, QPub &p) {
+    double sn, cs;
+    hh_sincos(hh_pymod(90.0 - m.hdg, 360.0) * (HH_PI / 180.0), &sn, &cs);
+    p.uc = cs;
+    p.us = sn;
+    p.un = hh_sqrt(cs * cs + sn * sn);
+    int shot = m.burst > 0 || (m.ac_type == 1 && m.has_missile);
+    p.flags = (m.alive ? FL_ALIVE : 0) | ((m.ac_type & 3) << 1) | (shot ? FL_SHOT : 0);
+    p.nlat = (float)hh_clip((m.lat - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
+    p.nlon = (float)hh_clip((m.lon - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
+    p.nspd = (float)hh_clip(m.spd / HH_AC_MAX_SPEED(m.ac_type), 0.0, 1.0);
+    p.nhdg = (float)hh_clip(hh_pymod(m.hdg, 359.0) / 359.0, 0.0, 1.0);
+}
+
+/* the pair table of pair_tables() in registers.  WAVE-UNIFORM control flow only. */
+__device__ __forceinline__ void quad_tables(const Unit &m, const QPub &p, int s, QTab &t) {
+    const double c1 = p.uc, s1 = p.us, n1 = p.un;
+    double ouc[3], ous[3], oun[3];
+#define HH_QFETCH(K)                                                                  \
+    t.lat[K - 1] = q_rot_d<K>(m.lat); t.lon[K - 1] = q_rot_d<K>(m.lon);                   \
+    ouc[K - 1] = q_rot_d<K>(p.uc); ous[K - 1] = q_rot_d<K>(p.us); oun[K - 1] = q_rot_d<K>(p.un); \
+    t.nlat[K - 1] = q_rot_f<K>(p.nlat); t.nlon[K - 1] = q_rot_f<K>(p.nlon);               \
+    t.nspd[K - 1] = q_rot_f<K>(p.nspd); t.nhdg[K - 1] = q_rot_f<K>(p.nhdg);               \
+    t.fl[K - 1] = q_rot_i<K>(p.flags);
+    HH_QFETCH(1)
+    HH_QFETCH(2)
+    HH_QFETCH(3)
+#undef HH_QFETCH
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double dx = t.lon[k] - m.lon, dy = t.lat[k] - m.lat;
+        double n2 = hh_sqrt(dx * dx + dy * dy);
+        double dot = c1 * dx + s1 * dy;
+        double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
+        t.dist[k] = n2;
+        t.foc[k] = hh_acos(x) * (180.0 / HH_PI);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        double dot = c1 * ouc[k] + s1 * ous[k];
+        double x = hh_clip(dot / (n1 * oun[k] + 1e-10), -1.0, 1.0);
+        t.hd[k] = hh_clip((hh_acos(x) * (180.0 / HH_PI)) / 180.0, 0.0, 1.0);
+    }
+    /* the pair (s, s+3) is the pair (s', s'+1) of lane s' = s+3: the expression is symmetric in its operands */
+    t.hd[2] = q_rot_d<3>(t.hd[0]);
+    /* focus of slot s+k at me = that lane's entry for ITS relative slot 4-k */
+    t.focr[0] = q_rot_d<1>(t.foc[2]);
+    t.focr[1] = q_rot_d<2>(t.foc[1]);
+    t.focr[2] = q_rot_d<3>(t.foc[0]);
+    t.amask = ((p.flags & FL_ALIVE) << s) | ((t.fl[0] & FL_ALIVE) << ((s + 1) & 3)) | ((t.fl[1] & FL_ALIVE) << ((s + 2) & 3)) |
+              ((t.fl[2] & FL_ALIVE) << ((s + 3) & 3));
+}
+
+/* env_base.py:400-422 _nearby_object for the OTHER side of a 2-vs-2 arena: live opponents, stable-sorted by
+ * normalised distance (ties keep id order) */
+struct Near2 {
+    int n, j0, k0, j1, k1;
+    double d0, d1, r0, r1;
+};
+__device__ __forceinline__ void quad_nearby(const DevCfg &c, const QTab &t, int s, Near2 &o) {
+    const int ja = s < 2 ? 2 : 0, jb = ja + 1;
+    const int ka = (ja - s) & 3, kb = (jb - s) & 3;
+    const int ala = (t.amask >> ja) & 1, alb = (t.amask >> jb) & 1;
+    const double ra = q_sel(t.dist, ka), rb = q_sel(t.dist, kb);
+    const double da = c.inv_diag * ra, db = c.inv_diag * rb;
+    const bool a_first = ala && (!alb || da <= db);
+    o.n = ala + alb;
+    o.j0 = a_first ? ja : jb; o.k0 = a_first ? ka : kb; o.d0 = a_first ? da : db; o.r0 = a_first ? ra : rb;
+    o.j1 = a_first ? jb : ja; o.k1 = a_first ? kb : ka; o.d1 = a_first ? db : da; o.r1 = a_first ? rb : ra;
+    if (o.n == 0) { o.j0 = o.k0 = 0; o.d0 = o.r0 = 0.0; }
+    if (o.n < 2) { o.j1 = o.k1 = 0; o.d1 = o.r1 = 0.0; }
+}
+
+/* env_base.py:185-212 opp_ac_values (mode 0 fight / 1 escape) from the register table */
+__device__ __forceinline__ int quad_opp_block(const QTab &t, int mode, int k, double dist, float *out) {
+    const double f_so = q_sel(t.foc, k), f_os = q_sel(t.focr, k);
+    int n = 0;
+    out[n++] = q_sel(t.nlat, k);
+    out[n++] = q_sel(t.nlon, k);
+    out[n++] = q_sel(t.nspd, k);
+    out[n++] = q_sel(t.nhdg, k);
+    out[n++] = (float)q_sel(t.hd, k);
+    if (mode == 0) {
+        out[n++] = (float)norm180(f_os);
+        out[n++] = (float)aspect(f_so);
+    } else {
+        out[n++] = (float)norm180(f_so);
+        out[n++] = (float)norm180(f_os);
+    }
+    out[n++] = (float)dist;
+    out[n++] = (q_sel(t.fl, k) & FL_SHOT) ? 1.0f : 0.0f;
+    return n;
+}
+
+/* env_hetero.py:65-103 lowlevel_state of the lane's own unit into its LDS staging row (D floats, zero padded);
+ * refreshes opp_to_attack (m.tgt0) */
+__device__ __forceinline__ void quad_lowlevel_obs(const DevCfg &c, const QTab &t, const QPub &p, int s, int mode, Unit &m, float *out, int D) {
+    m.n_tgt = 0; m.tgt0 = 0; m.tgt_d0 = 0.0;
+    Near2 nb;
+    quad_nearby(c, t, s, nb);
+    if (!m.alive || nb.n == 0) {
+        for (int k = 0; k < D; k++) out[k] = 0.0f;
+        return;
+    }
+    m.n_tgt = 1; m.tgt0 = nb.j0 + 1; m.tgt_d0 = nb.d0;
+    int n = 0;
+    out[n++] = p.nlat;
+    out[n++] = p.nlon;
+    out[n++] = p.nspd;
+    out[n++] = p.nhdg;
+    if (mode == HH_MODE_FIGHT) {
+        out[n++] = (float)norm180(q_sel(t.foc, nb.k0));
+        out[n++] = (float)aspect(q_sel(t.focr, nb.k0));
+        out[n++] = (float)q_sel(t.hd, nb.k0);
+        out[n++] = (float)nb.d0;
+        out[n++] = (float)hh_clip((double)m.cannon_remain / (double)m.cannon_max, 0.0, 1.0);
+        if (m.ac_type == 1) {
+            out[n++] = (float)hh_clip((double)m.missile_remain / (double)m.rocket_max, 0.0, 1.0);
+            out[n++] = m.missile_wait == 0 ? 1.0f : 0.0f;
+            out[n++] = (m.has_missile || m.burst > 0) ? 1.0f : 0.0f;
+        } else {
+            out[n++] = m.burst > 0 ? 1.0f : 0.0f;
+        }
+        n += quad_opp_block(t, 0, nb.k0, nb.d0, out + n);
+    } else {
+        out[n++] = (float)hh_clip((double)m.cannon_remain / (double)m.cannon_max, 0.0, 1.0);
+        if (m.ac_type == 1) out[n++] = (float)hh_clip((double)m.missile_remain / (double)m.rocket_max, 0.0, 1.0);
+        out[n++] = (p.flags & FL_SHOT) ? 1.0f : 0.0f;
+        quad_opp_block(t, 1, nb.k0, nb.d0, out + n);
+        if (nb.n >= 2) quad_opp_block(t, 1, nb.k1, nb.d1, out + n + 9);
+        else for (int k = 0; k < 9; k++) out[n + 9 + k] = 0.0f;
+        n += 18;
+    }
+    /* env_base.py:166-183 friendly_ac_values; env_hetero.py:71-75: the friend is the other aircraft of the side */
+    const int kf = ((s ^ 1) - s) & 3;
+    if ((t.amask >> (s ^ 1)) & 1) {
+        out[n++] = q_sel(t.nlat, kf);
+        out[n++] = q_sel(t.nlon, kf);
+        out[n++] = (float)norm180(q_sel(t.foc, kf));
+        out[n++] = (float)norm180(q_sel(t.focr, kf));
+        out[n++] = (float)(c.inv_diag * q_sel(t.dist, kf));
+    } else {
+        for (int k = 0; k < 5; k++) out[n++] = 0.0f;
+    }
+    for (; n < D; n++) out[n] = 0.0f;
+}
+
+/* one fused LowLevelEnv step of the lane's arena; `tb`/`pub` hold the pre-tick table on entry and the post-tick
+ * table on return.  Line-by-line counterpart of tick<4, 64>(tmode 0) in hh_kernels.h. */
+__device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, int tid, int g, int s, int base, bool active, Unit &m,
+                                          Arena &ar, const int8_t *act, QTab &tb, QPub &pub, StepOut &out,
+                                          uint32_t &ev_mask_out HH_PROF_ARGS) {
+    constexpr int A = 4;
+    const int id = s + 1;
+    const bool running = active && !ar.done;
+    const bool agent = s < 2;
+    out.reward = 0.0;
+    out.valid = 0;
+    out.kill_event = 0;
+    uint32_t evm = 0;
+    if (running) { ar.steps += 1; arena_rekey(ar); }
+    const bool snap = running && m.alive;
+    const int amask0 = tb.amask; /* alive at tick start, by absolute slot */
+    double opp_stat0 = 0.0;
+    int want_launch = 0, launch_tgt = 0;
+    int wait_after = -1;
+    bool base_gate = false;
+
+    /* ---------------- phase A: commands (env_hetero.py:160-182) ---------------- */
+    if (snap) {
+        if (agent || c.ext_opp) {
+            int t = m.n_tgt ? m.tgt0 : 0;
+            if (!agent) { /* env_base.py:349-398 _policy_actions -> lowlevel_state(opp_mode, i): refresh target */
+                Near2 nb;
+                quad_nearby(c, tb, s, nb);
+                m.n_tgt = nb.n ? 1 : 0; m.tgt0 = nb.n ? nb.j0 + 1 : 0; m.tgt_d0 = nb.n ? nb.d0 : 0.0;
+                t = m.tgt0;
+            } else {
+                out.valid = 1;
+                if (t && ((amask0 >> (t - 1)) & 1)) opp_stat0 = norm180(q_sel(tb.focr, (t - 1 - s) & 3)); /* env_hetero.py:169-170 */
+            }
+            /* env_base.py:214-238 _take_base_action */
+            double nh = hh_pymod(m.hdg + (double)(((int)act[0] - 6) * 15), 360.0);
+            if (nh >= 360.0 || nh < 0.0) nh = 0.0;
+            m.cmd_hdg = nh;
+            double mx = HH_AC_MAX_SPEED(m.ac_type);
+            m.cmd_spd = 100.0 + ((mx - 100.0) / 8.0) * (double)act[1];
+            if (act[2] && m.cannon_remain > 0) {
+                arm_cannon(m);
+                if (agent && c.agent_mode == HH_MODE_ESCAPE && m.cannon_remain < 90) out.reward -= 0.1;
+            }
+            if (m.ac_type == 1 && act[3]) {
+                if (t && m.missile_remain > 0 && !m.has_missile && m.missile_wait == 0) {
+                    base_gate = true;
+                    want_launch = 1;
+                    launch_tgt = t - 1;
+                }
+            }
+        } else if (c.level <= 2) { /* env_hetero.py:118-136 levels 1-2 */
+            if (c.level == 2) {
+                arm_cannon(m);
+                bool man = ar.steps <= 5;
+                if (!man) man = (ar.steps % hh_rng_randint(d_rng(ar, id, HH_SITE_L2_PERIOD, 0), 35, 45)) <= 5;
+                if (man) {
+                    int r = hh_rng_randint(d_rng(ar, id, HH_SITE_L2_TURN, 0), 0, 1);
+                    m.cmd_hdg = hh_pymod(m.hdg + (r ? -90.0 : 90.0), 360.0);
+                    m.cmd_spd = (double)(100 + hh_rng_randint(d_rng(ar, id, HH_SITE_L2_SPEED, 0), 0, 4) * 75);
+                }
+            }
+            if (!m.has_missile && (ar.steps % 40) < 3 && hh_rng_randint(d_rng(ar, id, HH_SITE_L12_COIN, 0), 0, 1) &&
+                m.missile_wait == 0 && m.ac_type == 1) {
+                Near2 nb;
+                quad_nearby(c, tb, s, nb);
+                if (nb.n) { want_launch = 1; launch_tgt = nb.j0; wait_after = 5; }
+            }
+        }
+    }
+    HH_PROF(11);
+    /* env_hetero.py:138-158 level 3: the arena-level escape flag, consumed once per live opponent in id order */
+    if (running && !c.ext_opp && c.level >= 3) {
+        int esc = ar.escaping, esc_t = ar.escaping_time;
+        bool my_escaping = false;
+#pragma unroll
+        for (int j = 2; j < A; j++) {
+            if (!((amask0 >> j) & 1)) continue;
+            if (ar.steps % 60 == 0 && !esc) {
+                esc = hh_rng_randint(d_rng(ar, j + 1, HH_SITE_L3_ESC_COIN, 0), 0, 1);
+                if (esc) esc_t = (int)hh_rng_uniform(d_rng(ar, j + 1, HH_SITE_L3_ESC_TIME, 0), 20.0, 30.0);
+            }
+            if (j == s) my_escaping = esc != 0;
+            if (esc) {
+                esc_t -= 1;
+                if (esc_t <= 0) esc = 0;
+            }
+        }
+        ar.escaping = esc;
+        ar.escaping_time = esc_t;
+        if (snap && !agent) {
+            int opp = -1, fire = 0, fire_m = 0;
+            double heading, speed;
+            if (my_escaping) { /* env_hetero.py:227-245 _escaping_opp */
+                double y = hh_clip((m.lat - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
+                double x = hh_clip((m.lon - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
+                double uh = d_rng(ar, id, HH_SITE_ESC_HDG, 0);
+                double lo_h = y < 0.5 ? (x < 0.5 ? 30.0 : 300.0) : (x < 0.5 ? 120.0 : 210.0);
+                heading = (double)(int)hh_rng_uniform(uh, lo_h, lo_h + 30.0);
+                speed = (double)(int)hh_rng_uniform(d_rng(ar, id, HH_SITE_ESC_SPEED, 0), 300.0, 600.0);
+                fire = hh_rng_randint(d_rng(ar, id, HH_SITE_ESC_FIRE, 0), 0, 1);
+            } else { /* env_hetero.py:247-271 _hardcoded_opp */
+                Near2 nb;
+                quad_nearby(c, tb, s, nb);
+                heading = m.hdg;
+                speed = (double)(int)hh_rng_uniform(d_rng(ar, id, HH_SITE_HC_SPEED1, 0), 100.0, 400.0);
+                if (nb.n) {
+                    const double ag_lat = q_sel(tb.lat, nb.k0), ag_lon = q_sel(tb.lon, nb.k0);
+                    /* env_base.py:464-487 _correct_angle_sign */
+                    double sn, cs;
+                    hh_sincos(hh_pymod(m.hdg, 360.0) * (HH_PI / 180.0), &sn, &cs);
+                    double x1 = m.lon + hh_round3(sn), y1 = m.lat + hh_round3(cs);
+                    double val = (x1 - m.lon) * (ag_lat - m.lat) - (ag_lon - m.lon) * (y1 - m.lat);
+                    double sign = val < 0.0 ? 1.0 : -1.0;
+                    double r = hh_rng_uniform(d_rng(ar, id, HH_SITE_HC_R, 0), 0.7, 1.3);
+                    double focus = q_sel(tb.foc, nb.k0);
+                    if (nb.d0 > 0.008 && focus > 4.0) heading = hh_pymod(heading + r * sign * focus, 360.0);
+                    if (nb.d0 > 0.05) {
+                        double us = d_rng(ar, id, HH_SITE_HC_SPEED2, 0);
+                        speed = focus < 30.0 ? (double)(int)hh_rng_uniform(us, 500.0, 800.0) : (double)(int)hh_rng_uniform(us, 100.0, 500.0);
+                    }
+                    fire = nb.d0 < 0.03 && focus < 10.0;
+                    fire_m = nb.d0 < 0.09 && focus < 5.0;
+                    opp = nb.j0;
+                }
+                if (m.ac_type == 2) speed = hh_clip(speed, 0.0, 600.0);
+            }
+            if (heading >= 360.0 || heading < 0.0) heading = 0.0;
+            m.cmd_hdg = heading;
+            m.cmd_spd = speed;
+            if (fire) arm_cannon(m);
+            if (fire_m && opp >= 0 && !m.has_missile && m.missile_wait == 0 && m.ac_type == 1) {
+                want_launch = 1; launch_tgt = opp; wait_after = 10;
+            }
+        }
+    }
+
+    HH_PROF(0);
+    /* ---------------- phase B: aircraft kinematics + move (ac1.py:81-133) ---------------- */
+    const double lat_old = m.lat, lon_old = m.lon, hdg_old = m.hdg;
+    bool fired = false;
+    const int rk_pre = m.rk_alive;
+    const int has_missile_pre = m.has_missile;
+    const bool try_launch = want_launch && !m.has_missile && m.missile_remain > 0; /* ac1.py:73 */
+    if (snap) {
+        int t = m.ac_type;
+        if (m.hdg != m.cmd_hdg) {
+            double delta = d_signed_heading_diff(m.hdg, m.cmd_hdg);
+            double max_deg = HH_AC_TURN_RATE(t) * 1.0;
+            if (hh_fabs(delta) <= max_deg) m.hdg = m.cmd_hdg;
+            else { m.hdg += delta >= 0.0 ? max_deg : -max_deg; m.hdg = hh_pymod(m.hdg, 360.0); }
+        }
+        if (m.spd != m.cmd_spd) {
+            double delta = m.cmd_spd - m.spd;
+            double max_delta = HH_AC_ACCEL(t) * 1.0;
+            if (hh_fabs(delta) <= max_delta) m.spd = m.cmd_spd;
+            else m.spd += delta >= 0.0 ? max_delta : -max_delta;
+        }
+        if (m.burst > 0) {
+            fired = true;
+            m.burst = m.burst - 1 > 0 ? m.burst - 1 : 0;
+            m.cannon_remain = m.cannon_remain - 1 > 0 ? m.cannon_remain - 1 : 0;
+        }
+        if (m.has_missile) { /* ac1.py:117-128, rocket launched in an earlier step */
+            if (!m.rk_alive) m.has_missile = 0;
+            else m.rk_cmd = hh_clip(m.rk_hdg * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
+        }
+    }
+    /* aircraft move + speculative move of this slot's rocket (in flight, or the one a pending launch creates) */
+    const bool rk_spec = running && (rk_pre ? m.rk_life <= HH_ROCKET_MAX_LIFE : try_launch);
+    double rk_nlat = 0.0, rk_nlon = 0.0, rk_nhdg = 0.0, rk_ncmd = 0.0;
+    {
+        const bool mv_a = snap && m.spd > 0.0;
+        const bool any_rk = __ballot(rk_spec) != 0ULL;
+        if (any_rk) {
+            const double speed_table[11] = HH_ROCKET_SPEED_TABLE;
+            double r_lat = rk_pre ? m.rk_lat : lat_old, r_lon = rk_pre ? m.rk_lon : lon_old;
+            double r_hdg = rk_pre ? m.rk_hdg : hdg_old;
+            rk_ncmd = rk_pre ? m.rk_cmd
+                             : hh_clip(hdg_old * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
+            if (r_hdg != rk_ncmd) {
+                double delta = d_signed_heading_diff(r_hdg, rk_ncmd);
+                if (hh_fabs(delta) <= HH_ROCKET_TURN_RATE) r_hdg = rk_ncmd;
+                else r_hdg += delta >= 0.0 ? HH_ROCKET_TURN_RATE : -HH_ROCKET_TURN_RATE;
+            }
+            rk_nhdg = r_hdg;
+            int life = rk_pre ? m.rk_life : 0;
+            double r_spd = speed_table[rk_spec ? life : 0];
+            double a_lat, a_lon;
+            d_geo_move2(m.lat, m.lon, m.hdg, mv_a ? m.spd * HH_KNOTS_TO_MS * 1.0 : 0.0, a_lat, a_lon,
+                        rk_spec ? r_lat : 5.0, rk_spec ? r_lon : 7.0, r_hdg, r_spd * HH_KNOTS_TO_MS * 1.0, rk_nlat, rk_nlon);
+            if (mv_a) { m.lat = a_lat; m.lon = a_lon; }
+        } else {
+            if (mv_a) d_geo_move(m.lat, m.lon, m.hdg, m.spd * HH_KNOTS_TO_MS * 1.0, m.lat, m.lon);
+        }
+    }
+    const double rk0_lat = rk_pre ? m.rk_lat : lat_old, rk0_lon = rk_pre ? m.rk_lon : lon_old;
+    /* what the dense queue pass reads (LDS stores are fire-and-forget; nobody waits unless the queue is non-empty) */
+    sh.lat0[tid] = lat_old; sh.lon0[tid] = lon_old; sh.hdg[tid] = hdg_old;
+    sh.flags[tid] = pub.flags;
+    sh.u.t.lat1[tid] = m.lat; sh.u.t.lon1[tid] = m.lon; sh.u.t.hdg1[tid] = m.hdg;
+    sh.u.t.rk_lat[tid] = rk0_lat; sh.u.t.rk_lon[tid] = rk0_lon;
+    sh.res[tid] = 0;
+    if (s == 0) sh.g_tkey[g] = ar.tkey;
+    /* positions of the other aircraft after their move (registers, by relative slot) */
+    double lat1[3], lon1[3];
+    lat1[0] = q_rot_d<1>(m.lat); lon1[0] = q_rot_d<1>(m.lon);
+    lat1[1] = q_rot_d<2>(m.lat); lon1[1] = q_rot_d<2>(m.lon);
+    lat1[2] = q_rot_d<3>(m.lat); lon1[2] = q_rot_d<3>(m.lon);
+
+    HH_PROF(1);
+    /* ---------------- phase Q: envelope tests that survive the prefilter -> workgroup queue (ballot-assigned slots) ---------------- */
+    const int rk_tgt = rk_pre ? m.rk_target - 1 : launch_tgt;
+    const bool rk_maybe = running && (rk_pre || try_launch);
+    int q_total = 0;
+    {
+        bool push[6];
+        int code[6];
+        push[0] = try_launch;
+        code[0] = tid | (0 << 8) | (launch_tgt << 10);
+        const int t = m.ac_type;
+#pragma unroll
+        for (int k = 1; k < A; k++) {
+            const int j = (s + k) & 3;
+            const bool snap_j = running && ((amask0 >> j) & 1); /* not alive at tick start -> can never be "currently alive" */
+            const bool enemy = (j >= 2) != (s >= 2);
+            /* target already moved iff its id is lower (cmano_simulator.py:142) */
+            const double tl = j < s ? lat1[k - 1] : tb.lat[k - 1];
+            const double to = j < s ? lon1[k - 1] : tb.lon[k - 1];
+            push[k] = fired && snap_j && (c.friendly_kill || enemy) && d_maybe_within_km(lat_old, lon_old, tl, to, HH_AC_CANNON_KM(t));
+            code[k] = tid | (1 << 8) | (j << 10);
+        }
+        {
+            const int kt = (rk_tgt - s) & 3;
+            const double tl = kt ? q_sel(lat1, kt) : m.lat, to = kt ? q_sel(lon1, kt) : m.lon;
+            push[4] = rk_maybe && d_maybe_within_km(rk0_lat, rk0_lon, tl, to, HH_ROCKET_FUSE_KM);
+            code[4] = tid | (2 << 8) | (rk_tgt << 10);
+            const int fid = s == 1 ? 0 : 1; /* rocket_unit.py:46: 1 if source.id == 2 else 2 */
+            const int kf = (fid - s) & 3;
+            const double fl_ = kf ? q_sel(lat1, kf) : m.lat, fo_ = kf ? q_sel(lon1, kf) : m.lon;
+            push[5] = rk_maybe && c.friendly_kill && d_maybe_within_km(rk0_lat, rk0_lon, fl_, fo_, HH_ROCKET_FUSE_KM);
+            code[5] = tid | (3 << 8) | (fid << 10);
+        }
+#pragma unroll
+        for (int e = 0; e < 6; e++) {
+            const unsigned long long bm = __ballot(push[e]);
+            if (bm) { /* wave-uniform */
+                if (push[e]) {
+                    int pos = q_total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+                    sh.u.t.q_code[pos] = code[e];
+                }
+                q_total += __popcll(bm);
+            }
+        }
+    }
+    HH_PROF(2);
+    /* ---------------- phase I: dense pass over the queue ---------------- */
+    int myres = 0;
+    if (q_total) { /* wave-uniform */
+        __syncthreads();
+        drain_envelope_queue(sh, tid, q_total);
+        __syncthreads();
+        myres = sh.res[tid];
+    }
+
+    HH_PROF(3);
+    /* ---------------- phase L: launch bookkeeping (env_base.py:227-236, ac1.py:76-79) ---------------- */
+    int launched = 0;
+    if (try_launch && (myres & 1)) {
+        launched = 1;
+        m.rk_alive = 1; m.rk_lat = lat_old; m.rk_lon = lon_old; m.rk_hdg = hdg_old;
+        m.rk_target = launch_tgt + 1; m.rk_life = 0;
+        m.has_missile = 1;
+        m.missile_remain = m.missile_remain - 1 > 0 ? m.missile_remain - 1 : 0;
+        evm |= 1u << (24 + s);
+        m.rk_cmd = rk_ncmd; /* the launcher's own update in this tick already steers it (ac1.py:127) */
+    }
+    if (base_gate) {
+        double uu = d_rng(ar, id, HH_SITE_MISSILE_WAIT, 0);
+        m.missile_wait = hh_rng_randint(uu, 7, 17);
+        if (agent && c.agent_mode == HH_MODE_ESCAPE && m.missile_remain < 3) out.reward -= 0.1;
+    }
+    if (snap && (agent || c.ext_opp)) { /* env_base.py:235-236, evaluated before do_tick */
+        if (m.missile_wait > 0 && !(launched || has_missile_pre)) m.missile_wait -= 1;
+    }
+    if (want_launch && wait_after >= 0) m.missile_wait = wait_after;
+    const int rk_at_start = m.rk_alive;
+    /* launch order = unit id order (cmano_simulator.py:104-108) */
+    const int aux = launched | ((fired ? (myres >> 1) & 0xff : 0) << 8);
+    int aux_[A];
+    aux_[0] = q_bc_i<0>(aux); aux_[1] = q_bc_i<1>(aux); aux_[2] = q_bc_i<2>(aux); aux_[3] = q_bc_i<3>(aux);
+    {
+        int before = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < A; j++) {
+            int l = aux_[j] & 1;
+            total += l;
+            if (j < s) before += l;
+        }
+        if (launched) m.rk_seq = ar.next_seq + before + 1;
+        ar.next_seq += total;
+    }
+    int rkw = 0; /* bit0 present, bit1 fuse on target, bit2 fuse on "friendly", bit3 end of life, bits4-6 target, bits 8.. seq */
+    if (running && rk_at_start) {
+        int eol = m.rk_life > HH_ROCKET_MAX_LIFE;
+        rkw = 1 | (((myres >> 9) & 1) << 1) | (((myres >> 10) & 1) << 2) | (eol << 3) | ((m.rk_target - 1) << 4) | (m.rk_seq << 8);
+    }
+    int res_[A];
+    res_[0] = q_bc_i<0>(rkw); res_[1] = q_bc_i<1>(rkw); res_[2] = q_bc_i<2>(rkw); res_[3] = q_bc_i<3>(rkw);
+
+    /* ---------------- phases C + D: id-ordered resolution, computed identically by the four lanes ---------------- */
+    int alive = amask0, nev = 0, dead = 0;
+    int evpack = 0; /* 5 bits per event: killer slot | victim slot << 2 | by rocket << 4 */
+    if (running) {
+        /* aircraft phase: shooter i (alive at tick start, even if killed earlier in this tick) hits the still-alive
+         * targets in id order (ac1.py:106-115) */
+#pragma unroll
+        for (int i = 0; i < A; i++) {
+            const int ci = aux_[i] >> 8;
+#pragma unroll
+            for (int j = 0; j < A; j++) {
+                if (((ci >> j) & 1) && ((alive >> j) & 1)) {
+                    alive &= ~(1 << j);
+                    evpack |= (i | (j << 2)) << (5 * nev);
+                    nev++;
+                }
+            }
+        }
+        /* rocket phase in launch order (rocket_unit.py:37-58) */
+        int done_mask = 0;
+#pragma unroll
+        for (int k = 0; k < A; k++) {
+            int best = -1, best_seq = 0x7fffffff, w = 0;
+#pragma unroll
+            for (int j = 0; j < A; j++) {
+                const int wj = res_[j];
+                if ((wj & 1) && !((done_mask >> j) & 1) && (wj >> 8) < best_seq) { best = j; best_seq = wj >> 8; w = wj; }
+            }
+            if (best >= 0) {
+                done_mask |= 1 << best;
+                const int tg = (w >> 4) & 7;
+                const int fid = best == 1 ? 0 : 1;
+                if (((w >> 1) & 1) && ((alive >> tg) & 1)) {
+                    alive &= ~(1 << tg); dead |= 1 << best;
+                    evpack |= (best | (tg << 2) | (1 << 4)) << (5 * nev);
+                    nev++;
+                } else if (c.friendly_kill && ((alive >> fid) & 1) && ((w >> 2) & 1)) {
+                    alive &= ~(1 << fid); dead |= 1 << best;
+                    evpack |= (best | (fid << 2) | (1 << 4)) << (5 * nev);
+                    nev++;
+                } else if ((w >> 3) & 1) {
+                    dead |= 1 << best;
+                }
+            }
+        }
+    }
+    if (running && rk_at_start) {
+        if ((dead >> s) & 1) {
+            m.rk_alive = 0; m.rk_target = 0; m.rk_life = 0; m.rk_seq = 0;
+            m.rk_lat = m.rk_lon = m.rk_hdg = m.rk_cmd = 0.0;
+        } else { /* commit the speculative turn + move (rocket_unit.py:61-73) */
+            m.rk_hdg = rk_nhdg; m.rk_lat = rk_nlat; m.rk_lon = rk_nlon;
+            m.rk_life += 1;
+        }
+    }
+
+    HH_PROF(4);
+    /* ---------------- phase E: out of bounds, rewards, done (env_base.py:240-310, env_hetero.py:188-225) ---------------- */
+    int oob = 0;
+    if (active) {
+        m.alive = (alive >> s) & 1;
+        if (running && m.alive) {
+            bool inb = HH_MAP_LON0 <= m.lon && m.lon <= c.lon_hi && HH_MAP_LAT0 <= m.lat && m.lat <= c.lat_hi;
+            if (!inb) { m.alive = 0; oob = 1; }
+        }
+    }
+    const int oobm = (int)(__ballot(oob) >> base) & 0xf; /* out-of-bounds removals of the arena */
+    double rews = 0.0;
+    int destroyed = 0;
+    if (running && agent) {
+        const double sc = c.rew_scale;
+        if (oob) { rews += -5.0 * sc; destroyed = 1; }
+        for (int e = 0; e < nev; e++) {
+            const int w = evpack >> (5 * e);
+            const int k = w & 3, d = (w >> 2) & 3, rocket = (w >> 4) & 1;
+            if (k < 2) {
+                if (d >= 2) {
+                    if (k == s && c.agent_mode == HH_MODE_FIGHT) {
+                        if (rocket) {
+                            rews += (1.0 + ((1.5 - 1.0) / (1.0 - 0.0)) * ((double)m.missile_remain / (double)m.rocket_max - 0.0)) * sc;
+                        } else {
+                            double r1 = 0.5 + ((1.0 - 0.5) / (1.0 - 0.0)) * ((double)m.cannon_remain / (double)m.cannon_max - 0.0);
+                            double r2 = 0.5 + ((1.0 - 0.5) / (1.0 - 0.0)) * (opp_stat0 - 0.0);
+                            rews += (r1 + r2) * sc;
+                        }
+                    }
+                } else {
+                    if (k == s) rews += -2.0 * sc;
+                    if (c.friendly_punish && d == s) { rews += -2.0 * sc; destroyed = 1; }
+                }
+            } else if (d < 2) {
+                if (d == s) { rews += -2.0 * sc; destroyed = 1; }
+            }
+        }
+    }
+    for (int e = 0; e < nev; e++) { /* event masks for parity checks */
+        const int w = evpack >> (5 * e);
+        evm |= ((w >> 4) & 1) ? (1u << (8 + ((w >> 2) & 3))) : (1u << ((w >> 2) & 3));
+    }
+    if (oob) evm |= 1u << (16 + s);
+    ev_mask_out = evm;
+    const double mate_rews = q_mate_d(rews);
+    HH_PROF(5);
+    /* post-tick table: escape shaping now, observation next, pre-step lookups of the next tick */
+    quad_publish(c, m, pub);
+    HH_PROF(6);
+    quad_tables(m, pub, s, tb);
+    HH_PROF(7);
+    if (running) {
+        out.kill_event = nev > 0 || oobm != 0;
+        const int ag = __popc(tb.amask & 3), op = __popc(tb.amask & 12);
+        ar.done = (ag <= 0 || op <= 0 || ar.steps >= c.horizon) ? 1 : 0;
+    }
+    if (running && agent) {
+        if (c.agent_mode == HH_MODE_ESCAPE && c.esc_dist_rew && m.alive) { /* env_hetero.py:198-214 */
+            Near2 nb;
+            quad_nearby(c, tb, s, nb);
+            const double dr[2] = {nb.r0, nb.r1};
+#pragma unroll
+            for (int j = 1; j <= 2; j++) {
+                if (j <= nb.n) {
+                    if (dr[j - 1] < 0.06) { rews += -0.02 / j; if (m.spd < 200.0) rews += -0.02 / j; }
+                    else if (dr[j - 1] > 0.13) { rews += 0.02 / j; if (m.spd > 500.0) rews += 0.02 / j; }
+                }
+            }
+        }
+        if (m.alive || destroyed) {
+            if (c.glob_frac > 0.0 && c.agent_mode == HH_MODE_FIGHT) out.reward += rews + c.glob_frac * mate_rews;
+            else out.reward += rews;
+        }
+    }
+    HH_PROF(8);
+}
+
+/* ROLLOUT of 2-vs-2 worlds: T fused steps per launch, one wave (16 arenas) per workgroup */
+template <int W>
+__global__ __launch_bounds__(64, W) void hh_k_world_quad(DevPtrs P, DevCfg c, int T, const int8_t *__restrict__ actions,
+                                                       float *__restrict__ obs_out, float *__restrict__ reward_out,
+                                                       uint8_t *__restrict__ valid_out, uint8_t *__restrict__ done_out) {
+    constexpr int A = 4, B = 64, GPB = B / A;
+    __shared__ Shared<A, B> sh;
+    const int tid = threadIdx.x;
+    const int g = tid >> 2, s = tid & 3;
+    const int base = g * A;
+    const int n = blockIdx.x * GPB + g;
+    const bool active = n < c.N;
+    const size_t U = (size_t)c.N * A;
+    const size_t u = (size_t)n * A + s;
+    const int D = c.D;
+    HH_PROF_DECL;
+    Unit m = Unit{};
+    Arena ar = Arena{};
+    double ep_ret = 0.0;
+    if (active) {
+        unit_load(P, U, u, m);
+        arena_load(P, c, n, ar);
+        ep_ret = P.ep_ret[n];
+    } else {
+        ar.done = 1;
+    }
+    uint32_t evm_last = 0;
+    QPub pub;
+    QTab tb;
+    quad_publish(c, m, pub);
+    quad_tables(m, pub, s, tb);
+    const bool has_act = active && s < c.n_ctrl;
+    int act_next = 0;
+    if (has_act) act_next = *reinterpret_cast<const int *>(actions + (((size_t)0 * c.N + n) * c.n_ctrl + s) * 4);
+    for (int t = 0; t < T; t++) {
+        StepOut so;
+        int8_t act[4] = {0, 0, 0, 0};
+        if (has_act) {
+            int w = act_next;
+            if (t + 1 < T) act_next = *reinterpret_cast<const int *>(actions + (((size_t)(t + 1) * c.N + n) * c.n_ctrl + s) * 4);
+            act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
+        }
+        const bool was_running = active && !ar.done;
+        tick_quad(c, sh, tid, g, s, base, active, m, ar, act, tb, pub, so, evm_last HH_PROF_PASS);
+        if (active && s < 2) {
+            size_t o = ((size_t)t * c.N + n) * 2 + s;
+            if (reward_out) reward_out[o] = (float)so.reward;
+            if (valid_out) valid_out[o] = (uint8_t)so.valid;
+        }
+        /* episode statistics in agent order (every lane of the arena keeps the same running sum) */
+        {
+            const double rv = so.valid ? so.reward : 0.0;
+            const double r0 = q_bc_d<0>(rv), r1 = q_bc_d<1>(rv);
+            if (was_running) {
+                ep_ret += r0;
+                ep_ret += r1;
+                if (ar.done && s == 0) {
+                    const int ag = __popc(tb.amask & 3), op = __popc(tb.amask & 12);
+                    P.last_ret[n] = (float)ep_ret;
+                    P.last_len[n] = ar.steps;
+                    P.last_outcome[n] = (op <= 0 && ar.steps < c.horizon) ? 1 : ((ag <= 0 && ar.steps < c.horizon) ? -1 : 0);
+                }
+            }
+        }
+        if (active && s == 0 && done_out) done_out[(size_t)t * c.N + n] = (uint8_t)ar.done;
+        const bool need_reset = active && ar.done && c.auto_reset;
+        if (__ballot(need_reset)) { /* K3, wave-uniform */
+            if (need_reset) {
+                reset_arena_scalars(ar);
+                reset_unit<A>(c, s, m, ar);
+                ep_ret = 0.0;
+            }
+            quad_publish(c, m, pub);
+            quad_tables(m, pub, s, tb);
+        }
+        HH_PROF(9);
+        /* K2: observation rows staged in LDS, then written with unit-stride 16-byte stores */
+        if (active && s < 2) quad_lowlevel_obs(c, tb, pub, s, c.agent_mode, m, &sh.u.obs[(g * 2 + s) * D], D);
+        __syncthreads();
+        if (obs_out) {
+            const int rows = min(GPB, c.N - (int)blockIdx.x * GPB);
+            const int cnt = rows * 2 * D;
+            float *dst = obs_out + ((size_t)t * c.N + (size_t)blockIdx.x * GPB) * 2 * D;
+            if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0) {
+                const float4 *src4 = reinterpret_cast<const float4 *>(sh.u.obs);
+                float4 *dst4 = reinterpret_cast<float4 *>(dst);
+                for (int k = tid; k < (cnt >> 2); k += B) dst4[k] = src4[k];
+            } else {
+                for (int k = tid; k < cnt; k += B) dst[k] = sh.u.obs[k];
+            }
+        }
+        __syncthreads();
+        HH_PROF(10);
+    }
+    HH_PROF_FLUSH;
+    if (active) {
+        unit_store(P, U, u, m);
+        if (s == 0) {
+            arena_store(P, n, ar);
+            P.ep_ret[n] = ep_ret;
+            P.ev_mask[n] = 0;
+        }
+    }
+    __syncthreads();
+    if (active && evm_last) atomicOr(&P.ev_mask[n], evm_last);
+}
+
+#endif /* HH_KERNELS_QUAD_H */

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "hh_kernels_hier.h"
+#include "hh_kernels_quad.h"
 #include "hh_gae.h"
 
 /* ===================================================================== host side */
@@ -36,6 +37,7 @@ struct hh_world {
     size_t slab_bytes;
     int *counter; /* device word: arenas still inside their macro step */
     int force_w;  /* 0 = choose the kernel variant by arena count, 1 / 2 = force (HH_FORCE_W, experiments/tests) */
+    int no_quad;  /* HH_NO_QUAD=1: 2-vs-2 rollouts on the generic LDS-exchange kernel (A/B tests; same results) */
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -78,6 +80,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     d.seed = cfg->seed; d.arena_offset = cfg->arena_offset;
     w->block = HH_BLOCK;
     { const char *fw = getenv("HH_FORCE_W"); w->force_w = fw ? atoi(fw) : 0; }
+    { const char *nq = getenv("HH_NO_QUAD"); w->no_quad = nq ? atoi(nq) : 0; }
     /* one slab, 256-byte aligned sub-arrays */
     size_t U = (size_t)d.N * A, N = (size_t)d.N;
     size_t off = 0;
@@ -154,9 +157,14 @@ static int launch(hh_world *w, int run, int T, const int8_t *actions, const uint
     constexpr int B = HH_BLOCK, GPB = B / 4;
     const int grid = (c.N + GPB - 1) / GPB;
     const int waves = grid * (B / 64);
-    if (run >= HH_RUN_LL_BEGIN)
+    const bool two = w->force_w == 2 || (w->force_w == 0 && waves >= 2048);
+    if (run == HH_RUN_ROLLOUT && !w->no_quad) {
+        static_assert(B == 64, "the register-exchange kernel is one wave per workgroup");
+        if (two) hipLaunchKernelGGL((hh_k_world_quad<2>), dim3(grid), dim3(B), 0, st, w->P, c, T, actions, obs, reward, valid, done);
+        else hipLaunchKernelGGL((hh_k_world_quad<1>), dim3(grid), dim3(B), 0, st, w->P, c, T, actions, obs, reward, valid, done);
+    } else if (run >= HH_RUN_LL_BEGIN)
         hipLaunchKernelGGL((hh_k_world<4, B, 1, true>), dim3(grid), dim3(B), 0, st, w->P, c, run, T, actions, mask, obs, reward, valid, done);
-    else if (w->force_w == 2 || (w->force_w == 0 && waves >= 2048))
+    else if (two)
         hipLaunchKernelGGL((hh_k_world<4, B, 2, false>), dim3(grid), dim3(B), 0, st, w->P, c, run, T, actions, mask, obs, reward, valid, done);
     else
         hipLaunchKernelGGL((hh_k_world<4, B, 1, false>), dim3(grid), dim3(B), 0, st, w->P, c, run, T, actions, mask, obs, reward, valid, done);

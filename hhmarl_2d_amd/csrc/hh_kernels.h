@@ -65,6 +65,7 @@ struct Shared {
                                                  relative position, speed and heading normalised (env_base.py:117-121) */
     double rew[B];
     unsigned long long g_tkey[GPB]; /* keyed-RNG tick key per arena (cannon draws made by worker lanes) */
+    double rk_speed[12];            /* rocket_unit.py:25-35 speed profile by age (register-exchange kernel) */
     int flags[B];                   /* bit0 alive, bits1-2 ac_type, bit3 shot flag */
     int aux[B];                     /* per-phase scratch */
     int res[B];                     /* envelope results per requesting lane: bit0 launch ok, bits1-8 cannon hit

@@ -238,6 +238,10 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     if (running) { ar.steps += 1; arena_rekey(ar); }
     const bool snap = running && m.alive;
     const int amask0 = tb.amask; /* alive at tick start, by absolute slot */
+    /* rocket_unit.py:25-35 speed profile of this slot's rocket (a launch in this tick starts at age 0).  Looked up
+     * here, a whole phase before its use, so the table read is off the critical path. */
+    const int rk_age0 = (m.rk_alive && m.rk_life <= HH_ROCKET_MAX_LIFE) ? m.rk_life : 0;
+    const double rk_speed0 = sh.rk_speed[rk_age0];
     double opp_stat0 = 0.0;
     int want_launch = 0, launch_tgt = 0;
     int wait_after = -1;
@@ -397,7 +401,6 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         const bool mv_a = snap && m.spd > 0.0;
         const bool any_rk = __ballot(rk_spec) != 0ULL;
         if (any_rk) {
-            const double speed_table[11] = HH_ROCKET_SPEED_TABLE;
             double r_lat = rk_pre ? m.rk_lat : lat_old, r_lon = rk_pre ? m.rk_lon : lon_old;
             double r_hdg = rk_pre ? m.rk_hdg : hdg_old;
             rk_ncmd = rk_pre ? m.rk_cmd
@@ -408,8 +411,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                 else r_hdg += delta >= 0.0 ? HH_ROCKET_TURN_RATE : -HH_ROCKET_TURN_RATE;
             }
             rk_nhdg = r_hdg;
-            int life = rk_pre ? m.rk_life : 0;
-            double r_spd = speed_table[rk_spec ? life : 0];
+            const double r_spd = rk_speed0;
             double a_lat, a_lon;
             d_geo_move2(m.lat, m.lon, m.hdg, mv_a ? m.spd * HH_KNOTS_TO_MS * 1.0 : 0.0, a_lat, a_lon,
                         rk_spec ? r_lat : 5.0, rk_spec ? r_lon : 7.0, r_hdg, r_spd * HH_KNOTS_TO_MS * 1.0, rk_nlat, rk_nlon);
@@ -693,23 +695,33 @@ __global__ __launch_bounds__(64, W) void hh_k_world_quad(DevPtrs P, DevCfg c, in
         ar.done = 1;
     }
     uint32_t evm_last = 0;
+    {
+        const double speed_table[11] = HH_ROCKET_SPEED_TABLE;
+        if (tid < 11) sh.rk_speed[tid] = speed_table[tid];
+    }
     QPub pub;
     QTab tb;
     quad_publish(c, m, pub);
     quad_tables(m, pub, s, tb);
+    /* Action words: vmcnt is one in-order counter for loads AND stores, so waiting for a load also waits for the
+     * write acknowledgements of every store issued before it.  The word of tick t+1 is therefore taken (waited
+     * for) right after tick t's compute and BEFORE tick t's output stores, when the load is a whole tick old and
+     * the previous tick's stores have long been acknowledged; the request for tick t+2 goes out at the same place. */
     const bool has_act = active && s < c.n_ctrl;
-    int act_next = 0;
-    if (has_act) act_next = *reinterpret_cast<const int *>(actions + (((size_t)0 * c.N + n) * c.n_ctrl + s) * 4);
+    const size_t act_stride = (size_t)c.N * c.n_ctrl * 4;
+    const int8_t *act_ptr = has_act ? actions + ((size_t)n * c.n_ctrl + s) * 4 : actions; /* lanes without a row re-read row 0, unused */
+    int act_cur = *reinterpret_cast<const int *>(act_ptr);
+    int act_next = *reinterpret_cast<const int *>(act_ptr + (size_t)min(1, T - 1) * act_stride);
+    __syncthreads();
     for (int t = 0; t < T; t++) {
         StepOut so;
-        int8_t act[4] = {0, 0, 0, 0};
-        if (has_act) {
-            int w = act_next;
-            if (t + 1 < T) act_next = *reinterpret_cast<const int *>(actions + (((size_t)(t + 1) * c.N + n) * c.n_ctrl + s) * 4);
-            act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
-        }
+        int8_t act[4];
+        act[0] = (int8_t)(act_cur & 0xff); act[1] = (int8_t)((act_cur >> 8) & 0xff); act[2] = (int8_t)((act_cur >> 16) & 0xff); act[3] = (int8_t)((act_cur >> 24) & 0xff);
         const bool was_running = active && !ar.done;
         tick_quad(c, sh, tid, g, s, base, active, m, ar, act, tb, pub, so, evm_last HH_PROF_PASS);
+        asm volatile("" : "+v"(act_next)); /* take the word of tick t+1 HERE (see above) ... */
+        act_cur = act_next;
+        act_next = *reinterpret_cast<const int *>(act_ptr + (size_t)min(t + 2, T - 1) * act_stride); /* ... and request t+2 */
         if (active && s < 2) {
             size_t o = ((size_t)t * c.N + n) * 2 + s;
             if (reward_out) reward_out[o] = (float)so.reward;

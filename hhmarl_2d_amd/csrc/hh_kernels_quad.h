@@ -103,23 +103,36 @@ __device__ __forceinline__ void quad_tables(const Unit &m, const QPub &p, int s,
     HH_QFETCH(2)
     HH_QFETCH(3)
 #undef HH_QFETCH
+    /* planar distances: the pair (s, s+3) is the pair (s', s'+1) of lane s' = s+3, and dx*dx + dy*dy does not
+     * change when both differences flip sign, so two square roots per lane cover the six pairs */
+    {
+        double dx0 = t.lon[0] - m.lon, dy0 = t.lat[0] - m.lat;
+        double dx1 = t.lon[1] - m.lon, dy1 = t.lat[1] - m.lat;
+        t.dist[0] = hh_sqrt(dx0 * dx0 + dy0 * dy0);
+        t.dist[1] = hh_sqrt(dx1 * dx1 + dy1 * dy1);
+        t.dist[2] = q_rot_d<3>(t.dist[0]);
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         double dx = t.lon[k] - m.lon, dy = t.lat[k] - m.lat;
-        double n2 = hh_sqrt(dx * dx + dy * dy);
+        double n2 = t.dist[k];
         double dot = c1 * dx + s1 * dy;
         double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
-        t.dist[k] = n2;
         t.foc[k] = hh_acos(x) * (180.0 / HH_PI);
     }
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        double dot = c1 * ouc[k] + s1 * ous[k];
-        double x = hh_clip(dot / (n1 * oun[k] + 1e-10), -1.0, 1.0);
-        t.hd[k] = hh_clip((hh_acos(x) * (180.0 / HH_PI)) / 180.0, 0.0, 1.0);
+    /* heading difference (env_base.py:448-456): read only by agents about opponents (observation), so the four
+     * agent-opponent pairs are split one per lane — (0,2) (1,3) (2,1) (3,0) — and handed over; the expression is
+     * symmetric in its operands, so either end computes the same bits */
+    {
+        const int kh = s < 2 ? 2 : (s == 2 ? 3 : 1);
+        const double c2 = q_sel(ouc, kh), s2 = q_sel(ous, kh), n2 = q_sel(oun, kh);
+        double dot = c1 * c2 + s1 * s2;
+        double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
+        const double hx = hh_clip((hh_acos(x) * (180.0 / HH_PI)) / 180.0, 0.0, 1.0);
+        t.hd[0] = q_rot_d<1>(hx); /* used by slot 1 about slot 2 */
+        t.hd[1] = hx;             /* agents: the opponent two slots up */
+        t.hd[2] = q_rot_d<3>(hx); /* used by slot 0 about slot 3 */
     }
-    /* the pair (s, s+3) is the pair (s', s'+1) of lane s' = s+3: the expression is symmetric in its operands */
-    t.hd[2] = q_rot_d<3>(t.hd[0]);
     /* focus of slot s+k at me = that lane's entry for ITS relative slot 4-k */
     t.focr[0] = q_rot_d<1>(t.foc[2]);
     t.focr[1] = q_rot_d<2>(t.foc[1]);
@@ -539,43 +552,67 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     int evpack = 0; /* 5 bits per event: killer slot | victim slot << 2 | by rocket << 4 */
     if (running) {
         /* aircraft phase: shooter i (alive at tick start, even if killed earlier in this tick) hits the still-alive
-         * targets in id order (ac1.py:106-115) */
+         * targets in id order (ac1.py:106-115).  Most ticks nobody in the arena has a hit to apply. */
+        if ((aux_[0] | aux_[1] | aux_[2] | aux_[3]) >> 8) {
 #pragma unroll
-        for (int i = 0; i < A; i++) {
-            const int ci = aux_[i] >> 8;
+            for (int i = 0; i < A; i++) {
+                const int ci = aux_[i] >> 8;
 #pragma unroll
-            for (int j = 0; j < A; j++) {
-                if (((ci >> j) & 1) && ((alive >> j) & 1)) {
-                    alive &= ~(1 << j);
-                    evpack |= (i | (j << 2)) << (5 * nev);
-                    nev++;
+                for (int j = 0; j < A; j++) {
+                    if (((ci >> j) & 1) && ((alive >> j) & 1)) {
+                        alive &= ~(1 << j);
+                        evpack |= (i | (j << 2)) << (5 * nev);
+                        nev++;
+                    }
                 }
             }
         }
-        /* rocket phase in launch order (rocket_unit.py:37-58) */
-        int done_mask = 0;
+        /* rocket phase in launch order (rocket_unit.py:37-58).  A rocket whose word has no fuse / end-of-life bit
+         * does nothing, so only the others are visited; with a single one the order is moot. */
+        int nact = 0, w1 = 0, b1 = 0;
 #pragma unroll
-        for (int k = 0; k < A; k++) {
-            int best = -1, best_seq = 0x7fffffff, w = 0;
-#pragma unroll
-            for (int j = 0; j < A; j++) {
-                const int wj = res_[j];
-                if ((wj & 1) && !((done_mask >> j) & 1) && (wj >> 8) < best_seq) { best = j; best_seq = wj >> 8; w = wj; }
+        for (int j = 0; j < A; j++) {
+            if ((res_[j] & 1) && (res_[j] & 0xe)) { nact++; w1 = res_[j]; b1 = j; }
+        }
+        if (nact == 1) {
+            const int tg = (w1 >> 4) & 7;
+            const int fid = b1 == 1 ? 0 : 1;
+            if (((w1 >> 1) & 1) && ((alive >> tg) & 1)) {
+                alive &= ~(1 << tg); dead |= 1 << b1;
+                evpack |= (b1 | (tg << 2) | (1 << 4)) << (5 * nev);
+                nev++;
+            } else if (c.friendly_kill && ((alive >> fid) & 1) && ((w1 >> 2) & 1)) {
+                alive &= ~(1 << fid); dead |= 1 << b1;
+                evpack |= (b1 | (fid << 2) | (1 << 4)) << (5 * nev);
+                nev++;
+            } else if ((w1 >> 3) & 1) {
+                dead |= 1 << b1;
             }
-            if (best >= 0) {
-                done_mask |= 1 << best;
-                const int tg = (w >> 4) & 7;
-                const int fid = best == 1 ? 0 : 1;
-                if (((w >> 1) & 1) && ((alive >> tg) & 1)) {
-                    alive &= ~(1 << tg); dead |= 1 << best;
-                    evpack |= (best | (tg << 2) | (1 << 4)) << (5 * nev);
-                    nev++;
-                } else if (c.friendly_kill && ((alive >> fid) & 1) && ((w >> 2) & 1)) {
-                    alive &= ~(1 << fid); dead |= 1 << best;
-                    evpack |= (best | (fid << 2) | (1 << 4)) << (5 * nev);
-                    nev++;
-                } else if ((w >> 3) & 1) {
-                    dead |= 1 << best;
+        } else if (nact > 1) {
+            int done_mask = 0;
+#pragma unroll
+            for (int k = 0; k < A; k++) {
+                int best = -1, best_seq = 0x7fffffff, w = 0;
+#pragma unroll
+                for (int j = 0; j < A; j++) {
+                    const int wj = res_[j];
+                    if ((wj & 1) && !((done_mask >> j) & 1) && (wj >> 8) < best_seq) { best = j; best_seq = wj >> 8; w = wj; }
+                }
+                if (best >= 0) {
+                    done_mask |= 1 << best;
+                    const int tg = (w >> 4) & 7;
+                    const int fid = best == 1 ? 0 : 1;
+                    if (((w >> 1) & 1) && ((alive >> tg) & 1)) {
+                        alive &= ~(1 << tg); dead |= 1 << best;
+                        evpack |= (best | (tg << 2) | (1 << 4)) << (5 * nev);
+                        nev++;
+                    } else if (c.friendly_kill && ((alive >> fid) & 1) && ((w >> 2) & 1)) {
+                        alive &= ~(1 << fid); dead |= 1 << best;
+                        evpack |= (best | (fid << 2) | (1 << 4)) << (5 * nev);
+                        nev++;
+                    } else if ((w >> 3) & 1) {
+                        dead |= 1 << best;
+                    }
                 }
             }
         }

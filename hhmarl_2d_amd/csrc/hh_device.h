@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include "hh_abi.h"
+#include "hh_envelope.h"
 #include "hh_geodesic.h"
 #include "hh_math.h"
 #include "hh_rng.h"

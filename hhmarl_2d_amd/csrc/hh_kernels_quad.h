@@ -75,18 +75,25 @@ struct QTab {
     int amask;                                /* alive bits by ABSOLUTE slot, own bit included */
 };
 
-__device__ __forceinline__ void quad_publish(const DevCfg &c, const Unit &m, QPub &p) {
+/* position / speed / heading part (final once the aircraft has moved) and the status flags (final at the end of the tick) */
+__device__ __forceinline__ void quad_publish_motion(const DevCfg &c, const Unit &m, QPub &p) {
     double sn, cs;
     hh_sincos(hh_pymod(90.0 - m.hdg, 360.0) * (HH_PI / 180.0), &sn, &cs);
     p.uc = cs;
     p.us = sn;
     p.un = hh_sqrt(cs * cs + sn * sn);
-    int shot = m.burst > 0 || (m.ac_type == 1 && m.has_missile);
-    p.flags = (m.alive ? FL_ALIVE : 0) | ((m.ac_type & 3) << 1) | (shot ? FL_SHOT : 0);
     p.nlat = (float)hh_clip((m.lat - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
     p.nlon = (float)hh_clip((m.lon - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
     p.nspd = (float)hh_clip(m.spd / HH_AC_MAX_SPEED(m.ac_type), 0.0, 1.0);
     p.nhdg = (float)hh_clip(hh_pymod(m.hdg, 359.0) / 359.0, 0.0, 1.0);
+}
+__device__ __forceinline__ void quad_publish_flags(const Unit &m, QPub &p) {
+    int shot = m.burst > 0 || (m.ac_type == 1 && m.has_missile);
+    p.flags = (m.alive ? FL_ALIVE : 0) | ((m.ac_type & 3) << 1) | (shot ? FL_SHOT : 0);
+}
+__device__ __forceinline__ void quad_publish(const DevCfg &c, const Unit &m, QPub &p) {
+    quad_publish_motion(c, m, p);
+    quad_publish_flags(m, p);
 }
 
 /* the pair table of pair_tables() in registers.  WAVE-UNIFORM control flow only. */
@@ -434,13 +441,10 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         }
     }
     const double rk0_lat = rk_pre ? m.rk_lat : lat_old, rk0_lon = rk_pre ? m.rk_lon : lon_old;
-    /* what the dense queue pass reads (LDS stores are fire-and-forget; nobody waits unless the queue is non-empty) */
-    sh.lat0[tid] = lat_old; sh.lon0[tid] = lon_old; sh.hdg[tid] = hdg_old;
-    sh.flags[tid] = pub.flags;
-    sh.u.t.lat1[tid] = m.lat; sh.u.t.lon1[tid] = m.lon; sh.u.t.hdg1[tid] = m.hdg;
-    sh.u.t.rk_lat[tid] = rk0_lat; sh.u.t.rk_lon[tid] = rk0_lon;
-    sh.res[tid] = 0;
-    if (s == 0) sh.g_tkey[g] = ar.tkey;
+    /* position, speed and heading are final for this tick: their published form is computed here, where it also
+     * serves the cannon prefilter (heading vector after the turn) and overlaps the envelope phases */
+    QPub pn;
+    quad_publish_motion(c, m, pn);
     /* positions of the other aircraft after their move (registers, by relative slot) */
     double lat1[3], lon1[3];
     lat1[0] = q_rot_d<1>(m.lat); lon1[0] = q_rot_d<1>(m.lon);
@@ -451,11 +455,21 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     /* ---------------- phase Q: envelope tests that survive the prefilter -> workgroup queue (ballot-assigned slots) ---------------- */
     const int rk_tgt = rk_pre ? m.rk_target - 1 : launch_tgt;
     const bool rk_maybe = running && (rk_pre || try_launch);
+    /* missile launch (ac1.py:72-79,135-146): launcher and target are tested where they stood before the tick, which
+     * is the geometry of the pair table — its planar focus angle decides all but the ~1 % of launches within half a
+     * degree of the cone's edges (hh_envelope.h); only those go through the queue */
+    int launch_pre = -1;
+    if (try_launch) {
+        const int kl = (launch_tgt - s) & 3;
+        const double t_lat = q_sel(tb.lat, kl), t_lon = q_sel(tb.lon, kl);
+        const double cross = pub.uc * (t_lat - lat_old) - pub.us * (t_lon - lon_old);
+        launch_pre = hh_missile_cone_planar(lat_old, lon_old, t_lat, t_lon, q_sel(tb.foc, kl), cross, q_sel(tb.dist, kl));
+    }
     int q_total = 0;
     {
         bool push[6];
         int code[6];
-        push[0] = try_launch;
+        push[0] = try_launch && launch_pre < 0;
         code[0] = tid | (0 << 8) | (launch_tgt << 10);
         const int t = m.ac_type;
 #pragma unroll
@@ -466,7 +480,8 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
             /* target already moved iff its id is lower (cmano_simulator.py:142) */
             const double tl = j < s ? lat1[k - 1] : tb.lat[k - 1];
             const double to = j < s ? lon1[k - 1] : tb.lon[k - 1];
-            push[k] = fired && snap_j && (c.friendly_kill || enemy) && d_maybe_within_km(lat_old, lon_old, tl, to, HH_AC_CANNON_KM(t));
+            push[k] = fired && snap_j && (c.friendly_kill || enemy) && d_maybe_within_km(lat_old, lon_old, tl, to, HH_AC_CANNON_KM(t)) &&
+                      !hh_cannon_cone_planar_outside(lat_old, lon_old, tl, to, pn.uc, pn.us, t);
             code[k] = tid | (1 << 8) | (j << 10);
         }
         {
@@ -489,18 +504,32 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                     sh.u.t.q_code[pos] = code[e];
                 }
                 q_total += __popcll(bm);
+#ifdef HH_PROFILE_PHASES
+                if (tid == 0) atomicAdd(&hh_prof_cycles[e == 0 ? 13 : (e < 4 ? 14 : 15)], (unsigned long long)__popcll(bm));
+#endif
             }
         }
+#ifdef HH_PROFILE_PHASES
+        if (tid == 0 && q_total) atomicAdd(&hh_prof_cycles[12], 1ULL);
+#endif
     }
     HH_PROF(2);
     /* ---------------- phase I: dense pass over the queue ---------------- */
     int myres = 0;
     if (q_total) { /* wave-uniform */
+        /* what the dense pass reads about the requesting and the target aircraft */
+        sh.lat0[tid] = lat_old; sh.lon0[tid] = lon_old; sh.hdg[tid] = hdg_old;
+        sh.flags[tid] = pub.flags;
+        sh.u.t.lat1[tid] = m.lat; sh.u.t.lon1[tid] = m.lon; sh.u.t.hdg1[tid] = m.hdg;
+        sh.u.t.rk_lat[tid] = rk0_lat; sh.u.t.rk_lon[tid] = rk0_lon;
+        sh.res[tid] = 0;
+        if (s == 0) sh.g_tkey[g] = ar.tkey;
         __syncthreads();
         drain_envelope_queue(sh, tid, q_total);
         __syncthreads();
         myres = sh.res[tid];
     }
+    if (launch_pre == 1) myres |= 1;
 
     HH_PROF(3);
     /* ---------------- phase L: launch bookkeeping (env_base.py:227-236, ac1.py:76-79) ---------------- */
@@ -675,7 +704,8 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     const double mate_rews = q_mate_d(rews);
     HH_PROF(5);
     /* post-tick table: escape shaping now, observation next, pre-step lookups of the next tick */
-    quad_publish(c, m, pub);
+    quad_publish_flags(m, pn);
+    pub = pn;
     HH_PROF(6);
     quad_tables(m, pub, s, tb);
     HH_PROF(7);

@@ -32,6 +32,7 @@
 #include <string.h>
 
 #include "hh_abi.h"
+#include "hh_envelope.h"
 #include "hh_geodesic.h"
 #include "hh_math.h"
 #include "hh_rng.h"
@@ -1400,6 +1401,47 @@ API void hho_geo_inverse_estimate(int n, const double *lat1, const double *lon1,
 }
 API void hho_geo_inverse(int n, const double *lat1, const double *lon1, const double *lat2, const double *lon2, double *s12, double *azi1) {
     for (int i = 0; i < n; i++) hh_geo_inverse(lat1[i], lon1[i], lat2[i], lon2[i], &s12[i], &azi1[i]);
+}
+/* probe for tests: the planar stage of the missile-launch predicate computed the way the kernels do (heading
+ * unit vector, planar focus angle, cross product; env_base.py:424-439) next to the exact predicate (ac1.py:135-146).
+ * pre: 1 / 0 / -1 (undecided); exact: 0 / 1; beta_p, beta: planar and geodesic relative bearing [deg] */
+API void hho_missile_cone_planar(int n, const double *lat1, const double *lon1, const double *hdg, const double *lat2,
+                                 const double *lon2, int32_t *pre, int32_t *exact, double *beta_p, double *beta) {
+    for (int i = 0; i < n; i++) {
+        double sn, cs;
+        hh_sincos(hh_pymod(90.0 - hdg[i], 360.0) * (HH_PI / 180.0), &sn, &cs);
+        double n1 = hh_sqrt(cs * cs + sn * sn);
+        double dx = lon2[i] - lon1[i], dy = lat2[i] - lat1[i];
+        double n2 = hh_sqrt(dx * dx + dy * dy);
+        double dot = cs * dx + sn * dy;
+        double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
+        double foc = hh_acos(x) * (180.0 / HH_PI);
+        double cross = cs * dy - sn * dx;
+        pre[i] = hh_missile_cone_planar(lat1[i], lon1[i], lat2[i], lon2[i], foc, cross, n2);
+        beta_p[i] = cross < 0.0 ? foc : -foc;
+        double s12, azi;
+        hh_geo_inverse(lat1[i], lon1[i], lat2[i], lon2[i], &s12, &azi);
+        double brg = normalize_angle(azi);
+        beta[i] = signed_heading_diff(hdg[i], brg);
+        int in = 0;
+        if (s12 / 1000.0 <= HH_MISSILE_RANGE_KM) {
+            double delta = hh_fabs(signed_heading_diff(normalize_angle(hdg[i] + HH_MISSILE_HALF_DEG), brg));
+            in = (int)delta <= (int)HH_MISSILE_HALF_DEG;
+        }
+        exact[i] = in;
+    }
+}
+/* probe for tests: planar "certainly outside the cannon cone" stage next to the exact predicate (ac1.py:106-115,135-141) */
+API void hho_cannon_cone_planar(int n, int ac_type, const double *lat1, const double *lon1, const double *hdg, const double *lat2,
+                                const double *lon2, int32_t *outside, int32_t *exact) {
+    for (int i = 0; i < n; i++) {
+        double sn, cs;
+        hh_sincos(hh_pymod(90.0 - hdg[i], 360.0) * (HH_PI / 180.0), &sn, &cs);
+        outside[i] = hh_cannon_cone_planar_outside(lat1[i], lon1[i], lat2[i], lon2[i], cs, sn, ac_type);
+        double km, brg;
+        dist_bearing(lat1[i], lon1[i], lat2[i], lon2[i], &km, &brg);
+        exact[i] = km < HH_AC_CANNON_KM(ac_type) && hh_fabs(signed_heading_diff(hdg[i], brg)) <= HH_AC_CANNON_HALF(ac_type);
+    }
 }
 API double hho_rng_u01(uint64_t seed, uint64_t arena, uint32_t episode, uint32_t tick, uint32_t unit, uint32_t site, uint32_t sub) {
     return hh_rng_u01(hh_rng_tick_key(hh_rng_arena_key(seed, arena), episode, tick), unit, site, sub);

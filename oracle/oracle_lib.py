@@ -271,6 +271,29 @@ def geo_inverse(lat1, lon1, lat2, lon2):
     return o0, o1
 
 
+def missile_cone_planar(lat1, lon1, hdg, lat2, lon2):
+    """planar stage of the launch predicate next to the exact one: (pre, exact, beta_planar, beta_geodesic)"""
+    arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (lat1, lon1, hdg, lat2, lon2)]
+    n = len(arrs[0])
+    pre = np.empty(n, dtype=np.int32)
+    exact = np.empty(n, dtype=np.int32)
+    bp = np.empty(n)
+    bg = np.empty(n)
+    D = C.c_double
+    lib().hho_missile_cone_planar(n, *[_ptr(x, D) for x in arrs], _ptr(pre, C.c_int32), _ptr(exact, C.c_int32), _ptr(bp, D), _ptr(bg, D))
+    return pre, exact, bp, bg
+
+
+def cannon_cone_planar(ac_type, lat1, lon1, hdg, lat2, lon2):
+    """planar 'certainly outside the cannon cone' stage next to the exact predicate: (outside, exact)"""
+    arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (lat1, lon1, hdg, lat2, lon2)]
+    n = len(arrs[0])
+    out = np.empty(n, dtype=np.int32)
+    exact = np.empty(n, dtype=np.int32)
+    lib().hho_cannon_cone_planar(n, int(ac_type), *[_ptr(x, C.c_double) for x in arrs], _ptr(out, C.c_int32), _ptr(exact, C.c_int32))
+    return out, exact
+
+
 def geo_inverse_estimate(lat1, lon1, lat2, lon2):
     arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (lat1, lon1, lat2, lon2)]
     o0 = np.empty_like(arrs[0])

@@ -23,3 +23,5 @@ tot = sum(buf[:12])
 for k, nm in enumerate(names):
     print(f"{nm:36s} {buf[k] / (waves * 4 * T):9.0f} cycles/wave-tick  {100.0 * buf[k] / tot:5.1f} %")
 print(f"{'total':36s} {tot / (waves * 4 * T):9.0f} cycles/wave-tick")
+wt = waves * 4 * T
+print(f"queue: non-empty on {buf[12] / wt:.3f} of wave-ticks; entries per wave-tick: launch {buf[13] / wt:.3f}, cannon {buf[14] / wt:.3f}, rocket fuse {buf[15] / wt:.3f}")

@@ -90,15 +90,17 @@ __device__ __forceinline__ int sh_alive(const Shared<A, B> &sh, int idx) { retur
 template <int A, int B>
 __device__ __forceinline__ int sh_type(const Shared<A, B> &sh, int idx) { return (sh.flags[idx] >> 1) & 3; }
 
+/* heading unit vector (east, north) of env_base.py:428 */
+__device__ __forceinline__ void heading_vec(double hdg, double &c, double &s) {
+    hh_sincos(hh_pymod(90.0 - hdg, 360.0) * (HH_PI / 180.0), &s, &c);
+}
 /* publish the state other lanes read */
 template <int A, int B>
-__device__ __forceinline__ void publish(Shared<A, B> &sh, int tid, const Unit &m) {
+__device__ __forceinline__ void publish_hv(Shared<A, B> &sh, int tid, const Unit &m, double c, double s) {
     sh.lat0[tid] = m.lat;
     sh.lon0[tid] = m.lon;
     sh.hdg[tid] = m.hdg;
     sh.spd[tid] = m.spd;
-    double s, c;
-    hh_sincos(hh_pymod(90.0 - m.hdg, 360.0) * (HH_PI / 180.0), &s, &c);
     sh.uc[tid] = c;
     sh.us[tid] = s;
     sh.un[tid] = hh_sqrt(c * c + s * s);
@@ -106,14 +108,27 @@ __device__ __forceinline__ void publish(Shared<A, B> &sh, int tid, const Unit &m
     sh.flags[tid] = (m.alive ? FL_ALIVE : 0) | ((m.ac_type & 3) << 1) | (shot ? FL_SHOT : 0);
 }
 
+template <int A, int B>
+__device__ __forceinline__ void publish(Shared<A, B> &sh, int tid, const Unit &m) {
+    double c, s;
+    heading_vec(m.hdg, c, s);
+    publish_hv(sh, tid, m, c, s);
+}
+
 /* publish + the normalised entries of the observation (needs the map extents) */
 template <int A, int B>
-__device__ __forceinline__ void publish_obs(const DevCfg &c, Shared<A, B> &sh, int tid, const Unit &m) {
-    publish(sh, tid, m);
+__device__ __forceinline__ void publish_obs_hv(const DevCfg &c, Shared<A, B> &sh, int tid, const Unit &m, double hc, double hs) {
+    publish_hv(sh, tid, m, hc, hs);
     sh.nlat[tid] = (float)hh_clip((m.lat - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
     sh.nlon[tid] = (float)hh_clip((m.lon - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
     sh.nspd[tid] = (float)hh_clip(m.spd / HH_AC_MAX_SPEED(m.ac_type), 0.0, 1.0);
     sh.nhdg[tid] = (float)hh_clip(hh_pymod(m.hdg, 359.0) / 359.0, 0.0, 1.0);
+}
+template <int A, int B>
+__device__ __forceinline__ void publish_obs(const DevCfg &c, Shared<A, B> &sh, int tid, const Unit &m) {
+    double hc, hs;
+    heading_vec(m.hdg, hc, hs);
+    publish_obs_hv(c, sh, tid, m, hc, hs);
 }
 
 /* the per-arena pair table (call between two barriers, after publish).  Branch-free and fully unrolled on
@@ -429,6 +444,15 @@ __device__ __forceinline__ void arm_cannon(Unit &m) { /* ac1.py:69-70 / ac2.py:6
     m.burst = m.cannon_remain < b ? m.cannon_remain : b;
 }
 
+/* planar stage of the launch predicate from the LDS pair table (hh_envelope.h); lane's aircraft -> slot j, both where
+ * they stood when the table was built: 1 inside / 0 outside / -1 ask the queue */
+template <int A, int B>
+__device__ __forceinline__ int launch_planar(const Shared<A, B> &sh, int tid, int base, int j) {
+    const double la = sh.lat0[tid], lo = sh.lon0[tid], tl = sh.lat0[base + j], to = sh.lon0[base + j];
+    const double cross = sh.uc[tid] * (tl - la) - sh.us[tid] * (to - lo);
+    return hh_missile_cone_planar(la, lo, tl, to, sh.p_foc[j][tid], cross, sh.p_dist[j][tid]);
+}
+
 template <int A, int B>
 __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid, int g, int s, int base, bool active,
                                      Unit &m, Arena &ar, const int8_t *act, StepOut &out, uint32_t &ev_mask_out,
@@ -641,6 +665,8 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
 #endif
         }
     }
+    double hv_c, hv_s; /* heading vector after the turn: cannon prefilter now, published with the post-tick state */
+    heading_vec(m.hdg, hv_c, hv_s);
     sh.u.t.lat1[tid] = m.lat;
     sh.u.t.lon1[tid] = m.lon;
     sh.u.t.hdg1[tid] = m.hdg;
@@ -656,6 +682,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     /* ---------------- phase Q: enqueue every geodesic envelope test that survives the prefilter ---------------- */
     const int rk_tgt = rk_pre ? m.rk_target - 1 : launch_tgt; /* slot the (possibly pending) rocket is aimed at */
     const bool rk_maybe = running && (rk_pre || try_launch);
+    const int launch_pre = try_launch ? launch_planar(sh, tid, base, launch_tgt) : -1; /* pair table = pre-tick geometry */
     {
         int nq = 0;
         int c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
@@ -666,7 +693,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
                       case 4: c4 = cd_; break; case 5: c5 = cd_; break; case 6: c6 = cd_; break; default: c7 = cd_; break; } \
         nq++;                                                                                               \
     } while (0)
-        if (try_launch) HH_PUSH(tid | (0 << 8) | (launch_tgt << 10));
+        if (try_launch && launch_pre < 0) HH_PUSH(tid | (0 << 8) | (launch_tgt << 10));
         if (fired) {
             int t = m.ac_type;
 #pragma unroll
@@ -678,7 +705,9 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
                 /* target already moved iff its id is lower (cmano_simulator.py:142) */
                 double tl = j < s ? sh.u.t.lat1[base + j] : sh.lat0[base + j];
                 double to = j < s ? sh.u.t.lon1[base + j] : sh.lon0[base + j];
-                if (d_maybe_within_km(lat_old, lon_old, tl, to, HH_AC_CANNON_KM(t))) HH_PUSH(tid | (1 << 8) | (j << 10));
+                if (d_maybe_within_km(lat_old, lon_old, tl, to, HH_AC_CANNON_KM(t)) &&
+                    !hh_cannon_cone_planar_outside(lat_old, lon_old, tl, to, hv_c, hv_s, t))
+                    HH_PUSH(tid | (1 << 8) | (j << 10));
             }
         }
         if (rk_maybe) {
@@ -713,7 +742,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
 
     HH_PROF(3);
     /* ---------------- phase L: launch bookkeeping (env_base.py:227-236, ac1.py:76-79) ---------------- */
-    const int myres = sh.res[tid];
+    const int myres = sh.res[tid] | (launch_pre == 1 ? 1 : 0);
     int launched = 0;
     if (try_launch && (myres & 1)) {
         launched = 1;
@@ -872,7 +901,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     sh.rew[tid] = rews;
     /* post-tick state + pair table: escape shaping now, observation next, pre-step lookups of the next tick */
     HH_PROF(5);
-    publish_obs(c, sh, tid, m);
+    publish_obs_hv(c, sh, tid, m, hv_c, hv_s);
     __syncthreads();
     HH_PROF(6);
     pair_tables(sh, tid, base, s, active);
@@ -971,7 +1000,8 @@ __device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int
     sh.res[tid] = 0;
     if (tid == 0) sh.u.t.q_count = 0;
     __syncthreads();
-    if (try_launch) {
+    const int launch_pre = try_launch ? launch_planar(sh, tid, base, launch_tgt) : -1;
+    if (try_launch && launch_pre < 0) {
         int at = atomicAdd(&sh.u.t.q_count, 1);
         sh.u.t.q_code[at] = tid | (0 << 8) | (launch_tgt << 10);
     }
@@ -979,7 +1009,7 @@ __device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int
     drain_envelope_queue(sh, tid, sh.u.t.q_count);
     __syncthreads();
     int launched = 0;
-    if (try_launch && (sh.res[tid] & 1)) { /* ac1.py:76-79 */
+    if (try_launch && ((sh.res[tid] & 1) || launch_pre == 1)) { /* ac1.py:76-79 */
         launched = 1;
         m.rk_alive = 1; m.rk_lat = m.lat; m.rk_lon = m.lon; m.rk_hdg = m.hdg; m.rk_cmd = m.hdg;
         m.rk_target = launch_tgt + 1; m.rk_life = 0;

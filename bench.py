@@ -161,7 +161,9 @@ def main():
         pass
 
     value = N * world * args.steps / dt
-    variant = "W=2 (2 waves/SIMD)" if (N + 15) // 16 >= 2048 else "W=1"
+    two = os.environ.get("HH_FORCE_W") == "2" or (os.environ.get("HH_FORCE_W") in (None, "", "0") and (N + 15) // 16 >= 2048)
+    kname = "hh_k_world<4,64,%d,false>" if os.environ.get("HH_NO_QUAD") == "1" else "hh_k_world_quad<%d>"
+    kname = kname % (2 if two else 1)
     line = {
         "metric": "env-steps/sec (2v2)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -171,8 +173,9 @@ def main():
                                f"(BASELINE configs[1])", "arenas_per_gpu": N, "ticks_per_launch": chunk,
                    "parallelism": f"arena-sharded x{world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": f"hh_k_world<4,64,{variant}>", "avg_launch_ms": avg_launch_s * 1e3,
-                     "algorithmic_bytes_per_launch": bytes_per_launch},
+                     "traffic": traffic, "kernel": kname, "avg_launch_ms": avg_launch_s * 1e3,
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "note": "FP64-VALU issue bound, not HBM bound: see DESIGN.md section 4 (SQ_INSTS_VALU per wave-tick x 4 cycles)"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(N, args.level, args.seed)

@@ -37,7 +37,7 @@ struct DevCfg {
     int N, env_kind, nA, nO, A, level, agent_mode, horizon;
     int friendly_kill, friendly_punish, esc_dist_rew, hier_action_assess, hier_opp_fight_ratio;
     int auto_reset, ext_opp, D, n_ctrl;
-    double glob_frac, rew_scale, ext_lat, ext_lon, lat_hi, lon_hi, inv_diag;
+    double glob_frac, rew_scale, ext_lat, ext_lon, inv_ext_lat, inv_ext_lon, lat_hi, lon_hi, inv_diag;
     uint64_t seed, arena_offset;
 };
 

@@ -119,10 +119,10 @@ __device__ __forceinline__ void publish(Shared<A, B> &sh, int tid, const Unit &m
 template <int A, int B>
 __device__ __forceinline__ void publish_obs_hv(const DevCfg &c, Shared<A, B> &sh, int tid, const Unit &m, double hc, double hs) {
     publish_hv(sh, tid, m, hc, hs);
-    sh.nlat[tid] = (float)hh_clip((m.lat - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
-    sh.nlon[tid] = (float)hh_clip((m.lon - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
-    sh.nspd[tid] = (float)hh_clip(m.spd / HH_AC_MAX_SPEED(m.ac_type), 0.0, 1.0);
-    sh.nhdg[tid] = (float)hh_clip(hh_pymod(m.hdg, 359.0) / 359.0, 0.0, 1.0);
+    sh.nlat[tid] = (float)hh_clip(hh_div_known(m.lat - HH_MAP_LAT0, c.ext_lat, c.inv_ext_lat), 0.0, 1.0);
+    sh.nlon[tid] = (float)hh_clip(hh_div_known(m.lon - HH_MAP_LON0, c.ext_lon, c.inv_ext_lon), 0.0, 1.0);
+    sh.nspd[tid] = (float)hh_clip(hh_div_known(m.spd, HH_AC_MAX_SPEED(m.ac_type), HH_AC_INV_MAX_SPEED(m.ac_type)), 0.0, 1.0);
+    sh.nhdg[tid] = (float)hh_clip(HH_DIVC(hh_pymod(m.hdg, 359.0), 359.0), 0.0, 1.0);
 }
 template <int A, int B>
 __device__ __forceinline__ void publish_obs(const DevCfg &c, Shared<A, B> &sh, int tid, const Unit &m) {
@@ -160,7 +160,7 @@ __device__ __forceinline__ void pair_tables(Shared<A, B> &sh, int tid, int base,
         double c2 = sh.uc[base + j], s2 = sh.us[base + j], n2 = sh.un[base + j];
         double dot = c1 * c2 + s1 * s2;
         double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
-        hd[k - 1] = hh_clip((hh_acos(x) * (180.0 / HH_PI)) / 180.0, 0.0, 1.0);
+        hd[k - 1] = hh_clip(HH_DIVC(hh_acos(x) * (180.0 / HH_PI), 180.0), 0.0, 1.0);
     }
     if (!active) return;
 #pragma unroll
@@ -210,8 +210,8 @@ __device__ __forceinline__ void nearby(const DevCfg &c, const Shared<A, B> &sh, 
     }
 }
 
-__device__ __forceinline__ double norm180(double deg) { return hh_clip(deg / 180.0, 0.0, 1.0); }          /* focus, norm=True */
-__device__ __forceinline__ double aspect(double deg) { return hh_clip((180.0 - deg) / 180.0, 0.0, 1.0); } /* env_base.py:441-446 */
+__device__ __forceinline__ double norm180(double deg) { return hh_clip(HH_DIVC(deg, 180.0), 0.0, 1.0); }          /* focus, norm=True */
+__device__ __forceinline__ double aspect(double deg) { return hh_clip(HH_DIVC(180.0 - deg, 180.0), 0.0, 1.0); } /* env_base.py:441-446 */
 
 /* ===================================================================== K3: reset */
 /* env_base.py:489-549 / env_hier.py:226-250 _sample_state + env_base.py:551-585 _reset_scenario */
@@ -553,8 +553,8 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
             double heading, speed;
             if (my_escaping) {
                 /* env_hetero.py:227-245 _escaping_opp */
-                double y = hh_clip((m.lat - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
-                double x = hh_clip((m.lon - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
+                double y = hh_clip(hh_div_known(m.lat - HH_MAP_LAT0, c.ext_lat, c.inv_ext_lat), 0.0, 1.0);
+                double x = hh_clip(hh_div_known(m.lon - HH_MAP_LON0, c.ext_lon, c.inv_ext_lon), 0.0, 1.0);
                 double uh = d_rng(ar, id, HH_SITE_ESC_HDG, 0);
                 double lo_h = y < 0.5 ? (x < 0.5 ? 30.0 : 300.0) : (x < 0.5 ? 120.0 : 210.0);
                 heading = (double)(int)hh_rng_uniform(uh, lo_h, lo_h + 30.0);

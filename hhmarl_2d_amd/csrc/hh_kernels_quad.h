@@ -82,10 +82,10 @@ __device__ __forceinline__ void quad_publish_motion(const DevCfg &c, const Unit 
     p.uc = cs;
     p.us = sn;
     p.un = hh_sqrt(cs * cs + sn * sn);
-    p.nlat = (float)hh_clip((m.lat - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
-    p.nlon = (float)hh_clip((m.lon - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
-    p.nspd = (float)hh_clip(m.spd / HH_AC_MAX_SPEED(m.ac_type), 0.0, 1.0);
-    p.nhdg = (float)hh_clip(hh_pymod(m.hdg, 359.0) / 359.0, 0.0, 1.0);
+    p.nlat = (float)hh_clip(hh_div_known(m.lat - HH_MAP_LAT0, c.ext_lat, c.inv_ext_lat), 0.0, 1.0);
+    p.nlon = (float)hh_clip(hh_div_known(m.lon - HH_MAP_LON0, c.ext_lon, c.inv_ext_lon), 0.0, 1.0);
+    p.nspd = (float)hh_clip(hh_div_known(m.spd, HH_AC_MAX_SPEED(m.ac_type), HH_AC_INV_MAX_SPEED(m.ac_type)), 0.0, 1.0);
+    p.nhdg = (float)hh_clip(HH_DIVC(hh_pymod(m.hdg, 359.0), 359.0), 0.0, 1.0);
 }
 __device__ __forceinline__ void quad_publish_flags(const Unit &m, QPub &p) {
     int shot = m.burst > 0 || (m.ac_type == 1 && m.has_missile);
@@ -135,7 +135,7 @@ __device__ __forceinline__ void quad_tables(const Unit &m, const QPub &p, int s,
         const double c2 = q_sel(ouc, kh), s2 = q_sel(ous, kh), n2 = q_sel(oun, kh);
         double dot = c1 * c2 + s1 * s2;
         double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
-        const double hx = hh_clip((hh_acos(x) * (180.0 / HH_PI)) / 180.0, 0.0, 1.0);
+        const double hx = hh_clip(HH_DIVC(hh_acos(x) * (180.0 / HH_PI), 180.0), 0.0, 1.0);
         t.hd[0] = q_rot_d<1>(hx); /* used by slot 1 about slot 2 */
         t.hd[1] = hx;             /* agents: the opponent two slots up */
         t.hd[2] = q_rot_d<3>(hx); /* used by slot 0 about slot 3 */
@@ -340,8 +340,8 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
             int opp = -1, fire = 0, fire_m = 0;
             double heading, speed;
             if (my_escaping) { /* env_hetero.py:227-245 _escaping_opp */
-                double y = hh_clip((m.lat - HH_MAP_LAT0) / c.ext_lat, 0.0, 1.0);
-                double x = hh_clip((m.lon - HH_MAP_LON0) / c.ext_lon, 0.0, 1.0);
+                double y = hh_clip(hh_div_known(m.lat - HH_MAP_LAT0, c.ext_lat, c.inv_ext_lat), 0.0, 1.0);
+                double x = hh_clip(hh_div_known(m.lon - HH_MAP_LON0, c.ext_lon, c.inv_ext_lon), 0.0, 1.0);
                 double uh = d_rng(ar, id, HH_SITE_ESC_HDG, 0);
                 double lo_h = y < 0.5 ? (x < 0.5 ? 30.0 : 300.0) : (x < 0.5 ? 120.0 : 210.0);
                 heading = (double)(int)hh_rng_uniform(uh, lo_h, lo_h + 30.0);

@@ -76,6 +76,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     double ms = cfg->map_size;
     d.lat_hi = HH_MAP_LAT0 + ms; d.lon_hi = HH_MAP_LON0 + ms;
     d.ext_lat = d.lat_hi - HH_MAP_LAT0; d.ext_lon = d.lon_hi - HH_MAP_LON0;
+    d.inv_ext_lat = 1.0 / d.ext_lat; d.inv_ext_lon = 1.0 / d.ext_lon;
     d.inv_diag = (1.0 - 0.0) / (__builtin_sqrt(2.0 * (ms * ms)) - 0.0);
     d.seed = cfg->seed; d.arena_offset = cfg->arena_offset;
     w->block = HH_BLOCK;

@@ -20,6 +20,7 @@
  * type 2 "RafaleLong" warsim/simulator/ac2.py:23-32 */
 #define HH_AC_TURN_RATE(t)   ((t) == 1 ? 5.0 : 3.5)    /* max_deg_sec */
 #define HH_AC_MAX_SPEED(t)   ((t) == 1 ? 900.0 : 600.0) /* max_speed_knots */
+#define HH_AC_INV_MAX_SPEED(t) ((t) == 1 ? (1.0 / 900.0) : (1.0 / 600.0))
 #define HH_AC_ACCEL(t)       ((t) == 1 ? 35.0 : 28.0)   /* max_knots_sec */
 #define HH_AC_CANNON_KM(t)   ((t) == 1 ? 2.0 : 4.5)     /* cannon_range_km */
 #define HH_AC_CANNON_HALF(t) ((t) == 1 ? (10.0 / 2.0) : (7.0 / 2.0)) /* cannon_width_deg / 2.0 */

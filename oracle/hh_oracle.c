@@ -80,7 +80,7 @@ typedef struct {
 typedef struct {
     hh_config cfg;
     int A, D, n_ctrl;
-    double ext_lat, ext_lon, lat_hi, lon_hi, inv_diag;
+    double ext_lat, ext_lon, inv_ext_lat, inv_ext_lon, lat_hi, lon_hi, inv_diag;
     o_arena *ar;
 } o_world;
 
@@ -125,9 +125,9 @@ static double focus_deg(const o_ac *a, const o_ac *b) {
     double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
     return hh_acos(x) * (180.0 / HH_PI);
 }
-static double focus_norm(const o_ac *a, const o_ac *b) { return hh_clip(focus_deg(a, b) / 180.0, 0.0, 1.0); }
+static double focus_norm(const o_ac *a, const o_ac *b) { return hh_clip(HH_DIVC(focus_deg(a, b), 180.0), 0.0, 1.0); }
 /* env_base.py:441-446 _aspect_angle(norm=True) */
-static double aspect_norm(const o_ac *a, const o_ac *b) { return hh_clip((180.0 - focus_deg(a, b)) / 180.0, 0.0, 1.0); }
+static double aspect_norm(const o_ac *a, const o_ac *b) { return hh_clip(HH_DIVC(180.0 - focus_deg(a, b), 180.0), 0.0, 1.0); }
 /* env_base.py:448-456 _heading_diff(norm=True) */
 static double heading_diff_norm(const o_ac *a, const o_ac *b) {
     double s1, c1, s2, c2;
@@ -136,7 +136,7 @@ static double heading_diff_norm(const o_ac *a, const o_ac *b) {
     double dot = c1 * c2 + s1 * s2;
     double n1 = hh_sqrt(c1 * c1 + s1 * s1), n2 = hh_sqrt(c2 * c2 + s2 * s2);
     double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
-    return hh_clip((hh_acos(x) * (180.0 / HH_PI)) / 180.0, 0.0, 1.0);
+    return hh_clip(HH_DIVC(hh_acos(x) * (180.0 / HH_PI), 180.0), 0.0, 1.0);
 }
 /* env_base.py:434-439 _distance */
 static double dist_raw(const o_ac *a, const o_ac *b) { return hh_hypot(b->lon - a->lon, b->lat - a->lat); }
@@ -173,8 +173,8 @@ static int nearby(const o_world *w, const o_arena *a, int id, int friendly, int 
 
 /* map_limits.py:37-40 relative_position -> (lat_rel, lon_rel) */
 static void rel_pos(const o_world *w, const o_ac *u, double *lat_rel, double *lon_rel) {
-    *lat_rel = hh_clip((u->lat - HH_MAP_LAT0) / w->ext_lat, 0.0, 1.0);
-    *lon_rel = hh_clip((u->lon - HH_MAP_LON0) / w->ext_lon, 0.0, 1.0);
+    *lat_rel = hh_clip(hh_div_known(u->lat - HH_MAP_LAT0, w->ext_lat, w->inv_ext_lat), 0.0, 1.0);
+    *lon_rel = hh_clip(hh_div_known(u->lon - HH_MAP_LON0, w->ext_lon, w->inv_ext_lon), 0.0, 1.0);
 }
 /* map_limits.py:47-48 */
 static int in_boundary(const o_world *w, const o_ac *u) {
@@ -196,8 +196,8 @@ static int opp_ac_values(const o_world *w, const o_arena *a, int mode, int opp_i
     rel_pos(w, o, &x, &y);
     st[n++] = x;
     st[n++] = y;
-    st[n++] = hh_clip(o->spd / HH_AC_MAX_SPEED(o->ac_type), 0.0, 1.0);
-    st[n++] = hh_clip(hh_pymod(o->hdg, 359.0) / 359.0, 0.0, 1.0);
+    st[n++] = hh_clip(hh_div_known(o->spd, HH_AC_MAX_SPEED(o->ac_type), HH_AC_INV_MAX_SPEED(o->ac_type)), 0.0, 1.0);
+    st[n++] = hh_clip(HH_DIVC(hh_pymod(o->hdg, 359.0), 359.0), 0.0, 1.0);
     st[n++] = heading_diff_norm(o, s);
     if (mode == 0) {
         st[n++] = focus_norm(o, s);
@@ -239,8 +239,8 @@ static int fight_state_values(const o_world *w, const o_arena *a, int id, int op
     rel_pos(w, u, &x, &y);
     st[n++] = x;
     st[n++] = y;
-    st[n++] = hh_clip(u->spd / HH_AC_MAX_SPEED(u->ac_type), 0.0, 1.0);
-    st[n++] = hh_clip(hh_pymod(u->hdg, 359.0) / 359.0, 0.0, 1.0);
+    st[n++] = hh_clip(hh_div_known(u->spd, HH_AC_MAX_SPEED(u->ac_type), HH_AC_INV_MAX_SPEED(u->ac_type)), 0.0, 1.0);
+    st[n++] = hh_clip(HH_DIVC(hh_pymod(u->hdg, 359.0), 359.0), 0.0, 1.0);
     st[n++] = focus_norm(u, o);
     st[n++] = aspect_norm(o, u);
     st[n++] = heading_diff_norm(u, o);
@@ -267,8 +267,8 @@ static int esc_state_values(const o_world *w, const o_arena *a, int id, int n_op
     rel_pos(w, u, &x, &y);
     st[n++] = x;
     st[n++] = y;
-    st[n++] = hh_clip(u->spd / HH_AC_MAX_SPEED(u->ac_type), 0.0, 1.0);
-    st[n++] = hh_clip(hh_pymod(u->hdg, 359.0) / 359.0, 0.0, 1.0);
+    st[n++] = hh_clip(hh_div_known(u->spd, HH_AC_MAX_SPEED(u->ac_type), HH_AC_INV_MAX_SPEED(u->ac_type)), 0.0, 1.0);
+    st[n++] = hh_clip(HH_DIVC(hh_pymod(u->hdg, 359.0), 359.0), 0.0, 1.0);
     st[n++] = hh_clip((double)u->cannon_remain / (double)u->cannon_max, 0.0, 1.0);
     if (u->ac_type == 1) st[n++] = hh_clip((double)u->missile_remain / (double)u->rocket_max, 0.0, 1.0);
     st[n++] = (double)shot_flag(u);
@@ -873,8 +873,8 @@ static void hl_state(const o_world *w, o_arena *a) {
                     rel_pos(w, u, &x, &y);
                     st[n++] = x;
                     st[n++] = y;
-                    st[n++] = hh_clip(u->spd / HH_AC_MAX_SPEED(u->ac_type), 0.0, 1.0);
-                    st[n++] = hh_clip(hh_pymod(u->hdg, 359.0) / 359.0, 0.0, 1.0);
+                    st[n++] = hh_clip(hh_div_known(u->spd, HH_AC_MAX_SPEED(u->ac_type), HH_AC_INV_MAX_SPEED(u->ac_type)), 0.0, 1.0);
+                    st[n++] = hh_clip(HH_DIVC(hh_pymod(u->hdg, 359.0), 359.0), 0.0, 1.0);
                     double os[20]; int m = 0;
                     for (int k = 0; k < 20; k++) os[k] = 0.0;
                     for (int k = 0; k < no; k++) {
@@ -924,6 +924,8 @@ API int hho_create(const hh_config *cfg, void **out) {
     w->lon_hi = HH_MAP_LON0 + m;
     w->ext_lat = w->lat_hi - HH_MAP_LAT0; /* map_limits.py:19-23 */
     w->ext_lon = w->lon_hi - HH_MAP_LON0;
+    w->inv_ext_lat = 1.0 / w->ext_lat;
+    w->inv_ext_lon = 1.0 / w->ext_lon;
     w->inv_diag = (1.0 - 0.0) / (hh_sqrt(2.0 * (m * m)) - 0.0); /* env_base.py:439,458-462 */
     w->ar = (o_arena *)calloc((size_t)cfg->n_arenas, sizeof(o_arena));
     for (int n = 0; n < cfg->n_arenas; n++) {
@@ -1386,6 +1388,7 @@ API void hho_math_eval(int fn, int n, const double *a, const double *b, double *
             case 6: o0[i] = hh_remainder(a[i], b[i]); break;
             case 7: o0[i] = hh_fmod(a[i], b[i]); break;
             case 8: o0[i] = hh_round3(a[i]); break;
+            case 9: o0[i] = hh_div_known(a[i], b[i], 1.0 / b[i]); break;
             default: break;
         }
     }

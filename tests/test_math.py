@@ -80,3 +80,15 @@ def test_keyed_rng_matches_python_mirror(oracle):
     for seed, arena, ep, tick, unit, site, sub in [(0, 0, 1, 0, 0, 1, 0), (1234, 7, 3, 150, 4, 21, 2), (2**63 + 5, 65535, 9, 499, 6, 24, 0)]:
         want = H.u01(H.tick_key(H.arena_key(seed, arena), ep, tick), unit, site, sub)
         assert lib.hho_rng_u01(seed, arena, ep, tick, unit, site, sub) == want
+
+
+def test_division_by_a_known_divisor_is_the_division(oracle):
+    """hh_div_known (Markstein correction with the reciprocal taken once) must give the correctly rounded quotient:
+    the kernels use it for every normalisation of the observation (x/180, x/359, x/max_speed, x/map extent)"""
+    rng = np.random.default_rng(6)
+    n = 2_000_000
+    for c in (180.0, 359.0, 900.0, 600.0, 0.3, 0.29999999999999982, 0.30000000000000071, 0.5, 0.7):
+        x = np.concatenate([rng.uniform(-400.0, 1000.0, n), rng.uniform(0.0, 1.0, n) * c, 10.0 ** rng.uniform(-12, 3, n // 4),
+                            c * rng.integers(0, 4000, n // 4) / 1024.0, [0.0, -0.0, c, -c, 2 * c, 180.0, 179.99999999999997]])
+        q, _ = oracle.math_eval(9, x, np.full(x.size, c))
+        assert np.array_equal(q, x / c), c

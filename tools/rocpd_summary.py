@@ -52,8 +52,8 @@ def traffic_json(fetch_db, write_db, kernel, min_us, arenas, ticks):
     for name, path in (("FETCH_SIZE", fetch_db), ("WRITE_SIZE", write_db)):
         db = sqlite3.connect(path)
         rows = list(db.execute("select kernel_name, avg(value), max(value) from counters_collection where counter_name=? group by kernel_name", (name,)))
-        rows = [r for r in rows if kernel in str(r[0])]
-        vals[name] = rows[0][2] if rows else None   # max over dispatches = a full-length launch
+        rows = sorted((r for r in rows if kernel in str(r[0])), key=lambda r: -r[2])
+        vals[name] = rows[0][2] if rows else None   # the dominant matching kernel; max over dispatches = a full-length launch
     b = None if None in vals.values() else int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
     print(json.dumps({"arenas": arenas, "ticks_per_launch": ticks, "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
                       "hbm_bytes_per_launch": b, "note": "2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate passes"}))

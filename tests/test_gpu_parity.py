@@ -195,6 +195,35 @@ def test_full_size_rollout_parity(oracle, monkeypatch, N, T, force_w):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("kw", [dict(level=3), dict(level=3, agent_mode=1, esc_dist_rew=1), dict(level=5, ext_opp_actions=1)],
+                         ids=["L3-fight", "L3-escape", "L5-external-opponents"])
+def test_register_exchange_kernel_equals_lds_kernel(monkeypatch, kw):
+    """the two implementations of the 2-vs-2 rollout — DPP quad exchange (hh_kernels_quad.h) and LDS exchange
+    (hh_kernels.h, HH_NO_QUAD=1) — on 65536 arenas x 120 ticks: too large for the oracle in a test, so the
+    cross-check is kernel against kernel, bit for bit, outputs and final state (both W variants)"""
+    import torch
+    from hhmarl_2d_amd.world import World, make_config
+    N, T = 65536, 120
+    cfg = dict(n_arenas=N, seed=4321, auto_reset=True, **kw)
+    worlds = []
+    for no_quad, force_w in (("0", "0"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("HH_NO_QUAD", no_quad)
+        monkeypatch.setenv("HH_FORCE_W", force_w)
+        worlds.append(World(make_config(**cfg)))
+    obs0 = [w.reset() for w in worlds]
+    assert all(torch.equal(obs0[0], o) for o in obs0[1:])
+    rng = np.random.default_rng(5)
+    act = torch.from_numpy(random_actions(rng, (T, N), worlds[0].n_ctrl)).cuda()
+    outs = [w.rollout(act) for w in worlds]
+    for k, name in enumerate(("obs", "reward", "valid", "done")):
+        for o in outs[1:]:
+            assert torch.equal(outs[0][k], o[k]), name
+    states = [w.get_state() for w in worlds]
+    for st in states[1:]:
+        _assert_same_state(states[0], st, "final")
+    assert int(outs[0][3].sum()) > N // 8   # episodes ended and were re-sampled inside the launch
+
+
 @pytest.mark.parametrize("level,opp_mode", [(4, 0), (5, 1)], ids=["L4-fight-opps", "L5-escape-opps"])
 def test_split_step_parity_levels_4_5(oracle, level, opp_mode):
     """frozen-policy opponents: hh_step_begin (agents act, opponents observe) / hh_step_finish"""

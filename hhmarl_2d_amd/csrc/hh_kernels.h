@@ -78,7 +78,8 @@ struct Shared {
             int q_code[B * 8];                /* Inverse work queue: src lane | kind<<8 | slot<<10 */
             int q_count;
         } t;
-        float obs[GPB * (A / 2) * HH_OBS_HL]; /* observation staging tile (after the tick) */
+        float obs[GPB * A * 30 > GPB * (A / 2) * HH_OBS_HL ? GPB * A * 30 : GPB * (A / 2) * HH_OBS_HL]; /* observation staging tile (after the
+                                                 tick): agents' rows, or every unit's 30-float pilot row (HighLevelEnv) */
     } u;
 };
 

@@ -146,8 +146,9 @@ __device__ __forceinline__ double hl_action_assess(const DevCfg &c, const Shared
     return rew;
 }
 
-template <int A, int B>
-__global__ __launch_bounds__(B) void hh_k_hier(DevPtrs P, DevCfg c, int phase, const int8_t *__restrict__ cmd,
+/* W = resident waves per SIMD the register allocation is held to (1: no spills, for up to one wave per SIMD) */
+template <int A, int B, int W>
+__global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase, const int8_t *__restrict__ cmd,
                                                const int8_t *__restrict__ actions, float *__restrict__ pilot_obs,
                                                uint8_t *__restrict__ pilot_mode, float *__restrict__ obs_out,
                                                float *__restrict__ reward_out, uint8_t *__restrict__ valid_out,
@@ -279,26 +280,46 @@ __global__ __launch_bounds__(B) void hh_k_hier(DevPtrs P, DevCfg c, int phase, c
             pair_tables(sh, tid, base, s, active);
             __syncthreads();
         }
-        if (active) {
-            float row[HH_OBS_HL];
+        __syncthreads();
+        if (active) { /* rows of the agents staged in LDS (opponents: a scratch row past the tile's agent part, never stored) */
+            float *row = agent ? &sh.u.obs[(g * c.nA + s) * HH_OBS_HL] : &sh.u.obs[GPB * c.nA * HH_OBS_HL];
             hl_commander_obs(c, sh, tid, base, s, m, row);
-            const bool wr = phase != HH_HL_RESET || mask == nullptr || mask[n];
-            if (agent && obs_out && wr) {
-                float *dst = obs_out + ((size_t)n * c.nA + s) * HH_OBS_HL;
-                for (int k = 0; k < HH_OBS_HL; k++) dst[k] = row[k];
+        }
+        __syncthreads();
+        if (obs_out) {
+            const int arenas = min(GPB, c.N - (int)blockIdx.x * GPB);
+            const int per = c.nA * HH_OBS_HL, cnt = arenas * per;
+            float *dst = obs_out + (size_t)blockIdx.x * GPB * per;
+            for (int k = tid; k < cnt; k += B) {
+                const bool wr = phase != HH_HL_RESET || mask == nullptr || mask[blockIdx.x * GPB + k / per];
+                if (wr) dst[k] = sh.u.obs[k];
             }
         }
     }
-    /* RESET / set_state style refresh of the stored lists is done by HL_END; pilot observations: */
-    if (obs_side >= 0 && active && pilot_obs) {
-        float row[30];
-        int mode = 0;
-        bool mine = obs_side == 0 ? agent : !agent;
-        if (ar.hl_run && m.alive && mine) mode = hl_pilot_obs(c, sh, tid, base, s, m, row);
-        else for (int k = 0; k < 30; k++) row[k] = 0.0f;
-        float *dst = pilot_obs + u * 30;
-        for (int k = 0; k < 30; k++) dst[k] = row[k];
-        if (pilot_mode) pilot_mode[u] = (uint8_t)mode;
+    /* RESET / set_state style refresh of the stored lists is done by HL_END; pilot observations: every unit's row is
+     * staged in LDS (the tick's exchange area is free by now) and the workgroup's rows, contiguous in [N, A, 30], leave
+     * with unit-stride 16-byte stores */
+    if (obs_side >= 0 && pilot_obs) {
+        __syncthreads(); /* all reads of the tick's LDS area are done */
+        if (active) {
+            float *row = &sh.u.obs[tid * 30];
+            int mode = 0;
+            bool mine = obs_side == 0 ? agent : !agent;
+            if (ar.hl_run && m.alive && mine) mode = hl_pilot_obs(c, sh, tid, base, s, m, row);
+            else for (int k = 0; k < 30; k++) row[k] = 0.0f;
+            if (pilot_mode) pilot_mode[u] = (uint8_t)mode;
+        }
+        __syncthreads();
+        const int rows = min(GPB, c.N - (int)blockIdx.x * GPB) * A;
+        const int cnt = rows * 30;
+        float *dst = pilot_obs + (size_t)blockIdx.x * GPB * A * 30;
+        if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0) {
+            const float4 *src4 = reinterpret_cast<const float4 *>(sh.u.obs);
+            float4 *dst4 = reinterpret_cast<float4 *>(dst);
+            for (int k = tid; k < (cnt >> 2); k += B) dst4[k] = src4[k];
+        } else {
+            for (int k = tid; k < cnt; k += B) dst[k] = sh.u.obs[k];
+        }
     }
     if (active) {
         unit_store(P, U, u, m);

@@ -141,8 +141,13 @@ static int launch_hier(hh_world *w, int phase, const int8_t *cmd, const int8_t *
     if (w->cfg.env_kind != HH_ENV_HIGHLEVEL || c.A != 6) { g_err = "not a HighLevelEnv (3-vs-3) world"; return HH_E_ARG; }
     constexpr int B = HH_BLOCK, GPB = B / 6;
     int grid = (c.N + GPB - 1) / GPB;
-    hipLaunchKernelGGL((hh_k_hier<6, B>), dim3(grid), dim3(B), 0, st, w->P, c, phase, cmd, actions, pilot_obs, pilot_mode, obs, reward,
-                       valid, done, w->counter, mask);
+    const bool two = w->force_w == 2 || (w->force_w == 0 && grid >= 2048);
+    if (two)
+        hipLaunchKernelGGL((hh_k_hier<6, B, 2>), dim3(grid), dim3(B), 0, st, w->P, c, phase, cmd, actions, pilot_obs, pilot_mode, obs, reward,
+                           valid, done, w->counter, mask);
+    else
+        hipLaunchKernelGGL((hh_k_hier<6, B, 1>), dim3(grid), dim3(B), 0, st, w->P, c, phase, cmd, actions, pilot_obs, pilot_mode, obs, reward,
+                           valid, done, w->counter, mask);
     HIPCHK(hipGetLastError());
     return HH_OK;
 }

@@ -78,8 +78,9 @@ struct Shared {
             int q_code[B * 8];                /* Inverse work queue: src lane | kind<<8 | slot<<10 */
             int q_count;
         } t;
-        float obs[GPB * A * 30 > GPB * (A / 2) * HH_OBS_HL ? GPB * A * 30 : GPB * (A / 2) * HH_OBS_HL]; /* observation staging tile (after the
-                                                 tick): agents' rows, or every unit's 30-float pilot row (HighLevelEnv) */
+        /* observation staging tile (after the tick): agents' rows; 3-vs-3: every unit's 30-float pilot row.  Kept as small
+         * as the arena size allows — at two waves per SIMD eight workgroups share the CU's 160 KB */
+        float obs[A == 6 ? GPB * A * 30 : GPB * (A / 2) * HH_OBS_HL];
     } u;
 };
 

@@ -736,11 +736,19 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
 }
 
 /* ROLLOUT of 2-vs-2 worlds: T fused steps per launch, one wave (16 arenas) per workgroup */
-template <int W>
-__global__ __launch_bounds__(64, W) void hh_k_world_quad(DevPtrs P, DevCfg c, int T, const int8_t *__restrict__ actions,
+/* L3 = the reference's default training configuration of the level the benchmark is quoted on (config.py:17-54 with
+ * --level 3: fight mode, scripted opponents, friendly fire on, no friendly punishment, no escape shaping, glob_frac 0,
+ * rew_scale 1) compiled with those values as constants: the other configurations' code and its scalar registers drop
+ * out.  Every other configuration runs the L3 = false instance of the same source; both give the same results. */
+template <int W, bool L3>
+__global__ __launch_bounds__(64, W) void hh_k_world_quad(DevPtrs P, DevCfg c_in, int T, const int8_t *__restrict__ actions,
                                                        float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                        uint8_t *__restrict__ valid_out, uint8_t *__restrict__ done_out) {
     constexpr int A = 4, B = 64, GPB = B / A;
+    DevCfg c_l3 = c_in;
+    c_l3.level = 3; c_l3.agent_mode = HH_MODE_FIGHT; c_l3.ext_opp = 0; c_l3.friendly_kill = 1; c_l3.friendly_punish = 0;
+    c_l3.esc_dist_rew = 0; c_l3.glob_frac = 0.0; c_l3.rew_scale = 1.0; c_l3.D = HH_OBS_FIGHT_AC1; c_l3.n_ctrl = 2; c_l3.nA = 2; c_l3.nO = 2;
+    const DevCfg &c = L3 ? c_l3 : c_in;
     __shared__ Shared<A, B> sh;
     const int tid = threadIdx.x;
     const int g = tid >> 2, s = tid & 3;

@@ -206,9 +206,10 @@ def test_register_exchange_kernel_equals_lds_kernel(monkeypatch, kw):
     N, T = 65536, 120
     cfg = dict(n_arenas=N, seed=4321, auto_reset=True, **kw)
     worlds = []
-    for no_quad, force_w in (("0", "0"), ("1", "0"), ("0", "1")):
+    for no_quad, force_w, no_spec in (("0", "0", "0"), ("1", "0", "0"), ("0", "1", "0"), ("0", "0", "1"), ("0", "1", "1")):
         monkeypatch.setenv("HH_NO_QUAD", no_quad)
         monkeypatch.setenv("HH_FORCE_W", force_w)
+        monkeypatch.setenv("HH_NO_SPEC", no_spec)   # the instance compiled for the default level-3 configuration vs the general one
         worlds.append(World(make_config(**cfg)))
     obs0 = [w.reset() for w in worlds]
     assert all(torch.equal(obs0[0], o) for o in obs0[1:])

@@ -242,6 +242,11 @@ __device__ __forceinline__ void quad_lowlevel_obs(const DevCfg &c, const QTab &t
     for (; n < D; n++) out[n] = 0.0f;
 }
 
+/* ordering point between LDS accesses of ONE wave (the LDS unit executes a wave's instructions in order, so this
+ * only has to stop the compiler from moving them and to drain the counter); the two-wave kernel below cannot use
+ * __syncthreads() inside the simulation wave — that would be a workgroup barrier the output wave does not take */
+__device__ __forceinline__ void q_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 /* one fused LowLevelEnv step of the lane's arena; `tb`/`pub` hold the pre-tick table on entry and the post-tick
  * table on return.  Line-by-line counterpart of tick<4, 64>(tmode 0) in hh_kernels.h. */
 __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, int tid, int g, int s, int base, bool active, Unit &m,
@@ -524,9 +529,9 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         sh.u.t.rk_lat[tid] = rk0_lat; sh.u.t.rk_lon[tid] = rk0_lon;
         sh.res[tid] = 0;
         if (s == 0) sh.g_tkey[g] = ar.tkey;
-        __syncthreads();
+        q_wave_sync();
         drain_envelope_queue(sh, tid, q_total);
-        __syncthreads();
+        q_wave_sync();
         myres = sh.res[tid];
     }
     if (launch_pre == 1) myres |= 1;
@@ -736,28 +741,131 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
 }
 
 /* ROLLOUT of 2-vs-2 worlds: T fused steps per launch, one wave (16 arenas) per workgroup */
+/* ---- two-wave form for small worlds: a simulation wave and an output wave per 16 arenas ----
+ * Below ~16k arenas there are fewer waves than SIMDs and a tick costs the latency of one wave's dependent chains.
+ * Formatting and storing the observation / reward / done rows (16 % of that) does not feed the next tick, so a second
+ * wave of the workgroup — resident on another SIMD of the CU that would otherwise idle — takes it over: the simulation
+ * wave posts the agents' table entries into a double-buffered LDS mailbox, meets the output wave at one workgroup
+ * barrier per tick, and goes on with the next tick while the rows are built and written. */
+struct ObsMail {
+    double d[12][32];  /* dist[3] foc[3] focr[3] hd[3] of the agent's table, [field][agent row] */
+    float f[16][32];   /* others' nlat nlon nspd nhdg [3] each, own nlat nlon nspd nhdg */
+    int i[8][32];      /* fl[3], amask, own flags, 3 packed words of unit state / reward key / done */
+    float rew[32];
+};
+
+__device__ __forceinline__ void mail_post(ObsMail &mb, int r, const QTab &t, const QPub &p, const Unit &m, const StepOut &so, int done) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        mb.d[k][r] = t.dist[k]; mb.d[3 + k][r] = t.foc[k]; mb.d[6 + k][r] = t.focr[k]; mb.d[9 + k][r] = t.hd[k];
+        mb.f[k][r] = t.nlat[k]; mb.f[3 + k][r] = t.nlon[k]; mb.f[6 + k][r] = t.nspd[k]; mb.f[9 + k][r] = t.nhdg[k];
+        mb.i[k][r] = t.fl[k];
+    }
+    mb.f[12][r] = p.nlat; mb.f[13][r] = p.nlon; mb.f[14][r] = p.nspd; mb.f[15][r] = p.nhdg;
+    mb.i[3][r] = t.amask;
+    mb.i[4][r] = p.flags;
+    mb.i[5][r] = (m.cannon_remain & 0xffff) | ((m.cannon_max & 0xffff) << 16);
+    mb.i[6][r] = (m.missile_remain & 0xff) | ((m.rocket_max & 0xff) << 8) | ((m.missile_wait & 0xff) << 16) | ((m.burst & 0xff) << 24);
+    mb.i[7][r] = (m.ac_type & 0xff) | ((m.alive & 0xff) << 8) | ((m.has_missile & 0xff) << 16) | ((so.valid & 1) << 24) | ((done & 1) << 25);
+    mb.rew[r] = (float)so.reward;
+}
+
+__device__ __forceinline__ void mail_take(const ObsMail &mb, int r, QTab &t, QPub &p, Unit &m, int &valid, int &done, float &rew) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        t.dist[k] = mb.d[k][r]; t.foc[k] = mb.d[3 + k][r]; t.focr[k] = mb.d[6 + k][r]; t.hd[k] = mb.d[9 + k][r];
+        t.nlat[k] = mb.f[k][r]; t.nlon[k] = mb.f[3 + k][r]; t.nspd[k] = mb.f[6 + k][r]; t.nhdg[k] = mb.f[9 + k][r];
+        t.fl[k] = mb.i[k][r];
+        t.lat[k] = t.lon[k] = 0.0;
+    }
+    p.nlat = mb.f[12][r]; p.nlon = mb.f[13][r]; p.nspd = mb.f[14][r]; p.nhdg = mb.f[15][r];
+    p.uc = p.us = p.un = 0.0;
+    t.amask = mb.i[3][r];
+    p.flags = mb.i[4][r];
+    const int w5 = mb.i[5][r], w6 = mb.i[6][r], w7 = mb.i[7][r];
+    m = Unit{};
+    m.cannon_remain = w5 & 0xffff; m.cannon_max = (w5 >> 16) & 0xffff;
+    m.missile_remain = w6 & 0xff; m.rocket_max = (w6 >> 8) & 0xff; m.missile_wait = (w6 >> 16) & 0xff; m.burst = (w6 >> 24) & 0xff;
+    m.ac_type = w7 & 0xff; m.alive = (w7 >> 8) & 0xff; m.has_missile = (w7 >> 16) & 0xff;
+    valid = (w7 >> 24) & 1;
+    done = (w7 >> 25) & 1;
+    rew = mb.rew[r];
+}
+
+template <bool TWO> struct QuadMailbox { /* LDS of the two-wave form only */
+    ObsMail mail[2];
+    alignas(16) float tile[16 * 2 * HH_OBS_ESC_AC1];
+};
+template <> struct QuadMailbox<false> {};
+
+/* env_hetero.py:99-101: the observation also refreshes opp_to_attack; the simulation wave needs only that part */
+__device__ __forceinline__ void quad_target_refresh(const DevCfg &c, const QTab &t, int s, Unit &m) {
+    m.n_tgt = 0; m.tgt0 = 0; m.tgt_d0 = 0.0;
+    Near2 nb;
+    quad_nearby(c, t, s, nb);
+    if (m.alive && nb.n) { m.n_tgt = 1; m.tgt0 = nb.j0 + 1; m.tgt_d0 = nb.d0; }
+}
+
 /* L3 = the reference's default training configuration of the level the benchmark is quoted on (config.py:17-54 with
  * --level 3: fight mode, scripted opponents, friendly fire on, no friendly punishment, no escape shaping, glob_frac 0,
  * rew_scale 1) compiled with those values as constants: the other configurations' code and its scalar registers drop
  * out.  Every other configuration runs the L3 = false instance of the same source; both give the same results. */
-template <int W, bool L3>
-__global__ __launch_bounds__(64, W) void hh_k_world_quad(DevPtrs P, DevCfg c_in, int T, const int8_t *__restrict__ actions,
-                                                       float *__restrict__ obs_out, float *__restrict__ reward_out,
-                                                       uint8_t *__restrict__ valid_out, uint8_t *__restrict__ done_out) {
+template <int W, bool L3, bool TWO>
+__global__ __launch_bounds__(TWO ? 128 : 64, W) void hh_k_world_quad(DevPtrs P, DevCfg c_in, int T, const int8_t *__restrict__ actions,
+                                                                  float *__restrict__ obs_out, float *__restrict__ reward_out,
+                                                                  uint8_t *__restrict__ valid_out, uint8_t *__restrict__ done_out) {
     constexpr int A = 4, B = 64, GPB = B / A;
     DevCfg c_l3 = c_in;
     c_l3.level = 3; c_l3.agent_mode = HH_MODE_FIGHT; c_l3.ext_opp = 0; c_l3.friendly_kill = 1; c_l3.friendly_punish = 0;
     c_l3.esc_dist_rew = 0; c_l3.glob_frac = 0.0; c_l3.rew_scale = 1.0; c_l3.D = HH_OBS_FIGHT_AC1; c_l3.n_ctrl = 2; c_l3.nA = 2; c_l3.nO = 2;
     const DevCfg &c = L3 ? c_l3 : c_in;
     __shared__ Shared<A, B> sh;
-    const int tid = threadIdx.x;
+    __shared__ QuadMailbox<TWO> mbx;
+    const int tid = threadIdx.x & 63;
+    const int D = c.D;
+    if constexpr (TWO) {
+        if (threadIdx.x >= 64) { /* ---------------- the output wave ---------------- */
+            const int g = tid >> 1, s = tid & 1; /* lanes 0..31: one agent row each */
+            const int n = blockIdx.x * GPB + g;
+            const bool row = tid < 32 && n < c.N;
+            for (int t = 0; t < T; t++) {
+                __syncthreads(); /* mailbox t is posted */
+                const ObsMail &mb = mbx.mail[t & 1];
+                if (row) {
+                    QTab tb; QPub pub; Unit m;
+                    int valid, done; float rew;
+                    mail_take(mb, tid, tb, pub, m, valid, done, rew);
+                    quad_lowlevel_obs(c, tb, pub, s, c.agent_mode, m, &mbx.tile[tid * D], D);
+                    const size_t o = ((size_t)t * c.N + n) * 2 + s;
+                    if (reward_out) reward_out[o] = rew;
+                    if (valid_out) valid_out[o] = (uint8_t)valid;
+                    if (s == 0 && done_out) done_out[(size_t)t * c.N + n] = (uint8_t)done;
+                }
+                q_wave_sync();
+                if (obs_out) {
+                    const int rows = min(GPB, c.N - (int)blockIdx.x * GPB);
+                    const int cnt = rows * 2 * D;
+                    float *dst = obs_out + ((size_t)t * c.N + (size_t)blockIdx.x * GPB) * 2 * D;
+                    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0) {
+                        const float4 *src4 = reinterpret_cast<const float4 *>(mbx.tile);
+                        float4 *dst4 = reinterpret_cast<float4 *>(dst);
+                        for (int k = tid; k < (cnt >> 2); k += 64) dst4[k] = src4[k];
+                    } else {
+                        for (int k = tid; k < cnt; k += 64) dst[k] = mbx.tile[k];
+                    }
+                }
+                q_wave_sync(); /* the tile is free again */
+            }
+            return;
+        }
+    }
+    /* ---------------- the simulation wave (the only wave when !TWO) ---------------- */
     const int g = tid >> 2, s = tid & 3;
     const int base = g * A;
     const int n = blockIdx.x * GPB + g;
     const bool active = n < c.N;
     const size_t U = (size_t)c.N * A;
     const size_t u = (size_t)n * A + s;
-    const int D = c.D;
     HH_PROF_DECL;
     Unit m = Unit{};
     Arena ar = Arena{};
@@ -787,17 +895,21 @@ __global__ __launch_bounds__(64, W) void hh_k_world_quad(DevPtrs P, DevCfg c_in,
     const int8_t *act_ptr = has_act ? actions + ((size_t)n * c.n_ctrl + s) * 4 : actions; /* lanes without a row re-read row 0, unused */
     int act_cur = *reinterpret_cast<const int *>(act_ptr);
     int act_next = *reinterpret_cast<const int *>(act_ptr + (size_t)min(1, T - 1) * act_stride);
-    __syncthreads();
+    q_wave_sync();
     for (int t = 0; t < T; t++) {
         StepOut so;
         int8_t act[4];
         act[0] = (int8_t)(act_cur & 0xff); act[1] = (int8_t)((act_cur >> 8) & 0xff); act[2] = (int8_t)((act_cur >> 16) & 0xff); act[3] = (int8_t)((act_cur >> 24) & 0xff);
         const bool was_running = active && !ar.done;
         tick_quad(c, sh, tid, g, s, base, active, m, ar, act, tb, pub, so, evm_last HH_PROF_PASS);
+        const int done_now = ar.done;
+        if constexpr (TWO) { /* post the agents' rows as early as they exist: the LDS stores drain behind the work below */
+            if (s < 2) mail_post(mbx.mail[t & 1], g * 2 + s, tb, pub, m, so, done_now);
+        }
         asm volatile("" : "+v"(act_next)); /* take the word of tick t+1 HERE (see above) ... */
         act_cur = act_next;
         act_next = *reinterpret_cast<const int *>(act_ptr + (size_t)min(t + 2, T - 1) * act_stride); /* ... and request t+2 */
-        if (active && s < 2) {
+        if (!TWO && active && s < 2) {
             size_t o = ((size_t)t * c.N + n) * 2 + s;
             if (reward_out) reward_out[o] = (float)so.reward;
             if (valid_out) valid_out[o] = (uint8_t)so.valid;
@@ -817,7 +929,7 @@ __global__ __launch_bounds__(64, W) void hh_k_world_quad(DevPtrs P, DevCfg c_in,
                 }
             }
         }
-        if (active && s == 0 && done_out) done_out[(size_t)t * c.N + n] = (uint8_t)ar.done;
+        if (!TWO && active && s == 0 && done_out) done_out[(size_t)t * c.N + n] = (uint8_t)ar.done;
         const bool need_reset = active && ar.done && c.auto_reset;
         if (__ballot(need_reset)) { /* K3, wave-uniform */
             if (need_reset) {
@@ -827,11 +939,21 @@ __global__ __launch_bounds__(64, W) void hh_k_world_quad(DevPtrs P, DevCfg c_in,
             }
             quad_publish(c, m, pub);
             quad_tables(m, pub, s, tb);
+            if constexpr (TWO) { /* the first observation of the new episode replaces the posted rows */
+                if (s < 2) mail_post(mbx.mail[t & 1], g * 2 + s, tb, pub, m, so, done_now);
+            }
         }
         HH_PROF(9);
+        if constexpr (TWO) {
+            /* hand the agents' rows to the output wave and go on */
+            if (active && s < 2) quad_target_refresh(c, tb, s, m);
+            __syncthreads(); /* the one workgroup barrier of the tick */
+            HH_PROF(10);
+            continue;
+        }
         /* K2: observation rows staged in LDS, then written with unit-stride 16-byte stores */
         if (active && s < 2) quad_lowlevel_obs(c, tb, pub, s, c.agent_mode, m, &sh.u.obs[(g * 2 + s) * D], D);
-        __syncthreads();
+        q_wave_sync();
         if (obs_out) {
             const int rows = min(GPB, c.N - (int)blockIdx.x * GPB);
             const int cnt = rows * 2 * D;
@@ -844,7 +966,7 @@ __global__ __launch_bounds__(64, W) void hh_k_world_quad(DevPtrs P, DevCfg c_in,
                 for (int k = tid; k < cnt; k += B) dst[k] = sh.u.obs[k];
             }
         }
-        __syncthreads();
+        q_wave_sync();
         HH_PROF(10);
     }
     HH_PROF_FLUSH;
@@ -856,7 +978,7 @@ __global__ __launch_bounds__(64, W) void hh_k_world_quad(DevPtrs P, DevCfg c_in,
             P.ev_mask[n] = 0;
         }
     }
-    __syncthreads();
+    q_wave_sync();
     if (active && evm_last) atomicOr(&P.ev_mask[n], evm_last);
 }
 

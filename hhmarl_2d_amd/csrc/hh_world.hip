@@ -39,6 +39,7 @@ struct hh_world {
     int force_w;  /* 0 = choose the kernel variant by arena count, 1 / 2 = force (HH_FORCE_W, experiments/tests) */
     int no_quad;  /* HH_NO_QUAD=1: 2-vs-2 rollouts on the generic LDS-exchange kernel (A/B tests; same results) */
     int no_spec;  /* HH_NO_SPEC=1: never pick the instance compiled for the default level-3 configuration */
+    int no_two;   /* HH_NO_TWO=1: never pick the two-wave (simulation + output wave) form for small worlds */
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -84,6 +85,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     { const char *fw = getenv("HH_FORCE_W"); w->force_w = fw ? atoi(fw) : 0; }
     { const char *nq = getenv("HH_NO_QUAD"); w->no_quad = nq ? atoi(nq) : 0; }
     { const char *ns = getenv("HH_NO_SPEC"); w->no_spec = ns ? atoi(ns) : 0; }
+    { const char *nt = getenv("HH_NO_TWO"); w->no_two = nt ? atoi(nt) : 0; }
     /* one slab, 256-byte aligned sub-arrays */
     size_t U = (size_t)d.N * A, N = (size_t)d.N;
     size_t off = 0;
@@ -170,10 +172,13 @@ static int launch(hh_world *w, int run, int T, const int8_t *actions, const uint
         static_assert(B == 64, "the register-exchange kernel is one wave per workgroup");
         const bool l3 = !w->no_spec && c.level == 3 && c.agent_mode == HH_MODE_FIGHT && !c.ext_opp && c.friendly_kill == 1 && !c.friendly_punish &&
                         !c.esc_dist_rew && c.glob_frac == 0.0 && c.rew_scale == 1.0;
-        if (two && l3) hipLaunchKernelGGL((hh_k_world_quad<2, true>), dim3(grid), dim3(B), 0, st, w->P, c, T, actions, obs, reward, valid, done);
-        else if (two) hipLaunchKernelGGL((hh_k_world_quad<2, false>), dim3(grid), dim3(B), 0, st, w->P, c, T, actions, obs, reward, valid, done);
-        else if (l3) hipLaunchKernelGGL((hh_k_world_quad<1, true>), dim3(grid), dim3(B), 0, st, w->P, c, T, actions, obs, reward, valid, done);
-        else hipLaunchKernelGGL((hh_k_world_quad<1, false>), dim3(grid), dim3(B), 0, st, w->P, c, T, actions, obs, reward, valid, done);
+        /* small worlds (every workgroup resident with a SIMD pair to itself): simulation wave + output wave per 16 arenas */
+        const bool pair = !two && !w->no_two && waves <= 512; /* 128-thread groups at one wave per SIMD: 512 resident on 256 CUs */
+#define HH_QLAUNCH(Wv, L3v, TWOv) hipLaunchKernelGGL((hh_k_world_quad<Wv, L3v, TWOv>), dim3(grid), dim3(TWOv ? 128 : 64), 0, st, w->P, c, T, actions, obs, reward, valid, done)
+        if (two) { if (l3) HH_QLAUNCH(2, true, false); else HH_QLAUNCH(2, false, false); }
+        else if (pair) { if (l3) HH_QLAUNCH(1, true, true); else HH_QLAUNCH(1, false, true); }
+        else { if (l3) HH_QLAUNCH(1, true, false); else HH_QLAUNCH(1, false, false); }
+#undef HH_QLAUNCH
     } else if (run >= HH_RUN_LL_BEGIN)
         hipLaunchKernelGGL((hh_k_world<4, B, 1, true>), dim3(grid), dim3(B), 0, st, w->P, c, run, T, actions, mask, obs, reward, valid, done);
     else if (two)

@@ -210,6 +210,7 @@ def test_register_exchange_kernel_equals_lds_kernel(monkeypatch, kw):
         monkeypatch.setenv("HH_NO_QUAD", no_quad)
         monkeypatch.setenv("HH_FORCE_W", force_w)
         monkeypatch.setenv("HH_NO_SPEC", no_spec)   # the instance compiled for the default level-3 configuration vs the general one
+        monkeypatch.setenv("HH_NO_TWO", "1" if no_spec == "1" else "0")   # W=1 at this size is single-wave anyway
         worlds.append(World(make_config(**cfg)))
     obs0 = [w.reset() for w in worlds]
     assert all(torch.equal(obs0[0], o) for o in obs0[1:])
@@ -223,6 +224,38 @@ def test_register_exchange_kernel_equals_lds_kernel(monkeypatch, kw):
     for st in states[1:]:
         _assert_same_state(states[0], st, "final")
     assert int(outs[0][3].sum()) > N // 8   # episodes ended and were re-sampled inside the launch
+
+
+@pytest.mark.parametrize("kw", [dict(level=3), dict(level=3, agent_mode=1, esc_dist_rew=1, glob_frac=0.0), dict(level=1)],
+                         ids=["L3-fight", "L3-escape", "L1"])
+def test_two_wave_form_equals_single_wave(monkeypatch, kw):
+    """small worlds run a simulation wave + an output wave per 16 arenas (hh_kernels_quad.h); outputs and state must
+    equal the single-wave form and the LDS kernel bit for bit — sizes with a partial last workgroup included"""
+    import torch
+    from hhmarl_2d_amd.world import World, make_config
+    for N, T in ((4096, 330), (8189, 90), (37, 200)):
+        cfg = dict(n_arenas=N, seed=99, auto_reset=True, **kw)
+        worlds = []
+        for no_two, no_quad, no_spec in (("0", "0", "0"), ("1", "0", "0"), ("0", "0", "1"), ("1", "1", "0")):
+            monkeypatch.setenv("HH_NO_TWO", no_two)
+            monkeypatch.setenv("HH_NO_QUAD", no_quad)
+            monkeypatch.setenv("HH_NO_SPEC", no_spec)
+            monkeypatch.setenv("HH_FORCE_W", "0")
+            worlds.append(World(make_config(**cfg)))
+        obs0 = [w.reset() for w in worlds]
+        assert all(torch.equal(obs0[0], o) for o in obs0[1:])
+        rng = np.random.default_rng(N)
+        act = torch.from_numpy(random_actions(rng, (T, N), worlds[0].n_ctrl)).cuda()
+        outs = [w.rollout(act) for w in worlds]
+        for k, name in enumerate(("obs", "reward", "valid", "done")):
+            for o in outs[1:]:
+                assert torch.equal(outs[0][k], o[k]), (N, name)
+        states = [w.get_state() for w in worlds]
+        for st in states[1:]:
+            _assert_same_state(states[0], st, f"final N={N}")
+        stats = [[x.cpu() for x in w.episode_stats()] for w in worlds]
+        for st in stats[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(stats[0], st))
 
 
 @pytest.mark.parametrize("level,opp_mode", [(4, 0), (5, 1)], ids=["L4-fight-opps", "L5-escape-opps"])

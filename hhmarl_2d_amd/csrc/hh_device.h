@@ -2,17 +2,17 @@
  * hh_device.h — device-side world layout and the per-lane helpers of the gfx950 kernels.
  *
  * Thread mapping (all kernels): ONE LANE PER AIRCRAFT SLOT.  An arena with A aircraft occupies
- * A consecutive lanes ("group"); a 256-thread workgroup holds GPB = 256 / A arenas
- * (64 for 2-vs-2, 42 for 3-vs-3).  Unit u = arena * A + slot, so every per-unit array is read
+ * A consecutive lanes ("group"); a 64-lane workgroup (one wave) holds GPB = 64 / A arenas
+ * (16 for 2-vs-2, 10 for 3-vs-3).  Unit u = arena * A + slot, so every per-unit array is read
  * and written with unit-stride-1 addresses: fully coalesced 8-byte (double) and 16-byte (packed
  * ints) accesses per lane.  The rocket launched by slot s lives in rocket slot s (the reference
  * allows at most one missile in flight per aircraft: ac1.py:73).
  *
- * Everything one lane needs from the other aircraft of its arena (positions before/after the
- * move, heading unit vectors, status flags, cannon candidate masks, rocket fuse flags) is
- * exchanged through LDS arrays indexed by thread id (stride-1 -> conflict free), separated by
- * workgroup barriers.  The id-ordered kill semantics of cmano_simulator.py:142-144 are resolved
- * by one lane per arena on integer masks only.
+ * What one lane needs from the other aircraft of its arena is exchanged either through LDS arrays
+ * indexed by thread id (hh_kernels.h, any arena size) or, for 2-vs-2 where an arena is an aligned
+ * quad of lanes, through DPP quad permutes with the pair table in registers (hh_kernels_quad.h).
+ * The id-ordered kill semantics of cmano_simulator.py:142-144 are resolved on integer masks only
+ * (SURVEY.md App. A.2).
  */
 #ifndef HH_DEVICE_H
 #define HH_DEVICE_H

@@ -7,6 +7,8 @@
  *      rocket_unit.py:37-73)  ->  env_hetero.py:188-225 rewards  ->  env_hetero.py:65-103 state
  * and envs/env_base.py:62-77,551-585 reset.
  *
+ * This file is the LDS-exchange implementation (any arena size; RESET / OBSERVE / split steps / 3-vs-3, and the A/B
+ * reference of the 2-vs-2 rollout whose production form is the register-exchange kernel of hh_kernels_quad.h).
  * One persistent kernel, hh_k_world<A,B> (one lane per aircraft slot, see hh_device.h), keeps
  * the state of its arenas in registers for T ticks; per tick it runs
  *   K1 "step"    fused action decode + scripted opponents + turn/thrust kinematics + WGS84 move,

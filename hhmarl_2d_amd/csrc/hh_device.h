@@ -151,7 +151,7 @@ __device__ __forceinline__ void d_dist_bearing(double lat1, double lon1, double 
 /* The exact envelope predicates (ac1.py:72-79,135-146, rocket_unit.py:39,49) on the Karney solution.
  * Out of line: reached only for the ~1e-5 of tests the estimate filter cannot decide.
  * kind 0 missile launch, 1 cannon cone, 2/3 rocket fuse; returns 1 inside the envelope. */
-__device__ __noinline__ int d_envelope_exact(int kind, int ac_type, double la1, double lo1, double la2, double lo2, double hdg) {
+__device__ __forceinline__ int d_envelope_exact_body(int kind, int ac_type, double la1, double lo1, double la2, double lo2, double hdg) {
     double km, brg;
     d_dist_bearing(la1, lo1, la2, lo2, km, brg);
     if (kind == 0) {
@@ -166,6 +166,12 @@ __device__ __noinline__ int d_envelope_exact(int kind, int ac_type, double la1, 
         return 0;
     }
     return km < HH_ROCKET_FUSE_KM;
+}
+/* Out of line for the kernels that own a whole SIMD (the call keeps the hot loop's allocation and instruction cache
+ * footprint small).  A callee saves registers into AGPRs, which counts against the caller: kernels held to two waves per SIMD
+ * (256 registers in all) inline the body instead, where the rare path's pressure turns into spills in cold blocks only. */
+__device__ __noinline__ int d_envelope_exact(int kind, int ac_type, double la1, double lo1, double la2, double lo2, double hdg) {
+    return d_envelope_exact_body(kind, ac_type, la1, lo1, la2, lo2, hdg);
 }
 
 /* Exactness-preserving prefilter for "geodesic range < R km" tests.  Below 25 deg latitude one

@@ -381,7 +381,7 @@ struct StepOut {
 /* phase I of the tick: dense pass over the workgroup's envelope queue.  Every entry is decided by the
  * filtered exact predicate (mid-latitude estimate with proven error bounds; the Karney solution for
  * the undecided sliver) and its verdict is OR-ed into the requesting lane's result word. */
-template <int A, int B>
+template <int A, int B, bool INLINE_EXACT = false>
 __device__ __forceinline__ void drain_envelope_queue(Shared<A, B> &sh, int tid, int count) {
 #ifdef HH_ABL_NO_ENVELOPE
     count = 0;
@@ -429,7 +429,8 @@ __device__ __forceinline__ void drain_envelope_queue(Shared<A, B> &sh, int tid, 
             }
         }
 #ifndef HH_ABL_NO_EXACT
-        if (verdict < 0) verdict = d_envelope_exact(kind, t, la1, lo1, la2, lo2, hdg_src);
+        if (verdict < 0) verdict = INLINE_EXACT ? d_envelope_exact_body(kind, t, la1, lo1, la2, lo2, hdg_src)
+                                                : d_envelope_exact(kind, t, la1, lo1, la2, lo2, hdg_src);
 #endif
         int bit = 0;
         if (verdict) {
@@ -457,7 +458,7 @@ __device__ __forceinline__ int launch_planar(const Shared<A, B> &sh, int tid, in
     return hh_missile_cone_planar(la, lo, tl, to, sh.p_foc[j][tid], cross, sh.p_dist[j][tid]);
 }
 
-template <int A, int B>
+template <int A, int B, bool IX = false>
 __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid, int g, int s, int base, bool active,
                                      Unit &m, Arena &ar, const int8_t *act, StepOut &out, uint32_t &ev_mask_out,
                                      const int tmode, const bool run_arena HH_PROF_ARGS) {
@@ -741,7 +742,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
 
     HH_PROF(2);
     /* ---------------- phase I: dense pass over the queue (estimate filter + out-of-line exact Karney) ---------------- */
-    drain_envelope_queue(sh, tid, sh.u.t.q_count);
+    drain_envelope_queue<A, B, IX>(sh, tid, sh.u.t.q_count);
     __syncthreads();
 
     HH_PROF(3);
@@ -966,7 +967,7 @@ __device__ __forceinline__ int hl_target_slot(const Unit &m, double &dist) {
 /* env_base.py:214-238 _take_base_action for the lanes selected by `acts` (one side), including the missile
  * envelope test (one pass over the workgroup queue) and launch bookkeeping.  Used where pilot / frozen-policy
  * inference runs between the two sides' actions: HighLevelEnv sub-steps (hl) and LowLevelEnv levels 4-5. */
-template <int A, int B>
+template <int A, int B, bool IX = false>
 __device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int tid, int s, int base, bool active, bool running,
                                           Unit &m, Arena &ar, const int8_t *act, bool acts, bool hl, double &pre_reward,
                                           double &opp_stat0, int &valid, uint32_t &evm) {
@@ -1010,7 +1011,7 @@ __device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int
         sh.u.t.q_code[at] = tid | (0 << 8) | (launch_tgt << 10);
     }
     __syncthreads();
-    drain_envelope_queue(sh, tid, sh.u.t.q_count);
+    drain_envelope_queue<A, B, IX>(sh, tid, sh.u.t.q_count);
     __syncthreads();
     int launched = 0;
     if (try_launch && ((sh.res[tid] & 1) || launch_pre == 1)) { /* ac1.py:76-79 */
@@ -1105,7 +1106,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
             }
             double pre = 0.0, os0 = 0.0;
             int valid = 0;
-            act_phase(c, sh, tid, s, base, active, running, m, ar, act, s < c.nA, false, pre, os0, valid, evm_last);
+            act_phase<A, B, (W >= 2)>(c, sh, tid, s, base, active, running, m, ar, act, s < c.nA, false, pre, os0, valid, evm_last);
             if (active) {
                 m.cmd_act = valid;          /* reward key present (agents alive at step start) */
                 P.acc_rew[u] = pre;         /* escape-mode ammunition penalties (env_base.py:223-233) */
@@ -1150,12 +1151,12 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
                     double pre = 0.0, os0 = 0.0;
                     int vl = 0;
                     uint32_t evm_act = 0;
-                    act_phase(c, sh, tid, s, base, active, was_running, m, ar, act, s >= c.nA, false, pre, os0, vl, evm_act);
+                    act_phase<A, B, (W >= 2)>(c, sh, tid, s, base, active, was_running, m, ar, act, s >= c.nA, false, pre, os0, vl, evm_act);
                     so.reward = (active && s < c.nA) ? P.acc_rew[u] : 0.0;
                     so.valid = (active && s < c.nA) ? m.cmd_act : 0;
                     so.opp_stat0 = m.tgt_d1;
                     uint32_t evm_tick = 0;
-                    tick<A, B>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_tick, 1, was_running HH_PROF_PASS);
+                    tick<A, B, (W >= 2)>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_tick, 1, was_running HH_PROF_PASS);
                     evm_last |= evm_act | evm_tick;
                     if (was_running) {
                         int ag = 0, op = 0;
@@ -1165,10 +1166,10 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
                     }
                     if (active) { m.cmd_act = 0; m.tgt_d1 = 0.0; }
                 } else {
-                    tick<A, B>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_last, 0, true HH_PROF_PASS);
+                    tick<A, B, (W >= 2)>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_last, 0, true HH_PROF_PASS);
                 }
             } else {
-                tick<A, B>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_last, 0, true HH_PROF_PASS);
+                tick<A, B, (W >= 2)>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_last, 0, true HH_PROF_PASS);
             }
             /* outputs of this tick */
             if (active && s < c.nA) {

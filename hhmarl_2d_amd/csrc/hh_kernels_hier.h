@@ -199,7 +199,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
             int w = *reinterpret_cast<const int *>(actions + u * 4);
             act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
         }
-        { double pr = 0.0, os0 = 0.0; int vl = 0; act_phase(c, sh, tid, s, base, active, ar.hl_run != 0, m, ar, act, agent, true, pr, os0, vl, evm); }
+        { double pr = 0.0, os0 = 0.0; int vl = 0; act_phase<A, B, (W >= 2)>(c, sh, tid, s, base, active, ar.hl_run != 0, m, ar, act, agent, true, pr, os0, vl, evm); }
         obs_side = 1;
     } else if (phase == HH_HL_TICK) {
         int8_t act[4] = {0, 0, 0, 0};
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
             int w = *reinterpret_cast<const int *>(actions + u * 4);
             act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
         }
-        { double pr = 0.0, os0 = 0.0; int vl = 0; act_phase(c, sh, tid, s, base, active, ar.hl_run != 0, m, ar, act, !agent, true, pr, os0, vl, evm); }
+        { double pr = 0.0, os0 = 0.0; int vl = 0; act_phase<A, B, (W >= 2)>(c, sh, tid, s, base, active, ar.hl_run != 0, m, ar, act, !agent, true, pr, os0, vl, evm); }
         StepOut so;
         so.reward = 0.0; so.valid = 0; so.opp_stat0 = 0.0;
         const bool was_running = active && ar.hl_run;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
 #ifdef HH_PROFILE_PHASES
         unsigned long long prof_t0_ = 0, prof_acc_[12] = {0};
 #endif
-        tick<A, B>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_tick, 1, ar.hl_run != 0 HH_PROF_PASS);
+        tick<A, B, (W >= 2)>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_tick, 1, ar.hl_run != 0 HH_PROF_PASS);
         evm |= evm_tick;
         if (was_running) {
             if (agent) acc += so.reward;

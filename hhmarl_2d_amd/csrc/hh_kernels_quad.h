@@ -249,6 +249,7 @@ __device__ __forceinline__ void q_wave_sync() { asm volatile("s_waitcnt lgkmcnt(
 
 /* one fused LowLevelEnv step of the lane's arena; `tb`/`pub` hold the pre-tick table on entry and the post-tick
  * table on return.  Line-by-line counterpart of tick<4, 64>(tmode 0) in hh_kernels.h. */
+template <bool IX>
 __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, int tid, int g, int s, int base, bool active, Unit &m,
                                           Arena &ar, const int8_t *act, QTab &tb, QPub &pub, StepOut &out,
                                           uint32_t &ev_mask_out HH_PROF_ARGS) {
@@ -530,7 +531,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         sh.res[tid] = 0;
         if (s == 0) sh.g_tkey[g] = ar.tkey;
         q_wave_sync();
-        drain_envelope_queue(sh, tid, q_total);
+        drain_envelope_queue<4, 64, IX>(sh, tid, q_total);
         q_wave_sync();
         myres = sh.res[tid];
     }
@@ -811,7 +812,7 @@ __device__ __forceinline__ void quad_target_refresh(const DevCfg &c, const QTab 
  * rew_scale 1) compiled with those values as constants: the other configurations' code and its scalar registers drop
  * out.  Every other configuration runs the L3 = false instance of the same source; both give the same results. */
 template <int W, bool L3, bool TWO>
-__global__ __launch_bounds__(TWO ? 128 : 64, W) void hh_k_world_quad(DevPtrs P, DevCfg c_in, int T, const int8_t *__restrict__ actions,
+__global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_eu(W, W))) void hh_k_world_quad(DevPtrs P, DevCfg c_in, int T, const int8_t *__restrict__ actions,
                                                                   float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                                   uint8_t *__restrict__ valid_out, uint8_t *__restrict__ done_out) {
     constexpr int A = 4, B = 64, GPB = B / A;
@@ -901,7 +902,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) void hh_k_world_quad(DevPtrs P, 
         int8_t act[4];
         act[0] = (int8_t)(act_cur & 0xff); act[1] = (int8_t)((act_cur >> 8) & 0xff); act[2] = (int8_t)((act_cur >> 16) & 0xff); act[3] = (int8_t)((act_cur >> 24) & 0xff);
         const bool was_running = active && !ar.done;
-        tick_quad(c, sh, tid, g, s, base, active, m, ar, act, tb, pub, so, evm_last HH_PROF_PASS);
+        tick_quad<(W >= 2)>(c, sh, tid, g, s, base, active, m, ar, act, tb, pub, so, evm_last HH_PROF_PASS);
         const int done_now = ar.done;
         if constexpr (TWO) { /* post the agents' rows as early as they exist: the LDS stores drain behind the work below */
             if (s < 2) mail_post(mbx.mail[t & 1], g * 2 + s, tb, pub, m, so, done_now);

@@ -229,56 +229,59 @@ HH_HD void hh_geo_direct(double lat1, double lon1, double azi1, double s12, doub
 #define HH_GEO_SHORT_MAX_LAT 70.0
 
 HH_HD void hh_geo_direct_short(double lat1, double lon1, double azi1, double s12, double *lat2, double *lon2) {
-    const double E2 = HH_GEO_E2, K1 = 1.0 / (1.0 - HH_GEO_E2), TH = 1.0 / 3.0;
+    const double E2 = HH_GEO_E2, K1 = 1.0 / (1.0 - HH_GEO_E2), TH = 1.0 / 3.0, M2E2 = -2.0 * HH_GEO_E2;
     double S0, C0, Sa0, Ca0;
     hh_sincosd_small(lat1, &S0, &C0);
     hh_sincosd_small(azi1, &Sa0, &Ca0);
     const double h = s12 * (1.0 / HH_GEO_A);
-    const double U0 = 1.0 - E2 * S0 * S0;
+    const double U0 = hh_fma(-E2 * S0, S0, 1.0);
     const double W0 = hh_sqrt(U0);
     const double iC = 1.0 / C0, hW = 0.5 / W0;
     const double Q0 = W0 * iC, P0 = W0 * U0 * K1;
+    /* every Cauchy sum below is one multiply followed by fused multiply-adds (hh_fma on both sides of the parity) */
     /* order 1 */
     const double f1 = Ca0 * P0;
     const double SS0 = Sa0 * S0;
     const double a1 = SS0 * Q0;
     const double l1 = Sa0 * Q0;
     const double S1 = C0 * f1, C1 = -S0 * f1, Sa1 = Ca0 * a1, Ca1 = -Sa0 * a1;
-    const double U1 = -E2 * (2.0 * S0 * S1);
+    const double U1 = (M2E2 * S0) * S1;
     const double W1 = U1 * hW;
-    const double Q1 = (W1 - C1 * Q0) * iC;
-    const double P1 = (W0 * U1 + W1 * U0) * K1;
-    /* order 2 */
-    const double f2 = 0.5 * (Ca0 * P1 + Ca1 * P0);
-    const double SS1 = Sa0 * S1 + Sa1 * S0;
-    const double a2 = 0.5 * (SS0 * Q1 + SS1 * Q0);
-    const double l2 = 0.5 * (Sa0 * Q1 + Sa1 * Q0);
-    const double S2 = 0.5 * (C0 * (2.0 * f2) + C1 * f1), C2 = -0.5 * (S0 * (2.0 * f2) + S1 * f1);
-    const double Sa2 = 0.5 * (Ca0 * (2.0 * a2) + Ca1 * a1), Ca2 = -0.5 * (Sa0 * (2.0 * a2) + Sa1 * a1);
-    const double U2 = -E2 * (2.0 * S0 * S2 + S1 * S1);
-    const double W2 = (U2 - W1 * W1) * hW;
-    const double Q2 = (W2 - C1 * Q1 - C2 * Q0) * iC;
-    const double P2 = (W0 * U2 + W1 * U1 + W2 * U0) * K1;
-    /* order 3 */
-    const double f3 = TH * (Ca0 * P2 + Ca1 * P1 + Ca2 * P0);
-    const double SS2 = Sa0 * S2 + Sa1 * S1 + Sa2 * S0;
-    const double a3 = TH * (SS0 * Q2 + SS1 * Q1 + SS2 * Q0);
-    const double l3 = TH * (Sa0 * Q2 + Sa1 * Q1 + Sa2 * Q0);
-    const double S3 = TH * (C0 * (3.0 * f3) + C1 * (2.0 * f2) + C2 * f1);
-    const double C3 = -TH * (S0 * (3.0 * f3) + S1 * (2.0 * f2) + S2 * f1);
-    const double Sa3 = TH * (Ca0 * (3.0 * a3) + Ca1 * (2.0 * a2) + Ca2 * a1);
-    const double Ca3 = -TH * (Sa0 * (3.0 * a3) + Sa1 * (2.0 * a2) + Sa2 * a1);
-    const double U3 = -E2 * (2.0 * S0 * S3 + 2.0 * S1 * S2);
-    const double W3 = (U3 - 2.0 * W1 * W2) * hW;
-    const double Q3 = (W3 - C1 * Q2 - C2 * Q1 - C3 * Q0) * iC;
-    const double P3 = (W0 * U3 + W1 * U2 + W2 * U1 + W3 * U0) * K1;
+    const double Q1 = hh_fma(-C1, Q0, W1) * iC;
+    const double P1 = hh_fma(W0, U1, W1 * U0) * K1;
+    /* order 2: g2 = 2 f2, h2 = 2 a2 */
+    const double g2 = hh_fma(Ca0, P1, Ca1 * P0);
+    const double f2 = 0.5 * g2;
+    const double SS1 = hh_fma(Sa0, S1, Sa1 * S0);
+    const double h2 = hh_fma(SS0, Q1, SS1 * Q0);
+    const double l2 = 0.5 * hh_fma(Sa0, Q1, Sa1 * Q0);
+    const double S2 = 0.5 * hh_fma(C0, g2, C1 * f1), C2 = -0.5 * hh_fma(S0, g2, S1 * f1);
+    const double Sa2 = 0.5 * hh_fma(Ca0, h2, Ca1 * a1), Ca2 = -0.5 * hh_fma(Sa0, h2, Sa1 * a1);
+    const double U2 = -E2 * hh_fma(2.0 * S0, S2, S1 * S1);
+    const double W2 = hh_fma(-W1, W1, U2) * hW;
+    const double Q2 = hh_fma(-C2, Q0, hh_fma(-C1, Q1, W2)) * iC;
+    const double P2 = hh_fma(W0, U2, hh_fma(W1, U1, W2 * U0)) * K1;
+    /* order 3: g3 = 3 f3, h3 = 3 a3 */
+    const double g3 = hh_fma(Ca0, P2, hh_fma(Ca1, P1, Ca2 * P0));
+    const double f3 = TH * g3;
+    const double SS2 = hh_fma(Sa0, S2, hh_fma(Sa1, S1, Sa2 * S0));
+    const double h3 = hh_fma(SS0, Q2, hh_fma(SS1, Q1, SS2 * Q0));
+    const double l3 = TH * hh_fma(Sa0, Q2, hh_fma(Sa1, Q1, Sa2 * Q0));
+    const double S3 = TH * hh_fma(C0, g3, hh_fma(C1, g2, C2 * f1));
+    const double C3 = -TH * hh_fma(S0, g3, hh_fma(S1, g2, S2 * f1));
+    const double Sa3 = TH * hh_fma(Ca0, h3, hh_fma(Ca1, h2, Ca2 * a1));
+    const double Ca3 = -TH * hh_fma(Sa0, h3, hh_fma(Sa1, h2, Sa2 * a1));
+    const double U3 = M2E2 * hh_fma(S0, S3, S1 * S2);
+    const double W3 = hh_fma(-2.0 * W1, W2, U3) * hW;
+    const double Q3 = hh_fma(-C3, Q0, hh_fma(-C2, Q1, hh_fma(-C1, Q2, W3))) * iC;
+    const double P3 = hh_fma(W0, U3, hh_fma(W1, U2, hh_fma(W2, U1, W3 * U0))) * K1;
     /* order 4 */
-    const double f4 = 0.25 * (Ca0 * P3 + Ca1 * P2 + Ca2 * P1 + Ca3 * P0);
-    const double l4 = 0.25 * (Sa0 * Q3 + Sa1 * Q2 + Sa2 * Q1 + Sa3 * Q0);
-    const double dphi = h * (f1 + h * (f2 + h * (f3 + h * f4)));
-    const double dlam = h * (l1 + h * (l2 + h * (l3 + h * l4)));
-    *lat2 = lat1 + dphi * HH_RAD2DEG;
-    *lon2 = lon1 + dlam * HH_RAD2DEG;
+    const double f4 = 0.25 * hh_fma(Ca0, P3, hh_fma(Ca1, P2, hh_fma(Ca2, P1, Ca3 * P0)));
+    const double l4 = 0.25 * hh_fma(Sa0, Q3, hh_fma(Sa1, Q2, hh_fma(Sa2, Q1, Sa3 * Q0)));
+    const double dphi = h * hh_fma(h, hh_fma(h, hh_fma(h, f4, f3), f2), f1);
+    const double dlam = h * hh_fma(h, hh_fma(h, hh_fma(h, l4, l3), l2), l1);
+    *lat2 = hh_fma(dphi, HH_RAD2DEG, lat1);
+    *lon2 = hh_fma(dlam, HH_RAD2DEG, lon1);
 }
 
 /* position update used by the simulator tick (cmano_simulator.py:65-72) */

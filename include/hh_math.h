@@ -111,10 +111,12 @@ HH_HD double hh_ksin(double x, double y) {
                  S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
                  S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
     double z = x * x;
-    double w = z * z;
-    double r = S2 + z * (S3 + z * S4) + z * w * (S5 + z * S6);
+    double r = hh_fma(z, hh_fma(z, hh_fma(z, hh_fma(z, S6, S5), S4), S3), S2);
     double v = z * x;
-    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+    /* x - ((z*(y/2 - v*r) - y) - v*S1), every product-sum as one fused operation */
+    double t = hh_fma(-v, r, 0.5 * y);
+    double u = hh_fma(z, t, -y);
+    return x - hh_fma(-v, S1, u);
 }
 
 HH_HD double hh_kcos(double x, double y) {
@@ -122,11 +124,10 @@ HH_HD double hh_kcos(double x, double y) {
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
     double z = x * x;
-    double w = z * z;
-    double r = z * (C1 + z * (C2 + z * C3)) + (w * w) * (C4 + z * (C5 + z * C6));
+    double r = z * hh_fma(z, hh_fma(z, hh_fma(z, hh_fma(z, hh_fma(z, C6, C5), C4), C3), C2), C1);
     double hz = 0.5 * z;
-    w = 1.0 - hz;
-    return w + (((1.0 - w) - hz) + (z * r - x * y));
+    double w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + hh_fma(z, r, -(x * y)));
 }
 
 /* sin and cos of x radians, |x| < ~1e5 (two-term Cody-Waite reduction by pi/2) */
@@ -193,42 +194,34 @@ HH_HD double hh_atan2(double y, double x) {
 }
 
 /* ---- acos ---- */
-HH_HD double hh_acos_R(double z) {
-    const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01,
-                 pS2 = 2.01212532134862925881e-01, pS3 = -4.00555345006794114027e-02,
-                 pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
-                 qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00,
-                 qS3 = -6.88283971605453293030e-01, qS4 = 7.70381505559019352791e-02;
-    double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-    double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-    return p / q;
-}
-
+/* acos(a) = sqrt(1 - a) * P(2a - 1) on [0, 1] (acos(x)/sqrt(1-x) is analytic there; degree-19 interpolant, truncation
+ * 3e-17 relative, coefficients from tools/gen_acos_coeffs.py), acos(-a) = pi - acos(a).  One square root and 21 fused
+ * multiply-adds in two independent Horner chains (even / odd powers): no division, straight-line, and 1 - a is exact for
+ * a >= 1/2, so small angles keep their relative accuracy.  Within 2 ulp of the correctly rounded value (tests/test_math.py). */
 HH_HD double hh_acos(double x) /* |x| <= 1 */ {
-    const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
-    double ax = hh_fabs(x);
-    const int edge = ax >= 1.0; /* |x| = 1 (callers clip): handled by a select so the routine stays straight-line */
-    if (edge) ax = 1.0;
-    /* the three classic ranges (|x| < 0.5, x <= -0.5, x >= 0.5) share one evaluation of the rational
-     * R and one square root; only the final assembly differs, so lanes of a wave do not diverge */
-    int small = ax < 0.5;
-    double z = small ? x * x : (1.0 - ax) * 0.5;
-    double r = hh_acos_R(z);
-    double s = hh_sqrt(z);
-    /* |x| < 0.5 */
-    double res_small = PIO2_HI - (x - (PIO2_LO - x * r));
-    res_small = ax < 0x1p-57 ? PIO2_HI + PIO2_LO : res_small;
-    /* x <= -0.5 */
-    double res_neg = HH_PI - 2.0 * (s + (r * s - PIO2_LO));
-    /* x >= 0.5: df = s with the low 32 bits cleared */
-    union { double d; uint64_t u; } cv;
-    cv.d = s;
-    cv.u &= 0xffffffff00000000ULL;
-    double df = cv.d;
-    double c = (z - df * df) / (s + df);
-    double res_pos = 2.0 * (df + (r * s + c));
-    double res = small ? res_small : (x < 0.0 ? res_neg : res_pos);
-    return edge ? (x > 0.0 ? 0.0 : HH_PI + 2.0 * PIO2_LO) : res;
+    const double P0 = 1.48096097938612203e+00, P1 = -7.60160912346649897e-02, P2 = 1.10293133179791107e-02,
+                 P3 = -2.14913585901438647e-03, P4 = 4.82054100561475694e-04, P5 = -1.17412504152359799e-04,
+                 P6 = 3.01871701458175376e-05, P7 = -8.06353963468094371e-06, P8 = 2.21601896416617581e-06,
+                 P9 = -6.22532301137391218e-07, P10 = 1.77975683093472170e-07, P11 = -5.16095474235324628e-08,
+                 P12 = 1.51278938015423088e-08, P13 = -4.48328265569854430e-09, P14 = 1.36250811190112031e-09,
+                 P15 = -4.10493165700480771e-10, P16 = 1.05376345601740400e-10, P17 = -3.20146929819632065e-11,
+                 P18 = 1.87618285989296095e-11, P19 = -5.79529090405995285e-12;
+    const double PI_LO = 1.22464679914735317723e-16; /* pi - HH_PI */
+    double a = hh_fabs(x);
+    a = a > 1.0 ? 1.0 : a; /* callers clip; keeps the root real */
+    const double t = hh_fma(2.0, a, -1.0);
+    const double t2 = t * t;
+    double pe = hh_fma(t2, P18, P16), po = hh_fma(t2, P19, P17);
+    pe = hh_fma(t2, pe, P14); po = hh_fma(t2, po, P15);
+    pe = hh_fma(t2, pe, P12); po = hh_fma(t2, po, P13);
+    pe = hh_fma(t2, pe, P10); po = hh_fma(t2, po, P11);
+    pe = hh_fma(t2, pe, P8); po = hh_fma(t2, po, P9);
+    pe = hh_fma(t2, pe, P6); po = hh_fma(t2, po, P7);
+    pe = hh_fma(t2, pe, P4); po = hh_fma(t2, po, P5);
+    pe = hh_fma(t2, pe, P2); po = hh_fma(t2, po, P3);
+    pe = hh_fma(t2, pe, P0); po = hh_fma(t2, po, P1);
+    const double r = hh_sqrt(1.0 - a) * hh_fma(t, po, pe);
+    return x < 0.0 ? (HH_PI - r) + PI_LO : r;
 }
 
 /* ---- degree helpers used by the geodesic layer (Karney 2013, Sec. 6 implementation notes:

@@ -955,12 +955,17 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
 
 /* index into the stored target list like Python: commander_actions[i]-1, with -1 = last */
 __device__ __forceinline__ int hl_target_slot(const Unit &m, double &dist) {
-    int k = m.cmd_act > 0 ? m.cmd_act - 1 : m.n_tgt - 1;
+    /* fields are read into values first: a select between the addresses of struct members would keep the whole Unit in
+     * scratch memory instead of registers */
+    const int n_tgt = m.n_tgt, t0 = m.tgt0, t1 = m.tgt1, t2 = m.tgt2;
+    const double d0 = m.tgt_d0, d1 = m.tgt_d1, d2 = m.tgt_d2;
+    int k = m.cmd_act > 0 ? m.cmd_act - 1 : n_tgt - 1;
     int t = 0;
-    dist = 0.0;
-    if (k == 0 && m.n_tgt > 0) { t = m.tgt0; dist = m.tgt_d0; }
-    else if (k == 1 && m.n_tgt > 1) { t = m.tgt1; dist = m.tgt_d1; }
-    else if (k == 2 && m.n_tgt > 2) { t = m.tgt2; dist = m.tgt_d2; }
+    double d = 0.0;
+    if (k == 0 && n_tgt > 0) { t = t0; d = d0; }
+    if (k == 1 && n_tgt > 1) { t = t1; d = d1; }
+    if (k == 2 && n_tgt > 2) { t = t2; d = d2; }
+    dist = d;
     return t; /* 1-based unit id, 0 = none */
 }
 
@@ -1113,15 +1118,20 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
                 m.tgt_d1 = os0;             /* tgt_d1 is unused by LowLevelEnv: carries opp_stats[i][0] to LL_FINISH */
             }
             /* observation of the frozen-policy opponents, after the agents acted (shot flags refreshed by act_phase) */
+            __syncthreads(); /* the queue area of act_phase is free: stage the rows there, store them coalesced */
             if (active && s >= c.nA) {
-                float row[30];
+                float *row = &sh.u.obs[(g * c.nO + (s - c.nA)) * 30];
                 if (running && m.alive) lowlevel_obs<A, B>(c, sh, tid, base, s, opp_mode, m, row, 30);
                 else for (int q = 0; q < 30; q++) row[q] = 0.0f;
-                if (obs_out) {
-                    float *dst = obs_out + ((size_t)n * c.nO + (s - c.nA)) * 30;
-                    for (int q = 0; q < 30; q++) dst[q] = row[q];
-                }
             }
+            __syncthreads();
+            if (obs_out) {
+                const int rows = min(GPB, c.N - (int)blockIdx.x * GPB);
+                const int cnt = rows * c.nO * 30;
+                float *dst = obs_out + (size_t)blockIdx.x * GPB * c.nO * 30;
+                for (int q = tid; q < cnt; q += B) dst[q] = sh.u.obs[q];
+            }
+            __syncthreads();
             T = 0; /* no tick in this launch */
         } else if (run == HH_RUN_LL_FINISH) {
             T = 1;

@@ -36,12 +36,15 @@ __device__ __forceinline__ int hl_pilot_obs(const DevCfg &c, const Shared<A, B> 
     out[n++] = sh.nspd[tid];
     out[n++] = sh.nhdg[tid];
     int mode;
-    if (m.cmd_act != 0) { /* fight the commander-chosen target, with the stale stored distance */
+    /* the stored list by value (a select between member addresses would pin the Unit in scratch memory) */
+    const int cmd_act = m.cmd_act, n_tgt = m.n_tgt, t0 = m.tgt0, t1 = m.tgt1, t2 = m.tgt2;
+    const double d0 = m.tgt_d0, d1 = m.tgt_d1, d2 = m.tgt_d2;
+    if (cmd_act != 0) { /* fight the commander-chosen target, with the stale stored distance */
         mode = 1;
-        double dist = m.tgt_d0;
-        int oj = m.tgt0 - 1;
-        if (m.cmd_act == 2) { dist = m.tgt_d1; oj = m.tgt1 - 1; }
-        else if (m.cmd_act >= 3) { dist = m.tgt_d2; oj = m.tgt2 - 1; }
+        double dist = d0;
+        int oj = t0 - 1;
+        if (cmd_act == 2) { dist = d1; oj = t1 - 1; }
+        if (cmd_act >= 3) { dist = d2; oj = t2 - 1; }
         out[n++] = (float)norm180(sh.p_foc[oj][tid]);
         out[n++] = (float)aspect(sh.p_foc[s][base + oj]);
         out[n++] = (float)sh.p_hd[oj][tid];
@@ -60,8 +63,8 @@ __device__ __forceinline__ int hl_pilot_obs(const DevCfg &c, const Shared<A, B> 
         out[n++] = (float)hh_clip((double)m.cannon_remain / (double)m.cannon_max, 0.0, 1.0);
         if (m.ac_type == 1) out[n++] = (float)hh_clip((double)m.missile_remain / (double)m.rocket_max, 0.0, 1.0);
         out[n++] = (sh.flags[tid] & FL_SHOT) ? 1.0f : 0.0f;
-        if (m.n_tgt >= 1) opp_block(c, sh, 1, tid, base, s, m.tgt0 - 1, m.tgt_d0, out + n);
-        if (m.n_tgt >= 2) opp_block(c, sh, 1, tid, base, s, m.tgt1 - 1, m.tgt_d1, out + n + 9);
+        if (n_tgt >= 1) opp_block(c, sh, 1, tid, base, s, t0 - 1, d0, out + n);
+        if (n_tgt >= 2) opp_block(c, sh, 1, tid, base, s, t1 - 1, d1, out + n + 9);
         n += 18;
     }
     if (fr.n) friend_block(c, sh, tid, base, s, fr.i0, out + n);
@@ -115,8 +118,9 @@ __device__ __forceinline__ double hl_action_assess(const DevCfg &c, const Shared
     if (s < c.nA) {
         int cc = cmd;
         if (cc > 0) {
+            const int t0 = m.tgt0, t1 = m.tgt1, t2 = m.tgt2; /* by value: see hl_target_slot */
             int opp = 0;
-            if (cc - 1 < m.n_tgt) opp = cc == 1 ? m.tgt0 : (cc == 2 ? m.tgt1 : m.tgt2);
+            if (cc - 1 < m.n_tgt) { opp = t2; if (cc == 2) opp = t1; if (cc == 1) opp = t0; }
             else cc = 1;
             if (!opp) rew = -0.1;
             if (c.hier_action_assess && opp) {

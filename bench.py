@@ -81,7 +81,8 @@ def main():
     ap.add_argument("--workload", choices=["low", "hier"], default="low",
                     help="low: BASELINE configs[1] (default, the headline).  hier: configs[3], 3-vs-3 HighLevelEnv commander "
                          "steps (use --arenas 8192); a step is one commander step = 16 sub-steps with pilot actions")
-    ap.add_argument("--pilot", choices=["random", "mlp"], default="random", help="hier: uniform action tape or random-init MLP pilots")
+    ap.add_argument("--pilot", choices=["tape", "random", "mlp"], default="tape",
+                    help="hier: uniform actions from a pre-resident tape (default), drawn by torch kernels inside the step, or random-init MLP pilots")
     ap.add_argument("--no-graph", action="store_true", help="hier: launch the macro step eagerly instead of replaying a HIP graph")
     args = ap.parse_args()
     if args.workload == "hier":
@@ -186,6 +187,10 @@ def main():
         dist.destroy_process_group()
 
 
+PILOT_DESC = {"tape": "uniform action tape resident in HBM", "random": "uniform actions drawn by torch kernels inside the step",
+              "mlp": "random-init MLP fight/escape nets"}
+
+
 def main_hier(args):
     """BASELINE configs[3]/[4]: N arenas x 3-vs-3 HighLevelEnv (map 0.5, horizon 500, N_OPP_HL=2), commander
     actions uniform {0,1,2}; pilots = uniform actions (default) or random-init MLPs evaluated on the same GPU."""
@@ -196,13 +201,16 @@ def main_hier(args):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from hhmarl_2d_amd.env_hier import macro_step
-    from hhmarl_2d_amd.pilots import MLPPilot, RandomPilot
+    from hhmarl_2d_amd.pilots import MLPPilot, RandomPilot, TapePilot
     from hhmarl_2d_amd.sharding import ShardedWorld
     N = args.arenas
     sw = ShardedWorld(dict(n_arenas=N, env_kind=1, seed=args.seed, auto_reset=True), rank=rank, world_size=world, device=local_rank)
     w = sw.world
     w.reset()
-    pilot = RandomPilot(dev, args.seed + rank) if args.pilot == "random" else MLPPilot(dev, seed=args.seed)
+    if args.pilot == "tape":
+        pilot = TapePilot(dev, N, 6, seed=args.seed + rank)
+    else:
+        pilot = RandomPilot(dev, args.seed + rank) if args.pilot == "random" else MLPPilot(dev, seed=args.seed)
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed + 17 + rank)
     steps, warm = args.steps, args.warmup
@@ -226,6 +234,8 @@ def main_hier(args):
 
     def run(n):
         for k in range(n):
+            if args.pilot == "tape":
+                pilot.load(k)
             if graph is not None:
                 cmd_static.copy_(cmds[k % 64])
                 graph.replay()
@@ -260,11 +270,11 @@ def main_hier(args):
         "warmup": warm, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic", "agent_steps_per_s": value * 3, "sim_ticks_per_s": value * 16,
         "config": {"workload": f"{N} arenas/GPU x 3-vs-3 HighLevelEnv commander steps (16 sub-steps each), uniform commander actions, "
-                               f"pilots = {'uniform action tape' if args.pilot == 'random' else 'random-init MLP fight/escape nets'}, "
+                               f"pilots = {PILOT_DESC[args.pilot]}, "
                                f"auto-reset (BASELINE configs[3])", "arenas_per_gpu": N,
                    "parallelism": f"arena-sharded x{world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "hh_k_hier<6,256> (all phases of the macro step, incl. pilot action generation)",
+                     "traffic": None, "kernel": "hh_k_hier<6,64> (all 34 phase launches of the macro step, plus the pilots' kernels if any)",
                      "algorithmic_bytes_per_step": ALGO_BYTES_3V3_CMD_STEP * N},
     }
     if rank == 0:

@@ -28,7 +28,8 @@ def macro_step(world, commander_actions, pilot, out=None, pilot_buf=None, early_
         act = pilot(po, pm).contiguous()
         po, pm = world.hl_agents_act(act, pilot_buf)
         act_o = pilot(po, pm)
-        act[:, nA:] = act_o[:, nA:]
+        if act_o.data_ptr() != act.data_ptr():
+            act[:, nA:] = act_o[:, nA:]
         po, pm, running = world.hl_tick(act, pilot_buf, count_running=early_exit)
         if early_exit and running == 0:
             break

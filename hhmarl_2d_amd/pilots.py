@@ -20,6 +20,30 @@ class RandomPilot:
         return (torch.rand((n, a, 4), device=pilot_obs.device) * self.hi).to(torch.int8)
 
 
+class TapePilot:
+    """uniform actions from a tape that is resident in HBM before the step starts (the way bench.py feeds LowLevelEnv):
+    `bank` holds `chunks` x `depth` sub-steps of int8 actions [N, A, 4]; `load(k)` copies chunk k into the static buffer the
+    calls hand out, one slice per sub-step (the agents' call and the opponents' call of a sub-step get the same tensor —
+    each side's rows are read by its own launch).  No kernel runs inside the macro step."""
+
+    def __init__(self, device, n_arenas, n_units, seed=0, depth=16, chunks=4):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        hi = torch.tensor([13, 9, 2, 2], device=device)
+        self.bank = (torch.rand((chunks, depth, n_arenas, n_units, 4), device=device, generator=g) * hi).to(torch.int8).contiguous()
+        self.static = self.bank[0].clone()
+        self.depth, self.calls = depth, 0
+
+    def load(self, k):
+        self.static.copy_(self.bank[k % self.bank.shape[0]])
+        self.calls = 0
+
+    def __call__(self, pilot_obs, pilot_mode):
+        act = self.static[(self.calls // 2) % self.depth]
+        self.calls += 1
+        return act
+
+
 class MLPPilot(torch.nn.Module):
     """randomly initialised fight / escape networks with the reference's I/O shapes (obs 30 padded ->
     logits 13+9+2+2, models/ac_models_hetero.py), greedy arg-max decode; batched over all units"""

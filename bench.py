@@ -162,7 +162,7 @@ def main():
         pass
 
     value = N * world * args.steps / dt
-    two = os.environ.get("HH_FORCE_W") == "2" or (os.environ.get("HH_FORCE_W") in (None, "", "0") and (N + 15) // 16 >= 2048)
+    two = os.environ.get("HH_FORCE_W") == "2" or (os.environ.get("HH_FORCE_W") in (None, "", "0") and (N + 15) // 16 > 1024)
     pair = not two and os.environ.get("HH_NO_TWO") != "1" and (N + 15) // 16 <= 512
     kname = ("hh_k_world<4,64,%d,false>" % (2 if two else 1)) if os.environ.get("HH_NO_QUAD") == "1" else \
         "hh_k_world_quad<W=%d,%s>" % (2 if two else 1, "simulation wave + output wave" if pair else "single wave")

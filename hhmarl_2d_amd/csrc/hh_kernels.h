@@ -1059,7 +1059,7 @@ enum { HH_RUN_ROLLOUT = 0, HH_RUN_RESET = 1, HH_RUN_OBSERVE = 2, HH_RUN_LL_BEGIN
 
 /* W = waves per SIMD the register allocation is held to: 1 = no spills, lowest per-tick latency (few arenas);
  * 2 = 256 registers per lane, spills to scratch but two resident waves per SIMD: +35 % throughput once there
- * are more than ~2 waves per SIMD to run (>= 32768 arenas).  Same source, same results. */
+ * are more waves than SIMDs (> 16384 arenas).  Same source, same results. */
 /* SPLIT adds the two half-step run modes of LowLevelEnv levels 4-5 (frozen opponent policies, env_hetero.py:160-172):
  *   LL_BEGIN   steps += 1, agents' _take_base_action          -> observations of the opponents [N, n_opps, 30] in obs_out
  *   LL_FINISH  opponents' _take_base_action, then the tick, rewards, done, reset, agents' observation like ROLLOUT (T = 1)

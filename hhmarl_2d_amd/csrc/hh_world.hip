@@ -145,7 +145,7 @@ static int launch_hier(hh_world *w, int phase, const int8_t *cmd, const int8_t *
     if (w->cfg.env_kind != HH_ENV_HIGHLEVEL || c.A != 6) { g_err = "not a HighLevelEnv (3-vs-3) world"; return HH_E_ARG; }
     constexpr int B = HH_BLOCK, GPB = B / 6;
     int grid = (c.N + GPB - 1) / GPB;
-    const bool two = w->force_w == 2 || (w->force_w == 0 && grid >= 2048);
+    const bool two = w->force_w == 2 || (w->force_w == 0 && grid > 1024);
     if (two)
         hipLaunchKernelGGL((hh_k_hier<6, B, 2>), dim3(grid), dim3(B), 0, st, w->P, c, phase, cmd, actions, pilot_obs, pilot_mode, obs, reward,
                            valid, done, w->counter, mask);
@@ -167,7 +167,7 @@ static int launch(hh_world *w, int run, int T, const int8_t *actions, const uint
     constexpr int B = HH_BLOCK, GPB = B / 4;
     const int grid = (c.N + GPB - 1) / GPB;
     const int waves = grid * (B / 64);
-    const bool two = w->force_w == 2 || (w->force_w == 0 && waves >= 2048);
+    const bool two = w->force_w == 2 || (w->force_w == 0 && waves > 1024); /* more waves than SIMDs: hold two per SIMD */
     if (run == HH_RUN_ROLLOUT && !w->no_quad) {
         static_assert(B == 64, "the register-exchange kernel is one wave per workgroup");
         const bool l3 = !w->no_spec && c.level == 3 && c.agent_mode == HH_MODE_FIGHT && !c.ext_opp && c.friendly_kill == 1 && !c.friendly_punish &&

@@ -458,6 +458,18 @@ __device__ __forceinline__ int launch_planar(const Shared<A, B> &sh, int tid, in
     return hh_missile_cone_planar(la, lo, tl, to, sh.p_foc[j][tid], cross, sh.p_dist[j][tid]);
 }
 
+/* the same stage when no pair table has been built for the published state: the one entry it needs, computed on demand
+ * (HighLevelEnv's HL_TICK launch: only the few opponents that try a launch pay for it instead of every lane for the table) */
+template <int A, int B>
+__device__ __forceinline__ int launch_planar_direct(const Shared<A, B> &sh, int tid, int base, int j) {
+    const double la = sh.lat0[tid], lo = sh.lon0[tid], tl = sh.lat0[base + j], to = sh.lon0[base + j];
+    const double c1 = sh.uc[tid], s1 = sh.us[tid], n1 = sh.un[tid];
+    const double dx = to - lo, dy = tl - la;
+    const double n2 = hh_sqrt(dx * dx + dy * dy);
+    const double x = hh_clip((c1 * dx + s1 * dy) / (n1 * n2 + 1e-10), -1.0, 1.0);
+    return hh_missile_cone_planar(la, lo, tl, to, hh_acos(x) * (180.0 / HH_PI), c1 * dy - s1 * dx, n2);
+}
+
 template <int A, int B, bool IX = false>
 __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid, int g, int s, int base, bool active,
                                      Unit &m, Arena &ar, const int8_t *act, StepOut &out, uint32_t &ev_mask_out,
@@ -972,7 +984,7 @@ __device__ __forceinline__ int hl_target_slot(const Unit &m, double &dist) {
 /* env_base.py:214-238 _take_base_action for the lanes selected by `acts` (one side), including the missile
  * envelope test (one pass over the workgroup queue) and launch bookkeeping.  Used where pilot / frozen-policy
  * inference runs between the two sides' actions: HighLevelEnv sub-steps (hl) and LowLevelEnv levels 4-5. */
-template <int A, int B, bool IX = false>
+template <int A, int B, bool IX = false, bool TAB = true>
 __device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int tid, int s, int base, bool active, bool running,
                                           Unit &m, Arena &ar, const int8_t *act, bool acts, bool hl, double &pre_reward,
                                           double &opp_stat0, int &valid, uint32_t &evm) {
@@ -1010,7 +1022,7 @@ __device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int
     sh.res[tid] = 0;
     if (tid == 0) sh.u.t.q_count = 0;
     __syncthreads();
-    const int launch_pre = try_launch ? launch_planar(sh, tid, base, launch_tgt) : -1;
+    const int launch_pre = !try_launch ? -1 : (TAB ? launch_planar(sh, tid, base, launch_tgt) : launch_planar_direct(sh, tid, base, launch_tgt));
     if (try_launch && launch_pre < 0) {
         int at = atomicAdd(&sh.u.t.q_count, 1);
         sh.u.t.q_code[at] = tid | (0 << 8) | (launch_tgt << 10);

@@ -183,8 +183,10 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
     uint32_t evm = 0;
     publish_obs(c, sh, tid, m);
     __syncthreads();
-    pair_tables(sh, tid, base, s, active);
-    __syncthreads();
+    if (phase != HH_HL_TICK) { /* HL_TICK builds its table after the tick; before it only a launch test may ask for an entry */
+        pair_tables(sh, tid, base, s, active);
+        __syncthreads();
+    }
     int obs_side = -1; /* which side's pilot observations this launch emits */
 
     if (phase == HH_HL_BEGIN) {
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
             int w = *reinterpret_cast<const int *>(actions + u * 4);
             act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
         }
-        { double pr = 0.0, os0 = 0.0; int vl = 0; act_phase<A, B, (W >= 2)>(c, sh, tid, s, base, active, ar.hl_run != 0, m, ar, act, !agent, true, pr, os0, vl, evm); }
+        { double pr = 0.0, os0 = 0.0; int vl = 0; act_phase<A, B, (W >= 2), false>(c, sh, tid, s, base, active, ar.hl_run != 0, m, ar, act, !agent, true, pr, os0, vl, evm); }
         StepOut so;
         so.reward = 0.0; so.valid = 0; so.opp_stat0 = 0.0;
         const bool was_running = active && ar.hl_run;

@@ -78,15 +78,19 @@ def main():
     ap.add_argument("--chunk", type=int, default=250, help="ticks per persistent-kernel launch")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["low", "hier"], default="low",
-                    help="low: BASELINE configs[1] (default, the headline).  hier: configs[3], 3-vs-3 HighLevelEnv commander "
-                         "steps (use --arenas 8192); a step is one commander step = 16 sub-steps with pilot actions")
+    ap.add_argument("--workload", choices=["low", "rollout", "hier"], default="low",
+                    help="low: BASELINE configs[1] (default, the headline).  rollout: configs[2], every tick a random-init fight policy "
+                         "(batched torch MLP on the same GPU) maps the observations to the next actions (use --arenas 16384).  hier: "
+                         "configs[3], 3-vs-3 HighLevelEnv commander steps (use --arenas 8192); a step is one commander step = 16 "
+                         "sub-steps with pilot actions")
     ap.add_argument("--pilot", choices=["tape", "random", "mlp"], default="tape",
                     help="hier: uniform actions from a pre-resident tape (default), drawn by torch kernels inside the step, or random-init MLP pilots")
     ap.add_argument("--no-graph", action="store_true", help="hier: launch the macro step eagerly instead of replaying a HIP graph")
     args = ap.parse_args()
     if args.workload == "hier":
         return main_hier(args)
+    if args.workload == "rollout":
+        return main_policy_rollout(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -181,6 +185,86 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(N, args.level, args.seed)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def main_policy_rollout(args):
+    """BASELINE configs[2]: N arenas x 2-vs-2 fight L3 driven by a policy in the loop — per tick: observations [N, 2, 26]
+    -> randomly initialised fight network (26 -> 200 -> 200 -> 13+9+2+2 logits, greedy decode as env_base.py:373-382 does)
+    -> hh_step.  The policy is the caller's side of the boundary (PyTorch / rocBLAS); policy + step are captured once into a
+    HIP graph and replayed per tick."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = init_dist(rank, local_rank, world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from hhmarl_2d_amd.sharding import ShardedWorld
+    N = args.arenas
+    sw = ShardedWorld(dict(n_arenas=N, level=args.level, seed=args.seed, auto_reset=True), rank=rank, world_size=world, device=local_rank)
+    w = sw.world
+    obs = w.reset()
+    g = torch.Generator().manual_seed(args.seed)
+    net = torch.nn.Sequential(torch.nn.Linear(26, 200), torch.nn.Tanh(), torch.nn.Linear(200, 200), torch.nn.Tanh(), torch.nn.Linear(200, 26))
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * 0.3)
+    net = net.to(dev)
+    out = w.alloc_outputs()
+    out[0].copy_(obs)
+    act = torch.zeros((N, 2, 4), dtype=torch.int8, device=dev)
+
+    @torch.no_grad()
+    def tick():
+        logits = net(out[0].reshape(N * 2, 26))
+        parts = logits.split((13, 9, 2, 2), dim=1)
+        act.copy_(torch.stack([p_.argmax(dim=1) for p_ in parts], dim=1).to(torch.int8).reshape(N, 2, 4))
+        w.step(act, out=out)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            tick()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        tick()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        graph.replay()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        graph.replay()
+        if k % 256 == 255:
+            sw.log_episode_stats()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = N * world * args.steps / dt
+    achieved = ALGO_BYTES_2V2_STEP * N * args.steps / dt / 1e9
+    line = {
+        "metric": "env-steps/sec (2v2, policy in the loop)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic", "agent_steps_per_s": value * 2,
+        "config": {"workload": f"{N} arenas/GPU x 2-vs-2 fight L{args.level}, actions from a random-init fight policy (fp32 MLP 26-200-200-26 "
+                               f"in PyTorch, greedy decode) evaluated every tick on the same GPU, auto-reset (BASELINE configs[2])",
+                   "arenas_per_gpu": N, "ticks_per_launch": 1, "parallelism": f"arena-sharded x{world}, no data-path collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "hh_k_world_quad (T = 1 per launch) + the policy's rocBLAS / elementwise kernels, one HIP graph per tick"},
+    }
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -304,3 +304,30 @@ def test_frozen_opponent_traces_on_gpu(path):
         assert np.array_equal(v[0], g["valid"][r]) and d[0] == g["done"][r], f"row {r}"
         assert np.abs(st["ac_f"][0] - g["ac_f"][r]).max() <= 1e-9 and np.abs(o[0] - g["obs"][r]).max() <= 1e-6, f"row {r}"
         assert np.abs(rw[0] - g["reward"][r]).max() <= 1e-6 * max(1.0, np.abs(g["reward"][r]).max()), f"row {r}"
+
+
+def test_error_codes_instead_of_exceptions():
+    """the C-ABI reports misuse through negative status codes and hh_last_error (include/hh_abi.h), never by crashing"""
+    import ctypes as C
+    import torch
+    from hhmarl_2d_amd import _lib as L
+    from hhmarl_2d_amd.world import World, make_config
+    lib = L.lib()
+    h = C.c_void_p()
+    for bad in (make_config(n_arenas=0), make_config(n_arenas=8, n_agents=3, n_opps=1), make_config(n_arenas=8, level=4)):
+        assert lib.hh_world_create(C.byref(bad), 0, C.byref(h)) == -1 and lib.hh_last_error()   # HH_E_ARG
+    assert lib.hh_world_create(C.byref(make_config(n_arenas=8)), 99, C.byref(h)) == -1                # no such device
+    ll = World(make_config(n_arenas=8, level=1))
+    hl = World(make_config(n_arenas=8, env_kind=1))
+    act = torch.zeros((8, 6, 4), dtype=torch.int8, device="cuda")
+    po, pm = hl.alloc_pilot()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.hh_step(hl.h, p(act), None, None, None, None, None) == -1          # HighLevelEnv steps through hh_hl_*
+    assert lib.hh_hl_agents_act(ll.h, p(act), p(po), p(pm), None) == -1           # ... and a 2-vs-2 world does not
+    assert lib.hh_step_begin(ll.h, p(act), 0, None, None) == -1                   # split step needs ext_opp_actions
+    assert lib.hh_rollout(ll.h, 0, p(act), None, None, None, None, None) == -1    # n_steps <= 0
+    assert lib.hh_step(ll.h, None, None, None, None, None, None) == -1            # null actions
+    with pytest.raises(RuntimeError):
+        L.check(lib.hh_step(ll.h, None, None, None, None, None, None))
+    ll.reset()
+    ll.step(torch.zeros((8, 2, 4), dtype=torch.int8, device="cuda"))              # the worlds are still usable

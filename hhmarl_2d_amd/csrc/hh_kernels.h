@@ -57,12 +57,13 @@ template <int A, int B>
 struct Shared {
     static constexpr int GPB = B / A;
     /* published unit state: pre-tick while a tick runs, refreshed after it */
-    double lat0[B], lon0[B], hdg[B], spd[B];
+    double lat0[B], lon0[B], hdg[B];
     double uc[B], us[B], un[B]; /* heading unit vector (env_base.py:428) and its norm */
     /* pair tables, [slot j][lane]: from the lane's aircraft towards slot j of its arena */
     double p_dist[A][B]; /* planar distance in degrees (env_base.py:434-439, un-normalised) */
     double p_foc[A][B];  /* focus angle [deg] at the lane's aircraft towards j (env_base.py:424-432) */
-    double p_hd[A][B];   /* normalised angle between heading vectors (env_base.py:448-456), symmetric */
+    float p_hd[A][B];    /* normalised angle between heading vectors (env_base.py:448-456), symmetric; read only into the
+                            float32 observation, so it is kept in that precision (the same value a later cast would give) */
     float nlat[B], nlon[B], nspd[B], nhdg[B]; /* observation entries every observer of this aircraft shares:
                                                  relative position, speed and heading normalised (env_base.py:117-121) */
     double rew[B];
@@ -82,7 +83,7 @@ struct Shared {
         } t;
         /* observation staging tile (after the tick): agents' rows; 3-vs-3: every unit's 30-float pilot row.  Kept as small
          * as the arena size allows — at two waves per SIMD eight workgroups share the CU's 160 KB */
-        float obs[A == 6 ? GPB * A * 30 : GPB * (A / 2) * HH_OBS_HL];
+        float obs[GPB * (A / 2) * HH_OBS_HL]; /* 3-vs-3: also the acting side's 30-float pilot rows (GPB * 3 * 30) */
     } u;
 };
 
@@ -104,7 +105,6 @@ __device__ __forceinline__ void publish_hv(Shared<A, B> &sh, int tid, const Unit
     sh.lat0[tid] = m.lat;
     sh.lon0[tid] = m.lon;
     sh.hdg[tid] = m.hdg;
-    sh.spd[tid] = m.spd;
     sh.uc[tid] = c;
     sh.us[tid] = s;
     sh.un[tid] = hh_sqrt(c * c + s * s);
@@ -178,8 +178,8 @@ __device__ __forceinline__ void pair_tables(Shared<A, B> &sh, int tid, int base,
     for (int k = 1; k <= A / 2; k++) {
         int j = s + k;
         if (j >= A) j -= A;
-        sh.p_hd[j][tid] = hd[k - 1];
-        sh.p_hd[s][base + j] = hd[k - 1];
+        sh.p_hd[j][tid] = (float)hd[k - 1];
+        sh.p_hd[s][base + j] = (float)hd[k - 1];
     }
 }
 
@@ -294,7 +294,7 @@ __device__ __forceinline__ int opp_block(const DevCfg &c, const Shared<A, B> &sh
     out[n++] = sh.nlon[o];
     out[n++] = sh.nspd[o];
     out[n++] = sh.nhdg[o];
-    out[n++] = (float)sh.p_hd[oj][tid];
+    out[n++] = sh.p_hd[oj][tid];
     if (mode == 0) {
         out[n++] = (float)norm180(f_os);
         out[n++] = (float)aspect(f_so);
@@ -348,7 +348,7 @@ __device__ __forceinline__ void lowlevel_obs(const DevCfg &c, const Shared<A, B>
         const int oj = nb.i0;
         out[n++] = (float)norm180(sh.p_foc[oj][tid]);
         out[n++] = (float)aspect(sh.p_foc[s][base + oj]);
-        out[n++] = (float)sh.p_hd[oj][tid];
+        out[n++] = sh.p_hd[oj][tid];
         out[n++] = (float)nb.d0;
         out[n++] = (float)hh_clip((double)m.cannon_remain / (double)m.cannon_max, 0.0, 1.0);
         if (m.ac_type == 1) {

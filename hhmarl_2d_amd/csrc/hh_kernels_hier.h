@@ -47,7 +47,7 @@ __device__ __forceinline__ int hl_pilot_obs(const DevCfg &c, const Shared<A, B> 
         if (cmd_act >= 3) { dist = d2; oj = t2 - 1; }
         out[n++] = (float)norm180(sh.p_foc[oj][tid]);
         out[n++] = (float)aspect(sh.p_foc[s][base + oj]);
-        out[n++] = (float)sh.p_hd[oj][tid];
+        out[n++] = sh.p_hd[oj][tid];
         out[n++] = (float)dist;
         out[n++] = (float)hh_clip((double)m.cannon_remain / (double)m.cannon_max, 0.0, 1.0);
         if (m.ac_type == 1) {
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
                                                const uint8_t *__restrict__ mask) {
     constexpr int GPB = B / A;
     __shared__ Shared<A, B> sh;
+    __shared__ alignas(16) float ptile[W == 1 ? GPB * A * 30 : 4]; /* every unit's pilot row (W = 1 only, see below) */
     const int tid = threadIdx.x;
     const int g = tid / A, s = tid % A;
     const int base = g * A;
@@ -287,8 +288,8 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
             __syncthreads();
         }
         __syncthreads();
-        if (active) { /* rows of the agents staged in LDS (opponents: a scratch row past the tile's agent part, never stored) */
-            float *row = agent ? &sh.u.obs[(g * c.nA + s) * HH_OBS_HL] : &sh.u.obs[GPB * c.nA * HH_OBS_HL];
+        if (active) { /* rows of the agents staged in LDS (opponents only refresh their stored target lists: nothing is written) */
+            float *row = agent ? &sh.u.obs[(g * c.nA + s) * HH_OBS_HL] : &sh.u.obs[0];
             hl_commander_obs(c, sh, tid, base, s, m, row);
         }
         __syncthreads();
@@ -307,24 +308,61 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
      * with unit-stride 16-byte stores */
     if (obs_side >= 0 && pilot_obs) {
         __syncthreads(); /* all reads of the tick's LDS area are done */
-        if (active) {
-            float *row = &sh.u.obs[tid * 30];
-            int mode = 0;
-            bool mine = obs_side == 0 ? agent : !agent;
-            if (ar.hl_run && m.alive && mine) mode = hl_pilot_obs(c, sh, tid, base, s, m, row);
-            else for (int k = 0; k < 30; k++) row[k] = 0.0f;
-            if (pilot_mode) pilot_mode[u] = (uint8_t)mode;
-        }
-        __syncthreads();
-        const int rows = min(GPB, c.N - (int)blockIdx.x * GPB) * A;
-        const int cnt = rows * 30;
-        float *dst = pilot_obs + (size_t)blockIdx.x * GPB * A * 30;
-        if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0) {
-            const float4 *src4 = reinterpret_cast<const float4 *>(sh.u.obs);
-            float4 *dst4 = reinterpret_cast<float4 *>(dst);
-            for (int k = tid; k < (cnt >> 2); k += B) dst4[k] = src4[k];
+        constexpr int HALF = A / 2; /* units per side */
+        const bool mine = obs_side == 0 ? agent : !agent;
+        const int arenas = min(GPB, c.N - (int)blockIdx.x * GPB);
+        float *dst = pilot_obs + (size_t)blockIdx.x * GPB * A * 30; /* the workgroup's rows are contiguous in [N, A, 30] */
+        if constexpr (W == 1) {
+            /* a workgroup per SIMD: LDS is plentiful, every unit stages its row (zeros for the side that does not act) and
+             * the tile leaves with 16-byte stores */
+            if (active) {
+                float *row = &ptile[tid * 30];
+                int mode = 0;
+                if (ar.hl_run && m.alive && mine) mode = hl_pilot_obs(c, sh, tid, base, s, m, row);
+                else for (int k = 0; k < 30; k++) row[k] = 0.0f;
+                if (pilot_mode) pilot_mode[u] = (uint8_t)mode;
+            }
+            __syncthreads();
+            const int cnt = arenas * A * 30;
+            if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0) {
+                const float4 *src4 = reinterpret_cast<const float4 *>(ptile);
+                float4 *dst4 = reinterpret_cast<float4 *>(dst);
+                for (int k = tid; k < (cnt >> 2); k += B) dst4[k] = src4[k];
+            } else {
+                for (int k = tid; k < cnt; k += B) dst[k] = ptile[k];
+            }
         } else {
-            for (int k = tid; k < cnt; k += B) dst[k] = sh.u.obs[k];
+            /* two workgroups per SIMD share the CU's 160 KB: only the acting side's rows are staged (in the tick's exchange
+             * area), the other side's zeros are produced by the store loop; 8-byte stores (a side's 90 floats are even) */
+            if (active) {
+                int mode = 0;
+                if (mine) {
+                    float *row = &sh.u.obs[(g * HALF + (s % HALF)) * 30];
+                    if (ar.hl_run && m.alive) mode = hl_pilot_obs(c, sh, tid, base, s, m, row);
+                    else for (int k = 0; k < 30; k++) row[k] = 0.0f;
+                }
+                if (pilot_mode) pilot_mode[u] = (uint8_t)mode;
+            }
+            __syncthreads();
+            const int cnt2 = arenas * A * 15; /* float2 elements */
+            const float2 *src2 = reinterpret_cast<const float2 *>(sh.u.obs);
+            if ((reinterpret_cast<uintptr_t>(dst) & 7) == 0) {
+                float2 *dst2 = reinterpret_cast<float2 *>(dst);
+                static_assert(B < A * 15, "index update below assumes one wrap per step");
+                int ar_ = 0, r = tid; /* arena, float2 index inside its A rows; advanced without divisions */
+                for (int k = tid; k < cnt2; k += B) {
+                    const int side = r >= HALF * 15, q = r - side * (HALF * 15);
+                    dst2[k] = side == obs_side ? src2[ar_ * (HALF * 15) + q] : make_float2(0.0f, 0.0f);
+                    r += B;
+                    if (r >= A * 15) { r -= A * 15; ar_ += 1; }
+                }
+            } else {
+                for (int k = tid; k < cnt2 * 2; k += B) {
+                    const int ar_ = k / (A * 30), r = k - ar_ * (A * 30);
+                    const int side = r / (HALF * 30), q = r - side * (HALF * 30);
+                    dst[k] = side == obs_side ? sh.u.obs[ar_ * (HALF * 30) + q] : 0.0f;
+                }
+            }
         }
     }
     if (active) {

@@ -2,37 +2,168 @@
 """bench.py — env-steps/s of the MI355X air-combat world on BASELINE.json's configs[1]:
 4096 arenas x 2-vs-2 fight level 3 (scripted opponent), random actions, auto-reset.
 
-A "step" is one pass of the hot path over one batch: every arena takes one LowLevelEnv.step()
-(action decode, scripted opponents, do_tick, rewards, done, observation, auto-reset), with the
-action tape and all outputs resident in HBM.  Steps are issued in chunks of --chunk ticks per
-persistent-kernel launch (hh_rollout); every tick writes its obs/reward/done rows.
+One *step* of `--steps` / `--warmup` is ONE pass of the hot path over one batch of synthetic input = one
+`hh_rollout` launch of the persistent kernel: every arena takes `--chunk` (250) consecutive
+LowLevelEnv.step() calls (action decode, scripted opponents, do_tick, rewards, done, observation,
+auto-reset), action tape and all outputs resident in HBM, every tick's obs/reward/done rows written.
+`value` = arenas x chunk x steps x ranks / wall time = env-steps/s (LowLevelEnv.step() calls per second).
 
-    python bench.py                     # 1 GPU
+    python bench.py                      # 1 GPU
+    python bench.py --gpus 8             # spawns 8 ranks itself (torch.distributed.run, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # what the driver does
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM, the
-algorithmic bytes of SURVEY.md §8d over the measured kernel time) and `cpu_baseline` (the CPU
-oracle = a C port of the reference path, timed on this box's host cores on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM: the algorithmic
+bytes of SURVEY.md §8d over the kernel time measured with HIP events; plus the FP64-issue fraction, which
+is the bound this kernel actually sits on) and `cpu_baseline` (the CPU oracle = a C port of the reference
+path timed live on this box's host cores, plus the reference's own Python rate measured in the build
+container and committed under profiles/).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_2V2_STEP = 1113   # SURVEY.md §8(d): state r/w 2*448 + actions 8 + obs 200 + reward 8 + done 1
-ALGO_BYTES_3V3_CMD_STEP = 27600  # SURVEY.md §8(d): 13.2 ticks x 2056 B + commander obs 408 + actions/rewards/done
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+ALGO_BYTES_2V2_STEP = 1113       # SURVEY.md §8(d): state r/w 2*448 + actions 8 + obs 200 + reward 8 + done 1
+ALGO_BYTES_3V3_TICK = 2056       # SURVEY.md §8(d): 656 + 656 + pilot obs 720 + pilot actions 24
+ALGO_BYTES_3V3_CMD_FIXED = 424   # commander obs 408 + actions 3 + rewards 12 + done 1
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+FP64_ISSUE_PEAK = 3.93e13        # lane-operations/s: 78.6 TFLOP/s vector FP64 / 2 flop per FMA (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz)
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40, help="timed launches (one step = one launch of --chunk ticks over all arenas)")
+    ap.add_argument("--warmup", type=int, default=8, help="untimed launches after the clock spin-up")
+    ap.add_argument("--arenas", type=int, default=None, help="arenas per GPU (configs[1]: 4096; rollout: 16384; hier: 8192)")
+    ap.add_argument("--level", type=int, default=3)
+    ap.add_argument("--chunk", type=int, default=250, help="ticks per persistent-kernel launch (= per step)")
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--spinup", type=float, default=0.6, help="seconds of untimed launches before the warm-up (GPU clocks ramp from idle)")
+    ap.add_argument("--log-every", type=int, default=8, help="launches between logging all-gathers of episode statistics (side stream)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU plumbing check of the multi-rank path (gloo, no world, no kernel): ranks, barriers, max-over-ranks, gather")
+    ap.add_argument("--workload", choices=["low", "rollout", "hier"], default="low",
+                    help="low: BASELINE configs[1] (default, the headline).  rollout: configs[2], every tick a fight policy with the "
+                         "reference's Fight1/Fight2 architecture maps the observations to the next actions (--arenas 16384).  hier: "
+                         "configs[3], 3-vs-3 HighLevelEnv commander steps (--arenas 8192); a step is one commander step")
+    ap.add_argument("--pilot", choices=["tape", "random", "mlp", "net"], default="tape",
+                    help="hier: uniform actions from a pre-resident tape (default), drawn by torch kernels inside the step, random-init "
+                         "MLP stand-ins in torch, or the reference's Fight/Esc architectures in the fused HIP kernel (net)")
+    ap.add_argument("--no-graph", action="store_true", help="hier/rollout: launch eagerly instead of replaying a HIP graph")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------ multi-rank plumbing
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one process per GPU
+    (the reference's analogue is num_rollout_workers, train_hetero.py:212).  Rank 0 of the child job prints the line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+class Ranks:
+    """RANK / LOCAL_RANK / WORLD_SIZE from the launcher; RCCL ("nccl") on GPUs, gloo for --dry-run"""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dry = args.dry_run
+        self.dist = None
+        if not self.dry:
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device("cuda", self.local_rank)
+        else:
+            self.dev = torch.device("cpu")
+        if "RANK" in os.environ:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            if self.dry:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        if not self.dry:
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], device=self.dev, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_floats(self, x):
+        if self.dist is None:
+            return [x]
+        t = self.torch.tensor([x], device=self.dev, dtype=self.torch.float64)
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+class DryWorld:
+    """--dry-run stand-in: no arenas, no kernel — only so that the rank plumbing above can be exercised on a box without
+    GPUs (tests/test_bench_launcher.py).  Its line is marked "dry_run": true and measures nothing."""
+
+    def __init__(self, kw):
+        import torch
+        self.N, self.n_ctrl, self.n_agents, self.D, self.device = kw["n_arenas"], 2, 2, 26, torch.device("cpu")
+        self.offset = kw["arena_offset"]
+
+    def reset(self):
+        return None
+
+    def alloc_outputs(self, T=None):
+        return (None, None, None, None)
+
+    def rollout(self, act, out=None):
+        time.sleep(0.002)
+
+    def kernel_name(self):
+        return "none (dry run)"
+
+    def episode_stats(self):
+        import torch
+        ids = torch.arange(self.N, dtype=torch.float32) + self.offset
+        return ids, ids.to(torch.int32), torch.ones(self.N, dtype=torch.int8)
+
+
+# ------------------------------------------------------------------------------------------------ baselines / evidence files
 def cpu_baseline(n_arenas, level, seed, budget_s=12.0):
-    """The oracle (plain-C port of the reference path, OpenMP over arenas) on the host cores.
+    """The oracle (plain-C port of the reference path; one OpenMP team, arena-outer / tick-inner) on the host cores.
     Test infrastructure used only as a reported baseline, never as the measured product."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
@@ -41,267 +172,250 @@ def cpu_baseline(n_arenas, level, seed, budget_s=12.0):
     w = O.OracleWorld(O.make_config(n_arenas=n_arenas, level=level, seed=seed, auto_reset=True))
     w.reset()
     rng = np.random.default_rng(seed)
-    T = 25
+    T = 50
     act = np.zeros((T, n_arenas, w.n_ctrl, 4), dtype=np.int8)
     act[..., 0] = rng.integers(0, 13, act.shape[:-1]); act[..., 1] = rng.integers(0, 9, act.shape[:-1])
     act[..., 2] = rng.integers(0, 2, act.shape[:-1]); act[..., 3] = rng.integers(0, 2, act.shape[:-1])
-    w.rollout(act[:2])  # warm
+    w.rollout(act[:4])  # warm
     steps = 0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
         w.rollout(act)
         steps += T
     dt = time.perf_counter() - t0
-    return {"value": n_arenas * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n_arenas} arenas x {steps} ticks, same config/seed/action distribution, OpenMP over arenas"}
+    out = {"value": n_arenas * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{n_arenas} arenas x {steps} ticks, same config/seed/action distribution, one OpenMP team, arenas outer / ticks inner"}
+    ref = load_json("reference_cpu_rate.json")
+    if ref:
+        out["reference_python"] = {
+            "value": ref["env_steps_per_s"].get(f"lowlevel_2v2_L{level}"), "unit": "env-steps/s", "cores": 1,
+            "kind": "the reference's own Python path, measured in the build container (it cannot travel to the GPU box)",
+            "where": ref.get("where"), "source": "profiles/reference_cpu_rate.json (oracle/time_reference.py)"}
+    return out
 
 
-def init_dist(rank, local_rank, world):
-    """one process per GPU over RCCL (backend "nccl" is RCCL on ROCm) whenever launched by torch.distributed.run"""
-    if "RANK" not in os.environ:
+def load_json(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
         return None
-    import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29500")
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    return dist
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10000)
-    ap.add_argument("--warmup", type=int, default=1000)
-    ap.add_argument("--arenas", type=int, default=4096, help="arenas per GPU (configs[1]: 4096)")
-    ap.add_argument("--level", type=int, default=3)
-    ap.add_argument("--chunk", type=int, default=250, help="ticks per persistent-kernel launch")
-    ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["low", "rollout", "hier"], default="low",
-                    help="low: BASELINE configs[1] (default, the headline).  rollout: configs[2], every tick a random-init fight policy "
-                         "(batched torch MLP on the same GPU) maps the observations to the next actions (use --arenas 16384).  hier: "
-                         "configs[3], 3-vs-3 HighLevelEnv commander steps (use --arenas 8192); a step is one commander step = 16 "
-                         "sub-steps with pilot actions")
-    ap.add_argument("--pilot", choices=["tape", "random", "mlp"], default="tape",
-                    help="hier: uniform actions from a pre-resident tape (default), drawn by torch kernels inside the step, or random-init MLP pilots")
-    ap.add_argument("--no-graph", action="store_true", help="hier: launch the macro step eagerly instead of replaying a HIP graph")
-    args = ap.parse_args()
-    if args.workload == "hier":
-        return main_hier(args)
-    if args.workload == "rollout":
-        return main_policy_rollout(args)
+def counter_evidence(kernel, n_arenas, ticks, units_per_s_per_gpu, arenas_per_wave):
+    """HBM bytes and instruction counts per launch from the PMC passes of a separate rocprofv3 run of this same command
+    (tools/prof_pmc.sh -> profiles/latest_traffic.json, profiles/latest_pmc.json; counters cannot be read from inside the
+    process).  Stored per arena-tick / per wave-tick, so they apply to any --chunk of the same kernel instance."""
+    traffic, fp64 = None, None
+    tj = load_json("latest_traffic.json")
+    if tj and tj.get("arenas") == n_arenas and tj.get("hbm_bytes_per_launch"):
+        per = tj.get("hbm_bytes_per_arena_tick") or tj["hbm_bytes_per_launch"] / (tj["arenas"] * tj["ticks_per_launch"])
+        traffic = int(per * n_arenas * ticks)
+    pj = load_json("latest_pmc.json")
+    if pj and pj.get("arenas") == n_arenas:
+        valu = pj["insts_valu_per_wave_tick"]
+        lane_ops = valu * 64.0 / arenas_per_wave * units_per_s_per_gpu   # every VALU instruction counted as one issue slot per lane
+        fp64 = {"bound": "fp64 valu issue", "insts_valu_per_wave_tick": valu, "insts_salu_per_wave_tick": pj.get("insts_salu_per_wave_tick"),
+                "achieved_lane_ops_s": lane_ops, "peak": FP64_ISSUE_PEAK, "unit": "lane-ops/s", "frac": lane_ops / FP64_ISSUE_PEAK,
+                "source": pj.get("source", "profiles/latest_pmc.json")}
+    return traffic, fp64
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = init_dist(rank, local_rank, world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
+# ------------------------------------------------------------------------------------------------ configs[1]: the headline
+def main_low(args):
+    R = Ranks(args)
+    torch = R.torch
     from hhmarl_2d_amd.sharding import ShardedWorld
-    N = args.arenas
-    sw = ShardedWorld(dict(n_arenas=N, level=args.level, seed=args.seed, auto_reset=True), rank=rank, world_size=world,
-                      device=local_rank)
+    N = args.arenas or 4096
+    chunk = max(1, args.chunk)
+    sw = ShardedWorld(dict(n_arenas=N, level=args.level, seed=args.seed, auto_reset=True), rank=R.rank, world_size=R.world,
+                      device=R.local_rank, world_factory=DryWorld if R.dry else None)
     w = sw.world
     w.reset()
-    chunk = max(1, min(args.chunk, args.steps))
-    # action tape resident in HBM before the timed region: i.i.d. uniform MultiDiscrete([13,9,2,2])
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(args.seed + rank)
+    tape, out, side = None, w.alloc_outputs(chunk), None
     n_tape = 4  # distinct chunks of actions, cycled
-    hi = torch.tensor([13, 9, 2, 2], device=dev)
-    tape = (torch.rand((n_tape, chunk, N, w.n_ctrl, 4), device=dev, generator=gen) * hi).to(torch.int8).contiguous()
-    out = w.alloc_outputs(chunk)
+    if not R.dry:
+        # action tape resident in HBM before the timed region: i.i.d. uniform MultiDiscrete([13,9,2,2])
+        gen = torch.Generator(device=R.dev)
+        gen.manual_seed(args.seed + R.rank)
+        hi = torch.tensor([13, 9, 2, 2], device=R.dev)
+        tape = (torch.rand((n_tape, chunk, N, w.n_ctrl, 4), device=R.dev, generator=gen) * hi).to(torch.int8).contiguous()
+        side = torch.cuda.Stream()
+    state = {"k": 0}
 
-    def run(n_steps, timed):
-        done_steps, launches, k = 0, 0, 0
-        evs = []
-        while done_steps < n_steps:
-            T = min(chunk, n_steps - done_steps)
-            if timed:
-                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-            w.rollout(tape[k % n_tape][:T], out=tuple(o[:T] for o in out))
-            if timed:
-                e1.record()
-                evs.append((e0, e1, T))
-            sw.log_episode_stats()   # RCCL all-gather of episode returns (logging only)
-            done_steps += T
-            launches += 1
-            k += 1
-        return evs
+    def launch(timed_events=None):
+        k = state["k"]
+        if timed_events is not None and not R.dry:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        w.rollout(None if R.dry else tape[k % n_tape], out=out)
+        if timed_events is not None and not R.dry:
+            e1.record()
+            timed_events.append((e0, e1))
+        state["k"] = k + 1
+        if state["k"] % args.log_every == 0:
+            sw.log_episode_stats(side)   # logging only: snapshot = one small launch, RCCL all-gather on the side stream
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup and not R.dry:   # clocks ramp up from idle: not part of W or K
+        launch()
         torch.cuda.synchronize()
-
-    run(args.warmup, False)
-    barrier()
+    for _ in range(args.warmup):
+        launch()
+    R.barrier()
+    evs = []
     t0 = time.perf_counter()
-    evs = run(args.steps, True)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    for _ in range(args.steps):
+        launch(evs)
+    R.barrier()
+    dt_local = time.perf_counter() - t0
+    dt = R.max_over_ranks(dt_local)
+    sw.log_episode_stats(side)
+    R.barrier()
+    per_rank = R.gather_floats(N * chunk * args.steps / dt_local)
 
-    # dominant kernel: average launch duration from HIP events on the launch stream
-    full = [(a.elapsed_time(b) * 1e-3, T) for a, b, T in evs if T == chunk] or [(a.elapsed_time(b) * 1e-3, T) for a, b, T in evs]
-    avg_launch_s = sum(x for x, _ in full) / len(full)
-    T_launch = full[0][1]
-    bytes_per_launch = ALGO_BYTES_2V2_STEP * N * T_launch
-    achieved = bytes_per_launch / avg_launch_s / 1e9
-
-    # HBM bytes per launch from the PMC counters of a separate rocprofv3 run of this same command
-    # (tools/prof_pmc.sh -> profiles/*_traffic.json; counters cannot be read from inside the process)
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
-        if tj.get("arenas") == N and tj.get("ticks_per_launch") == T_launch:
-            traffic = tj["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-
-    value = N * world * args.steps / dt
-    two = os.environ.get("HH_FORCE_W") == "2" or (os.environ.get("HH_FORCE_W") in (None, "", "0") and (N + 15) // 16 > 1024)
-    pair = not two and os.environ.get("HH_NO_TWO") != "1" and (N + 15) // 16 <= 512
-    kname = ("hh_k_world<4,64,%d,false>" % (2 if two else 1)) if os.environ.get("HH_NO_QUAD") == "1" else \
-        "hh_k_world_quad<W=%d,%s>" % (2 if two else 1, "simulation wave + output wave" if pair else "single wave")
+    value = N * chunk * args.steps * R.world / dt
     line = {
-        "metric": "env-steps/sec (2v2)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+        "metric": "env-steps/sec (2v2)", "value": value, "unit": "env-steps/s", "n_gpus": R.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "agent_steps_per_s": value * 2,
+        "agent_steps_per_s": value * 2, "per_rank_env_steps_per_s": per_rank,
         "config": {"workload": f"{N} arenas/GPU x 2-vs-2 fight L{args.level} (scripted opponent), random actions, auto-reset "
-                               f"(BASELINE configs[1])", "arenas_per_gpu": N, "ticks_per_launch": chunk,
-                   "parallelism": f"arena-sharded x{world}, no data-path collective"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": kname, "avg_launch_ms": avg_launch_s * 1e3,
-                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "note": "FP64-VALU issue bound, not HBM bound: see DESIGN.md section 4 (SQ_INSTS_VALU per wave-tick x 4 cycles)"},
+                               f"(BASELINE configs[1])", "arenas_per_gpu": N, "ticks_per_step": chunk,
+                   "env_steps_per_step": N * chunk * R.world,
+                   "step": "one hh_rollout launch = ticks_per_step consecutive LowLevelEnv.step() calls of every arena",
+                   "parallelism": f"arena-sharded x{R.world}, no data-path collective; logging all-gather every {args.log_every} launches on a side stream"},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(N, args.level, args.seed)
-    if rank == 0:
+    if R.dry:
+        line["dry_run"] = True
+        line["gathered_rows"] = None if sw.last_stats is None else int(sw.last_stats.shape[0])
+    else:
+        # dominant kernel: average launch duration from HIP events on the launch stream
+        durs = [a.elapsed_time(b) * 1e-3 for a, b in evs]
+        avg_launch_s = sum(durs) / len(durs)
+        bytes_per_launch = ALGO_BYTES_2V2_STEP * N * chunk
+        achieved = bytes_per_launch / avg_launch_s / 1e9
+        kname = w.kernel_name()
+        traffic, fp64 = counter_evidence(kname, N, chunk, N * chunk / avg_launch_s, 16)
+        line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                            "traffic": traffic, "kernel": kname, "avg_launch_ms": avg_launch_s * 1e3,
+                            "algorithmic_bytes_per_launch": bytes_per_launch, "fp64": fp64,
+                            "note": "FP64-VALU issue bound, not HBM bound (DESIGN.md section 4): `fp64.frac` is the fraction of the "
+                                    "vector-FP64 issue slots the measured rate uses; HBM traffic is far below the algorithmic bytes "
+                                    "because state stays in registers across the ticks of a launch"}
+        if R.rank == 0 and R.world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(N, args.level, args.seed)
+    if R.rank == 0:
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    R.close()
 
 
+# ------------------------------------------------------------------------------------------------ configs[2]: policy in the loop
 def main_policy_rollout(args):
-    """BASELINE configs[2]: N arenas x 2-vs-2 fight L3 driven by a policy in the loop — per tick: observations [N, 2, 26]
-    -> randomly initialised fight network (26 -> 200 -> 200 -> 13+9+2+2 logits, greedy decode as env_base.py:373-382 does)
-    -> hh_step.  The policy is the caller's side of the boundary (PyTorch / rocBLAS); policy + step are captured once into a
-    HIP graph and replayed per tick."""
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = init_dist(rank, local_rank, world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    """BASELINE configs[2]: N arenas x 2-vs-2 fight L3 driven by a policy in the loop — per tick: observations [N, 2, 26|24]
+    -> fight networks with the reference's architecture (models/ac_models_hetero.py Fight1 for agent 1, Fight2 for agent 2, actor
+    half, greedy decode as env_base.py:373-382) in the fused HIP kernel -> int8 actions -> hh_step.  A step is one tick of all arenas."""
+    R = Ranks(args)
+    torch = R.torch
+    from hhmarl_2d_amd.pilots import PolicyBank
     from hhmarl_2d_amd.sharding import ShardedWorld
-    N = args.arenas
-    sw = ShardedWorld(dict(n_arenas=N, level=args.level, seed=args.seed, auto_reset=True), rank=rank, world_size=world, device=local_rank)
+    N = args.arenas or 16384
+    sw = ShardedWorld(dict(n_arenas=N, level=args.level, seed=args.seed, auto_reset=True), rank=R.rank, world_size=R.world, device=R.local_rank)
     w = sw.world
     obs = w.reset()
-    g = torch.Generator().manual_seed(args.seed)
-    net = torch.nn.Sequential(torch.nn.Linear(26, 200), torch.nn.Tanh(), torch.nn.Linear(200, 200), torch.nn.Tanh(), torch.nn.Linear(200, 26))
-    with torch.no_grad():
-        for p_ in net.parameters():
-            p_.copy_(torch.randn(p_.shape, generator=g) * 0.3)
-    net = net.to(dev)
+    bank = PolicyBank.random_init(R.dev, seed=args.seed)
     out = w.alloc_outputs()
     out[0].copy_(obs)
-    act = torch.zeros((N, 2, 4), dtype=torch.int8, device=dev)
+    act = torch.zeros((N, 2, 4), dtype=torch.int8, device=R.dev)
+    # agent 1 is a type-1 aircraft (Fight1), agent 2 a type-2 (Fight2): env_base.py:560-561 fixes the first two slots
+    net_id = torch.tensor([PolicyBank.FIGHT1, PolicyBank.FIGHT2], dtype=torch.uint8, device=R.dev).repeat(N, 1).contiguous()
 
-    @torch.no_grad()
     def tick():
-        logits = net(out[0].reshape(N * 2, 26))
-        parts = logits.split((13, 9, 2, 2), dim=1)
-        act.copy_(torch.stack([p_.argmax(dim=1) for p_ in parts], dim=1).to(torch.int8).reshape(N, 2, 4))
+        bank.act(out[0], net_id, act)
         w.step(act, out=out)
 
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(3):
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                tick()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
             tick()
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        tick()
+    run = graph.replay if graph is not None else tick
+    log_side = torch.cuda.Stream()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup:
+        run()
         torch.cuda.synchronize()
-
     for _ in range(args.warmup):
-        graph.replay()
-    barrier()
+        run()
+    R.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e0.record()
     for k in range(args.steps):
-        graph.replay()
+        run()
         if k % 256 == 255:
-            sw.log_episode_stats()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    value = N * world * args.steps / dt
-    achieved = ALGO_BYTES_2V2_STEP * N * args.steps / dt / 1e9
+            sw.log_episode_stats(log_side)
+    e1.record()
+    R.barrier()
+    dt = R.max_over_ranks(time.perf_counter() - t0)
+    gpu_s = e0.elapsed_time(e1) * 1e-3
+    value = N * R.world * args.steps / dt
+    achieved = ALGO_BYTES_2V2_STEP * N * args.steps / gpu_s / 1e9
     line = {
-        "metric": "env-steps/sec (2v2, policy in the loop)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+        "metric": "env-steps/sec (2v2, policy in the loop)", "value": value, "unit": "env-steps/s", "n_gpus": R.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic", "agent_steps_per_s": value * 2,
-        "config": {"workload": f"{N} arenas/GPU x 2-vs-2 fight L{args.level}, actions from a random-init fight policy (fp32 MLP 26-200-200-26 "
-                               f"in PyTorch, greedy decode) evaluated every tick on the same GPU, auto-reset (BASELINE configs[2])",
-                   "arenas_per_gpu": N, "ticks_per_launch": 1, "parallelism": f"arena-sharded x{world}, no data-path collective"},
+        "dtype": "f64 world + f32 policy", "data": "synthetic", "agent_steps_per_s": value * 2,
+        "config": {"workload": f"{N} arenas/GPU x 2-vs-2 fight L{args.level}, actions from random-init Fight1/Fight2 actors (reference "
+                               f"architecture, fp32, fused HIP kernel, greedy decode) evaluated every tick on the same GPU, auto-reset "
+                               f"(BASELINE configs[2])",
+                   "arenas_per_gpu": N, "ticks_per_step": 1, "parallelism": f"arena-sharded x{R.world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "hh_k_world_quad (T = 1 per launch) + the policy's rocBLAS / elementwise kernels, one HIP graph per tick"},
+                     "kernel": f"{w.kernel_name()} (T = 1 per launch) + hh_k_policy, " + ("one HIP graph per tick" if graph is not None else "eager"),
+                     "policy_flops_per_s": bank.flops_per_row(PolicyBank.FIGHT1) * N * 2 * args.steps / gpu_s},
     }
-    if rank == 0:
+    if R.rank == 0:
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    R.close()
 
 
+# ------------------------------------------------------------------------------------------------ configs[3]/[4]: HighLevelEnv
 PILOT_DESC = {"tape": "uniform action tape resident in HBM", "random": "uniform actions drawn by torch kernels inside the step",
-              "mlp": "random-init MLP fight/escape nets"}
+              "mlp": "random-init MLP stand-ins (torch)", "net": "random-init Fight1/Fight2/Esc1/Esc2 actors (reference architecture) in the fused HIP kernel"}
 
 
 def main_hier(args):
-    """BASELINE configs[3]/[4]: N arenas x 3-vs-3 HighLevelEnv (map 0.5, horizon 500, N_OPP_HL=2), commander
-    actions uniform {0,1,2}; pilots = uniform actions (default) or random-init MLPs evaluated on the same GPU."""
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = init_dist(rank, local_rank, world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    """BASELINE configs[3]/[4]: N arenas x 3-vs-3 HighLevelEnv (map 0.5, horizon 500, N_OPPS_HL=2), commander actions uniform
+    {0,1,2}; a step is one commander step (HighLevelEnv.step) of every arena = up to 16 sub-steps with pilot actions."""
+    R = Ranks(args)
+    torch = R.torch
     from hhmarl_2d_amd.env_hier import macro_step
-    from hhmarl_2d_amd.pilots import MLPPilot, RandomPilot, TapePilot
+    from hhmarl_2d_amd.pilots import MLPPilot, NetPilot, RandomPilot, TapePilot
     from hhmarl_2d_amd.sharding import ShardedWorld
-    N = args.arenas
-    sw = ShardedWorld(dict(n_arenas=N, env_kind=1, seed=args.seed, auto_reset=True), rank=rank, world_size=world, device=local_rank)
+    N = args.arenas or 8192
+    sw = ShardedWorld(dict(n_arenas=N, env_kind=1, seed=args.seed, auto_reset=True), rank=R.rank, world_size=R.world, device=R.local_rank)
     w = sw.world
     w.reset()
     if args.pilot == "tape":
-        pilot = TapePilot(dev, N, 6, seed=args.seed + rank)
+        pilot = TapePilot(R.dev, N, 6, seed=args.seed + R.rank)
+    elif args.pilot == "random":
+        pilot = RandomPilot(R.dev, args.seed + R.rank)
+    elif args.pilot == "net":
+        pilot = NetPilot(w, seed=args.seed)
     else:
-        pilot = RandomPilot(dev, args.seed + rank) if args.pilot == "random" else MLPPilot(dev, seed=args.seed)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(args.seed + 17 + rank)
-    steps, warm = args.steps, args.warmup
-    cmds = (torch.rand((64, N, 3), device=dev, generator=gen) * 3).to(torch.int8).contiguous()
+        pilot = MLPPilot(R.dev, seed=args.seed)
+    gen = torch.Generator(device=R.dev)
+    gen.manual_seed(args.seed + 17 + R.rank)
+    cmds = (torch.rand((64, N, 3), device=R.dev, generator=gen) * 3).to(torch.int8).contiguous()
     out, pbuf = w.alloc_outputs(), w.alloc_pilot()
 
-    # the macro step is ~34 world launches + the pilots' torch kernels: capture it once into a HIP graph
+    # the macro step is a fixed sequence of world launches (+ the pilots' kernels): capture it once into a HIP graph
     # (launch-bound inner loop; no host synchronisation inside) and replay it per commander step
     cmd_static = cmds[0].clone()
     graph = None
@@ -315,9 +429,12 @@ def main_hier(args):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             macro_step(w, cmd_static, pilot, out=out, pilot_buf=pbuf)
+    log_side = torch.cuda.Stream()
+    state = {"k": 0}
 
     def run(n):
-        for k in range(n):
+        for _ in range(n):
+            k = state["k"]
             if args.pilot == "tape":
                 pilot.load(k)
             if graph is not None:
@@ -325,46 +442,57 @@ def main_hier(args):
                 graph.replay()
             else:
                 macro_step(w, cmds[k % 64], pilot, out=out, pilot_buf=pbuf)
-            if k % 16 == 15:
-                sw.log_episode_stats()
+            state["k"] = k + 1
+            if state["k"] % 16 == 0:
+                sw.log_episode_stats(log_side)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup:
+        run(1)
         torch.cuda.synchronize()
-
-    run(warm)
-    barrier()
+    run(args.warmup)
+    R.barrier()
+    ticks0 = w.hl_tick_count()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    run(steps)
+    run(args.steps)
     e1.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    R.barrier()
+    dt = R.max_over_ranks(time.perf_counter() - t0)
+    ticks = w.hl_tick_count() - ticks0            # arena-ticks actually run (arenas leave a macro step early)
     gpu_s = e0.elapsed_time(e1) * 1e-3
-    value = N * world * steps / dt
-    achieved = ALGO_BYTES_3V3_CMD_STEP * N * steps / gpu_s / 1e9
+    steps = args.steps
+    value = N * R.world * steps / dt
+    algo_bytes = ALGO_BYTES_3V3_TICK * ticks + ALGO_BYTES_3V3_CMD_FIXED * N * steps
+    achieved = algo_bytes / gpu_s / 1e9
     line = {
-        "metric": "commander-steps/sec (3v3 HighLevelEnv)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": steps,
-        "warmup": warm, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic", "agent_steps_per_s": value * 3, "sim_ticks_per_s": value * 16,
-        "config": {"workload": f"{N} arenas/GPU x 3-vs-3 HighLevelEnv commander steps (16 sub-steps each), uniform commander actions, "
-                               f"pilots = {PILOT_DESC[args.pilot]}, "
-                               f"auto-reset (BASELINE configs[3])", "arenas_per_gpu": N,
-                   "parallelism": f"arena-sharded x{world}, no data-path collective"},
+        "metric": "commander-steps/sec (3v3 HighLevelEnv)", "value": value, "unit": "env-steps/s", "n_gpus": R.world, "steps": steps,
+        "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic", "agent_steps_per_s": value * 3,
+        "sim_ticks_per_s": ticks * R.world / dt, "ticks_per_commander_step": ticks / float(N * steps),
+        "config": {"workload": f"{N} arenas/GPU x 3-vs-3 HighLevelEnv commander steps (<= 16 sub-steps each), uniform commander actions, "
+                               f"pilots = {PILOT_DESC[args.pilot]}, auto-reset (BASELINE configs[3])", "arenas_per_gpu": N,
+                   "parallelism": f"arena-sharded x{R.world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "hh_k_hier<6,64> (all 34 phase launches of the macro step, plus the pilots' kernels if any)",
-                     "algorithmic_bytes_per_step": ALGO_BYTES_3V3_CMD_STEP * N},
+                     "traffic": None, "kernel": f"{w.kernel_name()} (every launch of the macro step, plus the pilots' kernels if any)",
+                     "algorithmic_bytes": algo_bytes,
+                     "note": "2056 B per arena-tick actually run + 424 B per commander step (SURVEY.md 8d)"},
     }
-    if rank == 0:
+    if R.rank == 0:
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    R.close()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if args.workload == "hier":
+        return main_hier(args)
+    if args.workload == "rollout":
+        return main_policy_rollout(args)
+    return main_low(args)
 
 
 if __name__ == "__main__":

@@ -33,7 +33,8 @@ class HHStateView(C.Structure):
 
 EXPORTS = ["hh_world_create", "hh_world_destroy", "hh_last_error", "hh_obs_dim", "hh_n_ctrl", "hh_reset", "hh_step",
            "hh_rollout", "hh_episode_stats", "hh_get_state", "hh_set_state", "hh_get_event_masks", "hh_observe",
-           "hh_hl_begin", "hh_hl_agents_act", "hh_hl_tick", "hh_hl_end", "hh_step_begin", "hh_step_finish", "hh_gae", "hh_hl_commands"]
+           "hh_hl_begin", "hh_hl_agents_act", "hh_hl_tick", "hh_hl_end", "hh_step_begin", "hh_step_finish", "hh_gae", "hh_hl_commands",
+           "hh_episode_stats_packed", "hh_hl_tick_count", "hh_rollout_kernel_name"]
 
 _lib = None
 
@@ -58,7 +59,10 @@ def lib():
         L.hh_episode_stats.argtypes = [vp, vp, vp, vp, vp]
         L.hh_get_state.argtypes = [vp, C.POINTER(HHStateView)]
         L.hh_set_state.argtypes = [vp, C.POINTER(HHStateView)]
-        L.hh_get_event_masks.argtypes = [vp, vp]
+        L.hh_get_event_masks.argtypes = [vp, vp, vp]
+        L.hh_episode_stats_packed.argtypes = [vp, vp, vp]
+        L.hh_hl_tick_count.argtypes = [vp, C.POINTER(C.c_uint64), vp]
+        L.hh_rollout_kernel_name.argtypes = [vp, C.c_char_p, C.c_int32]
         L.hh_observe.argtypes = [vp, vp, vp]
         L.hh_hl_begin.argtypes = [vp, vp, vp, vp, vp]
         L.hh_hl_agents_act.argtypes = [vp, vp, vp, vp, vp]

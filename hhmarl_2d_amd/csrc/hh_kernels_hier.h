@@ -245,6 +245,10 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
             ar.hl_run = (ar.hl_s <= 15 && !so.kill_event && !situ) ? 1 : 0;
             if (s == 0 && ar.hl_run && running_count) atomicAdd(running_count, 1);
         }
+        {   /* cumulative arena-ticks of this world (hh_hl_tick_count): one atomic per wave */
+            const unsigned long long ran = __ballot(was_running && s == 0);
+            if (ran && (tid & 63) == 0 && running_count) atomicAdd(reinterpret_cast<unsigned long long *>(running_count + 2), (unsigned long long)__popcll(ran));
+        }
         obs_side = 0;
     } else { /* HH_HL_END, HH_HL_REFRESH, HH_HL_RESET */
         const bool ending = phase == HH_HL_END && active && !ar.done; /* arena took part in this macro step */

@@ -27,11 +27,30 @@ extern "C" const char *hh_last_error(void) { return g_err.c_str(); }
         }                                                                                  \
     } while (0)
 
+/* Every entry point that launches or copies runs with the world's device current and restores the caller's device on
+ * return (two worlds on two GPUs in one process; torch's current device may differ from the world's). */
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+#define HH_GUARD(w)                                                        \
+    DeviceGuard guard_((w)->device);                                       \
+    if (!guard_.ok) { g_err = "hipSetDevice(world device) failed"; return HH_E_HIP; }
+
 struct hh_world {
     hh_config cfg;
     DevCfg dc;
     DevPtrs P;
     int device;
+    int n_simd;   /* SIMDs of this device (multiProcessorCount x 4): one wave per SIMD up to here, then two */
     int block; /* threads per workgroup */
     void *slab;
     size_t slab_bytes;
@@ -62,10 +81,14 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device"; return HH_E_NODEV; }
     if (device < 0 || device >= ndev) { g_err = "bad device index"; return HH_E_ARG; }
-    HIPCHK(hipSetDevice(device));
+    DeviceGuard guard_(device);
+    if (!guard_.ok) { g_err = "hipSetDevice failed"; return HH_E_HIP; }
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
     hh_world *w = new hh_world();
     w->cfg = *cfg;
     w->device = device;
+    w->n_simd = prop.multiProcessorCount * 4; /* 4 SIMDs per CU; follows the partition mode (SPX 256 CUs, CPX 32) */
     DevCfg &d = w->dc;
     d.N = cfg->n_arenas; d.env_kind = cfg->env_kind; d.nA = cfg->n_agents; d.nO = cfg->n_opps; d.A = A;
     d.level = cfg->level; d.agent_mode = cfg->agent_mode; d.horizon = cfg->horizon;
@@ -130,7 +153,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
 
 extern "C" int hh_world_destroy(hh_world *w) {
     if (!w) return HH_E_ARG;
-    (void)hipSetDevice(w->device);
+    DeviceGuard guard_(w->device);
     (void)hipFree(w->slab);
     delete w;
     return HH_OK;
@@ -143,9 +166,10 @@ static int launch_hier(hh_world *w, int phase, const int8_t *cmd, const int8_t *
                        float *obs, float *reward, uint8_t *valid, uint8_t *done, const uint8_t *mask, hipStream_t st) {
     const DevCfg &c = w->dc;
     if (w->cfg.env_kind != HH_ENV_HIGHLEVEL || c.A != 6) { g_err = "not a HighLevelEnv (3-vs-3) world"; return HH_E_ARG; }
+    HH_GUARD(w);
     constexpr int B = HH_BLOCK, GPB = B / 6;
     int grid = (c.N + GPB - 1) / GPB;
-    const bool two = w->force_w == 2 || (w->force_w == 0 && grid > 1024);
+    const bool two = w->force_w == 2 || (w->force_w == 0 && grid > w->n_simd);
     if (two)
         hipLaunchKernelGGL((hh_k_hier<6, B, 2>), dim3(grid), dim3(B), 0, st, w->P, c, phase, cmd, actions, pilot_obs, pilot_mode, obs, reward,
                            valid, done, w->counter, mask);
@@ -164,16 +188,17 @@ static int launch(hh_world *w, int run, int T, const int8_t *actions, const uint
         return launch_hier(w, run == HH_RUN_RESET ? HH_HL_RESET : HH_HL_REFRESH, nullptr, nullptr, nullptr, nullptr, obs, nullptr, nullptr, nullptr, mask, st);
     }
     if (c.A != 4) { g_err = "LowLevelEnv worlds are 2-vs-2"; return HH_E_ARG; }
+    HH_GUARD(w);
     constexpr int B = HH_BLOCK, GPB = B / 4;
     const int grid = (c.N + GPB - 1) / GPB;
     const int waves = grid * (B / 64);
-    const bool two = w->force_w == 2 || (w->force_w == 0 && waves > 1024); /* more waves than SIMDs: hold two per SIMD */
+    const bool two = w->force_w == 2 || (w->force_w == 0 && waves > w->n_simd); /* more waves than SIMDs: hold two per SIMD */
     if (run == HH_RUN_ROLLOUT && !w->no_quad) {
         static_assert(B == 64, "the register-exchange kernel is one wave per workgroup");
         const bool l3 = !w->no_spec && c.level == 3 && c.agent_mode == HH_MODE_FIGHT && !c.ext_opp && c.friendly_kill == 1 && !c.friendly_punish &&
                         !c.esc_dist_rew && c.glob_frac == 0.0 && c.rew_scale == 1.0;
         /* small worlds (every workgroup resident with a SIMD pair to itself): simulation wave + output wave per 16 arenas */
-        const bool pair = !two && !w->no_two && waves <= 512; /* 128-thread groups at one wave per SIMD: 512 resident on 256 CUs */
+        const bool pair = !two && !w->no_two && waves <= w->n_simd / 2; /* 128-thread groups at one wave per SIMD: two per CU resident */
 #define HH_QLAUNCH(Wv, L3v, TWOv) hipLaunchKernelGGL((hh_k_world_quad<Wv, L3v, TWOv>), dim3(grid), dim3(TWOv ? 128 : 64), 0, st, w->P, c, T, actions, obs, reward, valid, done)
         if (two) { if (l3) HH_QLAUNCH(2, true, false); else HH_QLAUNCH(2, false, false); }
         else if (pair) { if (l3) HH_QLAUNCH(1, true, true); else HH_QLAUNCH(1, false, true); }
@@ -186,6 +211,38 @@ static int launch(hh_world *w, int run, int T, const int8_t *actions, const uint
     else
         hipLaunchKernelGGL((hh_k_world<4, B, 1, false>), dim3(grid), dim3(B), 0, st, w->P, c, run, T, actions, mask, obs, reward, valid, done);
     HIPCHK(hipGetLastError());
+    return HH_OK;
+}
+
+/* which instance hh_rollout / hh_step launches for this world on this device (bench.py and profiles name it) */
+extern "C" int hh_rollout_kernel_name(hh_world *w, char *buf, int32_t len) {
+    if (!w || !buf || len <= 0) return HH_E_ARG;
+    const DevCfg &c = w->dc;
+    if (w->cfg.env_kind != HH_ENV_LOWLEVEL) {
+        const int grid = (c.N + 9) / 10;
+        const bool two = w->force_w == 2 || (w->force_w == 0 && grid > w->n_simd);
+        snprintf(buf, (size_t)len, "hh_k_hier<6,64,%d>", two ? 2 : 1);
+        return HH_OK;
+    }
+    const int waves = (c.N + 15) / 16;
+    const bool two = w->force_w == 2 || (w->force_w == 0 && waves > w->n_simd);
+    const bool l3 = !w->no_spec && c.level == 3 && c.agent_mode == HH_MODE_FIGHT && !c.ext_opp && c.friendly_kill == 1 && !c.friendly_punish &&
+                    !c.esc_dist_rew && c.glob_frac == 0.0 && c.rew_scale == 1.0;
+    const bool pair = !two && !w->no_two && waves <= w->n_simd / 2;
+    if (w->no_quad) snprintf(buf, (size_t)len, "hh_k_world<4,64,%d,false>", two ? 2 : 1);
+    else snprintf(buf, (size_t)len, "hh_k_world_quad<W=%d,L3=%s,%s>", two ? 2 : 1, l3 ? "true" : "false",
+                  pair ? "simulation wave + output wave" : "single wave");
+    return HH_OK;
+}
+
+/* cumulative number of arena-ticks HighLevelEnv macro steps have run on this world (sub-steps of arenas that were
+ * still inside their macro step) — the honest numerator of a ticks/s figure, since arenas leave a macro step early */
+extern "C" int hh_hl_tick_count(hh_world *w, uint64_t *out /* [host] */, void *stream) {
+    if (!w || !out) return HH_E_ARG;
+    HH_GUARD(w);
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(out, (const char *)w->counter + 8, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return HH_OK;
 }
 
@@ -207,6 +264,7 @@ extern "C" int hh_rollout(hh_world *w, int32_t n_steps, const int8_t *actions, f
 
 extern "C" int hh_episode_stats(hh_world *w, float *ret, int32_t *len, int8_t *outcome, void *stream) {
     if (!w) return HH_E_ARG;
+    HH_GUARD(w);
     hipStream_t st = (hipStream_t)stream;
     size_t N = (size_t)w->dc.N;
     if (ret) HIPCHK(hipMemcpyAsync(ret, w->P.last_ret, N * 4, hipMemcpyDeviceToDevice, st));
@@ -215,16 +273,37 @@ extern "C" int hh_episode_stats(hh_world *w, float *ret, int32_t *len, int8_t *o
     return HH_OK;
 }
 
-extern "C" int hh_get_event_masks(hh_world *w, uint32_t *masks) {
+/* [N,3] f32 block (return, length, outcome) in ONE small launch: what the multi-GPU logging all-gather moves */
+__global__ __launch_bounds__(256) void hh_k_pack_stats(int N, const float *__restrict__ ret, const int *__restrict__ len,
+                                                       const int8_t *__restrict__ outcome, float *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x; /* one lane per output float: unit-stride stores */
+    if (i >= 3 * N) return;
+    const int n = i / 3, k = i - 3 * n;
+    out[i] = k == 0 ? ret[n] : (k == 1 ? (float)len[n] : (float)outcome[n]);
+}
+
+extern "C" int hh_episode_stats_packed(hh_world *w, float *out, void *stream) {
+    if (!w || !out) { g_err = "null argument"; return HH_E_ARG; }
+    HH_GUARD(w);
+    const int N = w->dc.N;
+    hipLaunchKernelGGL(hh_k_pack_stats, dim3((3 * N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, w->P.last_ret, w->P.last_len,
+                       w->P.last_outcome, out);
+    HIPCHK(hipGetLastError());
+    return HH_OK;
+}
+
+extern "C" int hh_get_event_masks(hh_world *w, uint32_t *masks, void *stream) {
     if (!w || !masks) return HH_E_ARG;
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(masks, w->P.ev_mask, (size_t)w->dc.N * 4, hipMemcpyDeviceToHost));
+    HH_GUARD(w);
+    hipStream_t st = (hipStream_t)stream; /* ordered after the step on the caller's stream; waits for that stream only */
+    HIPCHK(hipMemcpyAsync(masks, w->P.ev_mask, (size_t)w->dc.N * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return HH_OK;
 }
 
 extern "C" int hh_get_state(hh_world *w, hh_state_view *v) {
     if (!w || !v) return HH_E_ARG;
-    HIPCHK(hipSetDevice(w->device));
+    HH_GUARD(w);
     HIPCHK(hipDeviceSynchronize());
     const DevCfg &c = w->dc;
     size_t U = (size_t)c.N * c.A, N = (size_t)c.N;
@@ -272,7 +351,7 @@ extern "C" int hh_get_state(hh_world *w, hh_state_view *v) {
 
 extern "C" int hh_set_state(hh_world *w, const hh_state_view *v) {
     if (!w || !v) return HH_E_ARG;
-    HIPCHK(hipSetDevice(w->device));
+    HH_GUARD(w);
     HIPCHK(hipDeviceSynchronize());
     const DevCfg &c = w->dc;
     size_t U = (size_t)c.N * c.A, N = (size_t)c.N;
@@ -352,6 +431,7 @@ extern "C" int hh_hl_agents_act(hh_world *w, const int8_t *actions, float *pilot
 
 extern "C" int hh_hl_tick(hh_world *w, const int8_t *actions, float *pilot_obs, uint8_t *pilot_mode, int32_t *running, void *stream) {
     if (!w || !actions) { g_err = "null argument"; return HH_E_ARG; }
+    HH_GUARD(w);
     hipStream_t st = (hipStream_t)stream;
     if (running) HIPCHK(hipMemsetAsync(w->counter, 0, 4, st));
     int rc = launch_hier(w, HH_HL_TICK, nullptr, actions, pilot_obs, pilot_mode, nullptr, nullptr, nullptr, nullptr, nullptr, st);
@@ -405,7 +485,7 @@ extern "C" int hh_gae(int32_t T, int32_t N, int32_t n_agents, const float *rewar
  * escape; env_hier.py:142-190) — what evaluation.py's eval_info counters read (env_base.py:91-107) */
 extern "C" int hh_hl_commands(hh_world *w, int8_t *out /* [host] [N, A] */) {
     if (!w || !out) return HH_E_ARG;
-    HIPCHK(hipSetDevice(w->device));
+    HH_GUARD(w);
     HIPCHK(hipDeviceSynchronize());
     size_t U = (size_t)w->dc.N * w->dc.A;
     std::vector<int4> pack(U);

@@ -54,8 +54,28 @@ class ShardedWorld:
         else:
             self.world = world_factory(kw)
         self.last_stats = None
+        self._blocks, self._events, self._k = [None, None], [None, None], 0
 
-    def log_episode_stats(self):
-        ret, ln, oc = self.world.episode_stats()
-        self.last_stats = gather_stats(pack_stats(ret, ln, oc), self.world_size)
+    def log_episode_stats(self, side_stream=None):
+        """Logging only.  The [N,3] block is snapshotted by ONE small launch on the stepping stream
+        (hh_episode_stats_packed); with `side_stream` the all-gather then runs there, so the stepping stream goes straight
+        on to the next rollout launch — call it every K launches, not every launch.  Blocks are double-buffered: a
+        snapshot waits only for the gather that used the same buffer two calls ago."""
+        w = self.world
+        if not hasattr(w, "episode_stats_packed"):          # CPU test doubles
+            self.last_stats = gather_stats(pack_stats(*w.episode_stats()), self.world_size)
+            return self.last_stats
+        k = self._k = self._k ^ 1
+        cur = torch.cuda.current_stream(w.device)
+        if self._events[k] is not None:
+            cur.wait_event(self._events[k])
+        self._blocks[k] = w.episode_stats_packed(self._blocks[k])
+        if side_stream is None:
+            self.last_stats = gather_stats(self._blocks[k], self.world_size)
+            return self.last_stats
+        side_stream.wait_stream(cur)
+        with torch.cuda.stream(side_stream):
+            self.last_stats = gather_stats(self._blocks[k], self.world_size)
+            self._events[k] = torch.cuda.Event()
+            self._events[k].record(side_stream)
         return self.last_stats

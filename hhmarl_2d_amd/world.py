@@ -166,6 +166,24 @@ class World:
         L.check(L.lib().hh_episode_stats(self.h, _p(ret), _p(ln), _p(oc), self._stream()))
         return ret, ln, oc
 
+    def episode_stats_packed(self, out=None):
+        """f32 [N, 3] (return, length, outcome) of the last finished episode per arena, one launch"""
+        if out is None:
+            out = torch.empty((self.N, 3), dtype=torch.float32, device=self.device)
+        L.check(L.lib().hh_episode_stats_packed(self.h, _p(out), self._stream()))
+        return out
+
+    def hl_tick_count(self):
+        """cumulative arena-ticks run by macro steps on this world (synchronises the current stream)"""
+        v = C.c_uint64(0)
+        L.check(L.lib().hh_hl_tick_count(self.h, C.byref(v), self._stream()))
+        return int(v.value)
+
+    def kernel_name(self):
+        buf = C.create_string_buffer(128)
+        L.check(L.lib().hh_rollout_kernel_name(self.h, buf, 128))
+        return buf.value.decode()
+
     # ---- host snapshots (parity tests, checkpointing) ----
     def _alloc_state(self):
         n, a = self.N, self.A
@@ -197,5 +215,5 @@ class World:
 
     def event_masks(self):
         m = np.zeros((self.N,), dtype=np.uint32)
-        L.check(L.lib().hh_get_event_masks(self.h, m.ctypes.data_as(C.c_void_p)))
+        L.check(L.lib().hh_get_event_masks(self.h, m.ctypes.data_as(C.c_void_p), self._stream()))
         return m

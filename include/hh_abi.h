@@ -8,7 +8,8 @@
  * reference's dict protocol on top of it (INTEGRATION.md shows the stub).
  *
  * Conventions: every function returns 0 on success or a negative HH_E_* code and never throws.
- * `stream` is a hipStream_t passed as void* (NULL = default stream).  Buffers marked [dev] are
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).  Every call that launches or copies makes the
+ * world's device current for its duration and restores the caller's current device before it returns.  Buffers marked [dev] are
  * caller-owned device memory (e.g. torch tensors); [host] are host memory.  One host thread per
  * world.  The world owns only its struct-of-arrays state.
  *
@@ -138,14 +139,25 @@ int hh_hl_end(hh_world *w, float *obs, float *reward, uint8_t *reward_valid, uin
  * actions and the opponents' drawn ones, [host] i8 [N, 6]; read by the eval_info counters (env_base.py:91-107) */
 int hh_hl_commands(hh_world *w, int8_t *out);
 
+/* cumulative arena-ticks run by HighLevelEnv macro steps on this world ([host] u64; synchronises `stream`): arenas leave
+ * a macro step early (kill / surrounding event, env_hier.py:125), so ticks/s must be counted, not assumed 16 per step */
+int hh_hl_tick_count(hh_world *w, uint64_t *out, void *stream);
+
+/* name of the kernel instance hh_rollout / hh_step (or the hh_hl_* phases) launch for this world on this device */
+int hh_rollout_kernel_name(hh_world *w, char *buf, int32_t len);
+
 /* per-arena statistics of the most recently FINISHED episode (logging; this is what the
  * multi-GPU all-gather moves): ret [dev] f32[N] (sum of agent rewards), len [dev] i32[N],
  * outcome [dev] i8[N] (1 agents win, -1 opponents win, 0 draw, 2 none finished yet) */
 int hh_episode_stats(hh_world *w, float *ret, int32_t *len, int8_t *outcome, void *stream);
+/* the same three statistics as one [dev] f32[N, 3] block (return, length, outcome as floats), written by one small
+ * launch: the block each rank contributes to the logging all-gather (hhmarl_2d_amd/sharding.py) */
+int hh_episode_stats_packed(hh_world *w, float *out, void *stream);
 
 /* Generalised advantage estimation on the stacked outputs of hh_rollout (what RLlib's postprocessing does
  * for the reference: train_hetero.py:216 gamma=0.99, lambda_=0.95, complete episodes).  All [dev]:
- * reward, valid, adv, ret [T, N, n_agents]; value [T+1, N, n_agents] (critic incl. bootstrap row); done [T, N]. */
+ * reward, valid, adv, ret [T, N, n_agents]; value [T+1, N, n_agents] (critic incl. bootstrap row); done [T, N].
+ * Not tied to a world: launches on the calling thread's current device, which must own the buffers. */
 int hh_gae(int32_t T, int32_t N, int32_t n_agents, const float *reward, const float *value, const uint8_t *valid,
            const uint8_t *done, float gamma, float lam, float *adv, float *ret, void *stream);
 
@@ -153,10 +165,11 @@ int hh_gae(int32_t T, int32_t N, int32_t n_agents, const float *reward, const fl
 int hh_get_state(hh_world *w, hh_state_view *view);
 int hh_set_state(hh_world *w, const hh_state_view *view);
 
-/* integer event masks of the last step, for bit-exact parity checks ([host] after sync):
+/* integer event masks of the last step, for bit-exact parity checks ([host]; ordered after the work queued on
+ * `stream` and synchronises that stream only):
  * per arena u32: bits 0..7 units killed by cannon, 8..15 killed by rocket, 16..23 out of bounds,
  * 24..31 missile launched this step (by unit slot) */
-int hh_get_event_masks(hh_world *w, uint32_t *masks);
+int hh_get_event_masks(hh_world *w, uint32_t *masks, void *stream);
 
 #ifdef __cplusplus
 }

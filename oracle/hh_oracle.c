@@ -965,29 +965,35 @@ API int hho_reset(void *h, const uint8_t *mask, float *obs) {
     return HH_OK;
 }
 
+/* one env.step() of arena n (+ the caller-side reset when auto_reset); output rows are the arena's own */
+static void step_arena(const o_world *w, int n, const int8_t *act /* [n_ctrl,4] */, float *obs, float *reward, uint8_t *reward_valid, uint8_t *done) {
+    const int nA = w->cfg.n_agents;
+    o_arena *a = &w->ar[n];
+    if (a->done) {
+        for (int i = 0; i < nA; i++) { a->reward[i] = 0.0; a->reward_valid[i] = 0; }
+        a->ev_mask = 0;
+    } else {
+        ll_step(w, a, act);
+    }
+    if (reward) for (int i = 0; i < nA; i++) reward[i] = (float)a->reward[i];
+    if (reward_valid) for (int i = 0; i < nA; i++) reward_valid[i] = (uint8_t)a->reward_valid[i];
+    if (done) *done = (uint8_t)a->done;
+    if (a->done && w->cfg.auto_reset) {
+        uint32_t em = a->ev_mask; /* masks describe the step that just ended */
+        arena_reset(w, a);
+        a->ev_mask = em;
+    }
+    if (obs) copy_obs(w, a, obs);
+}
+
 API int hho_step(void *h, const int8_t *actions, float *obs, float *reward, uint8_t *reward_valid, uint8_t *done) {
     o_world *w = (o_world *)h;
     int N = w->cfg.n_arenas, nA = w->cfg.n_agents;
     if (w->cfg.env_kind != HH_ENV_LOWLEVEL) return HH_E_ARG;
 #pragma omp parallel for schedule(static)
-    for (int n = 0; n < N; n++) {
-        o_arena *a = &w->ar[n];
-        if (a->done) {
-            for (int i = 0; i < nA; i++) { a->reward[i] = 0.0; a->reward_valid[i] = 0; }
-            a->ev_mask = 0;
-        } else {
-            ll_step(w, a, actions + (size_t)n * w->n_ctrl * 4);
-        }
-        if (reward) for (int i = 0; i < nA; i++) reward[(size_t)n * nA + i] = (float)a->reward[i];
-        if (reward_valid) for (int i = 0; i < nA; i++) reward_valid[(size_t)n * nA + i] = (uint8_t)a->reward_valid[i];
-        if (done) done[n] = (uint8_t)a->done;
-        if (a->done && w->cfg.auto_reset) {
-            uint32_t em = a->ev_mask; /* masks describe the step that just ended */
-            arena_reset(w, a);
-            a->ev_mask = em;
-        }
-        if (obs) copy_obs(w, a, obs + (size_t)n * nA * w->D);
-    }
+    for (int n = 0; n < N; n++)
+        step_arena(w, n, actions + (size_t)n * w->n_ctrl * 4, obs ? obs + (size_t)n * nA * w->D : 0, reward ? reward + (size_t)n * nA : 0,
+                   reward_valid ? reward_valid + (size_t)n * nA : 0, done ? done + n : 0);
     return HH_OK;
 }
 
@@ -1041,15 +1047,20 @@ API int hho_step_finish(void *h, const int8_t *opp_actions /* [N, n_opps, 4] */,
     return HH_OK;
 }
 
+/* T steps of every arena.  Arenas are independent, so the loop nest is arena-outer / tick-inner: one OpenMP team for the
+ * whole rollout, each thread walks its arenas through all T ticks with the arena's state hot in its cache (this is also
+ * the shape timed as bench.py's cpu_baseline).  Same results as T calls of hho_step. */
 API int hho_rollout(void *h, int n_steps, const int8_t *actions, float *obs, float *reward, uint8_t *reward_valid, uint8_t *done) {
     o_world *w = (o_world *)h;
-    size_t N = (size_t)w->cfg.n_arenas, nA = (size_t)w->cfg.n_agents;
-    for (int t = 0; t < n_steps; t++) {
-        int rc = hho_step(h, actions + (size_t)t * N * w->n_ctrl * 4, obs ? obs + (size_t)t * N * nA * w->D : 0,
-                          reward ? reward + (size_t)t * N * nA : 0, reward_valid ? reward_valid + (size_t)t * N * nA : 0,
-                          done ? done + (size_t)t * N : 0);
-        if (rc) return rc;
-    }
+    const size_t N = (size_t)w->cfg.n_arenas, nA = (size_t)w->cfg.n_agents, D = (size_t)w->D, nc = (size_t)w->n_ctrl;
+    if (w->cfg.env_kind != HH_ENV_LOWLEVEL) return HH_E_ARG;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int n = 0; n < (int)N; n++)
+        for (int t = 0; t < n_steps; t++) {
+            const size_t r = (size_t)t * N + (size_t)n;
+            step_arena(w, n, actions + r * nc * 4, obs ? obs + r * nA * D : 0, reward ? reward + r * nA : 0,
+                       reward_valid ? reward_valid + r * nA : 0, done ? done + r : 0);
+        }
     return HH_OK;
 }
 

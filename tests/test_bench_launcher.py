@@ -1,0 +1,38 @@
+"""`python bench.py --gpus N` must produce an N-rank line by itself (no launcher around it): it re-execs under
+torch.distributed.run, one process per rank.  On this GPU-less box the rank plumbing is exercised with --dry-run
+(gloo, no world, no kernel): ranks, barriers, max-over-ranks timing, the logging all-gather in global arena order."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "3", "--warmup", "1", "--arenas", "8",
+                        "--log-every", "2"] + extra, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout   # exactly one JSON line, printed by rank 0
+    return json.loads(lines[0])
+
+
+def test_gpus_2_self_spawns_two_ranks():
+    line = _run(["--gpus", "2"])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True
+    assert len(line["per_rank_env_steps_per_s"]) == 2
+    assert line["gathered_rows"] == 16                      # both ranks' blocks arrived in the all-gather
+    assert line["config"]["env_steps_per_step"] == 8 * 250 * 2
+    assert line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+
+
+def test_single_rank_line_contract():
+    line = _run([])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config"):
+        assert k in line
+    assert line["n_gpus"] == 1 and line["vs_baseline"] is None and line["dtype"] == "f64"

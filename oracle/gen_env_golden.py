@@ -13,7 +13,11 @@ Record layout (R rows per file):
   obs[R,nA,D] f32, reward[R,nA] f64, valid[R,nA] u8 (key present in the rewards dict), done[R] u8
   meta         json: config kwargs, seed, arena id
 
-Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_env_golden.py
+Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_env_golden.py [--out DIR] [names...]     (re)generate
+      PYTHONDONTWRITEBYTECODE=1 python oracle/gen_env_golden.py --check                      regenerate to a temp dir and
+                                                                                            compare with tests/golden
+Everything is deterministic (keyed tape, crc32-seeded action policies), so --check must report no difference;
+tests/test_golden_provenance.py runs it whenever /root/reference is present.
 """
 import json
 import math
@@ -269,14 +273,203 @@ def record_hl(name, kw, style, episodes, max_rows, seed=20240917, arena=11):
           f"draws={meta['draws']} deaths={deaths} size={os.path.getsize(path)}")
 
 
-if __name__ == "__main__":
+# ---------------------------------------------------------------- hand-built edge cases on the REAL reference
+def _geo():
+    import geodesic_ref
+    return geodesic_ref
+
+
+def lon_at_range(lat, lon, metres):
+    """longitude east of (lat, lon) on the same parallel whose geodesic range from it is `metres` (bisection on the
+    reference's own Inverse stand-in; the answer is good to the last few ulps of longitude, ~1e-9 m)"""
+    G = _geo()
+    lo, hi = lon, lon + 2.0
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        if G.inverse(lat, lon, lat, mid)[0] < metres:
+            lo = mid
+        else:
+            hi = mid
+    return hi
+
+
+def find_arena(seed, need, start=0):
+    """first arena id whose keyed draws (episode 1) satisfy every (tick, unit, site, sub, predicate) in `need`"""
+    for arena in range(start, start + 200000):
+        ak = H.arena_key(seed, arena)
+        if all(pred(H.u01(H.tick_key(ak, 1, t), unit, H.SITES[site], sub)) for t, unit, site, sub, pred in need):
+            return arena
+    raise RuntimeError("no arena found")
+
+
+FAR = {2: dict(lat=5.28, lon=7.02, hdg=0.0), 4: dict(lat=5.02, lon=7.28, hdg=180.0, spd=0.0)}   # bystanders out of everybody's way
+
+
+def edge_cases(seed):
+    """name, args kw, arena, inject(units, rockets), per-step agent actions.  Opponents are level-1 (static, env_hetero.py:118-123)
+    so that the situation stays exactly as built; thresholds are approached to 1e-5 m / 1e-7 deg — far inside anything a random
+    trace reaches, far outside the 1e-9 m agreement of two Karney implementations."""
+    G = _geo()
+    hit1 = lambda u: u < 0.75 / 5.0          # ac1.py:112-113
+    hit2 = lambda u: u < 0.9 / 3.0           # ac2.py:99-100
+    noop = {1: [6, 0, 0, 0], 2: [6, 0, 0]}
+    cases = []
+    # 1. mutual cannon kill in one tick: a unit killed earlier in the tick still shoots (cmano_simulator.py:142)
+    ar = find_arena(seed, [(1, 1, "CANNON", 3, hit1), (1, 3, "CANNON", 1, hit1)])
+    cases.append(("mutual_cannon_kill", dict(level=1), ar,
+                  dict(units={1: dict(lat=5.15, lon=7.15, hdg=90.0, burst=5), 3: dict(lat=5.15, lon=7.16, hdg=270.0, spd=0.0, burst=5), **FAR}),
+                  [noop, noop]))
+    # 2. rocket fuse on the hard-coded "friendly" id (rocket_unit.py:44-52): agent 1 launches past agent 2, 400 m ahead of it
+    cases.append(("fuse_on_friendly_agent_source", dict(level=1), 3,
+                  dict(units={1: dict(lat=5.15, lon=7.05, hdg=90.0), 2: dict(lat=5.15, lon=7.0536, hdg=90.0),
+                              3: dict(lat=5.15, lon=7.13, hdg=270.0, spd=0.0), 4: FAR[4]}),
+                  [{1: [6, 0, 0, 1], 2: [6, 0, 0]}, noop, noop]))
+    # 3. the same clause for an opponent's rocket: source id 3 -> "friendly" id 2, i.e. it fuses on AGENT 2 on its way to agent 1
+    cases.append(("fuse_on_friendly_opp_source", dict(level=1), 4,
+                  dict(units={1: dict(lat=5.15, lon=7.05, hdg=90.0), 2: dict(lat=5.1503, lon=7.10, hdg=0.0),
+                              3: dict(lat=5.15, lon=7.16, hdg=270.0, spd=0.0, missile_remain=7), 4: FAR[4]},
+                       rockets=[dict(source=3, target=1, lat=5.15, lon=7.112, hdg=270.0, life=2)]),
+                  [noop, noop, noop]))
+    # 4. failed launch (target outside the radar cone) still draws missile_wait, then decrements it (env_base.py:228-236)
+    cases.append(("failed_launch_sets_missile_wait", dict(level=1), 5,
+                  dict(units={1: dict(lat=5.15, lon=7.10, hdg=270.0), 3: dict(lat=5.15, lon=7.20, hdg=0.0, spd=0.0), **FAR}),
+                  [{1: [6, 0, 0, 1], 2: [6, 0, 0]}] * 4))
+    # 5. inclusive map boundary (map_limits.py:47-48): a static opponent exactly ON the southern edge stays, one ulp below it goes
+    cases.append(("oob_inclusive_boundary", dict(level=1), 6,
+                  dict(units={1: dict(lat=5.15, lon=7.10, hdg=0.0), 2: FAR[2], 3: dict(lat=5.0, lon=7.15, hdg=0.0, spd=0.0),
+                              4: dict(lat=float(np.nextafter(5.0, 0.0)), lon=7.25, hdg=0.0, spd=0.0)}),
+                  [noop, noop]))
+    # 6./7. cannon range 2.0 km (type 1) and 4.5 km (type 2), 1e-5 m inside / outside, with hit draws that would kill
+    ar = find_arena(seed, [(1, 1, "CANNON", 3, hit1), (1, 2, "CANNON", 4, hit2)])
+    for tag, eps in (("inside", -1e-5), ("outside", +1e-5)):
+        cases.append((f"cannon_range_{tag}", dict(level=1), ar,
+                      dict(units={1: dict(lat=5.10, lon=7.05, hdg=90.0, burst=5), 3: dict(lat=5.10, lon=lon_at_range(5.10, 7.05, 2000.0 + eps), hdg=0.0, spd=0.0),
+                                  2: dict(lat=5.20, lon=7.05, hdg=90.0, burst=3), 4: dict(lat=5.20, lon=lon_at_range(5.20, 7.05, 4500.0 + eps), hdg=0.0, spd=0.0)}),
+                      [noop, noop]))
+    # 8./9. cannon cone half-width 5 deg (type 1) / 3.5 deg (type 2), 1e-7 deg inside / outside, at 1 km
+    for tag, eps in (("inside", -1e-7), ("outside", +1e-7)):
+        la3, lo3 = G.direct(5.10, 7.05, 90.0 + 5.0 + eps, 1000.0)
+        la4, lo4 = G.direct(5.20, 7.05, 90.0 - 3.5 - eps, 1000.0)
+        cases.append((f"cannon_cone_{tag}", dict(level=1), ar,
+                      dict(units={1: dict(lat=5.10, lon=7.05, hdg=90.0, burst=5), 3: dict(lat=la3, lon=lo3, hdg=0.0, spd=0.0),
+                                  2: dict(lat=5.20, lon=7.05, hdg=90.0, burst=3), 4: dict(lat=la4, lon=lo4, hdg=0.0, spd=0.0)}),
+                      [noop, noop]))
+    # 10./11. rocket fuse 1.0 km (rocket_unit.py:39), tested BEFORE the rocket moves against the target after ITS move
+    for tag, eps in (("inside", -1e-5), ("outside", +1e-5)):
+        cases.append((f"rocket_fuse_{tag}", dict(level=1), 8,
+                      dict(units={1: dict(lat=5.12, lon=7.02, hdg=90.0, missile_remain=4), 3: dict(lat=5.10, lon=lon_at_range(5.10, 7.05, 1000.0 + eps), hdg=0.0, spd=0.0), **FAR},
+                           rockets=[dict(source=1, target=3, lat=5.10, lon=7.05, hdg=90.0, life=3)]),
+                      [noop, noop]))
+    # 12./13. missile range 111 km inclusive (ac1.py:75) on a 1.2 deg map; 14.-17. the asymmetric radar cone (h - 1, h + 121) deg
+    for tag, eps in (("inside", -1e-4), ("outside", +1e-4)):
+        cases.append((f"missile_range_{tag}", dict(level=1, map_size=1.2), 9,
+                      dict(units={1: dict(lat=5.60, lon=7.05, hdg=90.0), 3: dict(lat=5.60, lon=lon_at_range(5.60, 7.05, 111000.0 + eps), hdg=0.0, spd=0.0),
+                                  2: dict(lat=6.10, lon=7.02, hdg=0.0), 4: dict(lat=5.02, lon=8.15, hdg=180.0, spd=0.0)}),
+                      [{1: [6, 0, 0, 1], 2: [6, 0, 0]}, noop]))
+    for tag, rel in (("low_inside", -1.0 + 1e-7), ("low_outside", -1.0 - 1e-7), ("high_inside", 121.0 - 1e-7), ("high_outside", 121.0 + 1e-7)):
+        la3, lo3 = G.direct(5.15, 7.15, 40.0 + rel, 9000.0)
+        cases.append((f"radar_cone_{tag}", dict(level=1), 10,
+                      dict(units={1: dict(lat=5.15, lon=7.15, hdg=40.0), 3: dict(lat=la3, lon=lo3, hdg=0.0, spd=0.0), **FAR}),
+                      [{1: [6, 0, 0, 1], 2: [6, 0, 0]}, noop]))
+    return cases
+
+
+def record_edge(seed=20240917):
+    """tests/golden/edge_cases.npz: every case = a reset row (kind 0), an inject row (kind 2: the world snapshot the replay
+    loads through hh_set_state, and the observation the reference's state() gives for it) and its step rows (kind 1)."""
+    rows = dict(kind=[], case=[], actions=[], ac_f=[], ac_i=[], rk_f=[], rk_i=[], ar_i=[], tgt_id=[], tgt_d=[], obs=[], reward=[],
+                valid=[], done=[])
+    metas = []
+    for ci, (name, kw, arena, inj, script) in enumerate(edge_cases(seed)):
+        args = H.make_args(**kw)
+        env = H.RefEnv("low", args, seed=seed, arena=arena)
+        A, nA = args.total_num, args.num_agents
+
+        def push(k, act, obs, rew, done):
+            st = env.state()
+            rows["kind"].append(k); rows["case"].append(ci)
+            a = np.zeros((A, 4), dtype=np.int8)
+            for i, v in (act or {}).items():
+                a[i - 1, : len(v)] = v
+            rows["actions"].append(a)
+            for key in ("ac_f", "ac_i", "rk_i", "tgt_id", "tgt_d"):
+                rows[key].append(st[key])
+            rows["ar_i"].append(np.concatenate([st["ar_i"], [env.tape.episode]]).astype(np.int32))
+            rows["rk_f"].append(st["rk_f"][:, :4])
+            rows["obs"].append(env.obs_array(obs, 26))
+            r = np.zeros(nA); v = np.zeros(nA, dtype=np.uint8)
+            for i, x in (rew or {}).items():
+                r[i - 1] = x; v[i - 1] = 1
+            rows["reward"].append(r); rows["valid"].append(v); rows["done"].append(int(done))
+
+        push(0, None, env.reset(), None, False)
+        push(2, None, env.inject(**inj), None, False)
+        for act in script:
+            obs, rew, term, trunc, info = env.step(act)
+            push(1, act, obs, rew, term["__all__"])
+            if term["__all__"]:   # RLlib resets a finished episode; stepping on is outside the boundary's contract
+                break
+        assert len(set(env.tape.log)) == len(env.tape.log), "keyed-RNG key collision"
+        metas.append(dict(name=name, env="low", args={k: v for k, v in vars(args).items()}, seed=seed, arena=arena, obs_dim=26))
+    out = {k: np.asarray(v) for k, v in rows.items()}
+    out["meta"] = np.array(json.dumps(metas))
+    path = os.path.join(OUT, "edge_cases.npz")
+    np.savez_compressed(path, **out)
+    alive = out["ac_i"][:, :, 0]
+    print(f"edge_cases: cases={len(metas)} rows={len(out['kind'])} size={os.path.getsize(path)}")
+    for ci, m in enumerate(metas):
+        sel = out["case"] == ci
+        print(f"   {m['name']:34s} arena={m['arena']:5d} alive after inject {alive[sel][1].tolist()} -> end {alive[sel][-1].tolist()} "
+              f"rockets {out['rk_i'][sel][:, :, 0].sum(axis=1).tolist()} wait {out['ac_i'][sel][:, 0, 7].tolist()}")
+
+
+def generate(out_dir, only=()):
+    global OUT
+    OUT = out_dir
     os.makedirs(OUT, exist_ok=True)
-    only = sys.argv[1:]
     for sc in SCENARIOS:
-        if only and sc[0] not in only:
-            continue
-        record(*sc)
+        if not only or sc[0] in only:
+            record(*sc)
     for sc in HL_SCENARIOS:
-        if only and sc[0] not in only:
-            continue
-        record_hl(*sc)
+        if not only or sc[0] in only:
+            record_hl(*sc)
+    if not only or "edge_cases" in only:
+        record_edge()
+
+
+def check(committed_dir):
+    """regenerate every fixture into a temporary directory and compare it, array by array, with the committed files"""
+    import glob
+    import tempfile
+    bad = []
+    with tempfile.TemporaryDirectory() as tmp:
+        generate(tmp)
+        new = sorted(os.path.basename(f) for f in glob.glob(os.path.join(tmp, "*.npz")))
+        old = sorted(os.path.basename(f) for f in glob.glob(os.path.join(committed_dir, "env_*.npz")) + glob.glob(os.path.join(committed_dir, "edge_*.npz")))
+        if new != old:
+            bad.append(f"file sets differ: generated {new} vs committed {old}")
+        for f in new:
+            if f not in old:
+                continue
+            a, b = np.load(os.path.join(tmp, f)), np.load(os.path.join(committed_dir, f))
+            if set(a.files) != set(b.files):
+                bad.append(f"{f}: keys differ {sorted(set(a.files) ^ set(b.files))}")
+                continue
+            for k in a.files:
+                if a[k].shape != b[k].shape or not np.array_equal(a[k], b[k]):
+                    bad.append(f"{f}: array {k} differs")
+    return bad
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("names", nargs="*", help="scenario names (default: all)")
+    ap.add_argument("--out", default=OUT, help="output directory (default tests/golden)")
+    ap.add_argument("--check", action="store_true", help="regenerate into a temp dir and compare with tests/golden; exit 1 on any difference")
+    a = ap.parse_args()
+    if a.check:
+        problems = check(a.out)
+        print("\n".join(problems) if problems else "golden fixtures reproduce from the committed generator")
+        sys.exit(1 if problems else 0)
+    generate(a.out, a.names)

@@ -385,6 +385,43 @@ class RefEnv:
         _patch_random(self.tape)
         return self.env.step(action_dict)
 
+    def inject(self, units=None, rockets=(), steps=None):
+        """Put the live reference objects into a hand-built situation (edge-case fixtures): `units` maps
+        unit id -> dict of fields (lat, lon, hdg, spd, cmd_hdg, cmd_spd, burst, cannon_remain, missile_remain,
+        missile_wait; alive=False removes the unit the way a kill would); `rockets` spawns Rocket objects the way
+        Rafale.fire_missile does (ac1.py:76-79) with a given age.  Afterwards the env's own state() refreshes
+        opp_to_attack exactly as the end of a step would."""
+        from datetime import timedelta
+        e, sim = self.env, self.env.sim
+        ref_sim = sys.modules["simulator.cmano_simulator"]
+        Rocket = sys.modules["simulator.rocket_unit"].Rocket
+        for uid, f in (units or {}).items():
+            u = e._hh_units[uid]
+            if "lat" in f: u.position.lat = float(f["lat"])
+            if "lon" in f: u.position.lon = float(f["lon"])
+            if "hdg" in f: u.heading = float(f["hdg"]); u.new_heading = float(f.get("cmd_hdg", f["hdg"]))
+            if "spd" in f: u.speed = float(f["spd"]); u.new_speed = float(f.get("cmd_spd", f["spd"]))
+            if "cmd_hdg" in f: u.new_heading = float(f["cmd_hdg"])
+            if "cmd_spd" in f: u.new_speed = float(f["cmd_spd"])
+            if "burst" in f: u.cannon_current_burst_secs = f["burst"]
+            if "cannon_remain" in f: u.cannon_remain_secs = f["cannon_remain"]
+            if "missile_remain" in f: u.missile_remain = f["missile_remain"]
+            if "missile_wait" in f: e.missile_wait[uid] = f["missile_wait"]
+            if f.get("alive", True) is False and sim.unit_exists(uid):
+                sim.remove_unit(uid)
+                if uid <= self.n_agents: e.alive_agents -= 1
+                else: e.alive_opps -= 1
+        for r in rockets:
+            src, tgt = e._hh_units[r["source"]], e._hh_units[r["target"]]
+            m = Rocket(ref_sim.Position(float(r["lat"]), float(r["lon"]), src.position.alt), float(r["hdg"]),
+                       sim.utc_time - timedelta(seconds=int(r.get("life", 0))), tgt, src, src.friendly_check)
+            m.new_heading = float(r.get("cmd_hdg", r["hdg"]))
+            sim.add_unit(m)
+            src.actual_missile = m
+        if steps is not None:
+            e.steps = int(steps)
+        return e.state()
+
     def obs_array(self, obs, dim):
         out = np.zeros((self.n_agents, dim), dtype=np.float32)
         for i in range(1, self.n_agents + 1):

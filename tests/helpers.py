@@ -21,6 +21,23 @@ def load_golden(path):
     return g, meta
 
 
+def edge_cases():
+    """tests/golden/edge_cases.npz (hand-built threshold situations run on the REAL reference, oracle/gen_env_golden.py):
+    -> list of (meta, rows) with rows a dict of the case's arrays (kind 0 reset, 2 inject = load through set_state, 1 step)"""
+    g = np.load(os.path.join(GOLDEN, "edge_cases.npz"))
+    metas = json.loads(str(g["meta"]))
+    out = []
+    for ci, m in enumerate(metas):
+        sel = g["case"] == ci
+        out.append((m, {k: g[k][sel] for k in g.files if k not in ("meta",)}))
+    return out
+
+
+def edge_state(rows, r):
+    """world snapshot (hh_get_state / hh_set_state layout, one arena) of row r of an edge case"""
+    return {k: np.ascontiguousarray(rows[k][r][None]) for k in ("ac_f", "ac_i", "rk_f", "rk_i", "ar_i", "tgt_id", "tgt_d")}
+
+
 def cfg_kwargs_from_meta(meta, **over):
     a = meta["args"]
     kw = dict(

@@ -6,7 +6,7 @@ masks, float64 kinematics, float32 observations and rewards."""
 import numpy as np
 import pytest
 
-from helpers import cfg_kwargs_from_meta, golden_files, load_golden, pursuit_actions, random_actions
+from helpers import cfg_kwargs_from_meta, edge_cases, golden_files, load_golden, pursuit_actions, random_actions
 
 pytestmark = pytest.mark.gpu
 
@@ -127,6 +127,24 @@ def test_golden_traces_on_gpu(path):
         assert np.abs(st["ac_f"][0] - g["ac_f"][r]).max() <= 1e-9, f"row {r}"   # north_star bar is 1e-5
         assert np.abs(obs - g["obs"][r]).max() <= 1e-6, f"row {r}"
         assert np.abs(rew - g["reward"][r]).max() <= 1e-6 * max(1.0, np.abs(g["reward"][r]).max()), f"row {r}"
+
+
+@pytest.mark.parametrize("case", edge_cases(), ids=lambda c: c[0]["name"])
+def test_reference_edge_cases_on_gpu(case):
+    """the hand-built threshold situations recorded from the REAL reference (tests/golden/edge_cases.npz) on the HIP world:
+    loaded through hh_set_state, stepped through hh_step — the staged envelope predicates must land on the reference's side
+    of every threshold (1e-5 m / 1e-7 deg away from it)"""
+    import torch
+    from hhmarl_2d_amd.world import World, make_config
+    from test_oracle_golden import check_edge_case
+    meta, rows = case
+    w = World(make_config(**cfg_kwargs_from_meta(meta)))
+
+    class _W:
+        n_agents, n_ctrl = w.n_agents, w.n_ctrl
+        reset, set_state, get_state, observe = w.reset, w.set_state, w.get_state, w.observe
+        step = staticmethod(lambda a: w.step(torch.from_numpy(np.ascontiguousarray(a)).cuda()))
+    check_edge_case(_W, lambda t: t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t), meta, rows)
 
 
 def test_set_state_round_trip_and_edge_cases(oracle):

@@ -8,6 +8,7 @@ LIB_PATH = os.environ.get("HH_WORLD_LIB") or os.path.join(HERE, "lib", "libhh_wo
 
 ENV_LOWLEVEL, ENV_HIGHLEVEL = 0, 1
 MODE_FIGHT, MODE_ESCAPE = 0, 1
+OPP_MODE_EPISODE = -1  # hh_step_begin: every arena observes in the mode of its own level-5 draw
 ACF_K, ACI_K, RKF_K, RKI_K, ARI_K, TGT_K = 6, 10, 4, 4, 6, 3
 
 
@@ -34,7 +35,7 @@ class HHStateView(C.Structure):
 EXPORTS = ["hh_world_create", "hh_world_destroy", "hh_last_error", "hh_obs_dim", "hh_n_ctrl", "hh_reset", "hh_step",
            "hh_rollout", "hh_episode_stats", "hh_get_state", "hh_set_state", "hh_get_event_masks", "hh_observe",
            "hh_hl_begin", "hh_hl_agents_act", "hh_hl_tick", "hh_hl_end", "hh_step_begin", "hh_step_finish", "hh_gae", "hh_hl_commands",
-           "hh_episode_stats_packed", "hh_hl_tick_count", "hh_rollout_kernel_name"]
+           "hh_episode_stats_packed", "hh_hl_tick_count", "hh_rollout_kernel_name", "hh_opp_policy"]
 
 _lib = None
 
@@ -71,6 +72,7 @@ def lib():
         L.hh_step_begin.argtypes = [vp, vp, C.c_int32, vp, vp]
         L.hh_step_finish.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.hh_hl_commands.argtypes = [vp, vp]
+        L.hh_opp_policy.argtypes = [vp, vp, vp]
         L.hh_gae.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
         _lib = L
     return _lib

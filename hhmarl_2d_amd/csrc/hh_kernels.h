@@ -1066,6 +1066,16 @@ __device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int
     __syncthreads();
 }
 
+/* hh_opp_policy: k of every arena's current episode (level 5, fight mode) */
+__global__ __launch_bounds__(256) void hh_k_opp_policy(DevPtrs P, DevCfg c, int8_t *__restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= c.N) return;
+    int k = 0;
+    if (c.env_kind == HH_ENV_LOWLEVEL && c.level == 5 && c.agent_mode == HH_MODE_FIGHT)
+        k = hh_l5_policy_pick(hh_rng_arena_key(c.seed, c.arena_offset + (uint64_t)n), (uint32_t)P.ar_pack[n].y);
+    out[n] = (int8_t)k;
+}
+
 /* ===================================================================== the kernel */
 enum { HH_RUN_ROLLOUT = 0, HH_RUN_RESET = 1, HH_RUN_OBSERVE = 2, HH_RUN_LL_BEGIN = 3, HH_RUN_LL_FINISH = 4 };
 
@@ -1113,7 +1123,8 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
     }
     if constexpr (SPLIT) {
         if (run == HH_RUN_LL_BEGIN) {
-            const int opp_mode = T;
+            /* T < 0 (HH_OPP_MODE_EPISODE): the arena's own level-5 draw of this episode decides (env_hetero.py:55-59) */
+            const int opp_mode = T >= 0 ? T : (hh_l5_policy_pick(ar.akey, (uint32_t)ar.episode) == 5 ? HH_MODE_ESCAPE : HH_MODE_FIGHT);
             const bool running = active && !ar.done;
             if (running) { ar.steps += 1; arena_rekey(ar); }
             int8_t act[4] = {0, 0, 0, 0};

@@ -470,6 +470,14 @@ extern "C" int hh_step_finish(hh_world *w, const int8_t *opp_actions, float *obs
     return launch(w, HH_RUN_LL_FINISH, 1, opp_actions, nullptr, obs, reward, reward_valid, done, (hipStream_t)stream);
 }
 
+extern "C" int hh_opp_policy(hh_world *w, int8_t *k_out, void *stream) {
+    if (!w || !k_out) { g_err = "null argument"; return HH_E_ARG; }
+    HH_GUARD(w);
+    hipLaunchKernelGGL(hh_k_opp_policy, dim3((w->dc.N + 255) / 256), dim3(256), 0, (hipStream_t)stream, w->P, w->dc, k_out);
+    HIPCHK(hipGetLastError());
+    return HH_OK;
+}
+
 /* ---- rollout post-processing: GAE over the [T, N, n_agents] tensors of hh_rollout ---- */
 extern "C" int hh_gae(int32_t T, int32_t N, int32_t n_agents, const float *reward, const float *value, const uint8_t *valid,
                       const uint8_t *done, float gamma, float lam, float *adv, float *ret, void *stream) {

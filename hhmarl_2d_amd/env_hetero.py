@@ -104,7 +104,12 @@ class LowLevelEnv(_Base):
         self.map_size = self.args.map_size
         self.num_envs = int(env_config.get("num_envs", 1))
         self.opponent_policy = env_config.get("opponent_policy", None)
-        self.opp_mode = "fight"  # env_hetero.py:23; level-5 callers switch it per episode (env_hetero.py:55-59)
+        # env_hetero.py:23,50,55-59: "fight", except that level 5 in fight mode draws k = randint(3,5) at every reset():
+        # the opponents fly policies[k] and observe in escape mode when k == 5.  The draw is the world's keyed one; the
+        # facade mirrors it in opp_k / opp_mode (arrays over arenas when num_envs > 1) for the opponent_policy callable.
+        self.opp_mode = "fight"
+        self.opp_k = None
+        self._l5_draw = self.args.level == 5 and self.agent_mode == "fight"
         if self.args.level >= 4 and self.opponent_policy is None:
             raise ValueError("levels 4-5 fly frozen opponent policies (envs/env_base.py:312-398); pass env_config["
                              "'opponent_policy'] = callable(opp_obs f32 [N,2,30], env) -> int8 actions [N,2,4] for units 3,4")
@@ -126,9 +131,16 @@ class LowLevelEnv(_Base):
             return {i: o[0, i - 1, : self.obs_dim_map[i]].copy() for i in sorted(self._agent_ids)}
         return {i: o[:, i - 1, : self.obs_dim_map[i]].copy() for i in sorted(self._agent_ids)}
 
+    def _refresh_opp_policy(self):
+        if self._l5_draw:
+            k = self.world.opp_policy().cpu().numpy()
+            modes = np.where(k == 5, "escape", "fight")
+            self.opp_k, self.opp_mode = (int(k[0]), str(modes[0])) if self.num_envs == 1 else (k, modes)
+
     def reset(self, *, seed=None, options=None):
         self.steps = 0
         obs = self.world.reset()
+        self._refresh_opp_policy()
         self.trace = []
         _snapshot(self)
         return self._obs_dict(obs), {}
@@ -151,7 +163,8 @@ class LowLevelEnv(_Base):
             self._act.copy_(torch.from_numpy(a))
             if self.opponent_policy is not None:
                 # env_hetero.py:160-172: agents act, then each frozen-policy opponent observes and acts
-                opp_obs = self.world.step_begin(self._act[:, :n_ag].contiguous(), 0 if self.opp_mode == "fight" else 1)
+                mode = L.OPP_MODE_EPISODE if self._l5_draw else (0 if self.opp_mode == "fight" else 1)
+                opp_obs = self.world.step_begin(self._act[:, :n_ag].contiguous(), mode)
                 opp_act = self.opponent_policy(opp_obs, self).to(torch.int8).contiguous()
                 obs, rew, val, done = self.world.step_finish(opp_act, out=self._out)
             else:

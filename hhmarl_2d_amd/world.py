@@ -102,6 +102,13 @@ class World:
         L.check(L.lib().hh_step_begin(self.h, _p(agent_actions), int(opp_mode), _p(opp_obs), self._stream()))
         return opp_obs
 
+    def opp_policy(self, out=None):
+        """level 5 / fight mode: k in {3,4,5} of every arena's current episode (env_hetero.py:55-59), int8 [N] on the device"""
+        if out is None:
+            out = torch.zeros((self.N,), dtype=torch.int8, device=self.device)
+        L.check(L.lib().hh_opp_policy(self.h, _p(out), self._stream()))
+        return out
+
     def step_finish(self, opp_actions, out=None):
         assert opp_actions.dtype == torch.int8 and opp_actions.is_contiguous()
         assert opp_actions.numel() == self.N * (self.A - self.n_agents) * 4

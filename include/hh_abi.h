@@ -112,10 +112,17 @@ int hh_rollout(hh_world *w, int32_t n_steps, const int8_t *actions, float *obs, 
  *       -> opp_obs [dev] f32[N, n_opps, 30]: lowlevel_state(opp_mode, i) of each live opponent (zeros if dead)
  *   (caller runs its frozen policies)
  *   hh_step_finish(opp_actions [dev] i8[N, n_opps, 4]) -> outputs exactly like hh_step.
- * hh_step with n_ctrl = n_agents + n_opps remains for callers that do not need the opponents' observations. */
+ * hh_step with n_ctrl = n_agents + n_opps remains for callers that do not need the opponents' observations.
+ * opp_mode = HH_OPP_MODE_EPISODE: level 5 in fight mode draws, per arena and per episode, which frozen policy set the
+ * opponents fly (k = randint(3,5), env_hetero.py:55-59) and k == 5 means "escape": each arena then observes in the mode of
+ * its own draw; hh_opp_policy reports k so that the caller evaluates policies[k]. */
+#define HH_OPP_MODE_EPISODE (-1)
 int hh_step_begin(hh_world *w, const int8_t *agent_actions, int32_t opp_mode, float *opp_obs, void *stream);
 int hh_step_finish(hh_world *w, const int8_t *opp_actions, float *obs, float *reward, uint8_t *reward_valid,
                    uint8_t *done, void *stream);
+
+/* level 5 / fight mode: k in {3,4,5} of every arena's CURRENT episode -> [dev] i8[N] (0 for every other configuration) */
+int hh_opp_policy(hh_world *w, int8_t *k_out, void *stream);
 
 /* current observation of every arena without stepping (state(): env_hetero.py:62-63 / env_hier.py:49-98) */
 int hh_observe(hh_world *w, float *obs, void *stream);

@@ -25,6 +25,7 @@
 
 #include <stdint.h>
 #include "hh_math.h"
+#include "hh_spec.h"
 
 HH_HD uint64_t hh_mix64(uint64_t z) {
     z ^= z >> 30;
@@ -52,5 +53,12 @@ HH_HD double hh_rng_u01(uint64_t tick_key, uint32_t unit, uint32_t site, uint32_
 
 HH_HD double hh_rng_uniform(double u, double a, double b) { return a + (b - a) * u; }
 HH_HD int hh_rng_randint(double u, int a, int b) { return a + (int)hh_floor(u * (double)(b - a + 1)); }
+
+/* envs/env_hetero.py:55-59: at level 5 (fight mode) every reset() draws k = randint(3,5): the opponents fly
+ * self.policies[k] for that episode and observe in escape mode when k == 5.  The draw is keyed by (arena, episode,
+ * tick 0, unit 0), so nothing needs to be stored: whoever knows the arena's episode counter recomputes it. */
+HH_HD int hh_l5_policy_pick(uint64_t arena_key, uint32_t episode) {
+    return hh_rng_randint(hh_rng_u01(hh_rng_tick_key(arena_key, episode, 0u), 0u, HH_SITE_RESET_L5K, 0u), 3, 5);
+}
 
 #endif /* HH_RNG_H */

@@ -79,7 +79,7 @@ SCENARIOS = [
     # levels 4-5: opponents fly frozen policies (env_base.py:312-398, files not shipped): taped actions, and the
     # opponents' own observations (the reference's lowlevel_state, evaluated after the agents acted) are recorded
     ("l4_fight_frozen_opps", "low", dict(level=4), pursuit_actions, 3, 300),
-    ("l5_fight_frozen_opps", "low", dict(level=5), pursuit_actions, 4, 360),
+    ("l5_fight_frozen_opps", "low", dict(level=5, horizon=70), pursuit_actions, 6, 420),   # short horizon: several episodes, i.e. several draws of k (env_hetero.py:57)
 ]
 
 

@@ -1017,8 +1017,18 @@ API int hho_step_begin(void *h, const int8_t *agent_actions /* [N, n_agents, 4] 
         for (int i = 0; i < nA * 4; i++) act[i] = agent_actions[(size_t)n * nA * 4 + i];
         ll_begin(a);
         ll_act_range(w, a, 1, nA, act);
-        ll_opp_obs(w, a, opp_mode, oo);
+        /* env_hetero.py:55-59: level 5 draws the opponents' policy set (and with it their observation mode) per episode */
+        int mode = opp_mode >= 0 ? opp_mode : (hh_l5_policy_pick(a->akey, (uint32_t)a->episode) == 5 ? HH_MODE_ESCAPE : HH_MODE_FIGHT);
+        ll_opp_obs(w, a, mode, oo);
     }
+    return HH_OK;
+}
+
+/* env_hetero.py:55-59: k = randint(3,5) of every arena's current episode (level 5, fight mode; 0 otherwise) */
+API int hho_opp_policy(void *h, int8_t *k_out) {
+    o_world *w = (o_world *)h;
+    int l5 = w->cfg.env_kind == HH_ENV_LOWLEVEL && w->cfg.level == 5 && w->cfg.agent_mode == HH_MODE_FIGHT;
+    for (int n = 0; n < w->cfg.n_arenas; n++) k_out[n] = l5 ? (int8_t)hh_l5_policy_pick(w->ar[n].akey, (uint32_t)w->ar[n].episode) : 0;
     return HH_OK;
 }
 

@@ -147,6 +147,11 @@ class OracleWorld:
         assert rc == 0, rc
         return oo
 
+    def opp_policy(self):
+        k = np.zeros((self.N,), dtype=np.int8)
+        lib().hho_opp_policy(self.h, _ptr(k, C.c_int8))
+        return k
+
     def step_finish(self, opp_actions):
         a = np.ascontiguousarray(opp_actions, dtype=np.int8).reshape(self.N, self.A - self.n_agents, 4)
         obs = np.zeros((self.N, self.n_agents, self.D), dtype=np.float32)

@@ -62,6 +62,52 @@ def test_macro_step_parity(oracle, kw):
     assert dones > 0 and kills > 0
 
 
+@pytest.mark.parametrize("N,force_w", [(8192, "0"), (12003, "0"), (173, "2")],
+                         ids=["configs3-8192-W1", "12003-auto-W2-partial-group", "173-forced-W2"])
+def test_macro_step_parity_at_size(oracle, monkeypatch, N, force_w):
+    """BASELINE configs[3] size (8192 arenas: hh_k_hier<6,64,1>) and the two-waves-per-SIMD instance hh_k_hier<6,64,2> that
+    the host picks above one workgroup per SIMD (N = 12003: 1201 workgroups, the last one partially filled; and forced at a
+    small size), >= 3 commander steps with every sub-step's pilot observations, outputs and the final state against the oracle"""
+    import torch
+    from hhmarl_2d_amd.world import World, make_config
+    monkeypatch.setenv("HH_FORCE_W", force_w)
+    base = dict(n_arenas=N, env_kind=1, seed=77, arena_offset=3, auto_reset=True, horizon=40)   # short horizon: resets inside the run
+    g = World(make_config(**base))
+    assert g.kernel_name() == ("hh_k_hier<6,64,2>" if (force_w == "2" or N > 10240) else "hh_k_hier<6,64,1>")
+    o = oracle.OracleWorld(oracle.make_config(**base))
+    assert np.array_equal(g.reset().cpu().numpy(), o.reset())
+    rng = np.random.default_rng(N)
+    dones = 0
+    for step in range(4):
+        cmd = rng.integers(0, 3, (N, 3)).astype(np.int8)
+        po, pm = g.hl_begin(torch.from_numpy(cmd).cuda())
+        o.hl_begin(cmd)
+        for sub in range(16):
+            po_o, pm_o = o.hl_pilot_obs(0)
+            assert np.array_equal(pm.cpu().numpy(), pm_o) and np.array_equal(po.cpu().numpy(), po_o), f"{step}/{sub}: agent pilot obs"
+            act = random_actions(rng, (N,), 6)
+            act[..., 2] = 1
+            ta = torch.from_numpy(act).cuda()
+            po, pm = g.hl_agents_act(ta)
+            o.hl_agents_act(act)
+            po_o, pm_o = o.hl_pilot_obs(1)
+            assert np.array_equal(pm.cpu().numpy(), pm_o) and np.array_equal(po.cpu().numpy(), po_o), f"{step}/{sub}: opp pilot obs"
+            po, pm, running = g.hl_tick(ta)
+            assert running == o.hl_tick(act), f"{step}/{sub}: running"
+            if running == 0:
+                break
+        outs = [x.cpu().numpy() for x in g.hl_end()]
+        for a, b, name in zip(outs, o.hl_end(), ("obs", "reward", "valid", "done")):
+            assert np.array_equal(a, b), f"step {step}: {name}"
+        dones += int(outs[3].sum())
+    _same_state(g.get_state(), o.get_state(), "final")
+    for a, b in zip([x.cpu().numpy() for x in g.episode_stats()], o.episode_stats()):
+        assert np.array_equal(a, b)
+    assert dones > 0
+    ticks = g.hl_tick_count()
+    assert 0 < ticks <= 4 * 16 * N
+
+
 @pytest.mark.parametrize("path", golden_files("high"), ids=lambda p: p.split("env_")[-1][:-4])
 def test_reference_traces_on_gpu(path):
     import torch

@@ -276,7 +276,7 @@ def test_two_wave_form_equals_single_wave(monkeypatch, kw):
             assert all(torch.equal(a, b) for a, b in zip(stats[0], st))
 
 
-@pytest.mark.parametrize("level,opp_mode", [(4, 0), (5, 1)], ids=["L4-fight-opps", "L5-escape-opps"])
+@pytest.mark.parametrize("level,opp_mode", [(4, 0), (5, 1), (5, -1)], ids=["L4-fight-opps", "L5-escape-opps", "L5-drawn-per-episode"])
 def test_split_step_parity_levels_4_5(oracle, level, opp_mode):
     """frozen-policy opponents: hh_step_begin (agents act, opponents observe) / hh_step_finish"""
     import torch
@@ -292,6 +292,7 @@ def test_split_step_parity_levels_4_5(oracle, level, opp_mode):
         oo = g.step_begin(torch.from_numpy(a_ag).cuda(), opp_mode).cpu().numpy()
         oo_o = o.step_begin(a_ag, opp_mode)
         assert np.array_equal(oo, oo_o), f"t={t}: opponents' observations"
+        assert np.array_equal(g.opp_policy().cpu().numpy(), o.opp_policy()), f"t={t}: level-5 policy draw"
         outs = [x.cpu().numpy() for x in g.step_finish(torch.from_numpy(a_op).cuda())]
         outs_o = o.step_finish(a_op)
         for a, b, name in zip(outs, outs_o, ("obs", "reward", "valid", "done")):
@@ -314,7 +315,11 @@ def test_frozen_opponent_traces_on_gpu(path):
             obs = w.reset().cpu().numpy()[0]
             continue
         a = g["actions"][r]
-        oo = w.step_begin(torch.from_numpy(np.ascontiguousarray(a[None, :2])).cuda(), int(g["opp_mode"][r])).cpu().numpy()[0]
+        mode = int(g["opp_mode"][r])
+        if meta["args"]["level"] == 5:   # the world draws the episode's policy set itself (env_hetero.py:55-59), never fed the recorded mode
+            assert (int(w.opp_policy().cpu()[0]) == 5) == (mode == 1), f"row {r}: level-5 policy draw"
+            mode = -1
+        oo = w.step_begin(torch.from_numpy(np.ascontiguousarray(a[None, :2])).cuda(), mode).cpu().numpy()[0]
         assert np.abs(oo - g["opp_obs"][r]).max() <= 1e-6, f"row {r}: opponents' policy observation"
         o, rw, v, d = [x.cpu().numpy() for x in w.step_finish(torch.from_numpy(np.ascontiguousarray(a[None, 2:])).cuda())]
         st = w.get_state()
@@ -322,6 +327,54 @@ def test_frozen_opponent_traces_on_gpu(path):
         assert np.array_equal(v[0], g["valid"][r]) and d[0] == g["done"][r], f"row {r}"
         assert np.abs(st["ac_f"][0] - g["ac_f"][r]).max() <= 1e-9 and np.abs(o[0] - g["obs"][r]).max() <= 1e-6, f"row {r}"
         assert np.abs(rw[0] - g["reward"][r]).max() <= 1e-6 * max(1.0, np.abs(g["reward"][r]).max()), f"row {r}"
+
+
+@pytest.mark.parametrize("env_kind", [0, 1], ids=["LowLevelEnv-2v2", "HighLevelEnv-3v3"])
+def test_two_sharded_worlds_equal_one_big_world(env_kind):
+    """rank r owns global arenas [r*N, (r+1)*N).  Two HIP worlds with arena_offset 0 and N (what two ranks hold)
+    give bit for bit the halves of one 2N world: sharding needs no communication and does not change results.  The packed
+    statistics block (what the logging all-gather moves) is the concatenation as well."""
+    import torch
+    from hhmarl_2d_amd.sharding import shard_kwargs
+    from hhmarl_2d_amd.world import World, make_config
+    N = 1500
+    kw = dict(n_arenas=N, env_kind=env_kind, seed=31, auto_reset=True, horizon=50, **({"level": 3} if env_kind == 0 else {}))
+    halves = [World(make_config(**shard_kwargs(kw, r, 2))) for r in range(2)]
+    big = World(make_config(**{**kw, "n_arenas": 2 * N}))
+    rng = np.random.default_rng(2)
+    o_h = torch.cat([w.reset() for w in halves]); o_b = big.reset()
+    assert torch.equal(o_h, o_b)
+    if env_kind == 0:
+        act = torch.from_numpy(random_actions(rng, (80, 2 * N), 2)).cuda()
+        outs_h = [w.rollout(act[:, r * N:(r + 1) * N].contiguous()) for r, w in enumerate(halves)]
+        outs_b = big.rollout(act)
+        for k in range(4):
+            assert torch.equal(torch.cat([o[k] for o in outs_h], dim=1), outs_b[k])
+    else:
+        from hhmarl_2d_amd.env_hier import macro_step
+        for step in range(5):
+            cmd = torch.from_numpy(rng.integers(0, 3, (2 * N, 3)).astype(np.int8)).cuda()
+            tape = torch.from_numpy(random_actions(rng, (16, 2 * N), 6)).cuda()
+
+            def pilot_for(lo, hi, calls):
+                def pilot(po, pm):
+                    a = tape[(calls[0] // 2) % 16, lo:hi].contiguous()
+                    calls[0] += 1
+                    return a
+                return pilot
+            outs_h = [macro_step(w, cmd[r * N:(r + 1) * N].contiguous(), pilot_for(r * N, (r + 1) * N, [0])) for r, w in enumerate(halves)]
+            outs_b = macro_step(big, cmd, pilot_for(0, 2 * N, [0]))
+            for k in range(4):
+                assert torch.equal(torch.cat([o[k] for o in outs_h]), outs_b[k]), (step, k)
+    sb = big.get_state()
+    for r, w in enumerate(halves):
+        sh = w.get_state()
+        for key in sh:
+            assert np.array_equal(sh[key], sb[key][r * N:(r + 1) * N]), key
+    assert torch.equal(torch.cat([w.episode_stats_packed() for w in halves]), big.episode_stats_packed())
+    ret, ln, oc = big.episode_stats()
+    assert torch.equal(big.episode_stats_packed(), torch.stack([ret, ln.float(), oc.float()], dim=1))
+    assert int((oc != 2).sum()) > 0
 
 
 def test_error_codes_instead_of_exceptions():

@@ -1,0 +1,108 @@
+"""The frozen pilot / opponent policy networks the reference evaluates INSIDE its environments
+(envs/env_base.py:312-398 `_get_policies` / `_policy_actions`): architecture description, weight
+containers keyed like the reference's `state_dict()`, a plain PyTorch fp32 restatement of the actor
+forward pass (the numerics reference for the fused HIP kernel), and the greedy decode.
+
+Architectures (models/ac_models_hetero.py; only the ACTOR half is needed for acting):
+
+    Esc1   (29-103)   obs 30: inp1 [0,7)->150 | inp2 [7,25)->250 | inp3 [25,30)->100   -> cat 500
+    Esc2   (105-180)  obs 29: inp1 [0,6)->150 | inp2 [6,24)->250 | inp3 [24,29)->100   -> cat 500
+    Fight1 (181-291)  obs 26: inp1 [0,12)->200 | inp2 [12,26)->200 | inp3 [0,26)->100 (+ attention) -> cat 500
+    Fight2 (293-404)  obs 24: inp1 [0,10)->200 | inp2 [10,24)->200 | inp3 [0,24)->100 (+ attention) -> cat 500
+    every FC is tanh; then shared_layer 500->500 tanh; act_out 500 -> 26 (type 1) | 24 (type 2) logits.
+
+The fight nets pass inp3's output through `nn.MultiheadAttention(100, 2, batch_first=True)` over a sequence whose
+length is 1 whenever the env calls them (`seq_lens=torch.tensor([1])`, env_base.py:393): the softmax over a single
+key is 1, so the attention output is out_proj(v_proj(x)); then x_full = normalize(x_full + att) (L2, eps 1e-12).
+`get_torch_action` (env_base.py:373-382) splits the logits [13,9,2,2] / [13,9,2] and takes the arg-max of each
+Categorical's probs = arg-max of the logits (first maximum).
+"""
+import numpy as np
+
+FIGHT1, FIGHT2, ESC1, ESC2 = 0, 1, 2, 3
+KIND_NAMES = {FIGHT1: "Fight1", FIGHT2: "Fight2", ESC1: "Esc1", ESC2: "Esc2"}
+OBS_DIM = {FIGHT1: 26, FIGHT2: 24, ESC1: 30, ESC2: 29}
+N_OUT = {FIGHT1: 26, FIGHT2: 24, ESC1: 26, ESC2: 24}
+# (first obs column, last+1, width) of inp1 / inp2 / inp3
+INPUTS = {
+    FIGHT1: ((0, 12, 200), (12, 26, 200), (0, 26, 100)),
+    FIGHT2: ((0, 10, 200), (10, 24, 200), (0, 24, 100)),
+    ESC1: ((0, 7, 150), (7, 25, 250), (25, 30, 100)),
+    ESC2: ((0, 6, 150), (6, 24, 250), (24, 29, 100)),
+}
+HAS_ATT = {FIGHT1: True, FIGHT2: True, ESC1: False, ESC2: False}
+ACTION_SPLIT = (13, 9, 2, 2)
+
+
+def actor_keys(kind):
+    """state_dict keys (reference module names; SlimFC wraps nn.Linear as `_model.0`) of the actor half -> shapes"""
+    (a0, a1, w1), (b0, b1, w2), (c0, c1, w3) = INPUTS[kind]
+    keys = {
+        "inp1._model.0.weight": (w1, a1 - a0), "inp1._model.0.bias": (w1,),
+        "inp2._model.0.weight": (w2, b1 - b0), "inp2._model.0.bias": (w2,),
+        "inp3._model.0.weight": (w3, c1 - c0), "inp3._model.0.bias": (w3,),
+        "shared_layer._model.0.weight": (500, 500), "shared_layer._model.0.bias": (500,),
+        "act_out._model.0.weight": (N_OUT[kind], 500), "act_out._model.0.bias": (N_OUT[kind],),
+    }
+    if HAS_ATT[kind]:
+        keys.update({"att_act.in_proj_weight": (300, 100), "att_act.in_proj_bias": (300,),
+                     "att_act.out_proj.weight": (100, 100), "att_act.out_proj.bias": (100,)})
+    return keys
+
+
+def random_weights(kind, seed):
+    """Deterministic synthetic weights (the reference's policies/*.pt are not shipped): numpy PCG64 streams, identical
+    on every machine, so fixtures store a seed instead of megabytes of matrices.  N(0, 1/fan_in) weights keep the tanh
+    layers in their responsive range; N(0, 0.1^2) biases make every bias path matter."""
+    rng = np.random.default_rng([int(seed), int(kind)])
+    sd = {}
+    for k, shp in actor_keys(kind).items():
+        if k.endswith("weight"):
+            sd[k] = (rng.standard_normal(shp) / np.sqrt(shp[-1])).astype(np.float32)
+        else:
+            sd[k] = (0.1 * rng.standard_normal(shp)).astype(np.float32)
+    return sd
+
+
+def from_torch_module(module):
+    """weights of a loaded reference policy (`torch.load('policies/L3_AC1_fight.pt')`) -> (kind, dict of numpy arrays)"""
+    sd = {k: v.detach().cpu().numpy().astype(np.float32) for k, v in module.state_dict().items()}
+    att = "att_act.in_proj_weight" in sd
+    cols1 = sd["inp1._model.0.weight"].shape[1]
+    kind = {(True, 12): FIGHT1, (True, 10): FIGHT2, (False, 7): ESC1, (False, 6): ESC2}[(att, cols1)]
+    return kind, {k: sd[k] for k in actor_keys(kind)}
+
+
+def torch_forward(kind, sd, obs):
+    """plain PyTorch fp32 actor forward (same op as the HIP kernel, statement order of the reference's forward()):
+    obs float32 [R, >= OBS_DIM[kind]] -> logits float32 [R, N_OUT[kind]]"""
+    import torch
+    import torch.nn.functional as F
+    t = {k: torch.as_tensor(v, dtype=torch.float32, device=obs.device) for k, v in sd.items()}
+    x = obs[:, :OBS_DIM[kind]].to(torch.float32)
+    h = []
+    for n, (c0, c1, _) in zip(("inp1", "inp2", "inp3"), INPUTS[kind]):
+        h.append(torch.tanh(F.linear(x[:, c0:c1], t[f"{n}._model.0.weight"], t[f"{n}._model.0.bias"])))
+    if HAS_ATT[kind]:
+        wv, bv = t["att_act.in_proj_weight"][200:300], t["att_act.in_proj_bias"][200:300]
+        att = F.linear(F.linear(h[2], wv, bv), t["att_act.out_proj.weight"], t["att_act.out_proj.bias"])
+        h[2] = F.normalize(h[2] + att)
+    z = torch.cat(h, dim=1)
+    s = torch.tanh(F.linear(z, t["shared_layer._model.0.weight"], t["shared_layer._model.0.bias"]))
+    return F.linear(s, t["act_out._model.0.weight"], t["act_out._model.0.bias"])
+
+
+def decode(logits, n_out):
+    """env_base.py:373-382: greedy action per MultiDiscrete component; type-2 aircraft have no 4th component (-> 0)"""
+    import torch
+    parts = logits[:, :n_out].split(ACTION_SPLIT[: 4 if n_out == 26 else 3], dim=1)
+    act = torch.zeros((logits.shape[0], 4), dtype=torch.int8, device=logits.device)
+    for i, p in enumerate(parts):
+        act[:, i] = p.argmax(dim=1).to(torch.int8)
+    return act
+
+
+def flops_per_row(kind):
+    (a0, a1, w1), (b0, b1, w2), (c0, c1, w3) = INPUTS[kind]
+    macs = (a1 - a0) * w1 + (b1 - b0) * w2 + (c1 - c0) * w3 + 500 * 500 + 500 * N_OUT[kind] + (100 * 100 * 2 if HAS_ATT[kind] else 0)
+    return 2 * macs

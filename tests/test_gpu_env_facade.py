@@ -125,7 +125,7 @@ def test_level5_facade_draws_the_opponent_policy_per_episode():
     orig = env_hetero.config_from_args
     env_hetero.config_from_args = lambda *a, **k: orig(*a, **{**k, "arena_offset": meta["arena"]})
     try:
-        env = LowLevelEnv({"args": make_args(0, level=5), "seed": meta["seed"], "opponent_policy": frozen})
+        env = LowLevelEnv({"args": make_args(0, level=5, horizon=meta["args"]["horizon"]), "seed": meta["seed"], "opponent_policy": frozen})
     finally:
         env_hetero.config_from_args = orig
     for r in range(len(g["kind"])):

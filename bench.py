@@ -317,18 +317,18 @@ def main_policy_rollout(args):
     half, greedy decode as env_base.py:373-382) in the fused HIP kernel -> int8 actions -> hh_step.  A step is one tick of all arenas."""
     R = Ranks(args)
     torch = R.torch
-    from hhmarl_2d_amd.pilots import PolicyBank
+    from hhmarl_2d_amd.pilots import SEL_FIGHT1, SEL_FIGHT2, PolicyBank
     from hhmarl_2d_amd.sharding import ShardedWorld
     N = args.arenas or 16384
     sw = ShardedWorld(dict(n_arenas=N, level=args.level, seed=args.seed, auto_reset=True), rank=R.rank, world_size=R.world, device=R.local_rank)
     w = sw.world
     obs = w.reset()
-    bank = PolicyBank.random_init(R.dev, seed=args.seed)
+    bank = PolicyBank.random_init(R.dev, seed=args.seed, max_rows=N * 2)
     out = w.alloc_outputs()
     out[0].copy_(obs)
     act = torch.zeros((N, 2, 4), dtype=torch.int8, device=R.dev)
     # agent 1 is a type-1 aircraft (Fight1), agent 2 a type-2 (Fight2): env_base.py:560-561 fixes the first two slots
-    net_id = torch.tensor([PolicyBank.FIGHT1, PolicyBank.FIGHT2], dtype=torch.uint8, device=R.dev).repeat(N, 1).contiguous()
+    net_id = torch.tensor([SEL_FIGHT1, SEL_FIGHT2], dtype=torch.uint8, device=R.dev).repeat(N, 1).contiguous()
 
     def tick():
         bank.act(out[0], net_id, act)

@@ -32,10 +32,18 @@ class HHStateView(C.Structure):
     ]
 
 
+class HHNetWeights(C.Structure):
+    """hh_net_weights (include/hh_policy.h): host pointers to one network's tensors, nn.Linear layout"""
+    _fields_ = [("kind", C.c_int32), ("inp_w", C.c_void_p * 3), ("inp_b", C.c_void_p * 3),
+                ("att_in_proj_w", C.c_void_p), ("att_in_proj_b", C.c_void_p), ("att_out_w", C.c_void_p), ("att_out_b", C.c_void_p),
+                ("shared_w", C.c_void_p), ("shared_b", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p)]
+
+
 EXPORTS = ["hh_world_create", "hh_world_destroy", "hh_last_error", "hh_obs_dim", "hh_n_ctrl", "hh_reset", "hh_step",
            "hh_rollout", "hh_episode_stats", "hh_get_state", "hh_set_state", "hh_get_event_masks", "hh_observe",
            "hh_hl_begin", "hh_hl_agents_act", "hh_hl_tick", "hh_hl_end", "hh_step_begin", "hh_step_finish", "hh_gae", "hh_hl_commands",
-           "hh_episode_stats_packed", "hh_hl_tick_count", "hh_rollout_kernel_name", "hh_opp_policy"]
+           "hh_episode_stats_packed", "hh_hl_tick_count", "hh_rollout_kernel_name", "hh_opp_policy",
+           "hh_policy_create", "hh_policy_destroy", "hh_policy_set_net", "hh_policy_set_lut", "hh_policy_act"]
 
 _lib = None
 
@@ -74,6 +82,11 @@ def lib():
         L.hh_hl_commands.argtypes = [vp, vp]
         L.hh_opp_policy.argtypes = [vp, vp, vp]
         L.hh_gae.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
+        L.hh_policy_create.argtypes = [C.c_int, C.c_int32, C.POINTER(vp)]
+        L.hh_policy_destroy.argtypes = [vp]
+        L.hh_policy_set_net.argtypes = [vp, C.c_int32, C.POINTER(HHNetWeights)]
+        L.hh_policy_set_lut.argtypes = [vp, vp]
+        L.hh_policy_act.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
         _lib = L
     return _lib
 

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
                 int mode = 0;
                 if (ar.hl_run && m.alive && mine) mode = hl_pilot_obs(c, sh, tid, base, s, m, row);
                 else for (int k = 0; k < 30; k++) row[k] = 0.0f;
-                if (pilot_mode) pilot_mode[u] = (uint8_t)mode;
+                if (pilot_mode) pilot_mode[u] = (uint8_t)(mode ? (mode | (m.ac_type << 2)) : 0); /* policy type | aircraft type: selects the network */
             }
             __syncthreads();
             const int cnt = arenas * A * 30;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
                     if (ar.hl_run && m.alive) mode = hl_pilot_obs(c, sh, tid, base, s, m, row);
                     else for (int k = 0; k < 30; k++) row[k] = 0.0f;
                 }
-                if (pilot_mode) pilot_mode[u] = (uint8_t)mode;
+                if (pilot_mode) pilot_mode[u] = (uint8_t)(mode ? (mode | (m.ac_type << 2)) : 0); /* policy type | aircraft type: selects the network */
             }
             __syncthreads();
             const int cnt2 = arenas * A * 15; /* float2 elements */

@@ -1,0 +1,379 @@
+/*
+ * hh_policy_kernel.h — the frozen pilot / opponent networks as ONE fused gfx950 kernel (C ABI: include/hh_policy.h).
+ *
+ * Replaces envs/env_base.py:349-398 `_policy_actions` (one PyTorch forward of batch 1 per live unit per tick) for every
+ * unit of every arena at once.  Actor half of models/ac_models_hetero.py (Esc1 29-103, Esc2 105-180, Fight1 181-291,
+ * Fight2 293-404):
+ *     three input FCs (tanh) on column ranges of the observation, concatenated to 500
+ *     [fight nets: the 100-wide third block x gets  x <- normalize(x + out_proj(v_proj(x)))  — MultiheadAttention over a
+ *      sequence of length 1, where the softmax is identically 1]
+ *     shared layer 500 -> 500 (tanh), act_out 500 -> 26 | 24 logits, arg-max per MultiDiscrete component.
+ *
+ * This is the one dense contraction on the whole path, so it runs on the matrix cores: fp32-in / fp32-accumulate
+ * v_mfma_f32_32x32x2_f32 (an exact, k-ordered fmaf chain: no precision is given up against the reference's fp32
+ * torch forward; gfx950 has no tf32-like mode).  One 256-thread workgroup (one wave per SIMD) carries a tile of 32 rows
+ * of ONE network through all layers with the activations resident in LDS:
+ *     L1   X[32 x 32] . W1[32 x 512]    the three FCs as one zero-padded matrix         (64 MFMAs per wave)
+ *     att  Y[32 x 104] . Wov[104 x 128] out_proj . v_proj folded on the host           (52, fight nets only)
+ *     L2   Z[32 x 512] . Ws[512 x 512]                                                  (1024)
+ *     L3   S[32 x 512] . Wa[512 x 32]   split-K over the four waves, summed in order    (64)
+ * Each wave owns 128 of the 512 output columns (4 MFMA tiles); the A operand comes from LDS and the B operand (weights)
+ * straight from L2 — both stored k-interleaved, P[k/8][k&1][col][(k/2)&3], so that ONE 16-byte access per lane feeds four
+ * consecutive MFMA k-steps (lane l of a 32x32x2 MFMA holds A[l&31][l>>5] / B[l>>5][l&31]) and every wave-wide access is
+ * unit-stride.  Rows of different networks are first binned into per-network lists (hh_k_policy_bin); rows without a
+ * network get a zero action.  Per-row results do not depend on which tile a row lands in, so the outputs are
+ * deterministic although the binning order is not.
+ */
+#ifndef HH_POLICY_KERNEL_H
+#define HH_POLICY_KERNEL_H
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "hh_policy.h"
+
+typedef float hh_f32x16 __attribute__((ext_vector_type(16)));
+
+#define HHP_ROWS 32        /* rows per workgroup tile */
+#define HHP_H 512          /* padded hidden width (500) */
+#define HHP_XK 32          /* padded observation width (<= 30) */
+#define HHP_ATT_K 104      /* padded attention width (100) as K */
+#define HHP_ATT_J 128      /* ... and as output columns */
+#define HHP_OUT 32         /* padded logits (26 | 24) */
+
+struct HhpNet {
+    const float *w1p, *b1;   /* [4][2][512][4], [512] */
+    const float *wovp, *bov; /* [13][2][128][4], [128]  (fight nets) */
+    const float *wsp, *bs;   /* [64][2][512][4], [512] */
+    const float *wap, *ba;   /* [64][2][32][4], [32] */
+    int kind, n_out, obs_dim, has_att;
+};
+struct HhpBank {
+    HhpNet net[HH_POLICY_MAX_NETS];
+};
+
+/* packed index of element (k, col) of a [K x J] operand */
+__host__ __device__ inline size_t hhp_pidx(int k, int col, int J) { return ((size_t)((k >> 3) * 2 + (k & 1)) * J + col) * 4 + ((k >> 1) & 3); }
+
+/* rows -> per-network lists */
+__global__ __launch_bounds__(256) void hh_k_policy_bin(int n_rows, const uint8_t *__restrict__ sel, const uint8_t *__restrict__ lut,
+                                                       int max_rows, int *__restrict__ counts, int *__restrict__ lists,
+                                                       int8_t *__restrict__ actions) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    const int s = lut[sel[r]];
+    if (s == 0) {
+        reinterpret_cast<int *>(actions)[r] = 0;
+        return;
+    }
+    const int pos = atomicAdd(&counts[s - 1], 1);
+    lists[(size_t)(s - 1) * max_rows + pos] = r;
+}
+
+__device__ __forceinline__ hh_f32x16 hhp_zero16() {
+    hh_f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; i++) z[i] = 0.0f;
+    return z;
+}
+/* C/D layout of the 32x32 MFMA: lane holds column (lane & 31), rows (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) */
+__device__ __forceinline__ int hhp_crow(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+/* NT tiles of 32 columns starting at column j0 (+32 per tile) over KB 8-k blocks: A from LDS (packed, 32 rows), B from global
+ * (packed, J columns).  Operands of block kb+1 are requested before the MFMAs of block kb issue. */
+template <int NT>
+__device__ __forceinline__ void hhp_gemm(const float4 *__restrict__ a_lds, int kb0, int KB, const float4 *__restrict__ b_glb, int bkb0, int J,
+                                         int j0, int lane, hh_f32x16 (&acc)[NT]) {
+    const int h = lane >> 5, i = lane & 31;
+    float4 a = a_lds[((kb0)*2 + h) * 32 + i];
+    float4 b[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) b[t] = b_glb[(size_t)((bkb0)*2 + h) * J + j0 + t * 32 + i];
+#pragma unroll 2
+    for (int kb = 0; kb < KB; kb++) {
+        float4 an = a, bn[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) bn[t] = b[t];
+        if (kb + 1 < KB) {
+            an = a_lds[((kb0 + kb + 1) * 2 + h) * 32 + i];
+#pragma unroll
+            for (int t = 0; t < NT; t++) bn[t] = b_glb[(size_t)((bkb0 + kb + 1) * 2 + h) * J + j0 + t * 32 + i];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+        a = an;
+#pragma unroll
+        for (int t = 0; t < NT; t++) b[t] = bn[t];
+    }
+}
+
+/* LDS: Z 64 KB | S 64 KB | X 4 KB | logits 4 KB | row ids, norm partials */
+#define HHP_LDS_FLOATS (16384 + 16384 + 1024 + 1024 + 32 + 128)
+#define HHP_LDS_BYTES (HHP_LDS_FLOATS * 4)
+
+__global__ __launch_bounds__(256, 1) void hh_k_policy(HhpBank bank, int n_nets, const float *__restrict__ obs, int obs_stride,
+                                                      const int *__restrict__ counts, const int *__restrict__ lists, int max_rows,
+                                                      int8_t *__restrict__ actions, float *__restrict__ logits_out) {
+    extern __shared__ __align__(16) float lds[];
+    float *Zp = lds;                 /* [64][2][32][4]  activations after L1 (A operand of att and L2); later the L3 partials */
+    float *Sp = lds + 16384;         /* [64][2][32][4]  activations after L2 (A operand of L3) */
+    float *Xp = lds + 32768;         /* [4][2][32][4]   observation tile */
+    float *Lg = lds + 33792;         /* [32][32]        logits */
+    int *rows = reinterpret_cast<int *>(lds + 34816); /* [32] */
+    float *npart = lds + 34848;      /* [4][32] squared-norm partials */
+
+    /* which (network, tile) is this workgroup's? */
+    int net = -1, tile = blockIdx.x, cnt = 0;
+    for (int n = 0; n < n_nets; n++) {
+        const int c = counts[n], nt = (c + HHP_ROWS - 1) / HHP_ROWS;
+        if (tile < nt) { net = n; cnt = c; break; }
+        tile -= nt;
+    }
+    if (net < 0) return;
+    const HhpNet N = bank.net[net];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ci = lane & 31;
+
+    if (tid < HHP_ROWS) {
+        const int q = tile * HHP_ROWS + tid;
+        rows[tid] = q < cnt ? lists[(size_t)net * max_rows + q] : -1;
+    }
+    __syncthreads();
+    for (int e = tid; e < HHP_ROWS * HHP_XK; e += 256) {
+        const int i = e >> 5, c = e & 31, r = rows[i];
+        Xp[hhp_pidx(c, i, 32)] = (r >= 0 && c < N.obs_dim) ? obs[(size_t)r * obs_stride + c] : 0.0f;
+    }
+    __syncthreads();
+
+    /* ---- L1: the three input FCs as one [32 x 512] matrix, tanh ---- */
+    {
+        hh_f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = hhp_zero16();
+        hhp_gemm<4>(reinterpret_cast<const float4 *>(Xp), 0, HHP_XK / 8, reinterpret_cast<const float4 *>(N.w1p), 0, HHP_H, wave * 128, lane, acc);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int j = wave * 128 + t * 32 + ci;
+            const float bj = N.b1[j];
+#pragma unroll
+            for (int r = 0; r < 16; r++) Zp[hhp_pidx(j, hhp_crow(r, lane), 32)] = tanhf(acc[t][r] + bj);
+        }
+    }
+    __syncthreads();
+
+    /* ---- fight nets: x <- normalize(x + Wov x + bov) on the third block (columns 400..499) ---- */
+    if (N.has_att) {
+        hh_f32x16 acc[1];
+        acc[0] = hhp_zero16();
+        hhp_gemm<1>(reinterpret_cast<const float4 *>(Zp), 400 / 8, HHP_ATT_K / 8, reinterpret_cast<const float4 *>(N.wovp), 0, HHP_ATT_J, wave * 32, lane, acc);
+        const int j = wave * 32 + ci; /* column inside the 100-wide block */
+        const float bj = N.bov[j];
+        float y[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float x = j < 100 ? Zp[hhp_pidx(400 + j, hhp_crow(r, lane), 32)] : 0.0f;
+            y[r] = j < 100 ? x + (acc[0][r] + bj) : 0.0f;
+            float s = y[r] * y[r];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
+            if (ci == 0) npart[wave * 32 + hhp_crow(r, lane)] = s;
+        }
+        __syncthreads(); /* every wave is done reading the block as an operand; partial sums are posted */
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = hhp_crow(r, lane);
+            const float nn = ((npart[row] + npart[32 + row]) + npart[64 + row]) + npart[96 + row];
+            const float den = fmaxf(sqrtf(nn), 1e-12f); /* F.normalize: x / max(||x||_2, eps) */
+            if (j < 100) Zp[hhp_pidx(400 + j, row, 32)] = y[r] / den;
+        }
+        __syncthreads();
+    }
+
+    /* ---- L2: shared layer 500 -> 500, tanh ---- */
+    {
+        hh_f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = hhp_zero16();
+        hhp_gemm<4>(reinterpret_cast<const float4 *>(Zp), 0, HHP_H / 8, reinterpret_cast<const float4 *>(N.wsp), 0, HHP_H, wave * 128, lane, acc);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int j = wave * 128 + t * 32 + ci;
+            const float bj = N.bs[j];
+#pragma unroll
+            for (int r = 0; r < 16; r++) Sp[hhp_pidx(j, hhp_crow(r, lane), 32)] = tanhf(acc[t][r] + bj);
+        }
+    }
+    __syncthreads(); /* S complete; Z is free: it now holds the four split-K partials of L3 */
+
+    /* ---- L3: logits, split-K: wave w contracts columns [128 w, 128 w + 128) of S ---- */
+    {
+        hh_f32x16 acc[1];
+        acc[0] = hhp_zero16();
+        hhp_gemm<1>(reinterpret_cast<const float4 *>(Sp), wave * 16, 16, reinterpret_cast<const float4 *>(N.wap), wave * 16, HHP_OUT, 0, lane, acc);
+#pragma unroll
+        for (int r = 0; r < 16; r++) Zp[(wave * 32 + hhp_crow(r, lane)) * 32 + ci] = acc[0][r];
+    }
+    __syncthreads();
+    for (int e = tid; e < HHP_ROWS * HHP_OUT; e += 256) {
+        const int i = e >> 5, c = e & 31;
+        const float v = (((Zp[e] + Zp[1024 + e]) + Zp[2048 + e]) + Zp[3072 + e]) + N.ba[c];
+        Lg[e] = v;
+        if (logits_out && rows[i] >= 0) logits_out[(size_t)rows[i] * HH_POLICY_LOGITS + c] = c < N.n_out ? v : 0.0f;
+    }
+    __syncthreads();
+    /* ---- greedy decode (env_base.py:373-382): first maximum of each MultiDiscrete component ---- */
+    if (tid < HHP_ROWS && rows[tid] >= 0) {
+        const float *lg = Lg + tid * 32;
+        int a[4] = {0, 0, 0, 0};
+        const int seg0[5] = {0, 13, 22, 24, 26};
+        const int ncomp = N.n_out == 26 ? 4 : 3;
+        for (int k = 0; k < ncomp; k++) {
+            int best = seg0[k];
+            for (int c = seg0[k] + 1; c < seg0[k + 1]; c++) if (lg[c] > lg[best]) best = c;
+            a[k] = best - seg0[k];
+        }
+        reinterpret_cast<int *>(actions)[rows[tid]] = (a[0] & 0xff) | ((a[1] & 0xff) << 8) | ((a[2] & 0xff) << 16) | ((a[3] & 0xff) << 24);
+    }
+}
+
+/* ===================================================================== host side */
+struct hh_policy {
+    int device, max_rows;
+    HhpBank bank;
+    int n_nets;               /* highest loaded slot + 1 */
+    float *blob[HH_POLICY_MAX_NETS];
+    uint8_t *lut;             /* [256] dev */
+    int *counts, *lists;      /* [MAX_NETS], [MAX_NETS][max_rows] dev */
+};
+
+static const int HHP_INPUTS[4][3][3] = {
+    /* first column, last + 1, width: models/ac_models_hetero.py Fight1 214-231, Fight2 326-343, Esc1 46-63, Esc2 122-139 */
+    {{0, 12, 200}, {12, 26, 200}, {0, 26, 100}},
+    {{0, 10, 200}, {10, 24, 200}, {0, 24, 100}},
+    {{0, 7, 150}, {7, 25, 250}, {25, 30, 100}},
+    {{0, 6, 150}, {6, 24, 250}, {24, 29, 100}},
+};
+
+extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
+    if (!out || max_rows <= 0) { g_err = "bad argument"; return HH_E_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device"; return HH_E_NODEV; }
+    if (device < 0 || device >= ndev) { g_err = "bad device index"; return HH_E_ARG; }
+    DeviceGuard guard_(device);
+    if (!guard_.ok) { g_err = "hipSetDevice failed"; return HH_E_HIP; }
+    hh_policy *p = new hh_policy();
+    p->device = device; p->max_rows = max_rows; p->n_nets = 0;
+    memset(&p->bank, 0, sizeof(p->bank));
+    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) p->blob[i] = nullptr;
+    p->lut = nullptr; p->counts = nullptr; p->lists = nullptr;
+    hipError_t e = hipMalloc(&p->lut, 256);
+    if (e == hipSuccess) e = hipMemset(p->lut, 0, 256);
+    if (e == hipSuccess) e = hipMalloc(&p->counts, HH_POLICY_MAX_NETS * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&p->lists, (size_t)HH_POLICY_MAX_NETS * max_rows * sizeof(int));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy), hipFuncAttributeMaxDynamicSharedMemorySize, HHP_LDS_BYTES);
+    if (e != hipSuccess) {
+        g_err = std::string("hh_policy_create: ") + hipGetErrorString(e);
+        if (p->lut) (void)hipFree(p->lut);
+        if (p->counts) (void)hipFree(p->counts);
+        if (p->lists) (void)hipFree(p->lists);
+        delete p;
+        return HH_E_HIP;
+    }
+    *out = p;
+    return HH_OK;
+}
+
+extern "C" int hh_policy_destroy(hh_policy *p) {
+    if (!p) return HH_E_ARG;
+    DeviceGuard guard_(p->device);
+    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) if (p->blob[i]) (void)hipFree(p->blob[i]);
+    (void)hipFree(p->lut); (void)hipFree(p->counts); (void)hipFree(p->lists);
+    delete p;
+    return HH_OK;
+}
+
+extern "C" int hh_policy_set_net(hh_policy *p, int32_t slot, const hh_net_weights *w) {
+    if (!p || !w || slot < 0 || slot >= HH_POLICY_MAX_NETS || w->kind < 0 || w->kind > 3) { g_err = "bad argument"; return HH_E_ARG; }
+    const bool att = w->kind <= HH_NET_FIGHT2;
+    if (!w->shared_w || !w->shared_b || !w->out_w || !w->out_b || (att && (!w->att_in_proj_w || !w->att_in_proj_b || !w->att_out_w || !w->att_out_b))) {
+        g_err = "hh_policy_set_net: missing weight pointer"; return HH_E_ARG;
+    }
+    for (int k = 0; k < 3; k++) if (!w->inp_w[k] || !w->inp_b[k]) { g_err = "hh_policy_set_net: missing input layer"; return HH_E_ARG; }
+    HH_GUARD(p);
+    const int n_out = (w->kind == HH_NET_FIGHT1 || w->kind == HH_NET_ESC1) ? 26 : 24;
+    /* blob: w1p | b1 | wovp | bov | wsp | bs | wap | ba   (float counts; every section 16-byte aligned) */
+    const size_t n_w1 = 4 * 2 * HHP_H * 4, n_wov = 13 * 2 * HHP_ATT_J * 4, n_ws = 64 * 2 * HHP_H * 4, n_wa = 64 * 2 * HHP_OUT * 4;
+    const size_t o_w1 = 0, o_b1 = o_w1 + n_w1, o_wov = o_b1 + HHP_H, o_bov = o_wov + n_wov, o_ws = o_bov + HHP_ATT_J, o_bs = o_ws + n_ws,
+                 o_wa = o_bs + HHP_H, o_ba = o_wa + n_wa, total = o_ba + HHP_OUT;
+    std::vector<float> B(total, 0.0f);
+    int off = 0, obs_dim = 0;
+    for (int k = 0; k < 3; k++) {
+        const int c0 = HHP_INPUTS[w->kind][k][0], c1 = HHP_INPUTS[w->kind][k][1], wd = HHP_INPUTS[w->kind][k][2];
+        for (int o = 0; o < wd; o++) {
+            for (int c = c0; c < c1; c++) B[o_w1 + hhp_pidx(c, off + o, HHP_H)] = w->inp_w[k][(size_t)o * (c1 - c0) + (c - c0)];
+            B[o_b1 + off + o] = w->inp_b[k][o];
+        }
+        off += wd;
+        if (c1 > obs_dim) obs_dim = c1;
+    }
+    if (att) { /* out_proj(v_proj(x)): Wov = Wo Wv, bov = Wo bv + bo, folded in double */
+        const float *wv = w->att_in_proj_w + (size_t)200 * 100, *bv = w->att_in_proj_b + 200;
+        for (int j = 0; j < 100; j++) {
+            for (int k = 0; k < 100; k++) {
+                double s = 0.0;
+                for (int m = 0; m < 100; m++) s += (double)w->att_out_w[(size_t)j * 100 + m] * (double)wv[(size_t)m * 100 + k];
+                B[o_wov + hhp_pidx(k, j, HHP_ATT_J)] = (float)s;
+            }
+            double s = (double)w->att_out_b[j];
+            for (int m = 0; m < 100; m++) s += (double)w->att_out_w[(size_t)j * 100 + m] * (double)bv[m];
+            B[o_bov + j] = (float)s;
+        }
+    }
+    for (int j = 0; j < 500; j++) {
+        for (int k = 0; k < 500; k++) B[o_ws + hhp_pidx(k, j, HHP_H)] = w->shared_w[(size_t)j * 500 + k];
+        B[o_bs + j] = w->shared_b[j];
+    }
+    for (int j = 0; j < n_out; j++) {
+        for (int k = 0; k < 500; k++) B[o_wa + hhp_pidx(k, j, HHP_OUT)] = w->out_w[(size_t)j * 500 + k];
+        B[o_ba + j] = w->out_b[j];
+    }
+    if (!p->blob[slot]) HIPCHK(hipMalloc(&p->blob[slot], total * sizeof(float)));
+    HIPCHK(hipMemcpy(p->blob[slot], B.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    HhpNet &N = p->bank.net[slot];
+    float *b = p->blob[slot];
+    N.w1p = b + o_w1; N.b1 = b + o_b1; N.wovp = b + o_wov; N.bov = b + o_bov; N.wsp = b + o_ws; N.bs = b + o_bs; N.wap = b + o_wa; N.ba = b + o_ba;
+    N.kind = w->kind; N.n_out = n_out; N.obs_dim = obs_dim; N.has_att = att ? 1 : 0;
+    if (slot + 1 > p->n_nets) p->n_nets = slot + 1;
+    return HH_OK;
+}
+
+extern "C" int hh_policy_set_lut(hh_policy *p, const uint8_t *lut) {
+    if (!p || !lut) { g_err = "null argument"; return HH_E_ARG; }
+    for (int i = 0; i < 256; i++) if (lut[i] > HH_POLICY_MAX_NETS || (lut[i] && !p->blob[lut[i] - 1])) { g_err = "hh_policy_set_lut: selector maps to an empty slot"; return HH_E_ARG; }
+    HH_GUARD(p);
+    HIPCHK(hipMemcpy(p->lut, lut, 256, hipMemcpyHostToDevice));
+    return HH_OK;
+}
+
+extern "C" int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, const uint8_t *sel, int8_t *actions,
+                             float *logits, void *stream) {
+    if (!p || !obs || !sel || !actions || n_rows <= 0 || obs_stride <= 0) { g_err = "bad argument"; return HH_E_ARG; }
+    if (n_rows > p->max_rows) { g_err = "hh_policy_act: n_rows exceeds max_rows of hh_policy_create"; return HH_E_ARG; }
+    if (p->n_nets == 0) { g_err = "hh_policy_act: no network loaded"; return HH_E_ARG; }
+    HH_GUARD(p);
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(p->counts, 0, HH_POLICY_MAX_NETS * sizeof(int), st));
+    hipLaunchKernelGGL(hh_k_policy_bin, dim3((n_rows + 255) / 256), dim3(256), 0, st, n_rows, sel, p->lut, p->max_rows, p->counts, p->lists, actions);
+    const int grid = (n_rows + HHP_ROWS - 1) / HHP_ROWS + p->n_nets; /* upper bound of the tiles over all networks */
+    hipLaunchKernelGGL(hh_k_policy, dim3(grid), dim3(256), HHP_LDS_BYTES, st, p->bank, p->n_nets, obs, obs_stride, p->counts, p->lists, p->max_rows,
+                       actions, logits);
+    HIPCHK(hipGetLastError());
+    return HH_OK;
+}
+
+#endif /* HH_POLICY_KERNEL_H */

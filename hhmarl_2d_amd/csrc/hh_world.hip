@@ -501,3 +501,6 @@ extern "C" int hh_hl_commands(hh_world *w, int8_t *out /* [host] [N, A] */) {
     for (size_t u = 0; u < U; u++) out[u] = (int8_t)((pack[u].w >> 24) & 0xff);
     return HH_OK;
 }
+
+/* ---- frozen pilot / opponent networks (C ABI in include/hh_policy.h) ---- */
+#include "hh_policy_kernel.h"

@@ -1,11 +1,150 @@
-"""Stand-ins for the frozen low-level pilot policies that HighLevelEnv runs inside the environment
-(envs/env_base.py:312-398).  The reference torch.load()s `policies/L*_AC*_{fight,escape}.pt`, which
-are not shipped (.gitignore:5); a deployment passes its own loaded policies as the `pilot` callable.
+"""The frozen low-level pilot / opponent policies the reference runs inside its environments
+(envs/env_base.py:312-398): `PolicyBank` evaluates the reference's own architectures (Fight1/Fight2/Esc1/Esc2 actors,
+models/ac_models_hetero.py) in the fused HIP kernel of csrc/hh_policy_kernel.h (C ABI include/hh_policy.h) and writes
+int8 actions for every unit of every arena in one launch sequence; `NetPilot` / `OpponentNets` plug it into
+HighLevelEnv / LowLevelEnv levels 4-5.  The reference torch.load()s `policies/L*_AC*_{fight,escape}.pt`, which are not
+shipped (.gitignore:5): a deployment loads its own files with `PolicyBank.from_modules`; benchmarks and tests use
+deterministic synthetic weights of the same shapes (`PolicyBank.random_init`).
 
 A pilot is `callable(pilot_obs f32 [N,A,30], pilot_mode u8 [N,A]) -> int8 actions [N,A,4]`
-(MultiDiscrete([13,9,2,2]); rows with mode 0 are ignored).  Greedy arg-max per action component is
-what the reference does (env_base.py:373-382)."""
+(MultiDiscrete([13,9,2,2]); rows with mode 0 are ignored; pilot_mode = policy type | aircraft type << 2).  Greedy
+arg-max per action component is what the reference does (env_base.py:373-382).  The uniform / tape / MLP pilots below
+are stand-ins for env-only measurements."""
+import ctypes as C
+
+import numpy as np
 import torch
+
+from . import _lib as L
+from . import policy_nets as PN
+
+# selector byte the world kernels emit as pilot_mode: (1 fight | 2 escape) | (aircraft type << 2)
+SEL_FIGHT1, SEL_ESC1, SEL_FIGHT2, SEL_ESC2 = 5, 6, 9, 10
+
+
+class PolicyBank:
+    """Up to 8 frozen actor networks resident on one GPU (hh_policy_* of include/hh_policy.h)."""
+    FIGHT1, FIGHT2, ESC1, ESC2 = PN.FIGHT1, PN.FIGHT2, PN.ESC1, PN.ESC2
+
+    def __init__(self, device, max_rows):
+        if not torch.cuda.is_available():
+            raise RuntimeError("hhmarl_2d_amd.PolicyBank needs a ROCm GPU (no CPU fallback)")
+        self.device = torch.device(device) if not isinstance(device, torch.device) else device
+        self.max_rows = int(max_rows)
+        self.h = C.c_void_p()
+        L.check(L.lib().hh_policy_create(self.device.index or 0, self.max_rows, C.byref(self.h)))
+        self.kinds = {}
+        self._lut = np.zeros(256, dtype=np.uint8)
+
+    def close(self):
+        if getattr(self, "h", None):
+            L.lib().hh_policy_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_net(self, slot, kind, sd):
+        """sd: the actor tensors keyed like the reference's state_dict() (policy_nets.actor_keys), numpy float32"""
+        a = {k: np.ascontiguousarray(sd[k], dtype=np.float32) for k in PN.actor_keys(kind)}
+        for k, shp in PN.actor_keys(kind).items():
+            assert a[k].shape == shp, (k, a[k].shape, shp)
+        p = lambda k: a[k].ctypes.data_as(C.c_void_p) if k in a else None
+        w = L.HHNetWeights()
+        w.kind = kind
+        for i in range(3):
+            w.inp_w[i] = p(f"inp{i + 1}._model.0.weight")
+            w.inp_b[i] = p(f"inp{i + 1}._model.0.bias")
+        w.att_in_proj_w, w.att_in_proj_b = p("att_act.in_proj_weight"), p("att_act.in_proj_bias")
+        w.att_out_w, w.att_out_b = p("att_act.out_proj.weight"), p("att_act.out_proj.bias")
+        w.shared_w, w.shared_b = p("shared_layer._model.0.weight"), p("shared_layer._model.0.bias")
+        w.out_w, w.out_b = p("act_out._model.0.weight"), p("act_out._model.0.bias")
+        L.check(L.lib().hh_policy_set_net(self.h, int(slot), C.byref(w)))
+        self.kinds[int(slot)] = kind
+
+    def set_lut(self, mapping):
+        """mapping: selector byte -> network slot (everything else: no action)"""
+        lut = np.zeros(256, dtype=np.uint8)
+        for sel, slot in mapping.items():
+            lut[int(sel)] = int(slot) + 1
+        L.check(L.lib().hh_policy_set_lut(self.h, lut.ctypes.data_as(C.c_void_p)))
+        self._lut = lut
+
+    @classmethod
+    def random_init(cls, device, seed=0, max_rows=1 << 20):
+        """one synthetic network per architecture in slots FIGHT1..ESC2, selected by the world's pilot_mode bytes"""
+        b = cls(device, max_rows)
+        for kind in (PN.FIGHT1, PN.FIGHT2, PN.ESC1, PN.ESC2):
+            b.set_net(kind, kind, PN.random_weights(kind, seed))
+        lut = {SEL_FIGHT1: PN.FIGHT1, SEL_FIGHT2: PN.FIGHT2, SEL_ESC1: PN.ESC1, SEL_ESC2: PN.ESC2}
+        # level-5 opponents: selector + 16 (k - 3) names the policy set of the arena's draw (OpponentNets); one synthetic set serves all
+        lut.update({SEL_FIGHT1 + 16: PN.FIGHT1, SEL_FIGHT2 + 16: PN.FIGHT2, SEL_ESC1 + 32: PN.ESC1, SEL_ESC2 + 32: PN.ESC2})
+        b.set_lut(lut)
+        return b
+
+    @classmethod
+    def from_modules(cls, device, modules, max_rows=1 << 20):
+        """modules: {slot: loaded reference policy (torch.load('policies/L3_AC1_fight.pt'))}"""
+        b = cls(device, max_rows)
+        for slot, m in modules.items():
+            kind, sd = PN.from_torch_module(m)
+            b.set_net(slot, kind, sd)
+        return b
+
+    def act(self, obs, sel, actions=None, logits=None):
+        """obs f32 [..., D] (rows = all leading dims), sel u8 [...] selector bytes -> int8 actions [..., 4]"""
+        assert obs.dtype == torch.float32 and obs.is_contiguous() and sel.dtype == torch.uint8 and sel.is_contiguous()
+        n_rows, stride = sel.numel(), obs.shape[-1]
+        assert obs.numel() == n_rows * stride
+        if actions is None:
+            actions = torch.empty(tuple(sel.shape) + (4,), dtype=torch.int8, device=obs.device)
+        assert actions.dtype == torch.int8 and actions.is_contiguous() and actions.numel() == n_rows * 4
+        st = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
+        lp = None if logits is None else C.c_void_p(logits.data_ptr())
+        L.check(L.lib().hh_policy_act(self.h, C.c_void_p(obs.data_ptr()), n_rows, stride, C.c_void_p(sel.data_ptr()),
+                                      C.c_void_p(actions.data_ptr()), lp, st))
+        return actions
+
+    @staticmethod
+    def flops_per_row(kind):
+        return PN.flops_per_row(kind)
+
+
+class NetPilot:
+    """HighLevelEnv pilots (env_base.py:349-398): every live unit's lowlevel_state row through the network its selector
+    byte names (fight / escape policy of its aircraft type), actions written into one static [N, A, 4] buffer."""
+
+    def __init__(self, world, bank=None, seed=0):
+        self.bank = bank if bank is not None else PolicyBank.random_init(world.device, seed=seed, max_rows=world.N * world.A)
+        self.act = torch.zeros((world.N, world.A, 4), dtype=torch.int8, device=world.device)
+
+    def __call__(self, pilot_obs, pilot_mode):
+        return self.bank.act(pilot_obs, pilot_mode, self.act)
+
+
+class OpponentNets:
+    """LowLevelEnv levels 4-5 `opponent_policy` callable: opponents 3 / 4 are type-1 / type-2 aircraft (env_base.py:560-561
+    fixes the first two slots of a side).  Level 4 flies the level-3 fight policies (selectors 5 / 9).  Level 5 draws k per
+    arena and episode (env_hetero.py:55-59): selector = fight selector + 16 (k - 3), + 1 when k == 5 (escape), so a bank
+    loaded with policies[3], policies[4] (fight sets) and policies[5] (escape set) maps 5/9, 21/25 and 38/42 to them."""
+
+    def __init__(self, world, bank=None, seed=0):
+        self.world = world
+        n_opp = world.A - world.n_agents
+        self.bank = bank if bank is not None else PolicyBank.random_init(world.device, seed=seed, max_rows=world.N * n_opp)
+        self.act = torch.zeros((world.N, n_opp, 4), dtype=torch.int8, device=world.device)
+        self.sel_fight = torch.tensor([SEL_FIGHT1, SEL_FIGHT2], dtype=torch.uint8, device=world.device).repeat(world.N, 1).contiguous()
+        self.k = torch.zeros((world.N,), dtype=torch.int8, device=world.device)
+
+    def __call__(self, opp_obs, env=None):
+        sel = self.sel_fight
+        if self.world.cfg.level == 5 and self.world.cfg.agent_mode == L.MODE_FIGHT:
+            k = self.world.opp_policy(self.k)
+            sel = (self.sel_fight + (16 * (k - 3) + (k == 5)).to(torch.uint8)[:, None]).contiguous()
+        return self.bank.act(opp_obs.contiguous(), sel, self.act)
 
 
 class RandomPilot:
@@ -67,7 +206,7 @@ class MLPPilot(torch.nn.Module):
         n, a, _ = pilot_obs.shape
         x = pilot_obs.reshape(n * a, 30)
         lf, le = self.fight(x), self.esc(x)
-        logits = torch.where((pilot_mode.reshape(-1, 1) == 2), le, lf)
+        logits = torch.where(((pilot_mode.reshape(-1, 1) & 3) == 2), le, lf)
         parts = logits.split((13, 9, 2, 2), dim=1)
         act = torch.stack([p.argmax(dim=1) for p in parts], dim=1)
         return act.to(torch.int8).reshape(n, a, 4)

@@ -134,7 +134,8 @@ int hh_observe(hh_world *w, float *obs, void *stream);
  * The frozen pilot policies (env_base.py:349-398) run in the caller between the launches on the
  * observations these calls emit: pilot_obs [dev] f32 [N, 6, 30] = lowlevel_state (env_hier.py:100-112)
  * of the side that acts next (agents after begin/tick, opponents after agents_act), zero elsewhere;
- * pilot_mode [dev] u8 [N, 6]: 0 = no action needed, 1 = fight policy, 2 = escape policy.
+ * pilot_mode [dev] u8 [N, 6]: 0 = no action needed, else (policy type: 1 fight / 2 escape) | (aircraft type 1 / 2) << 2, i.e.
+ * 5 = Fight1, 6 = Esc1, 9 = Fight2, 10 = Esc2 — the selector byte hh_policy_act (hh_policy.h) maps to a network.
  * actions [dev] i8 [N, 6, 4] (rows of the side that acts).  commander_actions [dev] i8 [N, 3] in {0,1,2}.
  * `running` (host, nullable): number of arenas still inside their macro step after this tick. */
 int hh_hl_begin(hh_world *w, const int8_t *commander_actions, float *pilot_obs, uint8_t *pilot_mode, void *stream);

@@ -1,0 +1,71 @@
+/*
+ * hh_policy.h — C ABI of the frozen pilot / opponent policy networks (part of libhh_world.so).
+ *
+ * The reference evaluates frozen PyTorch policies INSIDE its environments: envs/env_base.py:312-347 `_get_policies`
+ * (torch.load of policies/L*_AC*_{fight,escape}.pt) and 349-398 `_policy_actions` (one forward per live unit per tick with
+ * dummy centralised-critic inputs, batch of one, seq_lens [1], arg-max per action component).  This header is what a
+ * binding for that part binds to: the ACTOR half of the four architectures of models/ac_models_hetero.py
+ * (Esc1 29-103, Esc2 105-180, Fight1 181-291, Fight2 293-404) as one fused gfx950 kernel over all units of all
+ * arenas at once, writing int8 actions straight into the buffer hh_step / hh_step_finish / hh_hl_agents_act / hh_hl_tick read.
+ *
+ * Conventions as in hh_abi.h: 0 on success or a negative HH_E_* code, never throws; [dev] = caller-owned device memory,
+ * [host] = host memory; `stream` is a hipStream_t passed as void*.
+ */
+#ifndef HH_POLICY_H
+#define HH_POLICY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HH_NET_FIGHT1 0 /* models/ac_models_hetero.py:181-291, obs 26 -> 26 logits */
+#define HH_NET_FIGHT2 1 /* 293-404, obs 24 -> 24 logits */
+#define HH_NET_ESC1 2   /* 29-103,  obs 30 -> 26 logits */
+#define HH_NET_ESC2 3   /* 105-180, obs 29 -> 24 logits */
+#define HH_POLICY_MAX_NETS 8
+#define HH_POLICY_LOGITS 32 /* row width of the optional logits output (zero padded) */
+
+/* One network, as the reference's state_dict() holds it ([host], row-major [out, in] like nn.Linear.weight):
+ * inp_w/inp_b[k] = inp{k+1}._model.0.{weight,bias}; att_* = att_act.{in_proj_weight [300,100], in_proj_bias [300],
+ * out_proj.weight [100,100], out_proj.bias [100]} (fight nets only, NULL otherwise); shared_* = shared_layer._model.0
+ * [500,500]; out_* = act_out._model.0 [26|24, 500].  The value branch is not used for acting. */
+typedef struct hh_net_weights {
+    int32_t kind;
+    const float *inp_w[3];
+    const float *inp_b[3];
+    const float *att_in_proj_w, *att_in_proj_b, *att_out_w, *att_out_b;
+    const float *shared_w, *shared_b;
+    const float *out_w, *out_b;
+} hh_net_weights;
+
+typedef struct hh_policy hh_policy;
+
+/* a bank of up to HH_POLICY_MAX_NETS networks on `device`; max_rows = the largest n_rows hh_policy_act will be given */
+int hh_policy_create(int device, int32_t max_rows, hh_policy **out);
+int hh_policy_destroy(hh_policy *p);
+
+/* load (or replace) network `slot`: weights are repacked on the host into the kernel's k-interleaved layout (the two
+ * attention projections folded into one 100x100 matrix in double precision: with a sequence of length 1 the softmax is 1
+ * and the attention output is out_proj(v_proj(x))) and copied to the device.  Synchronous. */
+int hh_policy_set_net(hh_policy *p, int32_t slot, const hh_net_weights *w);
+
+/* selector byte -> network: lut[256] [host], value 0 = "no action for this row" (its action is written as zeros), s + 1 =
+ * network slot s.  The world kernels emit selector bytes as pilot_mode (hh_hl_*: policy type | ac_type << 2); callers of the
+ * LowLevelEnv split step build them from the unit's slot and the arena's level-5 draw. */
+int hh_policy_set_lut(hh_policy *p, const uint8_t *lut);
+
+/* greedy actions of n_rows units in one launch sequence (row binning by network + the fused forward):
+ *   obs     [dev] f32 [n_rows, obs_stride]   zero-padded observation rows (hh_step's obs, hh_step_begin's opp_obs, pilot_obs)
+ *   sel     [dev] u8  [n_rows]               selector bytes (through the LUT)
+ *   actions [dev] i8  [n_rows, 4]            MultiDiscrete([13,9,2,2]) arg-max per component (4th = 0 for type-2 nets)
+ *   logits  [dev] f32 [n_rows, 32]           optional (NULL): the actor's logits, zero padded; rows without a network untouched
+ * Everything is ordered on `stream`; no host synchronisation (HIP-graph capturable). */
+int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, const uint8_t *sel, int8_t *actions,
+                  float *logits, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HH_POLICY_H */

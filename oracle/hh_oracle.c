@@ -1339,7 +1339,7 @@ API int hho_hl_pilot_obs(void *h, int side, float *obs /* [N, A, 30] */, uint8_t
             float *o = obs + ((size_t)n * A + (i - 1)) * 30;
             int md = 0;
             int mine = side == 0 ? i <= w->cfg.n_agents : i > w->cfg.n_agents;
-            if (a->hl_running && a->ac[i - 1].alive && mine) md = hl_pilot_obs_one(w, a, i, o);
+            if (a->hl_running && a->ac[i - 1].alive && mine) md = hl_pilot_obs_one(w, a, i, o) | (a->ac[i - 1].ac_type << 2); /* policy type | aircraft type */
             else for (int k = 0; k < 30; k++) o[k] = 0.0f;
             mode[(size_t)n * A + (i - 1)] = (uint8_t)md;
         }

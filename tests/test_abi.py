@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "hh_abi.h")).read()
+    txt = open(os.path.join(ROOT, "include", "hh_abi.h")).read() + open(os.path.join(ROOT, "include", "hh_policy.h")).read()
     return sorted(set(re.findall(r"\b(hh_[a-z_]+)\s*\(", txt)))
 
 

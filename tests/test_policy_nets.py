@@ -1,0 +1,129 @@
+"""The frozen pilot / opponent networks.  CPU part: the plain-PyTorch fp32 restatement of the actor forward
+(hhmarl_2d_amd/policy_nets.py) against vectors recorded from the REAL reference model classes called the way the
+environment calls them (oracle/gen_policy_golden.py -> tests/golden/policy_nets.npz): logits <= 1e-5, actions exact.
+GPU part (-m gpu): the fused HIP kernel against the same vectors and against the PyTorch restatement at larger sizes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hhmarl_2d_amd import policy_nets as PN
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "policy_nets.npz")
+LOGIT_TOL = 1e-5
+
+
+@pytest.mark.parametrize("kind", [PN.FIGHT1, PN.FIGHT2, PN.ESC1, PN.ESC2], ids=lambda k: PN.KIND_NAMES[k])
+def test_torch_restatement_matches_reference_classes(kind):
+    g = np.load(GOLD)
+    name = PN.KIND_NAMES[kind].lower()
+    sd = PN.random_weights(kind, int(g["seed"]))
+    obs = torch.from_numpy(g[f"obs_{name}"])
+    logits = PN.torch_forward(kind, sd, obs)
+    assert logits.shape == (obs.shape[0], PN.N_OUT[kind])
+    assert np.abs(logits.numpy() - g[f"logits_{name}"]).max() <= LOGIT_TOL
+    assert np.array_equal(PN.decode(logits, PN.N_OUT[kind]).numpy(), g[f"act_{name}"])
+
+
+def test_weight_tables_are_consistent():
+    for kind in (PN.FIGHT1, PN.FIGHT2, PN.ESC1, PN.ESC2):
+        (a0, a1, w1), (b0, b1, w2), (c0, c1, w3) = PN.INPUTS[kind]
+        assert w1 + w2 + w3 == 500 and max(a1, b1, c1) == PN.OBS_DIM[kind]
+        sd = PN.random_weights(kind, 1)
+        assert set(sd) == set(PN.actor_keys(kind)) and all(v.dtype == np.float32 for v in sd.values())
+        assert np.array_equal(sd["act_out._model.0.bias"], PN.random_weights(kind, 1)["act_out._model.0.bias"])
+        assert PN.flops_per_row(kind) > 5e5
+
+
+# ---------------------------------------------------------------------------------------------- GPU: the fused HIP kernel
+def _bank(seed, max_rows=1 << 16):
+    from hhmarl_2d_amd.pilots import PolicyBank
+    return PolicyBank.random_init(torch.device("cuda", 0), seed=seed, max_rows=max_rows)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [PN.FIGHT1, PN.FIGHT2, PN.ESC1, PN.ESC2], ids=lambda k: PN.KIND_NAMES[k])
+def test_hip_kernel_matches_reference_vectors(kind):
+    """hh_policy_act against the vectors recorded from the reference's own model classes: logits 1e-5, actions exact"""
+    from hhmarl_2d_amd import pilots
+    g = np.load(GOLD)
+    name = PN.KIND_NAMES[kind].lower()
+    bank = _bank(int(g["seed"]))
+    obs = torch.zeros((96, 30), dtype=torch.float32)
+    obs[:, : PN.OBS_DIM[kind]] = torch.from_numpy(g[f"obs_{name}"])
+    sel_byte = {PN.FIGHT1: pilots.SEL_FIGHT1, PN.FIGHT2: pilots.SEL_FIGHT2, PN.ESC1: pilots.SEL_ESC1, PN.ESC2: pilots.SEL_ESC2}[kind]
+    sel = torch.full((96,), sel_byte, dtype=torch.uint8, device="cuda")
+    logits = torch.full((96, 32), 7.0, dtype=torch.float32, device="cuda")
+    act = bank.act(obs.cuda(), sel, logits=logits).cpu().numpy()
+    lg = logits.cpu().numpy()
+    assert np.abs(lg[:, : PN.N_OUT[kind]] - g[f"logits_{name}"]).max() <= LOGIT_TOL
+    assert (lg[:, PN.N_OUT[kind]:] == 0).all()
+    assert np.array_equal(act, g[f"act_{name}"])
+
+
+@pytest.mark.gpu
+def test_hip_kernel_mixed_networks_against_torch_fp32():
+    """all four networks interleaved row by row, rows without a network, a row count that is no multiple of the tile, strided
+    observations: every row against the plain PyTorch fp32 forward of its network"""
+    from hhmarl_2d_amd import pilots
+    R, D = 20011, 30
+    bank = _bank(3, max_rows=R)
+    rng = np.random.default_rng(0)
+    obs = torch.from_numpy(rng.random((R, D)).astype(np.float32)).cuda()
+    sels = np.array([0, pilots.SEL_FIGHT1, pilots.SEL_FIGHT2, pilots.SEL_ESC1, pilots.SEL_ESC2, 77], dtype=np.uint8)
+    sel = torch.from_numpy(sels[rng.integers(0, len(sels), R)]).cuda()
+    logits = torch.full((R, 32), -3.0, dtype=torch.float32, device="cuda")
+    act = bank.act(obs, sel, logits=logits)
+    torch.cuda.synchronize()
+    kinds = {pilots.SEL_FIGHT1: PN.FIGHT1, pilots.SEL_FIGHT2: PN.FIGHT2, pilots.SEL_ESC1: PN.ESC1, pilots.SEL_ESC2: PN.ESC2}
+    checked = 0
+    for byte, kind in kinds.items():
+        idx = (sel == byte).nonzero().flatten()
+        x = torch.zeros((len(idx), D), device="cuda")
+        x[:, : PN.OBS_DIM[kind]] = obs[idx, : PN.OBS_DIM[kind]]     # the kernel must ignore columns beyond the net's width
+        ref = PN.torch_forward(kind, PN.random_weights(kind, 3), x.cpu())          # CPU fp32, like the reference
+        got = logits[idx, : PN.N_OUT[kind]].cpu()
+        assert (got - ref).abs().max() <= LOGIT_TOL, PN.KIND_NAMES[kind]
+        ra = PN.decode(ref, PN.N_OUT[kind])
+        # arg-max must agree wherever the reference's winner leads by more than the tolerance
+        parts = ref.split(PN.ACTION_SPLIT[: 4 if PN.N_OUT[kind] == 26 else 3], dim=1)
+        clear = torch.stack([(p.topk(2, dim=1).values[:, 0] - p.topk(2, dim=1).values[:, 1]) > 1e-4 for p in parts], dim=1).all(dim=1)
+        assert torch.equal(act[idx].cpu()[clear], ra[clear]) and clear.float().mean() > 0.99
+        checked += len(idx)
+    none = ((sel == 0) | (sel == 77)).nonzero().flatten()
+    assert (act[none] == 0).all() and (logits[none] == -3.0).all()
+    assert checked + len(none) == R
+    # a second call on the same bank (counters are re-zeroed on the stream) gives the same answer
+    assert torch.equal(bank.act(obs, sel), act)
+
+
+@pytest.mark.gpu
+def test_net_pilot_drives_highlevel_env_and_matches_torch():
+    """NetPilot inside the HighLevelEnv macro step: the selector bytes the world emits (policy type | aircraft type << 2) pick the
+    network; actions equal the PyTorch forward of the same rows"""
+    from hhmarl_2d_amd import pilots
+    from hhmarl_2d_amd.world import World, make_config
+    w = World(make_config(n_arenas=500, env_kind=1, seed=5, auto_reset=True))
+    w.reset()
+    pilot = pilots.NetPilot(w, seed=9)
+    cmd = torch.from_numpy(np.random.default_rng(1).integers(0, 3, (500, 3)).astype(np.int8)).cuda()
+    po, pm = w.hl_begin(cmd)
+    act = pilot(po, pm).clone()
+    kinds = {pilots.SEL_FIGHT1: PN.FIGHT1, pilots.SEL_FIGHT2: PN.FIGHT2, pilots.SEL_ESC1: PN.ESC1, pilots.SEL_ESC2: PN.ESC2}
+    seen = 0
+    for byte, kind in kinds.items():
+        idx = (pm == byte).nonzero()
+        if len(idx) == 0:
+            continue
+        rows = po[idx[:, 0], idx[:, 1]].cpu()
+        ref = PN.torch_forward(kind, PN.random_weights(kind, 9), rows)
+        parts = ref.split(PN.ACTION_SPLIT[: 4 if PN.N_OUT[kind] == 26 else 3], dim=1)
+        clear = torch.stack([(p.topk(2, dim=1).values[:, 0] - p.topk(2, dim=1).values[:, 1]) > 1e-4 for p in parts], dim=1).all(dim=1)
+        assert torch.equal(act[idx[:, 0], idx[:, 1]].cpu()[clear], PN.decode(ref, PN.N_OUT[kind])[clear])
+        seen += 1
+    assert seen >= 3 and (act[pm == 0] == 0).all()
+    from hhmarl_2d_amd.env_hier import macro_step
+    for _ in range(3):   # whole macro steps run with the networks in the loop
+        obs, rew, val, done = macro_step(w, cmd, pilot)
+    assert torch.isfinite(obs).all()

@@ -54,20 +54,41 @@ struct HhpBank {
 
 /* packed index of element (k, col) of a [K x J] operand */
 __host__ __device__ inline size_t hhp_pidx(int k, int col, int J) { return ((size_t)((k >> 3) * 2 + (k & 1)) * J + col) * 4 + ((k >> 1) & 3); }
+/* the same for the 32-row activation tiles in LDS, with the row slot XOR-swizzled by the plane (k/8, k&1): an MFMA epilogue
+ * writes one row of 32 consecutive k per instruction — 8 planes x 4 sub-slots — and without the swizzle those land on 4 banks */
+__device__ __forceinline__ int hhp_aidx(int k, int row) {
+    const int plane = (k >> 3) * 2 + (k & 1);
+    return (plane * 32 + (row ^ (plane & 7))) * 4 + ((k >> 1) & 3);
+}
+/* tanh from the hardware exp and reciprocal: |error| < 5e-7 absolute over the whole range (the logits tolerate 1e-5) */
+__device__ __forceinline__ float hhp_tanh(float x) {
+    const float t = __expf(-2.0f * fabsf(x));
+    return copysignf(__fdividef(1.0f - t, 1.0f + t), x);
+}
 
-/* rows -> per-network lists */
+/* rows -> per-network lists.  One atomic per wave and network (a per-row atomic on two or four hot counters serialises:
+ * measured 187 us for 32768 rows), the lanes of a wave take consecutive slots by their rank in the ballot. */
 __global__ __launch_bounds__(256) void hh_k_policy_bin(int n_rows, const uint8_t *__restrict__ sel, const uint8_t *__restrict__ lut,
                                                        int max_rows, int *__restrict__ counts, int *__restrict__ lists,
                                                        int8_t *__restrict__ actions) {
     const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= n_rows) return;
-    const int s = lut[sel[r]];
-    if (s == 0) {
-        reinterpret_cast<int *>(actions)[r] = 0;
-        return;
+    const int lane = threadIdx.x & 63;
+    const int s = r < n_rows ? (int)lut[sel[r]] : 0;
+    if (r < n_rows && s == 0) reinterpret_cast<int *>(actions)[r] = 0;
+    for (int n = 1; n <= HH_POLICY_MAX_NETS; n++) { /* wave-uniform */
+        const unsigned long long m = __ballot(s == n);
+        if (!m) continue;
+        const int first = __ffsll((long long)m) - 1;
+        int base = 0;
+        if (lane == first) base = atomicAdd(&counts[n - 1], __popcll(m));
+        base = __shfl(base, first);
+        if (s == n) lists[(size_t)(n - 1) * max_rows + base + __popcll(m & ((1ULL << lane) - 1ULL))] = r;
     }
-    const int pos = atomicAdd(&counts[s - 1], 1);
-    lists[(size_t)(s - 1) * max_rows + pos] = r;
+}
+
+/* the counters are cleared by a kernel, not a memset node: the call sequence is replayed from HIP graphs */
+__global__ void hh_k_policy_clear(int *__restrict__ counts) {
+    if (threadIdx.x < HH_POLICY_MAX_NETS) counts[threadIdx.x] = 0;
 }
 
 __device__ __forceinline__ hh_f32x16 hhp_zero16() {
@@ -80,25 +101,32 @@ __device__ __forceinline__ hh_f32x16 hhp_zero16() {
 __device__ __forceinline__ int hhp_crow(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 /* NT tiles of 32 columns starting at column j0 (+32 per tile) over KB 8-k blocks: A from LDS (packed, 32 rows), B from global
- * (packed, J columns).  Operands of block kb+1 are requested before the MFMAs of block kb issue. */
+ * (packed, J columns).  Software pipeline: the operands of block kb+1 are REQUESTED before the 4 NT MFMAs of block kb issue and
+ * first touched after them (4 NT x 64 cycles later: an L2 round trip fits).  hipcc's scheduler would otherwise sink each load
+ * to just before its use and reuse the registers — the scheduling barriers pin the order, the loop stays rolled. */
 template <int NT>
 __device__ __forceinline__ void hhp_gemm(const float4 *__restrict__ a_lds, int kb0, int KB, const float4 *__restrict__ b_glb, int bkb0, int J,
                                          int j0, int lane, hh_f32x16 (&acc)[NT]) {
     const int h = lane >> 5, i = lane & 31;
-    float4 a = a_lds[((kb0)*2 + h) * 32 + i];
+    const float4 *ap = a_lds + (kb0 * 2 + h) * 32 + (i ^ ((kb0 * 2 + h) & 7)); /* swizzled row slot: see hhp_aidx */
+    const float4 *bp = b_glb + (size_t)(bkb0 * 2 + h) * J + j0 + i;
+    float4 a = *ap;
     float4 b[NT];
 #pragma unroll
-    for (int t = 0; t < NT; t++) b[t] = b_glb[(size_t)((bkb0)*2 + h) * J + j0 + t * 32 + i];
-#pragma unroll 2
+    for (int t = 0; t < NT; t++) b[t] = bp[t * 32];
+#pragma nounroll
     for (int kb = 0; kb < KB; kb++) {
+        ap = a_lds + (((kb0 + kb + 1) * 2 + h) * 32 + (i ^ (((kb0 + kb + 1) * 2 + h) & 7))); /* next 8-k block, its own swizzle */
+        bp += (size_t)2 * J;
         float4 an = a, bn[NT];
 #pragma unroll
         for (int t = 0; t < NT; t++) bn[t] = b[t];
-        if (kb + 1 < KB) {
-            an = a_lds[((kb0 + kb + 1) * 2 + h) * 32 + i];
+        if (kb + 1 < KB) {        /* wave-uniform */
+            an = *ap;
 #pragma unroll
-            for (int t = 0; t < NT; t++) bn[t] = b_glb[(size_t)((bkb0 + kb + 1) * 2 + h) * J + j0 + t * 32 + i];
+            for (int t = 0; t < NT; t++) bn[t] = bp[t * 32];
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
 #pragma unroll
@@ -107,33 +135,42 @@ __device__ __forceinline__ void hhp_gemm(const float4 *__restrict__ a_lds, int k
         for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         a = an;
 #pragma unroll
         for (int t = 0; t < NT; t++) b[t] = bn[t];
     }
 }
 
-/* LDS: Z 64 KB | S 64 KB | X 4 KB | logits 4 KB | row ids, norm partials */
-#define HHP_LDS_FLOATS (16384 + 16384 + 1024 + 1024 + 32 + 128)
+/* LDS: one 64 KB activation tile (Z, then S in place, then the L3 partials) | X 4 KB | logits 4 KB | row ids, norm partials
+ * = 72.6 KB, so TWO workgroups share a CU (two waves per SIMD): one tile's global-latency phases (row lists, observation
+ * gather, first weight fetches, output stores) and epilogues hide behind the other tile's MFMA streams */
+#define HHP_LDS_FLOATS (16384 + 1024 + 1024 + 32 + 128)
 #define HHP_LDS_BYTES (HHP_LDS_FLOATS * 4)
 
-__global__ __launch_bounds__(256, 1) void hh_k_policy(HhpBank bank, int n_nets, const float *__restrict__ obs, int obs_stride,
+__global__ __launch_bounds__(256, 2) void hh_k_policy(HhpBank bank, int n_nets, const float *__restrict__ obs, int obs_stride,
                                                       const int *__restrict__ counts, const int *__restrict__ lists, int max_rows,
                                                       int8_t *__restrict__ actions, float *__restrict__ logits_out) {
     extern __shared__ __align__(16) float lds[];
-    float *Zp = lds;                 /* [64][2][32][4]  activations after L1 (A operand of att and L2); later the L3 partials */
-    float *Sp = lds + 16384;         /* [64][2][32][4]  activations after L2 (A operand of L3) */
-    float *Xp = lds + 32768;         /* [4][2][32][4]   observation tile */
-    float *Lg = lds + 33792;         /* [32][32]        logits */
-    int *rows = reinterpret_cast<int *>(lds + 34816); /* [32] */
-    float *npart = lds + 34848;      /* [4][32] squared-norm partials */
+    float *Zp = lds;                 /* [64][2][32][4]  activations after L1 (A operand of att and L2), then after L2 (A operand of
+                                        L3: wave w reads only its own columns = planes [32 w, 32 w + 32)), then wave w's L3 partial */
+    float *Xp = lds + 16384;         /* [4][2][32][4]   observation tile */
+    float *Lg = lds + 17408;         /* [32][32]        logits */
+    int *rows = reinterpret_cast<int *>(lds + 18432); /* [32] */
+    float *npart = lds + 18464;      /* [4][32] squared-norm partials */
 
-    /* which (network, tile) is this workgroup's? */
+    /* which (network, tile) is this workgroup's?  (all counters requested at once: one global round trip) */
+    int cn[HH_POLICY_MAX_NETS];
+#pragma unroll
+    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? counts[n] : 0;
     int net = -1, tile = blockIdx.x, cnt = 0;
-    for (int n = 0; n < n_nets; n++) {
-        const int c = counts[n], nt = (c + HHP_ROWS - 1) / HHP_ROWS;
-        if (tile < nt) { net = n; cnt = c; break; }
-        tile -= nt;
+#pragma unroll
+    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) {
+        const int nt = (cn[n] + HHP_ROWS - 1) / HHP_ROWS;
+        if (net < 0) {
+            if (tile < nt) { net = n; cnt = cn[n]; }
+            else tile -= nt;
+        }
     }
     if (net < 0) return;
     const HhpNet N = bank.net[net];
@@ -147,7 +184,7 @@ __global__ __launch_bounds__(256, 1) void hh_k_policy(HhpBank bank, int n_nets, 
     __syncthreads();
     for (int e = tid; e < HHP_ROWS * HHP_XK; e += 256) {
         const int i = e >> 5, c = e & 31, r = rows[i];
-        Xp[hhp_pidx(c, i, 32)] = (r >= 0 && c < N.obs_dim) ? obs[(size_t)r * obs_stride + c] : 0.0f;
+        Xp[hhp_aidx(c, i)] = (r >= 0 && c < N.obs_dim) ? obs[(size_t)r * obs_stride + c] : 0.0f;
     }
     __syncthreads();
 
@@ -162,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void hh_k_policy(HhpBank bank, int n_nets, 
             const int j = wave * 128 + t * 32 + ci;
             const float bj = N.b1[j];
 #pragma unroll
-            for (int r = 0; r < 16; r++) Zp[hhp_pidx(j, hhp_crow(r, lane), 32)] = tanhf(acc[t][r] + bj);
+            for (int r = 0; r < 16; r++) Zp[hhp_aidx(j, hhp_crow(r, lane))] = hhp_tanh(acc[t][r] + bj);
         }
     }
     __syncthreads();
@@ -177,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void hh_k_policy(HhpBank bank, int n_nets, 
         float y[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float x = j < 100 ? Zp[hhp_pidx(400 + j, hhp_crow(r, lane), 32)] : 0.0f;
+            const float x = j < 100 ? Zp[hhp_aidx(400 + j, hhp_crow(r, lane))] : 0.0f;
             y[r] = j < 100 ? x + (acc[0][r] + bj) : 0.0f;
             float s = y[r] * y[r];
             s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
@@ -189,12 +226,12 @@ __global__ __launch_bounds__(256, 1) void hh_k_policy(HhpBank bank, int n_nets, 
             const int row = hhp_crow(r, lane);
             const float nn = ((npart[row] + npart[32 + row]) + npart[64 + row]) + npart[96 + row];
             const float den = fmaxf(sqrtf(nn), 1e-12f); /* F.normalize: x / max(||x||_2, eps) */
-            if (j < 100) Zp[hhp_pidx(400 + j, row, 32)] = y[r] / den;
+            if (j < 100) Zp[hhp_aidx(400 + j, row)] = y[r] / den;
         }
         __syncthreads();
     }
 
-    /* ---- L2: shared layer 500 -> 500, tanh ---- */
+    /* ---- L2: shared layer 500 -> 500, tanh; the result replaces Z in place once every wave has finished reading Z ---- */
     {
         hh_f32x16 acc[4];
 #pragma unroll
@@ -202,26 +239,33 @@ __global__ __launch_bounds__(256, 1) void hh_k_policy(HhpBank bank, int n_nets, 
         hhp_gemm<4>(reinterpret_cast<const float4 *>(Zp), 0, HHP_H / 8, reinterpret_cast<const float4 *>(N.wsp), 0, HHP_H, wave * 128, lane, acc);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const int j = wave * 128 + t * 32 + ci;
-            const float bj = N.bs[j];
+            const float bj = N.bs[wave * 128 + t * 32 + ci];
 #pragma unroll
-            for (int r = 0; r < 16; r++) Sp[hhp_pidx(j, hhp_crow(r, lane), 32)] = tanhf(acc[t][r] + bj);
+            for (int r = 0; r < 16; r++) acc[t][r] = hhp_tanh(acc[t][r] + bj);
+        }
+        __syncthreads(); /* Z is dead */
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int j = wave * 128 + t * 32 + ci;
+#pragma unroll
+            for (int r = 0; r < 16; r++) Zp[hhp_aidx(j, hhp_crow(r, lane))] = acc[t][r];
         }
     }
-    __syncthreads(); /* S complete; Z is free: it now holds the four split-K partials of L3 */
+    __syncthreads();
 
-    /* ---- L3: logits, split-K: wave w contracts columns [128 w, 128 w + 128) of S ---- */
+    /* ---- L3: logits, split-K: wave w contracts its own columns [128 w, 128 w + 128) of S, then parks its partial in the
+     *      first 4 KB of that same region (its operand reads are complete by then; nobody else touches the region) ---- */
     {
         hh_f32x16 acc[1];
         acc[0] = hhp_zero16();
-        hhp_gemm<1>(reinterpret_cast<const float4 *>(Sp), wave * 16, 16, reinterpret_cast<const float4 *>(N.wap), wave * 16, HHP_OUT, 0, lane, acc);
+        hhp_gemm<1>(reinterpret_cast<const float4 *>(Zp), wave * 16, 16, reinterpret_cast<const float4 *>(N.wap), wave * 16, HHP_OUT, 0, lane, acc);
 #pragma unroll
-        for (int r = 0; r < 16; r++) Zp[(wave * 32 + hhp_crow(r, lane)) * 32 + ci] = acc[0][r];
+        for (int r = 0; r < 16; r++) Zp[wave * 4096 + hhp_crow(r, lane) * 32 + ci] = acc[0][r];
     }
     __syncthreads();
     for (int e = tid; e < HHP_ROWS * HHP_OUT; e += 256) {
         const int i = e >> 5, c = e & 31;
-        const float v = (((Zp[e] + Zp[1024 + e]) + Zp[2048 + e]) + Zp[3072 + e]) + N.ba[c];
+        const float v = (((Zp[e] + Zp[4096 + e]) + Zp[8192 + e]) + Zp[12288 + e]) + N.ba[c];
         Lg[e] = v;
         if (logits_out && rows[i] >= 0) logits_out[(size_t)rows[i] * HH_POLICY_LOGITS + c] = c < N.n_out ? v : 0.0f;
     }
@@ -367,7 +411,7 @@ extern "C" int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int
     if (p->n_nets == 0) { g_err = "hh_policy_act: no network loaded"; return HH_E_ARG; }
     HH_GUARD(p);
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(hipMemsetAsync(p->counts, 0, HH_POLICY_MAX_NETS * sizeof(int), st));
+    hipLaunchKernelGGL(hh_k_policy_clear, dim3(1), dim3(64), 0, st, p->counts);
     hipLaunchKernelGGL(hh_k_policy_bin, dim3((n_rows + 255) / 256), dim3(256), 0, st, n_rows, sel, p->lut, p->max_rows, p->counts, p->lists, actions);
     const int grid = (n_rows + HHP_ROWS - 1) / HHP_ROWS + p->n_nets; /* upper bound of the tiles over all networks */
     hipLaunchKernelGGL(hh_k_policy, dim3(grid), dim3(256), HHP_LDS_BYTES, st, p->bank, p->n_nets, obs, obs_stride, p->counts, p->lists, p->max_rows,

@@ -10,6 +10,8 @@ ENV_LOWLEVEL, ENV_HIGHLEVEL = 0, 1
 MODE_FIGHT, MODE_ESCAPE = 0, 1
 OPP_MODE_EPISODE = -1  # hh_step_begin: every arena observes in the mode of its own level-5 draw
 ACF_K, ACI_K, RKF_K, RKI_K, ARI_K, TGT_K = 6, 10, 4, 4, 6, 3
+EVAL_KEYS = ("agents_win", "opps_win", "draw", "agent_fight", "agent_escape", "opp_fight", "opp_escape", "agent_steps", "opp_steps",
+             "opp1", "opp2", "opp3")  # columns of hh_eval_info (env_base.py:104-106)
 
 
 class HHConfig(C.Structure):
@@ -42,7 +44,7 @@ class HHNetWeights(C.Structure):
 EXPORTS = ["hh_world_create", "hh_world_destroy", "hh_last_error", "hh_obs_dim", "hh_n_ctrl", "hh_reset", "hh_step",
            "hh_rollout", "hh_episode_stats", "hh_get_state", "hh_set_state", "hh_get_event_masks", "hh_observe",
            "hh_hl_begin", "hh_hl_agents_act", "hh_hl_tick", "hh_hl_end", "hh_step_begin", "hh_step_finish", "hh_gae", "hh_hl_commands",
-           "hh_episode_stats_packed", "hh_hl_tick_count", "hh_rollout_kernel_name", "hh_opp_policy",
+           "hh_episode_stats_packed", "hh_hl_tick_count", "hh_rollout_kernel_name", "hh_opp_policy", "hh_eval_info", "hh_arena_status",
            "hh_policy_create", "hh_policy_destroy", "hh_policy_set_net", "hh_policy_set_lut", "hh_policy_act"]
 
 _lib = None
@@ -81,6 +83,8 @@ def lib():
         L.hh_step_finish.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.hh_hl_commands.argtypes = [vp, vp]
         L.hh_opp_policy.argtypes = [vp, vp, vp]
+        L.hh_eval_info.argtypes = [vp, vp, vp, C.c_int32, vp]
+        L.hh_arena_status.argtypes = [vp, vp, vp]
         L.hh_gae.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
         L.hh_policy_create.argtypes = [C.c_int, C.c_int32, C.POINTER(vp)]
         L.hh_policy_destroy.argtypes = [vp]

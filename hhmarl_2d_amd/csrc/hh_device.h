@@ -55,6 +55,7 @@ struct DevPtrs {
     int8_t *last_outcome;                                /* [N] */
     uint32_t *ev_mask;                                   /* [N] */
     double *acc_rew;                                     /* [U] rewards accumulated over a HighLevelEnv macro step */
+    int *eval_last, *eval_tot;                           /* [N][HH_EVAL_K] eval_info of the last commander step / summed since cleared */
 };
 
 /* register-resident state of one aircraft slot (+ its rocket slot) */

@@ -267,6 +267,32 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
             }
         }
         if (phase == HH_HL_END) {
+            /* eval_info of this commander step (env_base.py:91-107): units that still exist, by assessed commander action */
+            sh.res[tid] = (ending && m.alive) ? (1 | ((m.cmd_act & 3) << 1)) : 0;
+            __syncthreads();
+            if (active && s == 0) {
+                int e[HH_EVAL_K];
+#pragma unroll
+                for (int k = 0; k < HH_EVAL_K; k++) e[k] = 0;
+                if (ending) {
+                    e[0] = (op <= 0 && ar.steps < c.horizon) ? 1 : 0;
+                    e[1] = (ag <= 0 && ar.steps < c.horizon) ? 1 : 0;
+                    e[2] = (ar.steps >= c.horizon && ag > 0 && op > 0) ? 1 : 0;
+#pragma unroll
+                    for (int j = 0; j < A; j++) {
+                        const int w_ = sh.res[base + j];
+                        if (!(w_ & 1)) continue;
+                        const int v = w_ >> 1;
+                        if (j < c.nA) { e[7] += 1; if (v) { e[3] += 1; e[8 + v] += 1; } else e[4] += 1; }
+                        else { e[8] += 1; if (v) e[5] += 1; else e[6] += 1; }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < HH_EVAL_K; k++) {
+                    P.eval_last[(size_t)n * HH_EVAL_K + k] = e[k];
+                    if (e[k]) P.eval_tot[(size_t)n * HH_EVAL_K + k] += e[k];
+                }
+            }
             ar.hl_run = 0;
             if (active && agent) {
                 size_t o = (size_t)n * c.nA + s;

@@ -118,6 +118,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     size_t o_rk[4]; for (int k = 0; k < 4; k++) o_rk[k] = take(U * 8);
     size_t o_rkp = take(U * 8), o_ar = take(N * 16), o_ep = take(N * 8), o_lr = take(N * 4), o_ll = take(N * 4);
     size_t o_lo = take(N), o_ev = take(N * 4), o_acc = take(U * 8), o_cnt = take(256);
+    size_t o_el = take(N * HH_EVAL_K * 4), o_et = take(N * HH_EVAL_K * 4);
     w->slab_bytes = off;
     {
         hipError_t e = hipMalloc(&w->slab, off);
@@ -139,6 +140,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     P.last_ret = (float *)(b + o_lr); P.last_len = (int *)(b + o_ll); P.last_outcome = (int8_t *)(b + o_lo);
     P.ev_mask = (uint32_t *)(b + o_ev);
     P.acc_rew = (double *)(b + o_acc);
+    P.eval_last = (int *)(b + o_el); P.eval_tot = (int *)(b + o_et);
     w->counter = (int *)(b + o_cnt);
     /* arenas start "done" (must be reset first); outcome 2 = no finished episode yet */
     {
@@ -288,6 +290,37 @@ extern "C" int hh_episode_stats_packed(hh_world *w, float *out, void *stream) {
     const int N = w->dc.N;
     hipLaunchKernelGGL(hh_k_pack_stats, dim3((3 * N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, w->P.last_ret, w->P.last_len,
                        w->P.last_outcome, out);
+    HIPCHK(hipGetLastError());
+    return HH_OK;
+}
+
+extern "C" int hh_eval_info(hh_world *w, int32_t *last, int32_t *total, int32_t clear_total, void *stream) {
+    if (!w) return HH_E_ARG;
+    HH_GUARD(w);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = (size_t)w->dc.N * HH_EVAL_K * 4;
+    if (last) HIPCHK(hipMemcpyAsync(last, w->P.eval_last, bytes, hipMemcpyDeviceToDevice, st));
+    if (total) HIPCHK(hipMemcpyAsync(total, w->P.eval_tot, bytes, hipMemcpyDeviceToDevice, st));
+    if (clear_total) HIPCHK(hipMemsetAsync(w->P.eval_tot, 0, bytes, st));
+    return HH_OK;
+}
+
+__global__ __launch_bounds__(256) void hh_k_arena_status(DevPtrs P, DevCfg c, int *__restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= c.N) return;
+    int ag = 0, op = 0;
+    for (int s = 0; s < c.A; s++) {
+        const int al = (P.pack[(size_t)n * c.A + s].z >> 8) & 0xff;
+        if (s < c.nA) ag += al; else op += al;
+    }
+    const int4 a = P.ar_pack[n];
+    reinterpret_cast<int4 *>(out)[n] = make_int4(a.x, ag, op, (ag <= 0 || op <= 0 || a.x >= c.horizon) ? 1 : 0);
+}
+
+extern "C" int hh_arena_status(hh_world *w, int32_t *out, void *stream) {
+    if (!w || !out) { g_err = "null argument"; return HH_E_ARG; }
+    HH_GUARD(w);
+    hipLaunchKernelGGL(hh_k_arena_status, dim3((w->dc.N + 255) / 256), dim3(256), 0, (hipStream_t)stream, w->P, w->dc, out);
     HIPCHK(hipGetLastError());
     return HH_OK;
 }

@@ -181,8 +181,7 @@ class LowLevelEnv(_Base):
             _snapshot(self)
         else:  # the reference skips _take_action for an empty action dict (env_base.py:87-88)
             obs_d = self.state()
-            st = self.world.get_state()["ar_i"]
-            dn = (st[:, 1] <= 0) | (st[:, 2] <= 0) | (st[:, 0] >= self.args.horizon)
+            dn = self.world.arena_status()[:, 3].cpu().numpy().astype(bool)   # 16 bytes per arena, not the world
             d = bool(dn[0]) if self.num_envs == 1 else dn
         terminateds = truncateds = {"__all__": d}
         return obs_d, self.rewards, terminateds, truncateds, {}

@@ -79,35 +79,14 @@ class HighLevelEnv(_Base):
         return self._obs_dict(self.world.observe())
 
     def _eval_info(self):
-        """env_base.py:91-107: win/lose/draw flags and fight / escape counters over the units that still exist
-        after the step (eval mode of evaluation.py).  Only meaningful without auto-reset (facade worlds)."""
-        nA = self.args.num_agents
-        st = self.world.get_state()
-        alive = st["ac_i"][0, :, 0]
-        steps, ag, op = int(st["ar_i"][0, 0]), int(st["ar_i"][0, 1]), int(st["ar_i"][0, 2])
-        cmd = self.world.hl_commands()[0]
-        af = ae = of = oe = ast = ost = 0
-        sel = {"opp1": 0, "opp2": 0, "opp3": 0}
-        for k in range(1, self.args.total_num + 1):
-            if not alive[k - 1]:
-                continue
-            v = int(cmd[k - 1])
-            if v:
-                if k <= nA:
-                    af += 1; ast += 1; sel[f"opp{v}"] += 1
-                else:
-                    of += 1; ost += 1
-            else:
-                if k <= nA:
-                    ae += 1; ast += 1
-                else:
-                    oe += 1; ost += 1
-        h = self.args.horizon
-        info = {"agents_win": int(op <= 0 and steps < h), "opps_win": int(ag <= 0 and steps < h),
-                "draw": int(steps >= h and ag > 0 and op > 0), "agent_fight": af, "agent_escape": ae, "opp_fight": of,
-                "opp_escape": oe, "agent_steps": ast, "opp_steps": ost}
-        info.update(sel)
-        return info
+        """env_base.py:91-107: win/lose/draw flags and fight / escape / target-choice counters over the units that still exist
+        after the step (eval mode of evaluation.py:66-82), counted on the device inside hh_hl_end for every arena
+        (hh_eval_info): ints for one arena, int32 arrays over arenas for num_envs > 1.  `self.world.eval_info()[1]` holds
+        the sums over all commander steps — what evaluation.py accumulates into eval_stats."""
+        last = self.world.eval_info()[0].cpu().numpy()
+        if self.num_envs == 1:
+            return {k: int(last[0, i]) for i, k in enumerate(L.EVAL_KEYS)}
+        return {k: last[:, i].copy() for i, k in enumerate(L.EVAL_KEYS)}
 
     def step(self, action):
         self.rewards = {}
@@ -122,7 +101,7 @@ class HighLevelEnv(_Base):
             self._cmd.copy_(torch.from_numpy(c))
             obs, rew, val, done = macro_step(self.world, self._cmd, self.pilot, early_exit=True)
             rew, val, done = rew.cpu().numpy(), val.cpu().numpy(), done.cpu().numpy()
-            if getattr(self.args, "eval_info", False) and self.num_envs == 1:
+            if getattr(self.args, "eval_info", False):
                 info = self._eval_info()
             if self.num_envs == 1:
                 self.rewards = {i: float(rew[0, i - 1]) for i in range(1, nA + 1) if val[0, i - 1]}
@@ -134,8 +113,7 @@ class HighLevelEnv(_Base):
             _snapshot(self)
         else:
             obs_d = self.state()
-            st = self.world.get_state()["ar_i"]
-            dn = (st[:, 1] <= 0) | (st[:, 2] <= 0) | (st[:, 0] >= self.args.horizon)
+            dn = self.world.arena_status()[:, 3].cpu().numpy().astype(bool)
             d = bool(dn[0]) if self.num_envs == 1 else dn
         terminateds = truncateds = {"__all__": d}
         return obs_d, self.rewards, terminateds, truncateds, info

@@ -180,6 +180,20 @@ class World:
         L.check(L.lib().hh_episode_stats_packed(self.h, _p(out), self._stream()))
         return out
 
+    def eval_info(self, clear_total=False):
+        """(last, total) int32 [N, 12] on the device: the reference's eval_info dict per arena for the most recent commander
+        step and summed since the last clear; columns = _lib.EVAL_KEYS"""
+        last = torch.empty((self.N, len(L.EVAL_KEYS)), dtype=torch.int32, device=self.device)
+        tot = torch.empty_like(last)
+        L.check(L.lib().hh_eval_info(self.h, _p(last), _p(tot), int(clear_total), self._stream()))
+        return last, tot
+
+    def arena_status(self):
+        """int32 [N, 4] on the device: steps, alive_agents, alive_opps, done"""
+        out = torch.empty((self.N, 4), dtype=torch.int32, device=self.device)
+        L.check(L.lib().hh_arena_status(self.h, _p(out), self._stream()))
+        return out
+
     def hl_tick_count(self):
         """cumulative arena-ticks run by macro steps on this world (synchronises the current stream)"""
         v = C.c_uint64(0)

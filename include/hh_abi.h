@@ -154,6 +154,19 @@ int hh_hl_tick_count(hh_world *w, uint64_t *out, void *stream);
 /* name of the kernel instance hh_rollout / hh_step (or the hh_hl_* phases) launch for this world on this device */
 int hh_rollout_kernel_name(hh_world *w, char *buf, int32_t len);
 
+/* Evaluation counters of HighLevelEnv.step (envs/env_base.py:91-107, read by evaluation.py:66-82), computed on the device
+ * for every arena inside hh_hl_end: columns = agents_win, opps_win, draw (flags of the step that ended the episode),
+ * agent_fight, agent_escape, opp_fight, opp_escape, agent_steps, opp_steps, opp1, opp2, opp3 (units that still exist after
+ * the step, by their assessed commander action; oppK = agents fighting their K-th stored target).
+ *   last  [dev] i32 [N, HH_EVAL_K]  nullable: the info dict of the most recent commander step of every arena
+ *   total [dev] i32 [N, HH_EVAL_K]  nullable: summed over every commander step since the world was created / last cleared
+ * clear_total != 0 zeroes the sums after copying them. */
+#define HH_EVAL_K 12
+int hh_eval_info(hh_world *w, int32_t *last, int32_t *total, int32_t clear_total, void *stream);
+
+/* steps, alive_agents, alive_opps, done of every arena -> [dev] i32 [N, 4] (what step({}) needs: env_base.py:87-90) */
+int hh_arena_status(hh_world *w, int32_t *out, void *stream);
+
 /* per-arena statistics of the most recently FINISHED episode (logging; this is what the
  * multi-GPU all-gather moves): ret [dev] f32[N] (sum of agent rewards), len [dev] i32[N],
  * outcome [dev] i8[N] (1 agents win, -1 opponents win, 0 draw, 2 none finished yet) */

@@ -71,6 +71,7 @@ typedef struct {
     int hl_s, hl_running, hl_kill, hl_situ;
     int cmd_act[MAXA]; /* self.commander_actions[i]: 0 escape, k>0 fight stored target k (agents and opponents) */
     double opp_stat0[MAXA]; /* env_hetero.py:169-170 opp_stats[i][0], kept between the two halves of a split step */
+    int eval_last[HH_EVAL_K], eval_tot[HH_EVAL_K]; /* env_base.py:91-107 info dict of the last commander step / summed */
     /* episode statistics */
     double ep_ret;
     float last_ret;
@@ -1364,10 +1365,22 @@ API int hho_hl_end(void *h, float *obs /* [N, n_agents, 34] */, float *reward, u
     int nA = w->cfg.n_agents;
     for (int n = 0; n < w->cfg.n_arenas; n++) {
         o_arena *a = &w->ar[n];
+        for (int k = 0; k < HH_EVAL_K; k++) a->eval_last[k] = 0;
         if (!a->done) {
             int ag, op;
             count_alive(w, a, &ag, &op);
             a->done = ag <= 0 || op <= 0 || a->steps >= w->cfg.horizon;
+            {   /* env_base.py:91-107 eval_info: `for k, v in action.items(): if self.sim.unit_exists(k)` after the step */
+                int *e = a->eval_last, h = w->cfg.horizon;
+                e[0] = op <= 0 && a->steps < h; e[1] = ag <= 0 && a->steps < h; e[2] = a->steps >= h && ag > 0 && op > 0;
+                for (int k = 1; k <= w->A; k++) {
+                    if (!a->ac[k - 1].alive) continue;
+                    int v = a->cmd_act[k - 1];
+                    if (v) { if (k <= nA) { e[3]++; e[7]++; e[8 + v]++; } else { e[5]++; e[8]++; } }
+                    else { if (k <= nA) { e[4]++; e[7]++; } else { e[6]++; e[8]++; } }
+                }
+                for (int k = 0; k < HH_EVAL_K; k++) a->eval_tot[k] += e[k];
+            }
             for (int i = 0; i < nA; i++) if (a->reward_valid[i]) a->ep_ret += a->reward[i];
             if (a->done) finish_episode(a, ag, op, w->cfg.horizon);
             hl_state(w, a);
@@ -1383,6 +1396,16 @@ API int hho_hl_end(void *h, float *obs /* [N, n_agents, 34] */, float *reward, u
         }
         if (obs) copy_obs(w, a, obs + (size_t)n * nA * w->D);
     }
+    return HH_OK;
+}
+
+API int hho_eval_info(void *h, int32_t *last /* [N, HH_EVAL_K] */, int32_t *total) {
+    o_world *w = (o_world *)h;
+    for (int n = 0; n < w->cfg.n_arenas; n++)
+        for (int k = 0; k < HH_EVAL_K; k++) {
+            if (last) last[(size_t)n * HH_EVAL_K + k] = w->ar[n].eval_last[k];
+            if (total) total[(size_t)n * HH_EVAL_K + k] = w->ar[n].eval_tot[k];
+        }
     return HH_OK;
 }
 

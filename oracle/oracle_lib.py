@@ -225,6 +225,12 @@ class OracleWorld:
         lib().hho_hl_end(self.h, _ptr(obs, C.c_float), _ptr(rew, C.c_float), _ptr(val, C.c_uint8), _ptr(done, C.c_uint8))
         return obs, rew, val, done
 
+    def eval_info(self):
+        last = np.zeros((self.N, 12), dtype=np.int32)
+        tot = np.zeros((self.N, 12), dtype=np.int32)
+        lib().hho_eval_info(self.h, _ptr(last, C.c_int32), _ptr(tot, C.c_int32))
+        return last, tot
+
     def hl_cmd(self):
         cmd = np.zeros((self.N, self.A), dtype=np.int32)
         sub = np.zeros((self.N,), dtype=np.int32)

@@ -57,9 +57,15 @@ def test_macro_step_parity(oracle, kw):
             assert np.array_equal(a, b), f"step {step}: {name}"
         dones += int(outs[3].sum())
         _same_state(g.get_state(), o.get_state(), f"step {step}")
+        for a, b, name in zip([x.cpu().numpy() for x in g.eval_info()], o.eval_info(), ("last", "total")):   # env_base.py:91-107 on the device
+            assert np.array_equal(a, b), f"step {step}: eval_info {name}"
+        st = g.arena_status().cpu().numpy()
+        assert np.array_equal(st[:, :3], o.get_state()["ar_i"][:, :3]), f"step {step}: arena status"
     for a, b in zip([x.cpu().numpy() for x in g.episode_stats()], o.episode_stats()):
         assert np.array_equal(a, b)
     assert dones > 0 and kills > 0
+    tot = g.eval_info(clear_total=True)[1]
+    assert int(tot[:, :3].sum()) == dones and int(tot[:, 7].sum()) > 0 and int(g.eval_info()[1].sum()) == 0
 
 
 @pytest.mark.parametrize("N,force_w", [(8192, "0"), (12003, "0"), (173, "2")],

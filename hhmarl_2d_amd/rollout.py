@@ -41,3 +41,36 @@ def central_critic_inputs(obs, actions):
     a1, a2 = scaled[..., 0, :ACTION_DIM_AC1], scaled[..., 1, :ACTION_DIM_AC2]
     return {1: {"obs_1_own": o1, "obs_2": o2, "act_1_own": a1, "act_2": a2},
             2: {"obs_1_own": o2, "obs_2": o1, "act_1_own": a2, "act_2": a1}}
+
+
+def central_critic_rows(obs, actions, agent):
+    """The flattened CUR_OBS rows the reference's critic is trained on, for the 2-vs-2 low-level setting: RLlib flattens the
+    observer's Dict in sorted key order (act_1_own, act_2, obs_1_own, obs_2) and `on_postprocess_trajectory`
+    (train_hetero.py:120-160) then writes the own and the friend's actions into the first 7 columns, heading / speed components
+    scaled by 1/12 and 1/8.  Agent 1 (type 1): [own act 4 | friend act 3 | own obs 26|30 | friend obs 24|29]; agent 2 (type 2):
+    [own act 3 | friend act 4 | own obs 24|29 | friend obs 26|30].  obs [..., 2, D] as the world emits it (zero padded), actions
+    int8 [..., 2, 4] -> float32 [..., 57] (fight) / [..., 66] (escape).  Pinned by tests/golden/critic_packing.npz (recorded
+    from the reference's own callbacks)."""
+    c = central_critic_inputs(obs, actions)[agent]
+    return torch.cat([c["act_1_own"], c["act_2"], c["obs_1_own"], c["obs_2"]], dim=-1).float()
+
+
+def central_critic_rows_hl(obs, actions, agent):
+    """train_hier.py:100-165 for the 3-vs-3 commander: sorted keys (act_1_own, act_2, act_3, obs_1_own, obs_2, obs_3); the own
+    action and the other two agents' actions (ascending id) divided by N_OPP_HL = 2 in columns 0..2.  obs [..., 3, 34],
+    actions int8 [..., 3] -> float32 [..., 105]."""
+    others = [i for i in (1, 2, 3) if i != agent]
+    order = [agent] + others
+    a = torch.stack([actions[..., i - 1].float() / 2.0 for i in order], dim=-1)
+    return torch.cat([a] + [obs[..., i - 1, :].float() for i in order], dim=-1)
+
+
+def episode_segments(done):
+    """batch_mode="complete_episodes" (train_hetero.py:212) on the [T, N] done flags of a rollout with auto-reset:
+    -> (segment id per row [T, N], starting at 0 per arena and increasing after every done row;
+        complete [T, N] bool: the row belongs to an episode that also ENDS inside this rollout — the rows RLlib would train on;
+        the trailing fragment of every arena is carried into the next rollout instead)"""
+    d = done.to(torch.int64)
+    seg = torch.cumsum(d, dim=0) - d                     # episodes finished strictly before this row
+    n_done = d.sum(dim=0, keepdim=True)                  # episodes that end inside the rollout, per arena
+    return seg, seg < n_done

@@ -59,6 +59,7 @@ def parse_args():
                     help="hier: uniform actions from a pre-resident tape (default), drawn by torch kernels inside the step, random-init "
                          "MLP stand-ins in torch, or the reference's Fight/Esc architectures in the fused HIP kernel (net)")
     ap.add_argument("--no-graph", action="store_true", help="hier/rollout: launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--phases", action="store_true", help="hier with --pilot tape: the 34-launch phase path instead of the one-launch macro step")
     return ap.parse_args()
 
 
@@ -415,11 +416,13 @@ def main_hier(args):
     cmds = (torch.rand((64, N, 3), device=R.dev, generator=gen) * 3).to(torch.int8).contiguous()
     out, pbuf = w.alloc_outputs(), w.alloc_pilot()
 
-    # the macro step is a fixed sequence of world launches (+ the pilots' kernels): capture it once into a HIP graph
-    # (launch-bound inner loop; no host synchronisation inside) and replay it per commander step
+    # pilot networks in the loop: the macro step is a fixed sequence of world launches + the pilots' kernels: capture it once
+    # into a HIP graph (launch-bound inner loop; no host synchronisation inside) and replay it per commander step.
+    # actions from a resident tape: the whole commander step is ONE persistent launch (hh_hl_rollout).
     cmd_static = cmds[0].clone()
     graph = None
-    if not args.no_graph:
+    one_launch = args.pilot == "tape" and not args.phases
+    if not args.no_graph and not one_launch:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -435,6 +438,12 @@ def main_hier(args):
     def run(n):
         for _ in range(n):
             k = state["k"]
+            if one_launch:
+                w.hl_rollout(cmds[k % 64], pilot.bank[k % pilot.bank.shape[0]], out=out)
+                state["k"] = k + 1
+                if state["k"] % 16 == 0:
+                    sw.log_episode_stats(log_side)
+                continue
             if args.pilot == "tape":
                 pilot.load(k)
             if graph is not None:
@@ -475,7 +484,8 @@ def main_hier(args):
                                f"pilots = {PILOT_DESC[args.pilot]}, auto-reset (BASELINE configs[3])", "arenas_per_gpu": N,
                    "parallelism": f"arena-sharded x{R.world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": f"{w.kernel_name()} (every launch of the macro step, plus the pilots' kernels if any)",
+                     "traffic": None, "kernel": ("hh_k_hier_macro (one persistent launch per commander step)" if one_launch else
+                                                 f"{w.kernel_name()} (every phase launch of the macro step, plus the pilots' kernels if any)"),
                      "algorithmic_bytes": algo_bytes,
                      "note": "2056 B per arena-tick actually run + 424 B per commander step (SURVEY.md 8d)"},
     }

@@ -150,6 +150,188 @@ __device__ __forceinline__ double hl_action_assess(const DevCfg &c, const Shared
     return rew;
 }
 
+/* ---- the phases of a commander step as device functions: the phase-by-phase kernel (pilot networks between launches) and
+ *      the persistent macro-step kernel (actions from a tape) run the SAME code, so their results are bit-identical ---- */
+
+/* everything a lane carries through a macro step */
+struct HlLane {
+    Unit m;
+    Arena ar;
+    double acc;     /* reward accumulated over the macro step (agents) */
+    double ep_ret;  /* episode return (lane s == 0) */
+    uint32_t evm;   /* event bits of the current sub-step */
+};
+
+__device__ __forceinline__ void hl_load_act(const int8_t *__restrict__ actions, size_t row, bool active, int8_t (&act)[4]) {
+    act[0] = act[1] = act[2] = act[3] = 0;
+    if (active) {
+        const int w = *reinterpret_cast<const int *>(actions + row * 4);
+        act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
+    }
+}
+
+/* HL_BEGIN: env_hier.py:142-190 _action_assess + the opponents' draws */
+template <int A, int B>
+__device__ __forceinline__ void hl_do_begin(const DevCfg &c, Shared<A, B> &sh, int tid, int base, int s, int n, bool active, HlLane &L,
+                                            const int8_t *__restrict__ cmd) {
+    const bool agent = s < c.nA;
+    L.ar.hl_s = 0;
+    L.ar.hl_run = active && !L.ar.done;
+    L.acc = 0.0;
+    if (L.ar.hl_run) {
+        int cc = agent ? (int)cmd[(size_t)n * c.nA + s] : 0;
+        double r = hl_action_assess(c, sh, tid, base, s, L.m, L.ar, cc);
+        if (agent) L.acc = r;
+    }
+}
+
+/* HL_AGENTS_ACT: the agents' _take_base_action (incl. the missile envelope) */
+template <int A, int B, int W>
+__device__ __forceinline__ void hl_do_agents_act(const DevCfg &c, Shared<A, B> &sh, int tid, int base, int s, bool active, HlLane &L,
+                                                 const int8_t (&act)[4]) {
+    double pr = 0.0, os0 = 0.0;
+    int vl = 0;
+    act_phase<A, B, (W >= 2)>(c, sh, tid, s, base, active, L.ar.hl_run != 0, L.m, L.ar, act, s < c.nA, true, pr, os0, vl, L.evm);
+}
+
+/* HL_TICK: the opponents' _take_base_action, do_tick, rewards, kill / surrounding events, s += 1 (env_hier.py:125-138).
+ * TAB: a pair table of the pre-tick positions is in LDS (persistent kernel: the previous tick left it); the phase kernel
+ * has none at this point and computes the one entry a launch test needs on demand — the same expression, the same bits.
+ * Returns 1 iff this lane's arena ran the tick. */
+template <int A, int B, int W, bool TAB>
+__device__ __forceinline__ int hl_do_tick(const DevCfg &c, Shared<A, B> &sh, int tid, int g, int base, int s, bool active, HlLane &L,
+                                          const int8_t (&act)[4]) {
+    const bool agent = s < c.nA;
+    { double pr = 0.0, os0 = 0.0; int vl = 0; act_phase<A, B, (W >= 2), TAB>(c, sh, tid, s, base, active, L.ar.hl_run != 0, L.m, L.ar, act, !agent, true, pr, os0, vl, L.evm); }
+    StepOut so;
+    so.reward = 0.0; so.valid = 0; so.opp_stat0 = 0.0;
+    const bool was_running = active && L.ar.hl_run;
+    uint32_t evm_tick = 0;
+#ifdef HH_PROFILE_PHASES
+    unsigned long long prof_t0_ = 0, prof_acc_[12] = {0};
+#endif
+    tick<A, B, (W >= 2)>(c, sh, tid, g, s, base, active, L.m, L.ar, act, so, evm_tick, 1, L.ar.hl_run != 0 HH_PROF_PASS);
+    L.evm |= evm_tick;
+    if (was_running) {
+        if (agent) L.acc += so.reward;
+        /* env_hier.py:133-138: surrounding event only after min_sub_steps, then s += 1, steps += 1 */
+        int situ = 0;
+        if (L.ar.hl_s > 10) {
+#pragma unroll
+            for (int i = 0; i < A; i++) {
+                if (i >= c.nA || !sh_alive(sh, base + i)) continue;
+#pragma unroll
+                for (int j = 0; j < A; j++) {
+                    if (j < c.nA || !sh_alive(sh, base + j)) continue;
+                    if (sh.p_dist[j][base + i] < 0.1 && (sh.p_foc[j][base + i] < 15.0 || sh.p_foc[i][base + j] < 15.0)) situ = 1;
+                }
+            }
+        }
+        L.ar.hl_s += 1;
+        L.ar.steps += 1;
+        arena_rekey(L.ar);
+        L.ar.hl_run = (L.ar.hl_s <= 15 && !so.kill_event && !situ) ? 1 : 0;
+    }
+    return was_running ? 1 : 0;
+}
+
+/* HL_END / HL_REFRESH / HL_RESET: done, rewards out, episode statistics, eval counters, (auto-)reset, commander observation +
+ * stored target lists (env_hier.py:49-98); the agents' rows are left staged in sh.u.obs for the caller to store */
+template <int A, int B>
+__device__ __forceinline__ void hl_do_end(const DevPtrs &P, const DevCfg &c, Shared<A, B> &sh, int tid, int g, int base, int s, int n, bool active,
+                                          HlLane &L, int phase, float *__restrict__ reward_out, uint8_t *__restrict__ valid_out,
+                                          uint8_t *__restrict__ done_out, const uint8_t *__restrict__ mask) {
+    const bool agent = s < c.nA;
+    Unit &m = L.m;
+    Arena &ar = L.ar;
+    const bool ending = phase == HH_HL_END && active && !ar.done; /* arena took part in this macro step */
+    int ag = 0, op = 0;
+#pragma unroll
+    for (int j = 0; j < A; j++) { int al = sh_alive(sh, base + j); if (j < c.nA) ag += al; else op += al; }
+    if (ending) ar.done = (ag <= 0 || op <= 0 || ar.steps >= c.horizon) ? 1 : 0;
+    sh.rew[tid] = (ending && agent) ? L.acc : 0.0;
+    __syncthreads();
+    if (ending && s == 0) {
+        for (int j = 0; j < c.nA; j++) L.ep_ret += sh.rew[base + j];
+        if (ar.done) {
+            P.last_ret[n] = (float)L.ep_ret;
+            P.last_len[n] = ar.steps;
+            P.last_outcome[n] = (op <= 0 && ar.steps < c.horizon) ? 1 : ((ag <= 0 && ar.steps < c.horizon) ? -1 : 0);
+        }
+    }
+    if (phase == HH_HL_END) {
+        /* eval_info of this commander step (env_base.py:91-107): units that still exist, by assessed commander action */
+        sh.res[tid] = (ending && m.alive) ? (1 | ((m.cmd_act & 3) << 1)) : 0;
+        __syncthreads();
+        if (active && s == 0) {
+            int e[HH_EVAL_K];
+#pragma unroll
+            for (int k = 0; k < HH_EVAL_K; k++) e[k] = 0;
+            if (ending) {
+                e[0] = (op <= 0 && ar.steps < c.horizon) ? 1 : 0;
+                e[1] = (ag <= 0 && ar.steps < c.horizon) ? 1 : 0;
+                e[2] = (ar.steps >= c.horizon && ag > 0 && op > 0) ? 1 : 0;
+#pragma unroll
+                for (int j = 0; j < A; j++) {
+                    const int w_ = sh.res[base + j];
+                    if (!(w_ & 1)) continue;
+                    const int v = w_ >> 1;
+                    if (j < c.nA) { e[7] += 1; if (v) { e[3] += 1; e[8 + v] += 1; } else e[4] += 1; }
+                    else { e[8] += 1; if (v) e[5] += 1; else e[6] += 1; }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < HH_EVAL_K; k++) {
+                P.eval_last[(size_t)n * HH_EVAL_K + k] = e[k];
+                if (e[k]) P.eval_tot[(size_t)n * HH_EVAL_K + k] += e[k];
+            }
+        }
+        ar.hl_run = 0;
+        if (active && agent) {
+            size_t o = (size_t)n * c.nA + s;
+            if (reward_out) reward_out[o] = ending ? (float)L.acc : 0.0f;
+            if (valid_out) valid_out[o] = ending ? 1 : 0; /* every agent id has a reward key (env_hier.py:154,188) */
+        }
+        if (active && s == 0 && done_out) done_out[n] = (uint8_t)ar.done;
+    }
+    bool need_reset = phase == HH_HL_END ? (active && ar.done && c.auto_reset)
+                                         : (phase == HH_HL_RESET && active && (mask == nullptr || mask[n]));
+    const int any_reset = __syncthreads_or(need_reset ? 1 : 0);
+    if (need_reset) {
+        reset_arena_scalars(ar);
+        reset_unit<A>(c, s, m, ar);
+        ar.hl_s = 0; ar.hl_run = 0;
+        L.ep_ret = 0.0;
+        L.acc = 0.0;
+    }
+    if (any_reset) {
+        publish_obs(c, sh, tid, m);
+        __syncthreads();
+        pair_tables(sh, tid, base, s, active);
+        __syncthreads();
+    }
+    __syncthreads();
+    if (active) { /* rows of the agents staged in LDS (opponents only refresh their stored target lists: nothing is written) */
+        float *row = agent ? &sh.u.obs[(g * c.nA + s) * HH_OBS_HL] : &sh.u.obs[0];
+        hl_commander_obs(c, sh, tid, base, s, m, row);
+    }
+    __syncthreads();
+}
+
+template <int A, int B>
+__device__ __forceinline__ void hl_store_commander_obs(const DevCfg &c, const Shared<A, B> &sh, int tid, int phase, float *__restrict__ obs_out,
+                                                       const uint8_t *__restrict__ mask) {
+    constexpr int GPB = B / A;
+    if (!obs_out) return;
+    const int arenas = min(GPB, c.N - (int)blockIdx.x * GPB);
+    const int per = c.nA * HH_OBS_HL, cnt = arenas * per;
+    float *dst = obs_out + (size_t)blockIdx.x * GPB * per;
+    for (int k = tid; k < cnt; k += B) {
+        const bool wr = phase != HH_HL_RESET || mask == nullptr || mask[blockIdx.x * GPB + k / per];
+        if (wr) dst[k] = sh.u.obs[k];
+    }
+}
+
 /* W = resident waves per SIMD the register allocation is held to (1: no spills, for up to one wave per SIMD) */
 template <int A, int B, int W>
 __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase, const int8_t *__restrict__ cmd,
@@ -169,19 +351,21 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
     const size_t U = (size_t)c.N * A;
     const size_t u = (size_t)n * A + s;
     const bool agent = s < c.nA;
-    Unit m = Unit{};
-    Arena ar = Arena{};
-    double acc = 0.0, ep_ret = 0.0;
+    HlLane L;
+    L.m = Unit{};
+    L.ar = Arena{};
+    L.acc = 0.0; L.ep_ret = 0.0; L.evm = 0;
+    Unit &m = L.m;
+    Arena &ar = L.ar;
     if (active) {
         unit_load(P, U, u, m);
         arena_load(P, c, n, ar);
-        acc = P.acc_rew[u];
-        if (s == 0) ep_ret = P.ep_ret[n];
+        L.acc = P.acc_rew[u];
+        if (s == 0) L.ep_ret = P.ep_ret[n];
     } else {
         ar.done = 1;
     }
     sh.aux[tid] = 0;
-    uint32_t evm = 0;
     publish_obs(c, sh, tid, m);
     __syncthreads();
     if (phase != HH_HL_TICK) { /* HL_TICK builds its table after the tick; before it only a launch test may ask for an entry */
@@ -191,151 +375,29 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
     int obs_side = -1; /* which side's pilot observations this launch emits */
 
     if (phase == HH_HL_BEGIN) {
-        ar.hl_s = 0;
-        ar.hl_run = active && !ar.done;
-        acc = 0.0;
-        if (ar.hl_run) {
-            int cc = agent ? (int)cmd[(size_t)n * c.nA + s] : 0;
-            double r = hl_action_assess(c, sh, tid, base, s, m, ar, cc);
-            if (agent) acc = r;
-        }
+        hl_do_begin<A, B>(c, sh, tid, base, s, n, active, L, cmd);
         obs_side = 0;
     } else if (phase == HH_HL_AGENTS_ACT) {
-        int8_t act[4] = {0, 0, 0, 0};
-        if (active) {
-            int w = *reinterpret_cast<const int *>(actions + u * 4);
-            act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
-        }
-        { double pr = 0.0, os0 = 0.0; int vl = 0; act_phase<A, B, (W >= 2)>(c, sh, tid, s, base, active, ar.hl_run != 0, m, ar, act, agent, true, pr, os0, vl, evm); }
+        int8_t act[4];
+        hl_load_act(actions, u, active, act);
+        hl_do_agents_act<A, B, W>(c, sh, tid, base, s, active, L, act);
         obs_side = 1;
     } else if (phase == HH_HL_TICK) {
-        int8_t act[4] = {0, 0, 0, 0};
-        if (active) {
-            int w = *reinterpret_cast<const int *>(actions + u * 4);
-            act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
-        }
-        { double pr = 0.0, os0 = 0.0; int vl = 0; act_phase<A, B, (W >= 2), false>(c, sh, tid, s, base, active, ar.hl_run != 0, m, ar, act, !agent, true, pr, os0, vl, evm); }
-        StepOut so;
-        so.reward = 0.0; so.valid = 0; so.opp_stat0 = 0.0;
-        const bool was_running = active && ar.hl_run;
-        uint32_t evm_tick = 0;
-#ifdef HH_PROFILE_PHASES
-        unsigned long long prof_t0_ = 0, prof_acc_[12] = {0};
-#endif
-        tick<A, B, (W >= 2)>(c, sh, tid, g, s, base, active, m, ar, act, so, evm_tick, 1, ar.hl_run != 0 HH_PROF_PASS);
-        evm |= evm_tick;
-        if (was_running) {
-            if (agent) acc += so.reward;
-            /* env_hier.py:133-138: surrounding event only after min_sub_steps, then s += 1, steps += 1 */
-            int situ = 0;
-            if (ar.hl_s > 10) {
-#pragma unroll
-                for (int i = 0; i < A; i++) {
-                    if (i >= c.nA || !sh_alive(sh, base + i)) continue;
-#pragma unroll
-                    for (int j = 0; j < A; j++) {
-                        if (j < c.nA || !sh_alive(sh, base + j)) continue;
-                        if (sh.p_dist[j][base + i] < 0.1 && (sh.p_foc[j][base + i] < 15.0 || sh.p_foc[i][base + j] < 15.0)) situ = 1;
-                    }
-                }
-            }
-            ar.hl_s += 1;
-            ar.steps += 1;
-            arena_rekey(ar);
-            ar.hl_run = (ar.hl_s <= 15 && !so.kill_event && !situ) ? 1 : 0;
-            if (s == 0 && ar.hl_run && running_count) atomicAdd(running_count, 1);
-        }
+        int8_t act[4];
+        hl_load_act(actions, u, active, act);
+        const int ran = hl_do_tick<A, B, W, false>(c, sh, tid, g, base, s, active, L, act);
+        if (s == 0 && ran && ar.hl_run && running_count) atomicAdd(running_count, 1);
         {   /* cumulative arena-ticks of this world (hh_hl_tick_count): one atomic per wave */
-            const unsigned long long ran = __ballot(was_running && s == 0);
-            if (ran && (tid & 63) == 0 && running_count) atomicAdd(reinterpret_cast<unsigned long long *>(running_count + 2), (unsigned long long)__popcll(ran));
+            const unsigned long long rn = __ballot(ran && s == 0);
+            if (rn && (tid & 63) == 0 && running_count) atomicAdd(reinterpret_cast<unsigned long long *>(running_count + 2), (unsigned long long)__popcll(rn));
         }
         obs_side = 0;
     } else { /* HH_HL_END, HH_HL_REFRESH, HH_HL_RESET */
-        const bool ending = phase == HH_HL_END && active && !ar.done; /* arena took part in this macro step */
-        int ag = 0, op = 0;
-#pragma unroll
-        for (int j = 0; j < A; j++) { int al = sh_alive(sh, base + j); if (j < c.nA) ag += al; else op += al; }
-        if (ending) ar.done = (ag <= 0 || op <= 0 || ar.steps >= c.horizon) ? 1 : 0;
-        sh.rew[tid] = (ending && agent) ? acc : 0.0;
-        __syncthreads();
-        if (ending && s == 0) {
-            for (int j = 0; j < c.nA; j++) ep_ret += sh.rew[base + j];
-            if (ar.done) {
-                P.last_ret[n] = (float)ep_ret;
-                P.last_len[n] = ar.steps;
-                P.last_outcome[n] = (op <= 0 && ar.steps < c.horizon) ? 1 : ((ag <= 0 && ar.steps < c.horizon) ? -1 : 0);
-            }
-        }
-        if (phase == HH_HL_END) {
-            /* eval_info of this commander step (env_base.py:91-107): units that still exist, by assessed commander action */
-            sh.res[tid] = (ending && m.alive) ? (1 | ((m.cmd_act & 3) << 1)) : 0;
-            __syncthreads();
-            if (active && s == 0) {
-                int e[HH_EVAL_K];
-#pragma unroll
-                for (int k = 0; k < HH_EVAL_K; k++) e[k] = 0;
-                if (ending) {
-                    e[0] = (op <= 0 && ar.steps < c.horizon) ? 1 : 0;
-                    e[1] = (ag <= 0 && ar.steps < c.horizon) ? 1 : 0;
-                    e[2] = (ar.steps >= c.horizon && ag > 0 && op > 0) ? 1 : 0;
-#pragma unroll
-                    for (int j = 0; j < A; j++) {
-                        const int w_ = sh.res[base + j];
-                        if (!(w_ & 1)) continue;
-                        const int v = w_ >> 1;
-                        if (j < c.nA) { e[7] += 1; if (v) { e[3] += 1; e[8 + v] += 1; } else e[4] += 1; }
-                        else { e[8] += 1; if (v) e[5] += 1; else e[6] += 1; }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < HH_EVAL_K; k++) {
-                    P.eval_last[(size_t)n * HH_EVAL_K + k] = e[k];
-                    if (e[k]) P.eval_tot[(size_t)n * HH_EVAL_K + k] += e[k];
-                }
-            }
-            ar.hl_run = 0;
-            if (active && agent) {
-                size_t o = (size_t)n * c.nA + s;
-                if (reward_out) reward_out[o] = ending ? (float)acc : 0.0f;
-                if (valid_out) valid_out[o] = ending ? 1 : 0; /* every agent id has a reward key (env_hier.py:154,188) */
-            }
-            if (active && s == 0 && done_out) done_out[n] = (uint8_t)ar.done;
-        }
-        bool need_reset = phase == HH_HL_END ? (active && ar.done && c.auto_reset)
-                                             : (phase == HH_HL_RESET && active && (mask == nullptr || mask[n]));
-        const int any_reset = __syncthreads_or(need_reset ? 1 : 0);
-        if (need_reset) {
-            reset_arena_scalars(ar);
-            reset_unit<A>(c, s, m, ar);
-            ar.hl_s = 0; ar.hl_run = 0;
-            ep_ret = 0.0;
-            acc = 0.0;
-        }
-        if (any_reset) {
-            publish_obs(c, sh, tid, m);
-            __syncthreads();
-            pair_tables(sh, tid, base, s, active);
-            __syncthreads();
-        }
-        __syncthreads();
-        if (active) { /* rows of the agents staged in LDS (opponents only refresh their stored target lists: nothing is written) */
-            float *row = agent ? &sh.u.obs[(g * c.nA + s) * HH_OBS_HL] : &sh.u.obs[0];
-            hl_commander_obs(c, sh, tid, base, s, m, row);
-        }
-        __syncthreads();
-        if (obs_out) {
-            const int arenas = min(GPB, c.N - (int)blockIdx.x * GPB);
-            const int per = c.nA * HH_OBS_HL, cnt = arenas * per;
-            float *dst = obs_out + (size_t)blockIdx.x * GPB * per;
-            for (int k = tid; k < cnt; k += B) {
-                const bool wr = phase != HH_HL_RESET || mask == nullptr || mask[blockIdx.x * GPB + k / per];
-                if (wr) dst[k] = sh.u.obs[k];
-            }
-        }
+        hl_do_end<A, B>(P, c, sh, tid, g, base, s, n, active, L, phase, reward_out, valid_out, done_out, mask);
+        hl_store_commander_obs<A, B>(c, sh, tid, phase, obs_out, mask);
     }
-    /* RESET / set_state style refresh of the stored lists is done by HL_END; pilot observations: every unit's row is
-     * staged in LDS (the tick's exchange area is free by now) and the workgroup's rows, contiguous in [N, A, 30], leave
-     * with unit-stride 16-byte stores */
+    /* pilot observations: every unit's row is staged in LDS (the tick's exchange area is free by now) and the workgroup's
+     * rows, contiguous in [N, A, 30], leave with unit-stride 16-byte stores */
     if (obs_side >= 0 && pilot_obs) {
         __syncthreads(); /* all reads of the tick's LDS area are done */
         constexpr int HALF = A / 2; /* units per side */
@@ -397,17 +459,90 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
     }
     if (active) {
         unit_store(P, U, u, m);
-        P.acc_rew[u] = acc;
+        P.acc_rew[u] = L.acc;
         if (s == 0) {
             arena_store(P, n, ar);
-            P.ep_ret[n] = ep_ret;
+            P.ep_ret[n] = L.ep_ret;
         }
     }
     if (phase == HH_HL_AGENTS_ACT || phase == HH_HL_TICK) {
         if (active && s == 0 && phase == HH_HL_AGENTS_ACT && ar.hl_run) P.ev_mask[n] = 0;
         __syncthreads();
-        if (active && evm) atomicOr(&P.ev_mask[n], evm);
+        if (active && L.evm) atomicOr(&P.ev_mask[n], L.evm);
     }
+}
+
+/* ---- the persistent macro step: ONE launch per commander step when the pilots' actions are resident before it starts
+ * (a tape: actions [16][N][A][4], sub-step major — the layout TapePilot hands out slice by slice).  State stays in registers
+ * from _action_assess to the commander observation; the pair table a tick leaves behind serves the next sub-step's act
+ * phases; a workgroup leaves the sub-step loop as soon as none of its arenas is still inside its macro step
+ * (13.2 of 16 sub-steps on average).  Same device functions as the phase kernel: bit-identical. ---- */
+template <int A, int B, int W>
+__global__ __launch_bounds__(B, W) void hh_k_hier_macro(DevPtrs P, DevCfg c, const int8_t *__restrict__ cmd, const int8_t *__restrict__ tape,
+                                                     float *__restrict__ obs_out, float *__restrict__ reward_out,
+                                                     uint8_t *__restrict__ valid_out, uint8_t *__restrict__ done_out,
+                                                     int *__restrict__ counters) {
+    constexpr int GPB = B / A;
+    __shared__ Shared<A, B> sh;
+    const int tid = threadIdx.x;
+    const int g = tid / A, s = tid % A;
+    const int base = g * A;
+    const int n = blockIdx.x * GPB + g;
+    const bool active = g < GPB && n < c.N;
+    const size_t U = (size_t)c.N * A;
+    const size_t u = (size_t)n * A + s;
+    HlLane L;
+    L.m = Unit{};
+    L.ar = Arena{};
+    L.acc = 0.0; L.ep_ret = 0.0; L.evm = 0;
+    if (active) {
+        unit_load(P, U, u, L.m);
+        arena_load(P, c, n, L.ar);
+        if (s == 0) L.ep_ret = P.ep_ret[n];
+    } else {
+        L.ar.done = 1;
+    }
+    sh.aux[tid] = 0;
+    publish_obs(c, sh, tid, L.m);
+    __syncthreads();
+    pair_tables(sh, tid, base, s, active);
+    __syncthreads();
+    hl_do_begin<A, B>(c, sh, tid, base, s, n, active, L, cmd);
+    int ticks = 0;
+    uint32_t evm_last = 0;
+    /* the action word of the next sub-step is requested a sub-step ahead (one wave per SIMD cannot hide the round trip) */
+    int act_next = active ? *reinterpret_cast<const int *>(tape + u * 4) : 0;
+    for (int sub = 0; sub < 16; sub++) {
+        if (!__syncthreads_or(L.ar.hl_run)) break; /* nobody in this workgroup is inside a macro step any more */
+        const int w = act_next;
+        if (active && sub + 1 < 16) act_next = *reinterpret_cast<const int *>(tape + ((size_t)(sub + 1) * U + u) * 4);
+        int8_t act[4];
+        act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
+        const bool running = active && L.ar.hl_run;
+        if (running) L.evm = 0;
+        hl_do_agents_act<A, B, W>(c, sh, tid, base, s, active, L, act);
+        ticks += hl_do_tick<A, B, W, true>(c, sh, tid, g, base, s, active, L, act);
+        if (running) evm_last = L.evm;
+    }
+    hl_do_end<A, B>(P, c, sh, tid, g, base, s, n, active, L, HH_HL_END, reward_out, valid_out, done_out, nullptr);
+    hl_store_commander_obs<A, B>(c, sh, tid, HH_HL_END, obs_out, nullptr);
+    if (active) {
+        unit_store(P, U, u, L.m);
+        P.acc_rew[u] = L.acc;
+        if (s == 0) {
+            arena_store(P, n, L.ar);
+            P.ep_ret[n] = L.ep_ret;
+        }
+    }
+    {   /* cumulative arena-ticks (hh_hl_tick_count): one atomic per wave */
+        int t = s == 0 ? ticks : 0;
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if ((tid & 63) == 0 && t && counters) atomicAdd(reinterpret_cast<unsigned long long *>(counters + 2), (unsigned long long)t);
+    }
+    /* event masks of each arena's last sub-step, like the phase path leaves them */
+    if (active && s == 0 && ticks) P.ev_mask[n] = 0;
+    __syncthreads();
+    if (active && ticks && evm_last) atomicOr(&P.ev_mask[n], evm_last);
 }
 
 #endif /* HH_KERNELS_HIER_H */

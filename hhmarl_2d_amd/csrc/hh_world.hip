@@ -481,6 +481,25 @@ extern "C" int hh_hl_end(hh_world *w, float *obs, float *reward, uint8_t *reward
     return launch_hier(w, HH_HL_END, nullptr, nullptr, nullptr, nullptr, obs, reward, reward_valid, done, nullptr, (hipStream_t)stream);
 }
 
+/* the whole commander step in ONE launch when the pilots' actions are resident before it starts */
+extern "C" int hh_hl_rollout(hh_world *w, const int8_t *commander_actions, const int8_t *pilot_tape, float *obs, float *reward, uint8_t *reward_valid,
+                             uint8_t *done, void *stream) {
+    if (!w || !commander_actions || !pilot_tape) { g_err = "null argument"; return HH_E_ARG; }
+    const DevCfg &c = w->dc;
+    if (w->cfg.env_kind != HH_ENV_HIGHLEVEL || c.A != 6) { g_err = "not a HighLevelEnv (3-vs-3) world"; return HH_E_ARG; }
+    HH_GUARD(w);
+    constexpr int B = HH_BLOCK, GPB = B / 6;
+    const int grid = (c.N + GPB - 1) / GPB;
+    const bool two = w->force_w == 2 || (w->force_w == 0 && grid > w->n_simd);
+    hipStream_t st = (hipStream_t)stream;
+    if (two)
+        hipLaunchKernelGGL((hh_k_hier_macro<6, B, 2>), dim3(grid), dim3(B), 0, st, w->P, c, commander_actions, pilot_tape, obs, reward, reward_valid, done, w->counter);
+    else
+        hipLaunchKernelGGL((hh_k_hier_macro<6, B, 1>), dim3(grid), dim3(B), 0, st, w->P, c, commander_actions, pilot_tape, obs, reward, reward_valid, done, w->counter);
+    HIPCHK(hipGetLastError());
+    return HH_OK;
+}
+
 #ifdef HH_PROFILE_PHASES
 extern "C" int hh_prof_read(unsigned long long *out16, int reset) {
     HIPCHK(hipDeviceSynchronize());

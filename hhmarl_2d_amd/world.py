@@ -160,6 +160,14 @@ class World:
         L.check(L.lib().hh_hl_end(self.h, _p(obs), _p(rew), _p(val), _p(done), self._stream()))
         return obs, rew, val, done
 
+    def hl_rollout(self, commander_actions, pilot_tape, out=None):
+        """one whole commander step per arena in ONE launch: commander_actions int8 [N, n_agents], pilot_tape int8 [16, N, A, 4]"""
+        assert commander_actions.dtype == torch.int8 and commander_actions.is_contiguous()
+        assert pilot_tape.dtype == torch.int8 and pilot_tape.is_contiguous() and pilot_tape.numel() == 16 * self.N * self.A * 4
+        obs, rew, val, done = out if out is not None else self.alloc_outputs()
+        L.check(L.lib().hh_hl_rollout(self.h, _p(commander_actions), _p(pilot_tape), _p(obs), _p(rew), _p(val), _p(done), self._stream()))
+        return obs, rew, val, done
+
     def hl_commands(self):
         """host int8 [N, A]: commander_actions after _action_assess (opponents' draws included)"""
         out = np.zeros((self.N, self.A), dtype=np.int8)

@@ -143,6 +143,14 @@ int hh_hl_agents_act(hh_world *w, const int8_t *actions, float *pilot_obs, uint8
 int hh_hl_tick(hh_world *w, const int8_t *actions, float *pilot_obs, uint8_t *pilot_mode, int32_t *running, void *stream);
 int hh_hl_end(hh_world *w, float *obs, float *reward, uint8_t *reward_valid, uint8_t *done, void *stream);
 
+/* HighLevelEnv.step in ONE launch for callers whose pilot actions exist before the step starts (a recorded / scripted tape,
+ * env-only throughput runs): pilot_tape [dev] i8 [16, N, 6, 4] = the actions of sub-step k in slice k (each side's rows are
+ * read at its turn).  Same result as hh_hl_begin + 16 x {hh_hl_agents_act, hh_hl_tick} + hh_hl_end with those actions, bit
+ * for bit; state stays in registers across the sub-steps and a workgroup stops as soon as none of its arenas is still inside
+ * its macro step.  Pilot observations are not emitted (nobody reads them when the actions are already known). */
+int hh_hl_rollout(hh_world *w, const int8_t *commander_actions, const int8_t *pilot_tape, float *obs, float *reward,
+                  uint8_t *reward_valid, uint8_t *done, void *stream);
+
 /* commander_actions of the current macro step after _action_assess (env_hier.py:142-190): agents' validated
  * actions and the opponents' drawn ones, [host] i8 [N, 6]; read by the eval_info counters (env_base.py:91-107) */
 int hh_hl_commands(hh_world *w, int8_t *out);

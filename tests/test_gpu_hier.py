@@ -114,6 +114,57 @@ def test_macro_step_parity_at_size(oracle, monkeypatch, N, force_w):
     assert 0 < ticks <= 4 * 16 * N
 
 
+@pytest.mark.parametrize("N,force_w", [(170, "0"), (8192, "0"), (12003, "0"), (333, "2")], ids=["170", "configs3-8192", "12003-W2", "333-forced-W2"])
+def test_persistent_macro_step_equals_phase_path(oracle, monkeypatch, N, force_w):
+    """hh_hl_rollout (one launch per commander step, actions from a resident tape) against the phase-by-phase path with the same
+    tape: outputs, final state, event masks, eval counters, episode statistics and tick counts bit for bit; at N = 170 also
+    against the oracle"""
+    import torch
+    from hhmarl_2d_amd.env_hier import macro_step
+    from hhmarl_2d_amd.world import World, make_config
+    monkeypatch.setenv("HH_FORCE_W", force_w)
+    base = dict(n_arenas=N, env_kind=1, seed=8, arena_offset=11, auto_reset=True, horizon=60)
+    a, b = World(make_config(**base)), World(make_config(**base))
+    o = oracle.OracleWorld(oracle.make_config(**base)) if N <= 200 else None
+    assert torch.equal(a.reset(), b.reset())
+    if o is not None:
+        o.reset()
+    rng = np.random.default_rng(N)
+    dones = 0
+    for step in range(8):
+        cmd_h = rng.integers(0, 3, (N, 3)).astype(np.int8)
+        tape_h = random_actions(rng, (16, N), 6)
+        tape_h[..., 2] |= (step % 2)            # every other step everybody keeps the trigger pulled
+        cmd, tape = torch.from_numpy(cmd_h).cuda(), torch.from_numpy(tape_h).cuda()
+        calls = [0]
+
+        def pilot(po, pm):
+            act = tape[(calls[0] // 2) % 16]
+            calls[0] += 1
+            return act
+        outs_a = macro_step(a, cmd, pilot)
+        outs_b = b.hl_rollout(cmd, tape)
+        for x, y, name in zip(outs_a, outs_b, ("obs", "reward", "valid", "done")):
+            assert torch.equal(x, y), f"step {step}: {name}"
+        assert np.array_equal(a.event_masks(), b.event_masks()), f"step {step}: event masks"
+        _same_state(a.get_state(), b.get_state(), f"step {step}")
+        for x, y in zip(a.eval_info(), b.eval_info()):
+            assert torch.equal(x, y), f"step {step}: eval counters"
+        assert a.hl_tick_count() == b.hl_tick_count(), f"step {step}: arena-ticks"
+        dones += int(outs_b[3].sum())
+        if o is not None:
+            o.hl_begin(cmd_h)
+            for k in range(16):
+                o.hl_agents_act(tape_h[k])
+                o.hl_tick(tape_h[k])
+            for x, y, name in zip([t.cpu().numpy() for t in outs_b], o.hl_end(), ("obs", "reward", "valid", "done")):
+                assert np.array_equal(x, y), f"step {step}: {name} vs oracle"
+            _same_state(b.get_state(), o.get_state(), f"step {step} vs oracle")
+    for x, y in zip(a.episode_stats(), b.episode_stats()):
+        assert torch.equal(x, y)
+    assert dones > 0 and b.hl_tick_count() < 8 * 16 * N   # arenas do leave their macro step early
+
+
 @pytest.mark.parametrize("path", golden_files("high"), ids=lambda p: p.split("env_")[-1][:-4])
 def test_reference_traces_on_gpu(path):
     import torch

@@ -19,3 +19,5 @@ python $R/tools/rocpd_summary.py --traffic $OUT/pmc3/pmc3_results.db $OUT/pmc4/p
 python $R/tools/rocpd_summary.py --pmcjson $OUT/pmc1/pmc1_results.db $K $A $C ${ARENAS_PER_WAVE:-16} > $OUT/pmc.json
 tail -1 $OUT/stats.log > $OUT/bench_line.json
 cat $OUT/summary.txt $OUT/traffic.json $OUT/pmc.json
+# the rocpd databases are tens of MB each and gpurun_out/ is capped at 64 MiB: keep the text summaries only
+find $OUT -name "*.db" -delete

@@ -1,7 +1,7 @@
 /*
  * hh_spec.h — every numeric constant of the air-combat world in one place, shared by the HIP
- * kernels, the C oracle and (mirrored, checked by tests/test_spec.py) hhmarl_2d_amd/spec.py.
- * Each block cites the reference lines the numbers come from.
+ * kernels and the C oracle (the Python side holds no copy of them: the spaces / observation widths it
+ * needs are in hhmarl_2d_amd/env_hetero.py and env_hier.py).  Each block cites the reference lines the numbers come from.
  */
 #ifndef HH_SPEC_H
 #define HH_SPEC_H

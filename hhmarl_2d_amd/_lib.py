@@ -44,7 +44,7 @@ class HHNetWeights(C.Structure):
 EXPORTS = ["hh_world_create", "hh_world_destroy", "hh_last_error", "hh_obs_dim", "hh_n_ctrl", "hh_reset", "hh_step",
            "hh_rollout", "hh_episode_stats", "hh_get_state", "hh_set_state", "hh_get_event_masks", "hh_observe",
            "hh_hl_begin", "hh_hl_agents_act", "hh_hl_tick", "hh_hl_end", "hh_step_begin", "hh_step_finish", "hh_gae", "hh_hl_commands",
-           "hh_episode_stats_packed", "hh_hl_tick_count", "hh_rollout_kernel_name", "hh_opp_policy", "hh_eval_info", "hh_arena_status", "hh_hl_rollout",
+           "hh_episode_stats_packed", "hh_hl_tick_count", "hh_rollout_kernel_name", "hh_opp_policy", "hh_eval_info", "hh_arena_status", "hh_hl_rollout", "hh_trace_enable", "hh_trace_read",
            "hh_policy_create", "hh_policy_destroy", "hh_policy_set_net", "hh_policy_set_lut", "hh_policy_act"]
 
 _lib = None
@@ -82,6 +82,8 @@ def lib():
         L.hh_step_begin.argtypes = [vp, vp, C.c_int32, vp, vp]
         L.hh_step_finish.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.hh_hl_commands.argtypes = [vp, vp]
+        L.hh_trace_enable.argtypes = [vp, C.c_int32, C.c_int32]
+        L.hh_trace_read.argtypes = [vp, vp, vp]
         L.hh_hl_rollout.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         L.hh_opp_policy.argtypes = [vp, vp, vp]
         L.hh_eval_info.argtypes = [vp, vp, vp, C.c_int32, vp]

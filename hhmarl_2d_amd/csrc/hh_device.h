@@ -56,7 +56,13 @@ struct DevPtrs {
     uint32_t *ev_mask;                                   /* [N] */
     double *acc_rew;                                     /* [U] rewards accumulated over a HighLevelEnv macro step */
     int *eval_last, *eval_tot;                           /* [N][HH_EVAL_K] eval_info of the last commander step / summed since cleared */
+    /* optional trajectory ring buffer (hh_trace_enable; cmano_simulator.py:125-130,159-162 record_unit_trace): the first trace_K
+     * arenas append one row of HH_TRACE_F floats per unit after reset and after every tick; slot = cursor % trace_cap */
+    float *trace;                                        /* [trace_cap][trace_K][A][HH_TRACE_F] or nullptr */
+    int *trace_pos;                                      /* [trace_K] rows written so far (monotonic) */
+    int trace_K, trace_cap;
 };
+
 
 /* register-resident state of one aircraft slot (+ its rocket slot) */
 struct Unit {
@@ -77,6 +83,15 @@ struct Arena {
 };
 
 __device__ __forceinline__ void arena_rekey(Arena &a) { a.tkey = hh_rng_tick_key(a.akey, (uint32_t)a.episode, (uint32_t)a.steps); }
+
+/* one trace row of the lane's unit: lat, lon, heading, speed, alive, rocket lat, rocket lon, rocket alive + 16 * episode */
+__device__ __forceinline__ void trace_append(const DevPtrs &P, int A, int n, int s, const Unit &m, const Arena &ar, int &cursor) {
+    if (P.trace == nullptr || n >= P.trace_K) return;
+    float4 *row = reinterpret_cast<float4 *>(P.trace + (((size_t)(cursor % P.trace_cap) * P.trace_K + n) * A + s) * HH_TRACE_F);
+    row[0] = make_float4((float)m.lat, (float)m.lon, (float)m.hdg, (float)m.spd);
+    row[1] = make_float4((float)m.alive, (float)m.rk_lat, (float)m.rk_lon, (float)(m.rk_alive + 16 * ar.episode));
+    cursor += 1;
+}
 
 __device__ __forceinline__ void unit_load(const DevPtrs &P, size_t U, size_t u, Unit &m) {
     m.lat = P.lat[u]; m.lon = P.lon[u]; m.hdg = P.hdg[u]; m.spd = P.spd[u];

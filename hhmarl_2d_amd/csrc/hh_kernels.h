@@ -1115,6 +1115,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
     sh.aux[tid] = 0;
     bool need_reset = run == HH_RUN_RESET && active && (mask == nullptr || mask[n]);
     uint32_t evm_last = 0;
+    int tcur = (P.trace != nullptr && active && n < P.trace_K) ? P.trace_pos[n] : 0; /* trace cursor of the lane's arena */
     if (run == HH_RUN_ROLLOUT || run >= HH_RUN_LL_BEGIN) { /* pair table of the pre-tick state */
         publish_obs(c, sh, tid, m);
         __syncthreads();
@@ -1224,6 +1225,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
                 }
             }
             if (active && s == 0 && done_out) done_out[(size_t)t * c.N + n] = (uint8_t)ar.done;
+            if (was_running) trace_append(P, A, n, s, m, ar, tcur);
             need_reset = active && ar.done && c.auto_reset;
         }
         const int any_reset = __syncthreads_or(need_reset ? 1 : 0);
@@ -1231,6 +1233,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
             reset_arena_scalars(ar);
             reset_unit<A>(c, s, m, ar);
             ep_ret = 0.0;
+            trace_append(P, A, n, s, m, ar, tcur); /* first row of the new episode */
         }
         if (run != HH_RUN_ROLLOUT || any_reset) { /* state changed (or never published) */
             publish_obs(c, sh, tid, m);
@@ -1262,6 +1265,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
     if (active) {
         unit_store(P, U, u, m);
         if (s == 0) {
+            if (P.trace != nullptr && n < P.trace_K) P.trace_pos[n] = tcur;
             arena_store(P, n, ar);
             P.ep_ret[n] = ep_ret;
             if (run == HH_RUN_ROLLOUT || run == HH_RUN_LL_BEGIN) P.ev_mask[n] = 0;

@@ -160,6 +160,7 @@ struct HlLane {
     double acc;     /* reward accumulated over the macro step (agents) */
     double ep_ret;  /* episode return (lane s == 0) */
     uint32_t evm;   /* event bits of the current sub-step */
+    int tcur;       /* trace cursor of the lane's arena (hh_trace_enable) */
 };
 
 __device__ __forceinline__ void hl_load_act(const int8_t *__restrict__ actions, size_t row, bool active, int8_t (&act)[4]) {
@@ -199,8 +200,8 @@ __device__ __forceinline__ void hl_do_agents_act(const DevCfg &c, Shared<A, B> &
  * has none at this point and computes the one entry a launch test needs on demand — the same expression, the same bits.
  * Returns 1 iff this lane's arena ran the tick. */
 template <int A, int B, int W, bool TAB>
-__device__ __forceinline__ int hl_do_tick(const DevCfg &c, Shared<A, B> &sh, int tid, int g, int base, int s, bool active, HlLane &L,
-                                          const int8_t (&act)[4]) {
+__device__ __forceinline__ int hl_do_tick(const DevPtrs &P, const DevCfg &c, Shared<A, B> &sh, int tid, int g, int base, int s, int n, bool active,
+                                          HlLane &L, const int8_t (&act)[4]) {
     const bool agent = s < c.nA;
     { double pr = 0.0, os0 = 0.0; int vl = 0; act_phase<A, B, (W >= 2), TAB>(c, sh, tid, s, base, active, L.ar.hl_run != 0, L.m, L.ar, act, !agent, true, pr, os0, vl, L.evm); }
     StepOut so;
@@ -231,6 +232,7 @@ __device__ __forceinline__ int hl_do_tick(const DevCfg &c, Shared<A, B> &sh, int
         L.ar.steps += 1;
         arena_rekey(L.ar);
         L.ar.hl_run = (L.ar.hl_s <= 15 && !so.kill_event && !situ) ? 1 : 0;
+        trace_append(P, A, n, s, L.m, L.ar, L.tcur);
     }
     return was_running ? 1 : 0;
 }
@@ -303,6 +305,7 @@ __device__ __forceinline__ void hl_do_end(const DevPtrs &P, const DevCfg &c, Sha
         ar.hl_s = 0; ar.hl_run = 0;
         L.ep_ret = 0.0;
         L.acc = 0.0;
+        trace_append(P, A, n, s, m, ar, L.tcur); /* first row of the new episode */
     }
     if (any_reset) {
         publish_obs(c, sh, tid, m);
@@ -355,6 +358,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
     L.m = Unit{};
     L.ar = Arena{};
     L.acc = 0.0; L.ep_ret = 0.0; L.evm = 0;
+    L.tcur = (P.trace != nullptr && active && n < P.trace_K) ? P.trace_pos[n] : 0;
     Unit &m = L.m;
     Arena &ar = L.ar;
     if (active) {
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
     } else if (phase == HH_HL_TICK) {
         int8_t act[4];
         hl_load_act(actions, u, active, act);
-        const int ran = hl_do_tick<A, B, W, false>(c, sh, tid, g, base, s, active, L, act);
+        const int ran = hl_do_tick<A, B, W, false>(P, c, sh, tid, g, base, s, n, active, L, act);
         if (s == 0 && ran && ar.hl_run && running_count) atomicAdd(running_count, 1);
         {   /* cumulative arena-ticks of this world (hh_hl_tick_count): one atomic per wave */
             const unsigned long long rn = __ballot(ran && s == 0);
@@ -461,6 +465,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
         unit_store(P, U, u, m);
         P.acc_rew[u] = L.acc;
         if (s == 0) {
+            if (P.trace != nullptr && n < P.trace_K) P.trace_pos[n] = L.tcur;
             arena_store(P, n, ar);
             P.ep_ret[n] = L.ep_ret;
         }
@@ -495,6 +500,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier_macro(DevPtrs P, DevCfg c, con
     L.m = Unit{};
     L.ar = Arena{};
     L.acc = 0.0; L.ep_ret = 0.0; L.evm = 0;
+    L.tcur = (P.trace != nullptr && active && n < P.trace_K) ? P.trace_pos[n] : 0;
     if (active) {
         unit_load(P, U, u, L.m);
         arena_load(P, c, n, L.ar);
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier_macro(DevPtrs P, DevCfg c, con
         const bool running = active && L.ar.hl_run;
         if (running) L.evm = 0;
         hl_do_agents_act<A, B, W>(c, sh, tid, base, s, active, L, act);
-        ticks += hl_do_tick<A, B, W, true>(c, sh, tid, g, base, s, active, L, act);
+        ticks += hl_do_tick<A, B, W, true>(P, c, sh, tid, g, base, s, n, active, L, act);
         if (running) evm_last = L.evm;
     }
     hl_do_end<A, B>(P, c, sh, tid, g, base, s, n, active, L, HH_HL_END, reward_out, valid_out, done_out, nullptr);
@@ -530,6 +536,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier_macro(DevPtrs P, DevCfg c, con
         unit_store(P, U, u, L.m);
         P.acc_rew[u] = L.acc;
         if (s == 0) {
+            if (P.trace != nullptr && n < P.trace_K) P.trace_pos[n] = L.tcur;
             arena_store(P, n, L.ar);
             P.ep_ret[n] = L.ep_ret;
         }

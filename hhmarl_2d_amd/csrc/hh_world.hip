@@ -59,6 +59,7 @@ struct hh_world {
     int no_quad;  /* HH_NO_QUAD=1: 2-vs-2 rollouts on the generic LDS-exchange kernel (A/B tests; same results) */
     int no_spec;  /* HH_NO_SPEC=1: never pick the instance compiled for the default level-3 configuration */
     int no_two;   /* HH_NO_TWO=1: never pick the two-wave (simulation + output wave) form for small worlds */
+    void *trace_mem; /* trajectory ring buffer + cursors (hh_trace_enable), separate allocation */
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -105,6 +106,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     d.inv_diag = (1.0 - 0.0) / (__builtin_sqrt(2.0 * (ms * ms)) - 0.0);
     d.seed = cfg->seed; d.arena_offset = cfg->arena_offset;
     w->block = HH_BLOCK;
+    w->trace_mem = nullptr;
     { const char *fw = getenv("HH_FORCE_W"); w->force_w = fw ? atoi(fw) : 0; }
     { const char *nq = getenv("HH_NO_QUAD"); w->no_quad = nq ? atoi(nq) : 0; }
     { const char *ns = getenv("HH_NO_SPEC"); w->no_spec = ns ? atoi(ns) : 0; }
@@ -157,7 +159,34 @@ extern "C" int hh_world_destroy(hh_world *w) {
     if (!w) return HH_E_ARG;
     DeviceGuard guard_(w->device);
     (void)hipFree(w->slab);
+    if (w->trace_mem) (void)hipFree(w->trace_mem);
     delete w;
+    return HH_OK;
+}
+
+extern "C" int hh_trace_enable(hh_world *w, int32_t n_arenas, int32_t capacity) {
+    if (!w || n_arenas < 0 || capacity < 0) { g_err = "bad argument"; return HH_E_ARG; }
+    HH_GUARD(w);
+    HIPCHK(hipDeviceSynchronize());
+    if (w->trace_mem) { (void)hipFree(w->trace_mem); w->trace_mem = nullptr; }
+    w->P.trace = nullptr; w->P.trace_pos = nullptr; w->P.trace_K = 0; w->P.trace_cap = 0;
+    if (n_arenas == 0 || capacity == 0) return HH_OK; /* tracing off */
+    const int K = n_arenas < w->dc.N ? n_arenas : w->dc.N;
+    const size_t rows = (size_t)capacity * K * w->dc.A * HH_TRACE_F * sizeof(float), pos = align_up((size_t)K * sizeof(int), 256);
+    HIPCHK(hipMalloc(&w->trace_mem, pos + rows));
+    HIPCHK(hipMemset(w->trace_mem, 0, pos + rows));
+    w->P.trace_pos = (int *)w->trace_mem;
+    w->P.trace = (float *)((char *)w->trace_mem + pos);
+    w->P.trace_K = K; w->P.trace_cap = capacity;
+    return HH_OK;
+}
+
+extern "C" int hh_trace_read(hh_world *w, float *rows, int32_t *count) {
+    if (!w || !w->trace_mem) { g_err = "tracing is not enabled (hh_trace_enable)"; return HH_E_ARG; }
+    HH_GUARD(w);
+    HIPCHK(hipDeviceSynchronize());
+    if (rows) HIPCHK(hipMemcpy(rows, w->P.trace, (size_t)w->P.trace_cap * w->P.trace_K * w->dc.A * HH_TRACE_F * sizeof(float), hipMemcpyDeviceToHost));
+    if (count) HIPCHK(hipMemcpy(count, w->P.trace_pos, (size_t)w->P.trace_K * sizeof(int), hipMemcpyDeviceToHost));
     return HH_OK;
 }
 
@@ -195,7 +224,7 @@ static int launch(hh_world *w, int run, int T, const int8_t *actions, const uint
     const int grid = (c.N + GPB - 1) / GPB;
     const int waves = grid * (B / 64);
     const bool two = w->force_w == 2 || (w->force_w == 0 && waves > w->n_simd); /* more waves than SIMDs: hold two per SIMD */
-    if (run == HH_RUN_ROLLOUT && !w->no_quad) {
+    if (run == HH_RUN_ROLLOUT && !w->no_quad && !w->P.trace) { /* tracing runs on the generic kernel */
         static_assert(B == 64, "the register-exchange kernel is one wave per workgroup");
         const bool l3 = !w->no_spec && c.level == 3 && c.agent_mode == HH_MODE_FIGHT && !c.ext_opp && c.friendly_kill == 1 && !c.friendly_punish &&
                         !c.esc_dist_rew && c.glob_frac == 0.0 && c.rew_scale == 1.0;

@@ -45,23 +45,26 @@ def config_from_args(args, env_kind, num_envs, seed, auto_reset=False, arena_off
         glob_frac=args.glob_frac, rew_scale=float(args.rew_scale), seed=seed, arena_offset=arena_offset)
 
 
-def _snapshot(env):
-    """per-step trace of arena 0 for plot() (cmano_simulator.py:125-130,159-162 record_unit_trace)"""
-    if getattr(env, "record_trace", False):
-        st = env.world.get_state()
-        env.trace.append((st["ac_f"][0, :, :3].copy(), st["ac_i"][0, :, 0].copy(), st["rk_f"][0, :, :2].copy(), st["rk_i"][0, :, 0].copy()))
+def _enable_trace(env):
+    """env_config["record_trace"]: the world keeps a trajectory ring buffer of arena 0 ON THE DEVICE (hh_trace_enable; the role of
+    cmano_simulator.py:125-130,159-162 record_unit_trace) — one row per unit after every reset and tick, read back only by plot()"""
+    if env.record_trace:
+        env.world.trace_enable(1, capacity=int(env.args.horizon) + 40)
 
 
 def plot_trace(env, out_file, paths=True):
-    if not env.trace:
-        raise RuntimeError("plot() needs env_config['record_trace'] = True and at least one reset()")
+    if not env.record_trace:
+        raise RuntimeError("plot() needs env_config['record_trace'] = True")
+    rows, ep = env.world.trace_read()[0]
+    if len(rows) == 0:
+        raise RuntimeError("plot() needs at least one reset()")
+    rows = rows[ep == ep[-1]]                         # the current episode of arena 0
     import matplotlib
     matplotlib.use("Agg")
     import matplotlib.pyplot as plt
     nA, m = env.args.num_agents, env.args.map_size
     fig, ax = plt.subplots(figsize=(6, 6), dpi=120)
-    pos = np.stack([t[0] for t in env.trace])      # [T, A, 3]
-    alive = np.stack([t[1] for t in env.trace])
+    pos, alive = rows[:, :, :2], rows[:, :, 4]        # [T, A, (lat, lon)], [T, A]
     for i in range(pos.shape[1]):
         col = "tab:blue" if i < nA else "tab:red"
         t_end = int(np.max(np.nonzero(alive[:, i])[0])) if alive[:, i].any() else 0
@@ -70,12 +73,11 @@ def plot_trace(env, out_file, paths=True):
         mk = "^" if alive[-1, i] else "x"
         ax.plot(pos[t_end, i, 1], pos[t_end, i, 0], mk, color=col, ms=8)
         ax.annotate(f"r_{i + 1}", (pos[t_end, i, 1], pos[t_end, i, 0]), fontsize=8)
-    rk_pos, rk_alive = env.trace[-1][2], env.trace[-1][3]
-    for i in range(len(rk_alive)):
-        if rk_alive[i]:
-            ax.plot(rk_pos[i, 1], rk_pos[i, 0], "*", color="tab:blue" if i < nA else "tab:red", ms=6)
+    for i in range(rows.shape[1]):
+        if rows[-1, i, 7]:
+            ax.plot(rows[-1, i, 6], rows[-1, i, 5], "*", color="tab:blue" if i < nA else "tab:red", ms=6)
     ax.set_xlim(7.0, 7.0 + m); ax.set_ylim(5.0, 5.0 + m)
-    ax.set_xlabel("lon [deg E]"); ax.set_ylabel("lat [deg N]"); ax.set_title(f"arena 0, step {len(env.trace) - 1}")
+    ax.set_xlabel("lon [deg E]"); ax.set_ylabel("lat [deg N]"); ax.set_title(f"arena 0, tick {len(rows) - 1}")
     if out_file is not None:
         fig.savefig(str(out_file))
     plt.close(fig)
@@ -121,7 +123,7 @@ class LowLevelEnv(_Base):
         self.steps = 0
         self.rewards = {}
         self.record_trace = bool(env_config.get("record_trace", False))
-        self.trace = []
+        _enable_trace(self)
         super().__init__()
 
     # -- helpers
@@ -141,8 +143,6 @@ class LowLevelEnv(_Base):
         self.steps = 0
         obs = self.world.reset()
         self._refresh_opp_policy()
-        self.trace = []
-        _snapshot(self)
         return self._obs_dict(obs), {}
 
     def state(self):
@@ -178,7 +178,6 @@ class LowLevelEnv(_Base):
                 self.rewards = {i: np.where(val[:, i - 1] > 0, rew[:, i - 1], 0.0) for i in range(1, n_ag + 1)}
                 d = done.astype(bool)
             obs_d = self._obs_dict(obs)
-            _snapshot(self)
         else:  # the reference skips _take_action for an empty action dict (env_base.py:87-88)
             obs_d = self.state()
             dn = self.world.arena_status()[:, 3].cpu().numpy().astype(bool)   # 16 bytes per arena, not the world
@@ -188,7 +187,7 @@ class LowLevelEnv(_Base):
 
     def plot(self, out_file=None, paths=True):
         """Trajectory plot of arena 0 (the role of env_base.py:622-645 + warsim/scenplotter, without the cartopy
-        background): needs env_config["record_trace"] = True, which snapshots the positions after every step."""
+        background): needs env_config["record_trace"] = True (the world then keeps arena 0's trajectory in a ring buffer on the device)."""
         return plot_trace(self, out_file, paths)
 
     def close(self):

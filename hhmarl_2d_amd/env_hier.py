@@ -11,7 +11,7 @@ import torch
 
 from . import _lib as L
 from . import spaces
-from .env_hetero import _Base, _snapshot, config_from_args, plot_trace
+from .env_hetero import _Base, _enable_trace, config_from_args, plot_trace
 from .world import World
 
 N_OPP_HL = 2
@@ -59,7 +59,7 @@ class HighLevelEnv(_Base):
         self.commander_actions = None
         self.rewards = {}
         self.record_trace = bool(env_config.get("record_trace", False))
-        self.trace = []
+        _enable_trace(self)
         super().__init__()
 
     def _obs_dict(self, obs):
@@ -71,8 +71,6 @@ class HighLevelEnv(_Base):
     def reset(self, *, seed=None, options=None):
         self.commander_actions = None
         obs = self.world.reset()
-        self.trace = []
-        _snapshot(self)
         return self._obs_dict(obs), {}
 
     def state(self):
@@ -110,7 +108,6 @@ class HighLevelEnv(_Base):
                 self.rewards = {i: rew[:, i - 1] for i in range(1, nA + 1)}
                 d = done.astype(bool)
             obs_d = self._obs_dict(obs)
-            _snapshot(self)
         else:
             obs_d = self.state()
             dn = self.world.arena_status()[:, 3].cpu().numpy().astype(bool)

@@ -202,6 +202,28 @@ class World:
         L.check(L.lib().hh_arena_status(self.h, _p(out), self._stream()))
         return out
 
+    def trace_enable(self, n_arenas=1, capacity=1024):
+        """device-side trajectory ring buffer for the first n_arenas arenas (0 turns it off)"""
+        L.check(L.lib().hh_trace_enable(self.h, int(n_arenas), int(capacity)))
+        self._trace_shape = (int(capacity), min(int(n_arenas), self.N), self.A, 8) if n_arenas and capacity else None
+
+    def trace_read(self):
+        """-> rows in time order per arena: list over traced arenas of float32 [T, A, 8] (lat, lon, hdg, spd, alive, rocket lat, rocket
+        lon, rocket alive) and the episode number of every row (int [T])"""
+        cap, K, A, F = self._trace_shape
+        rows = np.zeros((cap, K, A, F), dtype=np.float32)
+        cnt = np.zeros((K,), dtype=np.int32)
+        L.check(L.lib().hh_trace_read(self.h, rows.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
+        out = []
+        for k in range(K):
+            n = int(cnt[k])
+            idx = [(i % cap) for i in range(max(0, n - cap), n)]
+            r = rows[idx, k].copy()
+            ep = (r[:, 0, 7] // 16).astype(np.int32)
+            r[:, :, 7] = r[:, :, 7] % 16
+            out.append((r, ep))
+        return out
+
     def hl_tick_count(self):
         """cumulative arena-ticks run by macro steps on this world (synchronises the current stream)"""
         v = C.c_uint64(0)

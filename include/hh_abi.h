@@ -175,6 +175,15 @@ int hh_eval_info(hh_world *w, int32_t *last, int32_t *total, int32_t clear_total
 /* steps, alive_agents, alive_opps, done of every arena -> [dev] i32 [N, 4] (what step({}) needs: env_base.py:87-90) */
 int hh_arena_status(hh_world *w, int32_t *out, void *stream);
 
+/* Trajectory ring buffer on the device (rendering / trace export; cmano_simulator.py:125-130,159-162 record_unit_trace,
+ * env_base.py:587-645 plot): after hh_trace_enable the first n_arenas arenas append one row per unit after every reset and every
+ * tick, HH_TRACE_F floats = lat, lon, heading, speed, alive, rocket lat, rocket lon, rocket alive + 16 * episode; the ring keeps
+ * the last `capacity` rows.  hh_trace_read copies it out: rows [host] f32 [capacity, n_arenas, A, HH_TRACE_F] (slot = row index
+ * % capacity), count [host] i32 [n_arenas] = rows written so far.  While tracing is on, 2-vs-2 rollouts run on the generic kernel. */
+#define HH_TRACE_F 8
+int hh_trace_enable(hh_world *w, int32_t n_arenas, int32_t capacity);
+int hh_trace_read(hh_world *w, float *rows, int32_t *count);
+
 /* per-arena statistics of the most recently FINISHED episode (logging; this is what the
  * multi-GPU all-gather moves): ret [dev] f32[N] (sum of agent rewards), len [dev] i32[N],
  * outcome [dev] i8[N] (1 agents win, -1 opponents win, 0 draw, 2 none finished yet) */

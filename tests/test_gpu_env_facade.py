@@ -226,4 +226,36 @@ def test_plot_writes_a_png(tmp_path):
     out = tmp_path / "arena.png"
     env.plot(out)
     assert out.exists() and out.stat().st_size > 5000
+    # the trajectory comes from the device-side ring buffer and equals the world's state history
+    rows, ep = env.world.trace_read()[0]
+    assert len(rows) == 31 and (ep == 1).all()                   # reset row + 30 ticks of episode 1
+    st = env.world.get_state()
+    assert np.allclose(rows[-1, :, :4], st["ac_f"][0, :, :4].astype(np.float32)) and np.array_equal(rows[-1, :, 4], st["ac_i"][0, :, 0])
+    assert np.array_equal(rows[-1, :, 7], st["rk_i"][0, :, 0])
     env.close()
+
+
+def test_trace_ring_buffer_wraps_and_spans_episodes_in_hier():
+    """hh_trace_enable on a HighLevelEnv world with auto-reset: rows of several episodes, ring wrap-around, rows = state history"""
+    import torch
+    from hhmarl_2d_amd.world import World, make_config
+    w = World(make_config(n_arenas=40, env_kind=1, seed=2, auto_reset=True, horizon=40))
+    w.trace_enable(3, capacity=64)
+    w.reset()
+    rng = np.random.default_rng(0)
+    hist = [w.get_state()["ac_f"][:3, :, :2].astype(np.float32)]
+    total = 1
+    for step in range(9):
+        cmd = torch.from_numpy(rng.integers(0, 3, (40, 3)).astype(np.int8)).cuda()
+        tape = torch.from_numpy(np.stack([np.stack([rng.integers(0, 13, (40, 6)), rng.integers(0, 9, (40, 6)), rng.integers(0, 2, (40, 6)),
+                                                    rng.integers(0, 2, (40, 6))], axis=-1) for _ in range(16)]).astype(np.int8)).cuda()
+        w.hl_rollout(cmd, tape)
+    tr = w.trace_read()
+    assert len(tr) == 3
+    for k, (rows, ep) in enumerate(tr):
+        assert rows.shape[1:] == (6, 8) and len(rows) == 64          # more than 64 rows were written: the ring holds the last 64
+        assert ep.max() >= 2 and (np.diff(ep) >= 0).all()             # several episodes, in order
+        st = w.get_state()
+        assert np.allclose(rows[-1, :, :2], st["ac_f"][k, :, :2].astype(np.float32))   # the newest row is the current state
+    w.trace_enable(0, 0)                                              # off again
+    w.hl_rollout(cmd, tape)

@@ -224,6 +224,11 @@ __device__ __forceinline__ void reset_unit(const DevCfg &c, int s, Unit &m, Aren
     bool agent = s < c.nA;
     int i = agent ? s : s - c.nA;
     int id = s + 1;
+    if (s >= c.nA + c.nO) { /* unused slot of an n-vs-m arena (HighLevelEnv with fewer than six aircraft): never alive */
+        m = Unit{};
+        m.ac_type = 2; m.cannon_max = 1;
+        return;
+    }
     int r = hh_rng_randint(d_rng(ar, 0, HH_SITE_RESET_SIDE, 0), 1, 2);
     double ux = d_rng(ar, id, HH_SITE_RESET_X, 0), uy = d_rng(ar, id, HH_SITE_RESET_Y, 0), uh = d_rng(ar, id, HH_SITE_RESET_HDG, 0);
     bool near_side = agent ? (r == 1) : (r == 2);

@@ -67,8 +67,14 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out) {
     if (!cfg || !out) { g_err = "null argument"; return HH_E_ARG; }
     int A = cfg->n_agents + cfg->n_opps;
-    if (cfg->n_arenas <= 0 || cfg->n_agents < 1 || cfg->n_opps < 1 || (A != 4 && A != 6)) {
-        g_err = "unsupported configuration: need n_arenas > 0 and 2-vs-2 or 3-vs-3";
+    if (cfg->n_arenas <= 0 || cfg->n_agents < 1 || cfg->n_opps < 1) { g_err = "unsupported configuration: need n_arenas, n_agents, n_opps > 0"; return HH_E_ARG; }
+    if (cfg->env_kind == HH_ENV_HIGHLEVEL) {
+        /* evaluation.py's n-vs-m scenarios (README.md:43): any 1..3 agents against 1..3 opponents live in the six unit slots of the
+         * 3-vs-3 kernel — agents in slots 0..n_agents-1, opponents behind them, the remaining slots are never alive */
+        if (cfg->n_agents > 3 || cfg->n_opps > 3) { g_err = "HighLevelEnv: at most 3 aircraft per side"; return HH_E_ARG; }
+        A = 6;
+    } else if (A != 4) {
+        g_err = "LowLevelEnv is 2-vs-2 (envs/env_hetero.py:24-44)";
         return HH_E_ARG;
     }
     if (cfg->env_kind == HH_ENV_LOWLEVEL && (cfg->n_agents != 2 || cfg->n_opps != 2)) {
@@ -200,7 +206,8 @@ static int launch_hier(hh_world *w, int phase, const int8_t *cmd, const int8_t *
     HH_GUARD(w);
     constexpr int B = HH_BLOCK, GPB = B / 6;
     int grid = (c.N + GPB - 1) / GPB;
-    const bool two = w->force_w == 2 || (w->force_w == 0 && grid > w->n_simd);
+    /* the W = 2 instance stages the pilot rows per SIDE (three slots each): n-vs-m arenas use the W = 1 instance */
+    const bool two = (w->force_w == 2 || (w->force_w == 0 && grid > w->n_simd)) && c.nA == 3 && c.nO == 3;
     if (two)
         hipLaunchKernelGGL((hh_k_hier<6, B, 2>), dim3(grid), dim3(B), 0, st, w->P, c, phase, cmd, actions, pilot_obs, pilot_mode, obs, reward,
                            valid, done, w->counter, mask);
@@ -251,7 +258,7 @@ extern "C" int hh_rollout_kernel_name(hh_world *w, char *buf, int32_t len) {
     const DevCfg &c = w->dc;
     if (w->cfg.env_kind != HH_ENV_LOWLEVEL) {
         const int grid = (c.N + 9) / 10;
-        const bool two = w->force_w == 2 || (w->force_w == 0 && grid > w->n_simd);
+        const bool two = (w->force_w == 2 || (w->force_w == 0 && grid > w->n_simd)) && c.nA == 3 && c.nO == 3;
         snprintf(buf, (size_t)len, "hh_k_hier<6,64,%d>", two ? 2 : 1);
         return HH_OK;
     }

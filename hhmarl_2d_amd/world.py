@@ -44,7 +44,8 @@ class World:
         self.h = C.c_void_p()
         L.check(L.lib().hh_world_create(C.byref(cfg), device, C.byref(self.h)))
         self.N = cfg.n_arenas
-        self.A = cfg.n_agents + cfg.n_opps
+        self.n_units = cfg.n_agents + cfg.n_opps
+        self.A = 6 if cfg.env_kind == L.ENV_HIGHLEVEL else self.n_units   # unit slots (HighLevelEnv: always six, unused ones never alive)
         self.n_agents = cfg.n_agents
         self.D = L.lib().hh_obs_dim(self.h)
         self.n_ctrl = L.lib().hh_n_ctrl(self.h)

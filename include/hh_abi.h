@@ -14,7 +14,8 @@
  * world.  The world owns only its struct-of-arrays state.
  *
  * Units are addressed 1..A in the reference (agents 1..n_agents, opponents after); arrays here
- * are 0-based slots in the same order.
+ * are 0-based slots in the same order.  A HighLevelEnv world always has A = 6 unit slots: with fewer than six aircraft
+ * (n-vs-m evaluation scenarios) the slots behind the last opponent are never alive and their rows read as zeros.
  */
 #ifndef HH_ABI_H
 #define HH_ABI_H
@@ -34,8 +35,8 @@ extern "C" {
 typedef struct hh_config {
     int32_t n_arenas;         /* arenas held by THIS world (this rank's shard) */
     int32_t env_kind;         /* HH_ENV_LOWLEVEL | HH_ENV_HIGHLEVEL */
-    int32_t n_agents;         /* args.num_agents (2 low level, 3 high level) */
-    int32_t n_opps;           /* args.num_opps */
+    int32_t n_agents;         /* args.num_agents (2 low level; 1..3 high level) */
+    int32_t n_opps;           /* args.num_opps   (2 low level; 1..3 high level: evaluation.py's n-vs-m scenarios) */
     int32_t level;            /* args.level 1..5 */
     int32_t agent_mode;       /* HH_MODE_FIGHT | HH_MODE_ESCAPE (args.agent_mode) */
     int32_t horizon;          /* args.horizon */

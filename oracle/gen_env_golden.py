@@ -181,6 +181,9 @@ HL_SCENARIOS = [
     ("hl_pursuit_pilots", dict(mode=1), "pursuit", 4, 90),
     ("hl_pursuit_share", dict(mode=1, glob_frac=0.3, hier_opp_fight_ratio=50, hier_action_assess=False), "pursuit", 3, 70),
     ("hl_eval_info", dict(mode=1, eval_info=True), "pursuit", 3, 60),   # evaluation.py mode: info dict of env_base.py:91-107
+    # evaluation.py's n-vs-m scenarios (README.md:43 of the reference): fewer than six aircraft, asymmetric sides
+    ("hl_2v3_eval", dict(mode=1, num_agents=2, num_opps=3, eval_info=True, horizon=200), "pursuit", 3, 40),
+    ("hl_3v1_eval", dict(mode=1, num_agents=3, num_opps=1, eval_info=True, horizon=200, hier_opp_fight_ratio=100), "pursuit", 3, 30),
 ]
 
 

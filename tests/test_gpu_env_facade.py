@@ -141,7 +141,7 @@ def test_level5_facade_draws_the_opponent_policy_per_episode():
     env.close()
 
 
-@pytest.mark.parametrize("which", ["hl_random_pilots", "hl_eval_info"])
+@pytest.mark.parametrize("which", ["hl_random_pilots", "hl_eval_info", "hl_2v3_eval", "hl_3v1_eval"])
 def test_highlevel_dict_protocol_matches_reference_trace(which):
     """HighLevelEnv facade driven like RLlib / evaluation.py drive the reference, with the trace's taped pilot
     actions; with eval_info the info dict (env_base.py:91-107) must equal the reference's"""
@@ -153,14 +153,18 @@ def test_highlevel_dict_protocol_matches_reference_trace(which):
     g, meta = load_golden([p for p in golden_files("high") if which in p][0])
     infos = json.loads(str(g["infos"])) if "infos" in g.files else None
     a = meta["args"]
-    args = make_args(1, **{k: a[k] for k in ("horizon", "map_size", "glob_frac", "rew_scale", "friendly_kill",
+    args = make_args(1, **{k: a[k] for k in ("horizon", "map_size", "glob_frac", "rew_scale", "friendly_kill", "num_agents", "num_opps",
                                               "hier_action_assess", "hier_opp_fight_ratio", "level", "eval_info")})
+    nA = a["num_agents"]
     tape = {"ptr": 0}
 
     def pilot(po, pm):  # replays the recorded pilot actions; called for agents then opponents in each sub-step
         k = tape["ptr"] // 2
         tape["ptr"] += 1
-        return torch.from_numpy(np.ascontiguousarray(g["sub_act"][min(k, len(g["sub_act"]) - 1)][None])).to(po.device)
+        a6 = np.zeros((1, 6, 4), dtype=np.int8)                 # the world has six unit slots; n-vs-m traces fill the first n + m
+        sa = g["sub_act"][min(k, len(g["sub_act"]) - 1)]
+        a6[0, : sa.shape[0]] = sa
+        return torch.from_numpy(a6).to(po.device)
 
     orig = env_hetero.config_from_args
     import hhmarl_2d_amd.env_hier as eh
@@ -169,18 +173,18 @@ def test_highlevel_dict_protocol_matches_reference_trace(which):
         env = HighLevelEnv({"args": args, "seed": meta["seed"], "pilot": pilot})
     finally:
         eh.config_from_args = orig
-    assert env._agent_ids == {1, 2, 3} and env.observation_space.shape == (34,) and env.action_space.n == 3
+    assert env._agent_ids == set(range(1, nA + 1)) and env.observation_space.shape == (34,) and env.action_space.n == 3
     for r in range(len(g["kind"])):
         if g["kind"][r] == 0:
             obs, info = env.reset()
         else:
-            obs, rew, term, trunc, info = env.step({i + 1: int(g["cmd"][r][i]) for i in range(3)})
-            assert term is trunc and term["__all__"] == bool(g["done"][r]) and set(rew) == {1, 2, 3}
+            obs, rew, term, trunc, info = env.step({i + 1: int(g["cmd"][r][i]) for i in range(nA)})
+            assert term is trunc and term["__all__"] == bool(g["done"][r]) and set(rew) == set(range(1, nA + 1))
             if infos is not None:
                 assert info == infos[r], f"row {r}: eval info {info} != {infos[r]}"
             for i in rew:
                 assert abs(rew[i] - g["reward"][r][i - 1]) <= 1e-6
-        for i in (1, 2, 3):
+        for i in range(1, nA + 1):
             assert obs[i].dtype == np.float32 and obs[i].shape == (34,)
             assert np.abs(obs[i] - g["obs"][r][i - 1]).max() <= 1e-6
     assert tape["ptr"] == 2 * len(g["sub_act"])

@@ -114,6 +114,55 @@ def test_macro_step_parity_at_size(oracle, monkeypatch, N, force_w):
     assert 0 < ticks <= 4 * 16 * N
 
 
+@pytest.mark.parametrize("nA,nO", [(2, 3), (3, 1), (1, 1), (3, 2)], ids=lambda v: str(v))
+def test_n_vs_m_parity(oracle, nA, nO):
+    """evaluation.py's n-vs-m scenarios (README.md:43 of the reference): 1..3 agents against 1..3 opponents in the six unit slots of
+    the 3-vs-3 kernel, phase path and persistent macro step, against the oracle (which holds exactly n + m units)"""
+    import torch
+    from hhmarl_2d_amd.world import World, make_config
+    N, nU = 300, nA + nO
+    base = dict(n_arenas=N, env_kind=1, n_agents=nA, n_opps=nO, seed=5, arena_offset=9, auto_reset=True, horizon=80)
+    g, h = World(make_config(**base)), World(make_config(**base))
+    o = oracle.OracleWorld(oracle.make_config(**base))
+    assert g.A == 6 and g.n_units == nU and o.A == nU
+    assert np.array_equal(g.reset().cpu().numpy(), o.reset()) and torch.equal(h.reset(), g.reset())
+    rng = np.random.default_rng(nA * 10 + nO)
+    dones = 0
+    for step in range(12):
+        cmd = rng.integers(0, 3, (N, nA)).astype(np.int8)
+        tape = random_actions(rng, (16, N), 6)
+        tape[..., 2] = 1
+        po, pm = g.hl_begin(torch.from_numpy(cmd).cuda())
+        o.hl_begin(cmd)
+        for sub in range(16):
+            po_o, pm_o = o.hl_pilot_obs(0)
+            assert np.array_equal(pm.cpu().numpy()[:, :nU], pm_o) and np.array_equal(po.cpu().numpy()[:, :nU], po_o), f"{step}/{sub}: agents"
+            assert not pm[:, nU:].any()
+            ta = torch.from_numpy(tape[sub]).cuda()
+            po, pm = g.hl_agents_act(ta)
+            o.hl_agents_act(np.ascontiguousarray(tape[sub][:, :nU]))
+            po_o, pm_o = o.hl_pilot_obs(1)
+            assert np.array_equal(pm.cpu().numpy()[:, :nU], pm_o) and np.array_equal(po.cpu().numpy()[:, :nU], po_o), f"{step}/{sub}: opponents"
+            po, pm, running = g.hl_tick(ta)
+            assert running == o.hl_tick(np.ascontiguousarray(tape[sub][:, :nU])), f"{step}/{sub}"
+        outs = [x.cpu().numpy() for x in g.hl_end()]
+        for a, b, name in zip(outs, o.hl_end(), ("obs", "reward", "valid", "done")):
+            assert np.array_equal(a, b), f"step {step}: {name}"
+        outs_h = h.hl_rollout(torch.from_numpy(cmd).cuda(), torch.from_numpy(tape).cuda())       # the one-launch path
+        for a, b, name in zip(outs, outs_h, ("obs", "reward", "valid", "done")):
+            assert np.array_equal(a, b.cpu().numpy()), f"step {step}: {name} (hh_hl_rollout)"
+        sg, so = g.get_state(), o.get_state()
+        for k in sg:
+            if k == "ar_i":
+                assert np.array_equal(sg[k], so[k]), k
+            else:
+                assert np.array_equal(sg[k][:, :nU], so[k]), f"step {step}: {k}"
+        for a, b in zip([x.cpu().numpy() for x in g.eval_info()], o.eval_info()):
+            assert np.array_equal(a, b), f"step {step}: eval counters"
+        dones += int(outs[3].sum())
+    assert dones > 0
+
+
 @pytest.mark.parametrize("N,force_w", [(170, "0"), (8192, "0"), (12003, "0"), (333, "2")], ids=["170", "configs3-8192", "12003-W2", "333-forced-W2"])
 def test_persistent_macro_step_equals_phase_path(oracle, monkeypatch, N, force_w):
     """hh_hl_rollout (one launch per commander step, actions from a resident tape) against the phase-by-phase path with the same
@@ -171,7 +220,7 @@ def test_reference_traces_on_gpu(path):
     from hhmarl_2d_amd.world import World, make_config
     g, meta = load_golden(path)
     w = World(make_config(**cfg_kwargs_from_meta(meta)))
-    nA, ptr = w.n_agents, 0
+    nA, ptr, nU = w.n_agents, 0, w.n_units      # nU < 6 for the n-vs-m traces: the world's remaining unit slots are never alive
     for r in range(len(g["kind"])):
         if g["kind"][r] == 0:
             obs = w.reset().cpu().numpy()[0]
@@ -179,10 +228,13 @@ def test_reference_traces_on_gpu(path):
         else:
             po, pm = w.hl_begin(torch.from_numpy(np.ascontiguousarray(g["cmd"][r][None])).cuda())
             for k in range(g["nsub"][r]):
-                act = torch.from_numpy(np.ascontiguousarray(g["sub_act"][ptr][None])).cuda()
+                a6 = np.zeros((1, 6, 4), dtype=np.int8)
+                a6[0, :nU] = g["sub_act"][ptr]
+                act = torch.from_numpy(a6).cuda()
                 po1, pm1 = w.hl_agents_act(act)
-                mode = (pm + pm1).cpu().numpy()[0]
-                pobs = (po + po1).cpu().numpy()[0]
+                assert int((pm + pm1)[0, nU:].sum()) == 0 and float((po + po1)[0, nU:].abs().sum()) == 0.0
+                mode = (pm + pm1).cpu().numpy()[0, :nU]
+                pobs = (po + po1).cpu().numpy()[0, :nU]
                 assert np.array_equal(mode & 3, g["sub_mode"][ptr]), f"row {r} sub {k}"
                 assert np.abs(pobs - g["sub_obs"][ptr]).max() <= 1e-6, f"row {r} sub {k}"
                 po, pm, running = w.hl_tick(act)
@@ -191,8 +243,8 @@ def test_reference_traces_on_gpu(path):
             o, rw, v, d = [x.cpu().numpy() for x in w.hl_end()]
             obs, rew, val, done = o[0], rw[0], v[0], d[0]
         st = w.get_state()
-        assert np.array_equal(st["tgt_id"][0], g["tgt_id"][r]) and np.array_equal(st["rk_i"][0], g["rk_i"][r]), f"row {r}"
-        assert np.array_equal(st["ac_i"][0][:, :9], g["ac_i"][r][:, :9]), f"row {r}"
+        assert np.array_equal(st["tgt_id"][0][:nU], g["tgt_id"][r]) and np.array_equal(st["rk_i"][0][:nU], g["rk_i"][r]), f"row {r}"
+        assert np.array_equal(st["ac_i"][0][:nU, :9], g["ac_i"][r][:, :9]) and not st["ac_i"][0][nU:, 0].any(), f"row {r}"
         assert np.array_equal(val, g["valid"][r]) and done == g["done"][r], f"row {r}"
-        assert np.abs(st["ac_f"][0] - g["ac_f"][r]).max() <= 1e-9 and np.abs(obs - g["obs"][r]).max() <= 1e-6, f"row {r}"
+        assert np.abs(st["ac_f"][0][:nU] - g["ac_f"][r]).max() <= 1e-9 and np.abs(obs - g["obs"][r]).max() <= 1e-6, f"row {r}"
         assert np.abs(rew - g["reward"][r]).max() <= 1e-6, f"row {r}"

@@ -125,7 +125,8 @@ def test_n_vs_m_parity(oracle, nA, nO):
     g, h = World(make_config(**base)), World(make_config(**base))
     o = oracle.OracleWorld(oracle.make_config(**base))
     assert g.A == 6 and g.n_units == nU and o.A == nU
-    assert np.array_equal(g.reset().cpu().numpy(), o.reset()) and torch.equal(h.reset(), g.reset())
+    og = g.reset()
+    assert np.array_equal(og.cpu().numpy(), o.reset()) and torch.equal(h.reset(), og)
     rng = np.random.default_rng(nA * 10 + nO)
     dones = 0
     for step in range(12):

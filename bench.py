@@ -331,8 +331,10 @@ def main_policy_rollout(args):
     # agent 1 is a type-1 aircraft (Fight1), agent 2 a type-2 (Fight2): env_base.py:560-561 fixes the first two slots
     net_id = torch.tensor([SEL_FIGHT1, SEL_FIGHT2], dtype=torch.uint8, device=R.dev).repeat(N, 1).contiguous()
 
+    bank.act(out[0], net_id, act)     # builds the row lists once: agent 1 -> Fight1, agent 2 -> Fight2 never changes
+
     def tick():
-        bank.act(out[0], net_id, act)
+        bank.act(out[0], None, act)   # same selectors as before: no binning pass
         w.step(act, out=out)
 
     graph = None

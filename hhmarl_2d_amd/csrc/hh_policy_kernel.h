@@ -66,8 +66,10 @@ __device__ __forceinline__ float hhp_tanh(float x) {
     return copysignf(__fdividef(1.0f - t, 1.0f + t), x);
 }
 
-/* rows -> per-network lists.  One atomic per wave and network (a per-row atomic on two or four hot counters serialises:
- * measured 187 us for 32768 rows), the lanes of a wave take consecutive slots by their rank in the ballot. */
+/* rows -> per-network lists.  One atomic ROUND TRIP per wave: a per-row atomic on two or four hot counters serialises (measured
+ * 187 us for 32768 rows), and one returning atomic per network costs a memory round trip each; here lane n - 1 carries the wave's
+ * count for network n, the (up to eight) atomics leave as one instruction, and every row takes its slot from the base of its
+ * network plus its rank in that network's ballot. */
 __global__ __launch_bounds__(256) void hh_k_policy_bin(int n_rows, const uint8_t *__restrict__ sel, const uint8_t *__restrict__ lut,
                                                        int max_rows, int *__restrict__ counts, int *__restrict__ lists,
                                                        int8_t *__restrict__ actions) {
@@ -75,15 +77,17 @@ __global__ __launch_bounds__(256) void hh_k_policy_bin(int n_rows, const uint8_t
     const int lane = threadIdx.x & 63;
     const int s = r < n_rows ? (int)lut[sel[r]] : 0;
     if (r < n_rows && s == 0) reinterpret_cast<int *>(actions)[r] = 0;
-    for (int n = 1; n <= HH_POLICY_MAX_NETS; n++) { /* wave-uniform */
+    int mine = 0, rank = 0;
+#pragma unroll
+    for (int n = 1; n <= HH_POLICY_MAX_NETS; n++) {
         const unsigned long long m = __ballot(s == n);
-        if (!m) continue;
-        const int first = __ffsll((long long)m) - 1;
-        int base = 0;
-        if (lane == first) base = atomicAdd(&counts[n - 1], __popcll(m));
-        base = __shfl(base, first);
-        if (s == n) lists[(size_t)(n - 1) * max_rows + base + __popcll(m & ((1ULL << lane) - 1ULL))] = r;
+        if (lane == n - 1) mine = __popcll(m);
+        if (s == n) rank = __popcll(m & ((1ULL << lane) - 1ULL));
     }
+    int base = 0;
+    if (lane < HH_POLICY_MAX_NETS && mine) base = atomicAdd(&counts[lane], mine);
+    base = __shfl(base, s > 0 ? s - 1 : 0);
+    if (s > 0) lists[(size_t)(s - 1) * max_rows + base + rank] = r;
 }
 
 /* the counters are cleared by a kernel, not a memset node: the call sequence is replayed from HIP graphs */
@@ -285,12 +289,18 @@ __global__ __launch_bounds__(256, 2) void hh_k_policy(HhpBank bank, int n_nets, 
     }
 }
 
+#include "hh_policy_kernel_h16.h"
+
 /* ===================================================================== host side */
 struct hh_policy {
     int device, max_rows;
     HhpBank bank;
+    HhpBankH bankh;
+    int binned_rows;          /* n_rows of the call that built the current row lists (0: none) */
+    int fp32;                 /* HH_POLICY_FP32=1: the fp32-MFMA kernel (A/B runs; default is the split-fp16 kernel) */
     int n_nets;               /* highest loaded slot + 1 */
     float *blob[HH_POLICY_MAX_NETS];
+    uint16_t *blobh[HH_POLICY_MAX_NETS];
     uint8_t *lut;             /* [256] dev */
     int *counts, *lists;      /* [MAX_NETS], [MAX_NETS][max_rows] dev */
 };
@@ -311,15 +321,18 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     DeviceGuard guard_(device);
     if (!guard_.ok) { g_err = "hipSetDevice failed"; return HH_E_HIP; }
     hh_policy *p = new hh_policy();
-    p->device = device; p->max_rows = max_rows; p->n_nets = 0;
+    p->device = device; p->max_rows = max_rows; p->n_nets = 0; p->binned_rows = 0;
     memset(&p->bank, 0, sizeof(p->bank));
-    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) p->blob[i] = nullptr;
+    memset(&p->bankh, 0, sizeof(p->bankh));
+    { const char *e = getenv("HH_POLICY_FP32"); p->fp32 = e ? atoi(e) : 0; }
+    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { p->blob[i] = nullptr; p->blobh[i] = nullptr; }
     p->lut = nullptr; p->counts = nullptr; p->lists = nullptr;
     hipError_t e = hipMalloc(&p->lut, 256);
     if (e == hipSuccess) e = hipMemset(p->lut, 0, 256);
     if (e == hipSuccess) e = hipMalloc(&p->counts, HH_POLICY_MAX_NETS * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&p->lists, (size_t)HH_POLICY_MAX_NETS * max_rows * sizeof(int));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy), hipFuncAttributeMaxDynamicSharedMemorySize, HHP_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_h), hipFuncAttributeMaxDynamicSharedMemorySize, HHPH_LDS_BYTES);
     if (e != hipSuccess) {
         g_err = std::string("hh_policy_create: ") + hipGetErrorString(e);
         if (p->lut) (void)hipFree(p->lut);
@@ -335,7 +348,7 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
 extern "C" int hh_policy_destroy(hh_policy *p) {
     if (!p) return HH_E_ARG;
     DeviceGuard guard_(p->device);
-    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) if (p->blob[i]) (void)hipFree(p->blob[i]);
+    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { if (p->blob[i]) (void)hipFree(p->blob[i]); if (p->blobh[i]) (void)hipFree(p->blobh[i]); }
     (void)hipFree(p->lut); (void)hipFree(p->counts); (void)hipFree(p->lists);
     delete p;
     return HH_OK;
@@ -355,11 +368,19 @@ extern "C" int hh_policy_set_net(hh_policy *p, int32_t slot, const hh_net_weight
     const size_t o_w1 = 0, o_b1 = o_w1 + n_w1, o_wov = o_b1 + HHP_H, o_bov = o_wov + n_wov, o_ws = o_bov + HHP_ATT_J, o_bs = o_ws + n_ws,
                  o_wa = o_bs + HHP_H, o_ba = o_wa + n_wa, total = o_ba + HHP_OUT;
     std::vector<float> B(total, 0.0f);
+    /* the same four matrices as (hi, lo) fp16 fragment planes for hh_k_policy_h: w1 | wov | ws | wa, each [K/16][2][J][8] */
+    const size_t h_w1 = 0, h_wov = h_w1 + (size_t)2 * 2 * HHP_H * 8, h_ws = h_wov + (size_t)7 * 2 * HHP_ATT_J * 8, h_wa = h_ws + (size_t)32 * 2 * HHP_H * 8,
+                 h_total = h_wa + (size_t)32 * 2 * HHP_OUT * 8;
+    std::vector<uint16_t> Hh(h_total, 0), Hl(h_total, 0);
     int off = 0, obs_dim = 0;
     for (int k = 0; k < 3; k++) {
         const int c0 = HHP_INPUTS[w->kind][k][0], c1 = HHP_INPUTS[w->kind][k][1], wd = HHP_INPUTS[w->kind][k][2];
         for (int o = 0; o < wd; o++) {
-            for (int c = c0; c < c1; c++) B[o_w1 + hhp_pidx(c, off + o, HHP_H)] = w->inp_w[k][(size_t)o * (c1 - c0) + (c - c0)];
+            for (int c = c0; c < c1; c++) {
+                const float v = w->inp_w[k][(size_t)o * (c1 - c0) + (c - c0)];
+                B[o_w1 + hhp_pidx(c, off + o, HHP_H)] = v;
+                hhp_split_put(Hh, Hl, h_w1, c, off + o, HHP_H, v);
+            }
             B[o_b1 + off + o] = w->inp_b[k][o];
         }
         off += wd;
@@ -372,6 +393,7 @@ extern "C" int hh_policy_set_net(hh_policy *p, int32_t slot, const hh_net_weight
                 double s = 0.0;
                 for (int m = 0; m < 100; m++) s += (double)w->att_out_w[(size_t)j * 100 + m] * (double)wv[(size_t)m * 100 + k];
                 B[o_wov + hhp_pidx(k, j, HHP_ATT_J)] = (float)s;
+                hhp_split_put(Hh, Hl, h_wov, k, j, HHP_ATT_J, (float)s);
             }
             double s = (double)w->att_out_b[j];
             for (int m = 0; m < 100; m++) s += (double)w->att_out_w[(size_t)j * 100 + m] * (double)bv[m];
@@ -379,15 +401,26 @@ extern "C" int hh_policy_set_net(hh_policy *p, int32_t slot, const hh_net_weight
         }
     }
     for (int j = 0; j < 500; j++) {
-        for (int k = 0; k < 500; k++) B[o_ws + hhp_pidx(k, j, HHP_H)] = w->shared_w[(size_t)j * 500 + k];
+        for (int k = 0; k < 500; k++) { B[o_ws + hhp_pidx(k, j, HHP_H)] = w->shared_w[(size_t)j * 500 + k]; hhp_split_put(Hh, Hl, h_ws, k, j, HHP_H, w->shared_w[(size_t)j * 500 + k]); }
         B[o_bs + j] = w->shared_b[j];
     }
     for (int j = 0; j < n_out; j++) {
-        for (int k = 0; k < 500; k++) B[o_wa + hhp_pidx(k, j, HHP_OUT)] = w->out_w[(size_t)j * 500 + k];
+        for (int k = 0; k < 500; k++) { B[o_wa + hhp_pidx(k, j, HHP_OUT)] = w->out_w[(size_t)j * 500 + k]; hhp_split_put(Hh, Hl, h_wa, k, j, HHP_OUT, w->out_w[(size_t)j * 500 + k]); }
         B[o_ba + j] = w->out_b[j];
     }
     if (!p->blob[slot]) HIPCHK(hipMalloc(&p->blob[slot], total * sizeof(float)));
     HIPCHK(hipMemcpy(p->blob[slot], B.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    if (!p->blobh[slot]) HIPCHK(hipMalloc(&p->blobh[slot], 2 * h_total * sizeof(uint16_t)));
+    HIPCHK(hipMemcpy(p->blobh[slot], Hh.data(), h_total * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->blobh[slot] + h_total, Hl.data(), h_total * sizeof(uint16_t), hipMemcpyHostToDevice));
+    {
+        HhpNetH &Hn = p->bankh.net[slot];
+        const uint16_t *bh = p->blobh[slot], *bl = p->blobh[slot] + h_total;
+        Hn.w1h = reinterpret_cast<const float4 *>(bh + h_w1); Hn.w1l = reinterpret_cast<const float4 *>(bl + h_w1);
+        Hn.wovh = reinterpret_cast<const float4 *>(bh + h_wov); Hn.wovl = reinterpret_cast<const float4 *>(bl + h_wov);
+        Hn.wsh = reinterpret_cast<const float4 *>(bh + h_ws); Hn.wsl = reinterpret_cast<const float4 *>(bl + h_ws);
+        Hn.wah = reinterpret_cast<const float4 *>(bh + h_wa); Hn.wal = reinterpret_cast<const float4 *>(bl + h_wa);
+    }
     HhpNet &N = p->bank.net[slot];
     float *b = p->blob[slot];
     N.w1p = b + o_w1; N.b1 = b + o_b1; N.wovp = b + o_wov; N.bov = b + o_bov; N.wsp = b + o_ws; N.bs = b + o_bs; N.wap = b + o_wa; N.ba = b + o_ba;
@@ -406,16 +439,24 @@ extern "C" int hh_policy_set_lut(hh_policy *p, const uint8_t *lut) {
 
 extern "C" int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, const uint8_t *sel, int8_t *actions,
                              float *logits, void *stream) {
-    if (!p || !obs || !sel || !actions || n_rows <= 0 || obs_stride <= 0) { g_err = "bad argument"; return HH_E_ARG; }
+    if (!p || !obs || !actions || n_rows <= 0 || obs_stride <= 0) { g_err = "bad argument"; return HH_E_ARG; }
+    if (!sel && p->binned_rows != n_rows) { g_err = "hh_policy_act: sel == NULL re-uses the row lists of the previous call, which had another n_rows"; return HH_E_ARG; }
     if (n_rows > p->max_rows) { g_err = "hh_policy_act: n_rows exceeds max_rows of hh_policy_create"; return HH_E_ARG; }
     if (p->n_nets == 0) { g_err = "hh_policy_act: no network loaded"; return HH_E_ARG; }
     HH_GUARD(p);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(hh_k_policy_clear, dim3(1), dim3(64), 0, st, p->counts);
-    hipLaunchKernelGGL(hh_k_policy_bin, dim3((n_rows + 255) / 256), dim3(256), 0, st, n_rows, sel, p->lut, p->max_rows, p->counts, p->lists, actions);
+    if (sel) { /* sel == NULL: the selectors are the ones of the previous call (a fixed network per unit slot): the lists stand */
+        hipLaunchKernelGGL(hh_k_policy_clear, dim3(1), dim3(64), 0, st, p->counts);
+        hipLaunchKernelGGL(hh_k_policy_bin, dim3((n_rows + 255) / 256), dim3(256), 0, st, n_rows, sel, p->lut, p->max_rows, p->counts, p->lists, actions);
+        p->binned_rows = n_rows;
+    }
     const int grid = (n_rows + HHP_ROWS - 1) / HHP_ROWS + p->n_nets; /* upper bound of the tiles over all networks */
-    hipLaunchKernelGGL(hh_k_policy, dim3(grid), dim3(256), HHP_LDS_BYTES, st, p->bank, p->n_nets, obs, obs_stride, p->counts, p->lists, p->max_rows,
-                       actions, logits);
+    if (p->fp32)
+        hipLaunchKernelGGL(hh_k_policy, dim3(grid), dim3(256), HHP_LDS_BYTES, st, p->bank, p->n_nets, obs, obs_stride, p->counts, p->lists, p->max_rows,
+                           actions, logits);
+    else
+        hipLaunchKernelGGL(hh_k_policy_h, dim3(grid), dim3(256), HHPH_LDS_BYTES, st, p->bank, p->bankh, p->n_nets, obs, obs_stride, p->counts, p->lists,
+                           p->max_rows, actions, logits);
     HIPCHK(hipGetLastError());
     return HH_OK;
 }

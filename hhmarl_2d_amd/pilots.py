@@ -96,15 +96,17 @@ class PolicyBank:
 
     def act(self, obs, sel, actions=None, logits=None):
         """obs f32 [..., D] (rows = all leading dims), sel u8 [...] selector bytes -> int8 actions [..., 4]"""
-        assert obs.dtype == torch.float32 and obs.is_contiguous() and sel.dtype == torch.uint8 and sel.is_contiguous()
-        n_rows, stride = sel.numel(), obs.shape[-1]
-        assert obs.numel() == n_rows * stride
+        assert obs.dtype == torch.float32 and obs.is_contiguous()
+        stride = obs.shape[-1]
+        n_rows = obs.numel() // stride
+        if sel is not None:   # None: same selectors as the previous call, the kernel re-uses its row lists
+            assert sel.dtype == torch.uint8 and sel.is_contiguous() and sel.numel() == n_rows
         if actions is None:
-            actions = torch.empty(tuple(sel.shape) + (4,), dtype=torch.int8, device=obs.device)
+            actions = torch.empty(tuple(obs.shape[:-1]) + (4,), dtype=torch.int8, device=obs.device)
         assert actions.dtype == torch.int8 and actions.is_contiguous() and actions.numel() == n_rows * 4
         st = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
         lp = None if logits is None else C.c_void_p(logits.data_ptr())
-        L.check(L.lib().hh_policy_act(self.h, C.c_void_p(obs.data_ptr()), n_rows, stride, C.c_void_p(sel.data_ptr()),
+        L.check(L.lib().hh_policy_act(self.h, C.c_void_p(obs.data_ptr()), n_rows, stride, None if sel is None else C.c_void_p(sel.data_ptr()),
                                       C.c_void_p(actions.data_ptr()), lp, st))
         return actions
 

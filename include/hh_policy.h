@@ -58,7 +58,8 @@ int hh_policy_set_lut(hh_policy *p, const uint8_t *lut);
 
 /* greedy actions of n_rows units in one launch sequence (row binning by network + the fused forward):
  *   obs     [dev] f32 [n_rows, obs_stride]   zero-padded observation rows (hh_step's obs, hh_step_begin's opp_obs, pilot_obs)
- *   sel     [dev] u8  [n_rows]               selector bytes (through the LUT)
+ *   sel     [dev] u8  [n_rows]               selector bytes (through the LUT); NULL = the same selectors as the previous call (a fixed
+ *                                            network per unit slot, e.g. LowLevelEnv agents 1 / 2): the row lists are re-used, no binning pass
  *   actions [dev] i8  [n_rows, 4]            MultiDiscrete([13,9,2,2]) arg-max per component (4th = 0 for type-2 nets)
  *   logits  [dev] f32 [n_rows, 32]           optional (NULL): the actor's logits, zero padded; rows without a network untouched
  * Everything is ordered on `stream`; no host synchronisation (HIP-graph capturable). */

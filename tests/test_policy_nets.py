@@ -94,8 +94,15 @@ def test_hip_kernel_mixed_networks_against_torch_fp32():
     none = ((sel == 0) | (sel == 77)).nonzero().flatten()
     assert (act[none] == 0).all() and (logits[none] == -3.0).all()
     assert checked + len(none) == R
-    # a second call on the same bank (counters are re-zeroed on the stream) gives the same answer
+    # a second call on the same bank (counters are re-zeroed on the stream) gives the same answer, and so does a call that
+    # re-uses the row lists (sel = None: "same selectors as before") on changed observations
     assert torch.equal(bank.act(obs, sel), act)
+    obs2 = obs.flip(0).contiguous()
+    want = bank.act(obs2, sel).clone()
+    bank.act(obs, sel)
+    got = bank.act(obs2, None)
+    live = (sel != 0) & (sel != 77)
+    assert torch.equal(got[live], want[live])
 
 
 @pytest.mark.gpu

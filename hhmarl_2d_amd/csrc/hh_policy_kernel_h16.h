@@ -7,12 +7,12 @@
  *                                                 residual of a value below 2^-3 lands there, spaced 2^-24)
  * and a product is accumulated as  hi_a hi_b + hi_a lo_b + lo_a hi_b  in fp32 by three v_mfma_f32_32x32x16_f16 (the dropped
  * lo_a lo_b term is below 2^-22 |a b|): 3 instructions of 32 cycles cover 16 k-steps where the fp32 MFMA needs 8 of 64 — 5.3x
- * fewer matrix-pipe cycles, with an error (measured: 4e-7 on the logits) far inside the 1e-5 the parity tests allow and of the
- * same class as the fp32 kernel's own rounding.  Same tiling as the fp32 kernel: a 256-thread workgroup = 32 rows of one
+ * fewer matrix-pipe cycles, with an error (measured against a float64 forward, tools/policy_error.py: max 1.0e-6 / mean 1.9e-7 on the
+ * logits; the fp32 MFMA kernel 7.5e-7 / 1.3e-7; PyTorch's own fp32 CPU forward 8e-7 / 1.0e-7) far inside the 1e-5 the parity tests allow.  Same tiling as the fp32 kernel: a 256-thread workgroup = 32 rows of one
  * network, each wave 128 of the 512 columns (4 MFMA tiles), activations in one LDS tile (hi and lo planes, 32 KB each) that the
  * next layer's output overwrites in place, two workgroups per CU.  Operand layout: [k/16][(k/8)&1][col or row][8 halves] — lane l of
  * a 32x32x16 MFMA holds A[l&31][8 (l>>5) .. +7] / B[8 (l>>5) .. +7][l&31], so one 16-byte access per lane is one fragment.
- * Weight fragments are requested two 16-k blocks (2 x 12 MFMAs = 768 cycles) ahead of their use.
+ * Weight fragments are requested two 16-k blocks (2 x 12 MFMAs = 768 matrix-pipe cycles) ahead of their use.
  */
 #ifndef HH_POLICY_KERNEL_H16_H
 #define HH_POLICY_KERNEL_H16_H
@@ -47,7 +47,15 @@ __device__ __forceinline__ hh_h8 hhp_as_h8(const float4 &v) {
     return u.h;
 }
 
-/* NT tiles over KB 16-k blocks: acc += Ahi Bhi + Ahi Blo + Alo Bhi.  A fragments from the LDS planes, B fragments from global. */
+/* NT tiles over KB 16-k blocks: acc += Ahi Bhi + Ahi Blo + Alo Bhi.  A fragments from the LDS planes, B fragments from global.
+ * Three register sets of weight fragments rotate BY NAME (the block loop is unrolled by three): block kb computes from set kb % 3
+ * while the loads of block kb + 2 land in set (kb + 2) % 3.  Rotating by register moves instead would read the set that was just
+ * requested and make the wave wait for it — a prefetch distance of one block (384 cycles) where an L2 round trip under load is
+ * longer (measured: 37 % of the wave cycles waiting). */
+template <int NT>
+struct HhpBSet {
+    float4 h[NT], l[NT];
+};
 template <int NT>
 __device__ __forceinline__ void hhp_gemm_h(const float4 *__restrict__ a_hi, const float4 *__restrict__ a_lo, int kb0, int KB,
                                            const float4 *__restrict__ b_hi, const float4 *__restrict__ b_lo, int bkb0, int J, int j0, int lane,
@@ -56,42 +64,44 @@ __device__ __forceinline__ void hhp_gemm_h(const float4 *__restrict__ a_hi, cons
     const size_t bstep = (size_t)2 * J;
     const float4 *bph = b_hi + (size_t)(bkb0 * 2 + h) * J + j0 + i;
     const float4 *bpl = b_lo + (size_t)(bkb0 * 2 + h) * J + j0 + i;
-    float4 bh0[NT], bl0[NT], bh1[NT], bl1[NT], bh2[NT], bl2[NT];
+    HhpBSet<NT> S[3];
 #pragma unroll
-    for (int t = 0; t < NT; t++) { bh0[t] = bph[t * 32]; bl0[t] = bpl[t * 32]; bh1[t] = bh0[t]; bl1[t] = bl0[t]; }
+    for (int t = 0; t < NT; t++) { S[0].h[t] = bph[t * 32]; S[0].l[t] = bpl[t * 32]; S[1].h[t] = S[0].h[t]; S[1].l[t] = S[0].l[t]; S[2].h[t] = S[0].h[t]; S[2].l[t] = S[0].l[t]; }
     if (KB > 1) {
 #pragma unroll
-        for (int t = 0; t < NT; t++) { bh1[t] = bph[bstep + t * 32]; bl1[t] = bpl[bstep + t * 32]; }
+        for (int t = 0; t < NT; t++) { S[1].h[t] = bph[bstep + t * 32]; S[1].l[t] = bpl[bstep + t * 32]; }
     }
     int p0 = kb0 * 2 + h;
     float4 ah = a_hi[p0 * 32 + (i ^ (p0 & 7))], al = a_lo[p0 * 32 + (i ^ (p0 & 7))];
 #pragma nounroll
-    for (int kb = 0; kb < KB; kb++) {
-        /* request: weights of block kb + 2, activations of block kb + 1 */
+    for (int base = 0; base < KB; base += 3) {
 #pragma unroll
-        for (int t = 0; t < NT; t++) { bh2[t] = bh1[t]; bl2[t] = bl1[t]; }
-        if (kb + 2 < KB) {
+        for (int u = 0; u < 3; u++) {
+            const int kb = base + u;
+            if (kb < KB) { /* wave-uniform */
+                HhpBSet<NT> &cur = S[u], &far = S[(u + 2) % 3];
+                if (kb + 2 < KB) {
 #pragma unroll
-            for (int t = 0; t < NT; t++) { bh2[t] = bph[(size_t)(kb + 2) * bstep + t * 32]; bl2[t] = bpl[(size_t)(kb + 2) * bstep + t * 32]; }
+                    for (int t = 0; t < NT; t++) { far.h[t] = bph[(size_t)(kb + 2) * bstep + t * 32]; far.l[t] = bpl[(size_t)(kb + 2) * bstep + t * 32]; }
+                }
+                float4 ahn = ah, aln = al;
+                if (kb + 1 < KB) {
+                    const int p = (kb0 + kb + 1) * 2 + h;
+                    ahn = a_hi[p * 32 + (i ^ (p & 7))];
+                    aln = a_lo[p * 32 + (i ^ (p & 7))];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const hh_h8 fa_h = hhp_as_h8(ah), fa_l = hhp_as_h8(al);
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h, hhp_as_h8(cur.h[t]), acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h, hhp_as_h8(cur.l[t]), acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_l, hhp_as_h8(cur.h[t]), acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                ah = ahn; al = aln;
+            }
         }
-        float4 ahn = ah, aln = al;
-        if (kb + 1 < KB) {
-            const int p = (kb0 + kb + 1) * 2 + h;
-            ahn = a_hi[p * 32 + (i ^ (p & 7))];
-            aln = a_lo[p * 32 + (i ^ (p & 7))];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const hh_h8 fa_h = hhp_as_h8(ah), fa_l = hhp_as_h8(al);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h, hhp_as_h8(bh0[t]), acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h, hhp_as_h8(bl0[t]), acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_l, hhp_as_h8(bh0[t]), acc[t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        ah = ahn; al = aln;
-#pragma unroll
-        for (int t = 0; t < NT; t++) { bh0[t] = bh1[t]; bl0[t] = bl1[t]; bh1[t] = bh2[t]; bl1[t] = bl2[t]; }
     }
 }
 

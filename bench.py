@@ -103,6 +103,7 @@ class Ranks:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
+            os.environ.setdefault("NCCL_DEBUG", "WARN")   # keep RCCL's version banner out of the output: rank 0 prints ONE line
             if self.dry:
                 dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
             else:

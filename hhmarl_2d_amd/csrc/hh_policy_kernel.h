@@ -60,10 +60,11 @@ __device__ __forceinline__ int hhp_aidx(int k, int row) {
     const int plane = (k >> 3) * 2 + (k & 1);
     return (plane * 32 + (row ^ (plane & 7))) * 4 + ((k >> 1) & 3);
 }
-/* tanh from the hardware exp and reciprocal: |error| < 5e-7 absolute over the whole range (the logits tolerate 1e-5) */
+/* tanh(x) = 1 - 2 / (1 + e^(2x)) from the hardware exp2 and reciprocal: five instructions, |error| < 5e-7 absolute over the whole
+ * range including the saturated ends (e^(2x) = inf -> 1, 0 -> -1); the logits tolerate 1e-5 */
 __device__ __forceinline__ float hhp_tanh(float x) {
-    const float t = __expf(-2.0f * fabsf(x));
-    return copysignf(__fdividef(1.0f - t, 1.0f + t), x);
+    const float e = __expf(2.0f * x);
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f); /* raw v_rcp_f32 (1 ulp): __frcp_rn expands to the ten-instruction IEEE division */
 }
 
 /* rows -> per-network lists.  One atomic ROUND TRIP per wave: a per-row atomic on two or four hot counters serialises (measured
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(256, 2) void hh_k_policy(HhpBank bank, int n_nets, 
 #include "hh_policy_kernel_h16.h"
 
 /* ===================================================================== host side */
+#define HHP_SLOT_BYTES ((size_t)4 << 20) /* fp32 blob 1.19 MB + fp16 planes 1.18 MB per network, padded to 4 MB */
 struct hh_policy {
     int device, max_rows;
     HhpBank bank;
@@ -301,6 +303,8 @@ struct hh_policy {
     int n_nets;               /* highest loaded slot + 1 */
     float *blob[HH_POLICY_MAX_NETS];
     uint16_t *blobh[HH_POLICY_MAX_NETS];
+    char *slab;               /* ONE allocation for every network's weights (slot stride HHP_SLOT_BYTES): large, 2 MB-aligned mappings keep
+                                 the weight stream on a handful of TLB entries instead of a fresh small allocation per network */
     uint8_t *lut;             /* [256] dev */
     int *counts, *lists;      /* [MAX_NETS], [MAX_NETS][max_rows] dev */
 };
@@ -326,11 +330,13 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     memset(&p->bankh, 0, sizeof(p->bankh));
     { const char *e = getenv("HH_POLICY_FP32"); p->fp32 = e ? atoi(e) : 0; }
     for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { p->blob[i] = nullptr; p->blobh[i] = nullptr; }
+    p->slab = nullptr;
     p->lut = nullptr; p->counts = nullptr; p->lists = nullptr;
     hipError_t e = hipMalloc(&p->lut, 256);
     if (e == hipSuccess) e = hipMemset(p->lut, 0, 256);
     if (e == hipSuccess) e = hipMalloc(&p->counts, HH_POLICY_MAX_NETS * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&p->lists, (size_t)HH_POLICY_MAX_NETS * max_rows * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&p->slab, HHP_SLOT_BYTES * HH_POLICY_MAX_NETS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy), hipFuncAttributeMaxDynamicSharedMemorySize, HHP_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_h), hipFuncAttributeMaxDynamicSharedMemorySize, HHPH_LDS_BYTES);
     if (e != hipSuccess) {
@@ -338,6 +344,7 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
         if (p->lut) (void)hipFree(p->lut);
         if (p->counts) (void)hipFree(p->counts);
         if (p->lists) (void)hipFree(p->lists);
+        if (p->slab) (void)hipFree(p->slab);
         delete p;
         return HH_E_HIP;
     }
@@ -348,7 +355,7 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
 extern "C" int hh_policy_destroy(hh_policy *p) {
     if (!p) return HH_E_ARG;
     DeviceGuard guard_(p->device);
-    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { if (p->blob[i]) (void)hipFree(p->blob[i]); if (p->blobh[i]) (void)hipFree(p->blobh[i]); }
+    (void)hipFree(p->slab);
     (void)hipFree(p->lut); (void)hipFree(p->counts); (void)hipFree(p->lists);
     delete p;
     return HH_OK;
@@ -408,9 +415,11 @@ extern "C" int hh_policy_set_net(hh_policy *p, int32_t slot, const hh_net_weight
         for (int k = 0; k < 500; k++) { B[o_wa + hhp_pidx(k, j, HHP_OUT)] = w->out_w[(size_t)j * 500 + k]; hhp_split_put(Hh, Hl, h_wa, k, j, HHP_OUT, w->out_w[(size_t)j * 500 + k]); }
         B[o_ba + j] = w->out_b[j];
     }
-    if (!p->blob[slot]) HIPCHK(hipMalloc(&p->blob[slot], total * sizeof(float)));
+    static_assert(HHP_SLOT_BYTES >= (size_t)2 * 1024 * 1024 + 2 * 309248 * 2, "slot too small");
+    if (total * sizeof(float) > (size_t)2 * 1024 * 1024 || 2 * h_total * sizeof(uint16_t) > HHP_SLOT_BYTES - (size_t)2 * 1024 * 1024) { g_err = "internal: blob exceeds its slot"; return HH_E_ARG; }
+    p->blob[slot] = reinterpret_cast<float *>(p->slab + (size_t)slot * HHP_SLOT_BYTES);                                   /* first 2 MB of the slot */
+    p->blobh[slot] = reinterpret_cast<uint16_t *>(p->slab + (size_t)slot * HHP_SLOT_BYTES + (size_t)2 * 1024 * 1024);      /* second 2 MB */
     HIPCHK(hipMemcpy(p->blob[slot], B.data(), total * sizeof(float), hipMemcpyHostToDevice));
-    if (!p->blobh[slot]) HIPCHK(hipMalloc(&p->blobh[slot], 2 * h_total * sizeof(uint16_t)));
     HIPCHK(hipMemcpy(p->blobh[slot], Hh.data(), h_total * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->blobh[slot] + h_total, Hl.data(), h_total * sizeof(uint16_t), hipMemcpyHostToDevice));
     {
@@ -460,5 +469,14 @@ extern "C" int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int
     HIPCHK(hipGetLastError());
     return HH_OK;
 }
+
+#ifdef HHP_PROFILE
+extern "C" int hh_policy_prof_read(unsigned long long *out16, int reset) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(hhp_prof), 16 * 8));
+    if (reset) { unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(hhp_prof), z, 16 * 8)); }
+    return HH_OK;
+}
+#endif
 
 #endif /* HH_POLICY_KERNEL_H */

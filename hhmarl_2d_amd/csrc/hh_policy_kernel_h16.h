@@ -41,6 +41,25 @@ __device__ __forceinline__ void hhp_split_store(_Float16 *__restrict__ hi, _Floa
     hi[idx] = h;
     lo[idx] = (_Float16)(v - (float)h);
 }
+/* the 16 values a lane holds of one 32x32 C tile (column j, rows (r & 3) + 4 (lane >> 5) + 8 (r >> 2)) -> hi / lo planes.  The row
+ * slot is row ^ (plane & 7): the XOR touches the low three bits only, so the four (r & 3) slots are computed once per tile and the
+ * (r >> 2) part (+128 bytes) and the lo plane (+32 KB) ride in the ds_write offset field: no address arithmetic per element. */
+template <class F>
+__device__ __forceinline__ void hhp_store_tile(_Float16 *__restrict__ hi_plane, int lo_off_halves, int j, int lane, const hh_f32x16 &acc, F f) {
+    const int plane = (j >> 4) * 2 + ((j >> 3) & 1), swz = plane & 7, h4 = 4 * (lane >> 5);
+    _Float16 *base = hi_plane + plane * 256 + (j & 7); /* 32 rows x 8 halves per plane */
+    _Float16 *q0 = base + (((0 + h4) ^ swz) << 3), *q1 = base + (((1 + h4) ^ swz) << 3), *q2 = base + (((2 + h4) ^ swz) << 3),
+             *q3 = base + (((3 + h4) ^ swz) << 3);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        _Float16 *q = (r & 3) == 0 ? q0 : ((r & 3) == 1 ? q1 : ((r & 3) == 2 ? q2 : q3));
+        const float v = f(acc[r]);
+        const _Float16 hv = (_Float16)v;
+        q[(r >> 2) * 64] = hv;                                   /* +8 rows = 64 halves */
+        q[(r >> 2) * 64 + lo_off_halves] = (_Float16)(v - (float)hv);
+    }
+}
+
 __device__ __forceinline__ hh_h8 hhp_as_h8(const float4 &v) {
     union { float4 f; hh_h8 h; } u;
     u.f = v;
@@ -61,16 +80,16 @@ __device__ __forceinline__ void hhp_gemm_h(const float4 *__restrict__ a_hi, cons
                                            const float4 *__restrict__ b_hi, const float4 *__restrict__ b_lo, int bkb0, int J, int j0, int lane,
                                            hh_f32x16 (&acc)[NT]) {
     const int h = lane >> 5, i = lane & 31;
-    const size_t bstep = (size_t)2 * J;
-    const float4 *bph = b_hi + (size_t)(bkb0 * 2 + h) * J + j0 + i;
-    const float4 *bpl = b_lo + (size_t)(bkb0 * 2 + h) * J + j0 + i;
+    const unsigned bstep = 2u * (unsigned)J;
+    unsigned boff = (unsigned)((bkb0 * 2 + h) * J + j0 + i); /* fragment index from the (wave-uniform) plane bases: one 32-bit add per block */
     HhpBSet<NT> S[3];
 #pragma unroll
-    for (int t = 0; t < NT; t++) { S[0].h[t] = bph[t * 32]; S[0].l[t] = bpl[t * 32]; S[1].h[t] = S[0].h[t]; S[1].l[t] = S[0].l[t]; S[2].h[t] = S[0].h[t]; S[2].l[t] = S[0].l[t]; }
+    for (int t = 0; t < NT; t++) { S[0].h[t] = b_hi[boff + t * 32]; S[0].l[t] = b_lo[boff + t * 32]; S[1].h[t] = S[0].h[t]; S[1].l[t] = S[0].l[t]; S[2].h[t] = S[0].h[t]; S[2].l[t] = S[0].l[t]; }
     if (KB > 1) {
 #pragma unroll
-        for (int t = 0; t < NT; t++) { S[1].h[t] = bph[bstep + t * 32]; S[1].l[t] = bpl[bstep + t * 32]; }
+        for (int t = 0; t < NT; t++) { S[1].h[t] = b_hi[boff + bstep + t * 32]; S[1].l[t] = b_lo[boff + bstep + t * 32]; }
     }
+    boff += 2u * bstep; /* block kb + 2 */
     int p0 = kb0 * 2 + h;
     float4 ah = a_hi[p0 * 32 + (i ^ (p0 & 7))], al = a_lo[p0 * 32 + (i ^ (p0 & 7))];
 #pragma nounroll
@@ -82,8 +101,9 @@ __device__ __forceinline__ void hhp_gemm_h(const float4 *__restrict__ a_hi, cons
                 HhpBSet<NT> &cur = S[u], &far = S[(u + 2) % 3];
                 if (kb + 2 < KB) {
 #pragma unroll
-                    for (int t = 0; t < NT; t++) { far.h[t] = bph[(size_t)(kb + 2) * bstep + t * 32]; far.l[t] = bpl[(size_t)(kb + 2) * bstep + t * 32]; }
+                    for (int t = 0; t < NT; t++) { far.h[t] = b_hi[boff + t * 32]; far.l[t] = b_lo[boff + t * 32]; }
                 }
+                boff += bstep;
                 float4 ahn = ah, aln = al;
                 if (kb + 1 < KB) {
                     const int p = (kb0 + kb + 1) * 2 + h;
@@ -104,6 +124,61 @@ __device__ __forceinline__ void hhp_gemm_h(const float4 *__restrict__ a_hi, cons
         }
     }
 }
+
+/* The short contractions (L1: K = 32, attention: K = 112, L3: K = 128 per wave) have too few MFMAs per block to hide a weight
+ * fetch behind: all their weight fragments are requested up front (KB <= 8 blocks: at most 64 registers), so the wave pays ONE L2
+ * round trip instead of one per block (phase timers: attention 21 %, L3 10 %, L1 8 % of a tile before this). */
+template <int NT, int KB>
+__device__ __forceinline__ void hhp_gemm_h_short(const float4 *__restrict__ a_hi, const float4 *__restrict__ a_lo, int kb0,
+                                                 const float4 *__restrict__ b_hi, const float4 *__restrict__ b_lo, int bkb0, int J, int j0, int lane,
+                                                 hh_f32x16 (&acc)[NT]) {
+    const int h = lane >> 5, i = lane & 31;
+    const unsigned bstep = 2u * (unsigned)J, boff = (unsigned)((bkb0 * 2 + h) * J + j0 + i);
+    float4 bh[KB][NT], bl[KB][NT], ah[KB], al[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) { bh[kb][t] = b_hi[boff + kb * bstep + t * 32]; bl[kb][t] = b_lo[boff + kb * bstep + t * 32]; }
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+        const int p = (kb0 + kb) * 2 + h;
+        ah[kb] = a_hi[p * 32 + (i ^ (p & 7))];
+        al[kb] = a_lo[p * 32 + (i ^ (p & 7))];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+        const hh_h8 fa_h = hhp_as_h8(ah[kb]), fa_l = hhp_as_h8(al[kb]);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h, hhp_as_h8(bh[kb][t]), acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h, hhp_as_h8(bl[kb][t]), acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_l, hhp_as_h8(bh[kb][t]), acc[t], 0, 0, 0);
+    }
+}
+
+/* sum over the 32 lanes of a half wave, result on every lane: four DPP steps (quad xor 1, xor 2, mirror within 8, mirror within 16:
+ * VALU modifiers, no LDS) and one ds_swizzle for the two 16-lane rows — __shfl_xor would be five dependent ds_bpermute round trips */
+__device__ __forceinline__ float hhp_sum32(float v) {
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));  /* quad_perm [1,0,3,2] */
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));  /* quad_perm [2,3,0,1] */
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true)); /* row_half_mirror */
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true)); /* row_mirror */
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));             /* bit mode: xor 0x10, and 0x1f */
+    return v;
+}
+
+/* tuning builds only (-DHHP_PROFILE): s_memtime deltas per phase of wave 0 of every tile, summed into hhp_prof[] */
+#ifdef HHP_PROFILE
+__device__ unsigned long long hhp_prof[16];
+#define HHP_T(k) do { if (tid == 0) { unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&hhp_prof[k], t_ - pt_); pt_ = t_; } } while (0)
+#define HHP_T0 unsigned long long pt_ = __builtin_readcyclecounter()
+#else
+#define HHP_T(k)
+#define HHP_T0
+#endif
 
 /* LDS (bytes): Zh 32 KB | Zl 32 KB | Xh 2 KB | Xl 2 KB | L3 partials 16 KB alias Zh | logits 4 KB | rows, norm partials */
 #define HHPH_OFF_ZL 32768
@@ -144,6 +219,12 @@ __global__ __launch_bounds__(256, 2) void hh_k_policy_h(HhpBank bank, HhpBankH b
     const HhpNetH H = bankh.net[net];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ci = lane & 31;
+    HHP_T0;
+    /* every bias this lane will add, requested now: a global round trip in front of each epilogue is ~1.4 k cycles */
+    float b1r[4], bsr[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { b1r[t] = N.b1[wave * 128 + t * 32 + ci]; bsr[t] = N.bs[wave * 128 + t * 32 + ci]; }
+    const float bovr = N.bov[wave * 32 + ci], bar = N.ba[ci];
 
     if (tid < HHP_ROWS) {
         const int q = tile * HHP_ROWS + tid;
@@ -155,41 +236,45 @@ __global__ __launch_bounds__(256, 2) void hh_k_policy_h(HhpBank bank, HhpBankH b
         hhp_split_store(Xh, Xl, hhp_haidx(c, i), (r >= 0 && c < N.obs_dim) ? obs[(size_t)r * obs_stride + c] : 0.0f);
     }
     __syncthreads();
+    HHP_T(0);
 
     /* ---- L1 ---- */
     {
         hh_f32x16 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[t] = hhp_zero16();
-        hhp_gemm_h<4>(reinterpret_cast<const float4 *>(Xh), reinterpret_cast<const float4 *>(Xl), 0, HHP_XK / 16, H.w1h, H.w1l, 0, HHP_H, wave * 128, lane, acc);
+        hhp_gemm_h_short<4, HHP_XK / 16>(reinterpret_cast<const float4 *>(Xh), reinterpret_cast<const float4 *>(Xl), 0, H.w1h, H.w1l, 0, HHP_H, wave * 128, lane, acc);
+        HHP_T(1);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int j = wave * 128 + t * 32 + ci;
-            const float bj = N.b1[j];
-#pragma unroll
-            for (int r = 0; r < 16; r++) hhp_split_store(Zh, Zl, hhp_haidx(j, hhp_crow(r, lane)), hhp_tanh(acc[t][r] + bj));
+            const float bj = b1r[t];
+            hhp_store_tile(Zh, HHPH_OFF_ZL / 2, j, lane, acc[t], [bj](float a) { return hhp_tanh(a + bj); });
         }
     }
     __syncthreads();
+    HHP_T(2);
 
     /* ---- fight nets: x <- normalize(x + Wov x + bov) on columns 400..499 (K = 112: blocks 25..31 of the tile) ---- */
     if (N.has_att) {
         hh_f32x16 acc[1];
         acc[0] = hhp_zero16();
-        hhp_gemm_h<1>(reinterpret_cast<const float4 *>(Zh), reinterpret_cast<const float4 *>(Zl), 25, 7, H.wovh, H.wovl, 0, HHP_ATT_J, wave * 32, lane, acc);
+        hhp_gemm_h_short<1, 7>(reinterpret_cast<const float4 *>(Zh), reinterpret_cast<const float4 *>(Zl), 25, H.wovh, H.wovl, 0, HHP_ATT_J, wave * 32, lane, acc);
+        HHP_T(9);
         const int j = wave * 32 + ci;
-        const float bj = N.bov[j];
+        const float bj = bovr;
         float y[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int ix = hhp_haidx(400 + (j < 100 ? j : 0), hhp_crow(r, lane));
             const float x = (float)Zh[ix] + (float)Zl[ix];
             y[r] = j < 100 ? x + (acc[0][r] + bj) : 0.0f;
-            float s = y[r] * y[r];
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
+            const float s = hhp_sum32(y[r] * y[r]);
             if (ci == 0) npart[wave * 32 + hhp_crow(r, lane)] = s;
         }
+        HHP_T(10);
         __syncthreads();
+        HHP_T(11);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = hhp_crow(r, lane);
@@ -200,55 +285,58 @@ __global__ __launch_bounds__(256, 2) void hh_k_policy_h(HhpBank bank, HhpBankH b
         __syncthreads();
     }
 
+    HHP_T(3);
     /* ---- L2 ---- */
     {
         hh_f32x16 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[t] = hhp_zero16();
         hhp_gemm_h<4>(reinterpret_cast<const float4 *>(Zh), reinterpret_cast<const float4 *>(Zl), 0, HHP_H / 16, H.wsh, H.wsl, 0, HHP_H, wave * 128, lane, acc);
+        HHP_T(4);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const float bj = N.bs[wave * 128 + t * 32 + ci];
+            const float bj = bsr[t];
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[t][r] = hhp_tanh(acc[t][r] + bj);
         }
+        HHP_T(5);
         __syncthreads(); /* Z is dead */
+        HHP_T(6);
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int j = wave * 128 + t * 32 + ci;
-#pragma unroll
-            for (int r = 0; r < 16; r++) hhp_split_store(Zh, Zl, hhp_haidx(j, hhp_crow(r, lane)), acc[t][r]);
-        }
+        for (int t = 0; t < 4; t++) hhp_store_tile(Zh, HHPH_OFF_ZL / 2, wave * 128 + t * 32 + ci, lane, acc[t], [](float a) { return a; });
     }
     __syncthreads();
 
+    HHP_T(7);
     /* ---- L3: split-K, wave w contracts its own columns (blocks 8 w .. 8 w + 7) ---- */
     hh_f32x16 lacc[1];
     lacc[0] = hhp_zero16();
-    hhp_gemm_h<1>(reinterpret_cast<const float4 *>(Zh), reinterpret_cast<const float4 *>(Zl), wave * 8, 8, H.wah, H.wal, wave * 8, HHP_OUT, 0, lane, lacc);
+    hhp_gemm_h_short<1, 8>(reinterpret_cast<const float4 *>(Zh), reinterpret_cast<const float4 *>(Zl), wave * 8, H.wah, H.wal, wave * 8, HHP_OUT, 0, lane, lacc);
     __syncthreads(); /* every wave is done reading S: the hi plane now takes the four partials (16 KB) */
 #pragma unroll
     for (int r = 0; r < 16; r++) Pz[wave * 1024 + hhp_crow(r, lane) * 32 + ci] = lacc[0][r];
     __syncthreads();
     for (int e = tid; e < HHP_ROWS * HHP_OUT; e += 256) {
         const int i = e >> 5, c = e & 31;
-        const float v = (((Pz[e] + Pz[1024 + e]) + Pz[2048 + e]) + Pz[3072 + e]) + N.ba[c];
+        const float v = (((Pz[e] + Pz[1024 + e]) + Pz[2048 + e]) + Pz[3072 + e]) + bar; /* c == tid & 31 == ci for every e of this thread */
         Lg[e] = v;
         if (logits_out && rows[i] >= 0) logits_out[(size_t)rows[i] * HH_POLICY_LOGITS + c] = c < N.n_out ? v : 0.0f;
     }
     __syncthreads();
-    if (tid < HHP_ROWS && rows[tid] >= 0) {
-        const float *lg = Lg + tid * 32;
-        int a[4] = {0, 0, 0, 0};
-        const int seg0[5] = {0, 13, 22, 24, 26};
-        const int ncomp = N.n_out == 26 ? 4 : 3;
-        for (int k = 0; k < ncomp; k++) {
-            int best = seg0[k];
-            for (int c = seg0[k] + 1; c < seg0[k + 1]; c++) if (lg[c] > lg[best]) best = c;
-            a[k] = best - seg0[k];
-        }
-        reinterpret_cast<int *>(actions)[rows[tid]] = (a[0] & 0xff) | ((a[1] & 0xff) << 8) | ((a[2] & 0xff) << 16) | ((a[3] & 0xff) << 24);
+    /* greedy decode (env_base.py:373-382), one thread per (row, MultiDiscrete component): first maximum of its segment */
+    if (tid < HHP_ROWS * 4) {
+        const int row = tid >> 2, k = tid & 3;
+        const int lo = k == 0 ? 0 : (k == 1 ? 13 : (k == 2 ? 22 : 24)), hi = k == 0 ? 13 : (k == 1 ? 22 : (k == 2 ? 24 : 26));
+        const float *lg = Lg + row * 32;
+        int best = lo;
+        if (k < (N.n_out == 26 ? 4 : 3))
+            for (int c = lo + 1; c < hi; c++) if (lg[c] > lg[best]) best = c;
+        int a = (best - lo) << (8 * k);
+        a |= __builtin_amdgcn_mov_dpp(a, 0xB1, 0xf, 0xf, true); /* OR over the quad of the row's four components */
+        a |= __builtin_amdgcn_mov_dpp(a, 0x4E, 0xf, 0xf, true);
+        if (k == 0 && rows[row] >= 0) reinterpret_cast<int *>(actions)[rows[row]] = a;
     }
+    HHP_T(8);
 }
 
 /* ---- host side: fp32 -> (hi, lo) fp16, round to nearest even, subnormals kept ---- */

@@ -46,3 +46,19 @@ def test_world_fails_loudly_without_gpu():
     from hhmarl_2d_amd.world import World, make_config
     with pytest.raises(RuntimeError):
         World(make_config(n_arenas=4, level=3))
+
+
+def test_net_weights_struct_layout_matches_header():
+    from hhmarl_2d_amd import _lib
+    txt = open(os.path.join(ROOT, "include", "hh_policy.h")).read()
+    body = re.search(r"typedef struct hh_net_weights \{(.*?)\} hh_net_weights;", txt, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for nm in re.findall(r"\*?\s*([a-z_]+)(?:\[\d+\])?\s*(?:,|$)", decl.split(None, 1 if decl.startswith("int32_t") else 2)[-1]):
+            names.append(nm)
+    assert names == [f[0] for f in _lib.HHNetWeights._fields_], names
+    assert C.sizeof(_lib.HHNetWeights) == 8 + 8 * (3 + 3 + 4 + 2 + 2)   # int32 + padding, then 14 pointers

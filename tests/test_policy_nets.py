@@ -134,3 +134,71 @@ def test_net_pilot_drives_highlevel_env_and_matches_torch():
     for _ in range(3):   # whole macro steps run with the networks in the loop
         obs, rew, val, done = macro_step(w, cmd, pilot)
     assert torch.isfinite(obs).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [4, 5])
+def test_opponent_nets_drive_levels_4_5_through_the_facade(level):
+    """LowLevelEnv levels 4-5 with the frozen opponent policies in the fused kernel (env_base.py:312-398, env_hetero.py:160-172):
+    the facade hands the opponents' observations to OpponentNets, whose actions equal the PyTorch forward of the network the
+    arena's level-5 draw selects (fight nets, or the escape nets when k == 5)"""
+    from hhmarl_2d_amd import pilots
+    from hhmarl_2d_amd.config import make_args
+    from hhmarl_2d_amd.env_hetero import LowLevelEnv
+    n = 256
+    seen = {"calls": 0, "esc": 0}
+    holder = {}
+
+    def policy(opp_obs, env):
+        nets = holder.setdefault("nets", pilots.OpponentNets(env.world, seed=11))
+        act = nets(opp_obs, env).clone()
+        k = env.world.opp_policy().cpu().numpy()
+        for slot, (fight, esc) in enumerate(((PN.FIGHT1, PN.ESC1), (PN.FIGHT2, PN.ESC2))):
+            for kind, sel_rows in ((fight, k != 5), (esc, k == 5)):
+                idx = np.nonzero(sel_rows)[0]
+                if len(idx) == 0:
+                    continue
+                ref = PN.torch_forward(kind, PN.random_weights(kind, 11), opp_obs[idx, slot].cpu())
+                parts = ref.split(PN.ACTION_SPLIT[: 4 if PN.N_OUT[kind] == 26 else 3], dim=1)
+                clear = torch.stack([(p.topk(2, dim=1).values[:, 0] - p.topk(2, dim=1).values[:, 1]) > 1e-4 for p in parts], dim=1).all(dim=1)
+                assert torch.equal(act[idx, slot].cpu()[clear], PN.decode(ref, PN.N_OUT[kind])[clear])
+                seen["esc"] += int(kind in (PN.ESC1, PN.ESC2)) * len(idx)
+        seen["calls"] += 1
+        return act
+
+    env = LowLevelEnv({"args": make_args(0, level=level, horizon=30), "num_envs": n, "seed": 3, "opponent_policy": policy})
+    obs, _ = env.reset()
+    rng = np.random.default_rng(0)
+    for t in range(12):
+        obs, rew, term, _, _ = env.step({1: np.stack([rng.integers(0, 13, n), rng.integers(0, 9, n), rng.integers(0, 2, n), rng.integers(0, 2, n)], axis=1),
+                                         2: np.stack([rng.integers(0, 13, n), rng.integers(0, 9, n), rng.integers(0, 2, n)], axis=1)})
+    assert seen["calls"] == 12 and obs[1].shape == (n, 26)
+    if level == 5:
+        assert seen["esc"] > 0 and set(np.unique(env.opp_k)) <= {3, 4, 5}   # roughly a third of the arenas drew the escape set
+    else:
+        assert seen["esc"] == 0
+    env.close()
+
+
+@pytest.mark.gpu
+def test_policy_abi_misuse_is_reported_through_status_codes():
+    import ctypes as C
+    from hhmarl_2d_amd import _lib as L
+    lib = L.lib()
+    h = C.c_void_p()
+    assert lib.hh_policy_create(0, 0, C.byref(h)) < 0 and lib.hh_last_error()            # max_rows <= 0
+    assert lib.hh_policy_create(99, 64, C.byref(h)) < 0                                   # no such device
+    assert lib.hh_policy_create(0, 64, C.byref(h)) == 0
+    obs = torch.zeros((64, 30), device="cuda"); sel = torch.zeros((64,), dtype=torch.uint8, device="cuda"); act = torch.zeros((64, 4), dtype=torch.int8, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.hh_policy_act(h, p(obs), 64, 30, p(sel), p(act), None, None) < 0          # no network loaded
+    lut = np.zeros(256, dtype=np.uint8); lut[5] = 1
+    assert lib.hh_policy_set_lut(h, lut.ctypes.data_as(C.c_void_p)) < 0                   # selector maps to an empty slot
+    w = L.HHNetWeights(); w.kind = 7
+    assert lib.hh_policy_set_net(h, 0, C.byref(w)) < 0                                    # bad kind / missing pointers
+    assert lib.hh_policy_destroy(h) == 0
+    from hhmarl_2d_amd.pilots import PolicyBank
+    bank = PolicyBank.random_init(torch.device("cuda", 0), seed=1, max_rows=64)
+    assert lib.hh_policy_act(bank.h, p(obs), 65, 30, p(sel), p(act), None, None) < 0      # more rows than max_rows
+    assert lib.hh_policy_act(bank.h, p(obs), 64, 30, None, p(act), None, None) < 0        # sel == NULL before any binning call
+    bank.act(obs, sel)                                                                      # the bank is still usable

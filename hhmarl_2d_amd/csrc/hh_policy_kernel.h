@@ -300,6 +300,9 @@ struct hh_policy {
     HhpBankH bankh;
     int binned_rows;          /* n_rows of the call that built the current row lists (0: none) */
     int fp32;                 /* HH_POLICY_FP32=1: the fp32-MFMA kernel (A/B runs; default is the split-fp16 kernel) */
+    int tile_rows;            /* HH_POLICY_TILE=64: the 64-row-tile instance of the split-fp16 kernel (A/B runs; default 32-row tiles) */
+    int n_cu;
+    int persist;              /* HH_POLICY_PERSIST=0: 64-row tiles one workgroup per tile instead of a grid-stride walk (A/B runs) */
     int n_nets;               /* highest loaded slot + 1 */
     float *blob[HH_POLICY_MAX_NETS];
     uint16_t *blobh[HH_POLICY_MAX_NETS];
@@ -329,6 +332,9 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     memset(&p->bank, 0, sizeof(p->bank));
     memset(&p->bankh, 0, sizeof(p->bankh));
     { const char *e = getenv("HH_POLICY_FP32"); p->fp32 = e ? atoi(e) : 0; }
+    { const char *e = getenv("HH_POLICY_TILE"); p->tile_rows = e ? atoi(e) : 0; }
+    { const char *e = getenv("HH_POLICY_PERSIST"); p->persist = e ? atoi(e) : 1; }
+    { hipDeviceProp_t prop; p->n_cu = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256; }
     for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { p->blob[i] = nullptr; p->blobh[i] = nullptr; }
     p->slab = nullptr;
     p->lut = nullptr; p->counts = nullptr; p->lists = nullptr;
@@ -338,7 +344,8 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     if (e == hipSuccess) e = hipMalloc(&p->lists, (size_t)HH_POLICY_MAX_NETS * max_rows * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&p->slab, HHP_SLOT_BYTES * HH_POLICY_MAX_NETS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy), hipFuncAttributeMaxDynamicSharedMemorySize, HHP_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_h), hipFuncAttributeMaxDynamicSharedMemorySize, HHPH_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_h<1>), hipFuncAttributeMaxDynamicSharedMemorySize, HHPH_LDS_BYTES(1));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_h<2>), hipFuncAttributeMaxDynamicSharedMemorySize, HHPH_LDS_BYTES(2));
     if (e != hipSuccess) {
         g_err = std::string("hh_policy_create: ") + hipGetErrorString(e);
         if (p->lut) (void)hipFree(p->lut);
@@ -460,12 +467,17 @@ extern "C" int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int
         p->binned_rows = n_rows;
     }
     const int grid = (n_rows + HHP_ROWS - 1) / HHP_ROWS + p->n_nets; /* upper bound of the tiles over all networks */
-    if (p->fp32)
+    if (p->fp32) {
         hipLaunchKernelGGL(hh_k_policy, dim3(grid), dim3(256), HHP_LDS_BYTES, st, p->bank, p->n_nets, obs, obs_stride, p->counts, p->lists, p->max_rows,
                            actions, logits);
-    else
-        hipLaunchKernelGGL(hh_k_policy_h, dim3(grid), dim3(256), HHPH_LDS_BYTES, st, p->bank, p->bankh, p->n_nets, obs, obs_stride, p->counts, p->lists,
+    } else if (p->tile_rows == 64) { /* persistent: one workgroup per CU walks the tiles grid-stride */
+        const int tiles = (n_rows + 63) / 64 + p->n_nets;
+        hipLaunchKernelGGL(hh_k_policy_h<2>, dim3(p->persist && tiles > p->n_cu ? p->n_cu : tiles), dim3(512), HHPH_LDS_BYTES(2), st, p->bank, p->bankh, p->n_nets,
+                           obs, obs_stride, p->counts, p->lists, p->max_rows, actions, logits);
+    } else {
+        hipLaunchKernelGGL(hh_k_policy_h<1>, dim3(grid), dim3(256), HHPH_LDS_BYTES(1), st, p->bank, p->bankh, p->n_nets, obs, obs_stride, p->counts, p->lists,
                            p->max_rows, actions, logits);
+    }
     HIPCHK(hipGetLastError());
     return HH_OK;
 }

@@ -31,32 +31,39 @@ struct HhpBankH {
 
 /* index (in halves) of element (k, col) of a [K x J] operand */
 __host__ __device__ inline size_t hhp_hidx(int k, int col, int J) { return ((size_t)((k >> 4) * 2 + ((k >> 3) & 1)) * J + col) * 8 + (k & 7); }
-/* the same for the 32-row LDS activation planes, row slot XOR-swizzled by the plane like hhp_aidx */
+/* the same for the R-row LDS activation planes (R = 32 or 64 rows per tile), row slot XOR-swizzled by the plane like hhp_aidx (the
+ * XOR touches the low three bits only) */
+template <int R>
 __device__ __forceinline__ int hhp_haidx(int k, int row) {
     const int plane = (k >> 4) * 2 + ((k >> 3) & 1);
-    return (plane * 32 + (row ^ (plane & 7))) * 8 + (k & 7);
+    return (plane * R + (row ^ (plane & 7))) * 8 + (k & 7);
 }
+template <int R>
 __device__ __forceinline__ void hhp_split_store(_Float16 *__restrict__ hi, _Float16 *__restrict__ lo, int idx, float v) {
     const _Float16 h = (_Float16)v;
     hi[idx] = h;
     lo[idx] = (_Float16)(v - (float)h);
 }
-/* the 16 values a lane holds of one 32x32 C tile (column j, rows (r & 3) + 4 (lane >> 5) + 8 (r >> 2)) -> hi / lo planes.  The row
- * slot is row ^ (plane & 7): the XOR touches the low three bits only, so the four (r & 3) slots are computed once per tile and the
- * (r >> 2) part (+128 bytes) and the lo plane (+32 KB) ride in the ds_write offset field: no address arithmetic per element. */
-template <class F>
-__device__ __forceinline__ void hhp_store_tile(_Float16 *__restrict__ hi_plane, int lo_off_halves, int j, int lane, const hh_f32x16 &acc, F f) {
+/* the 16 values a lane holds of one 32x32 C tile (column j, rows row0 + (r & 3) + 4 (lane >> 5) + 8 (r >> 2)) -> hi / lo planes.  The
+ * row slot is row ^ (plane & 7): the four (r & 3) slots are computed once per tile and the (r >> 2) part (+128 bytes) rides in the
+ * ds_write offset field: no address arithmetic per element (the lo plane has its own four pointers: 64 KB away with 64-row tiles,
+ * one more than the offset field holds). */
+template <int R, class F>
+__device__ __forceinline__ void hhp_store_tile(_Float16 *__restrict__ hi_plane, _Float16 *__restrict__ lo_plane, int j, int row0, int lane,
+                                               const hh_f32x16 &acc, F f) {
     const int plane = (j >> 4) * 2 + ((j >> 3) & 1), swz = plane & 7, h4 = 4 * (lane >> 5);
-    _Float16 *base = hi_plane + plane * 256 + (j & 7); /* 32 rows x 8 halves per plane */
-    _Float16 *q0 = base + (((0 + h4) ^ swz) << 3), *q1 = base + (((1 + h4) ^ swz) << 3), *q2 = base + (((2 + h4) ^ swz) << 3),
-             *q3 = base + (((3 + h4) ^ swz) << 3);
+    const int base = plane * (R * 8) + row0 * 8 + (j & 7); /* R rows x 8 halves per plane; row0 is a multiple of 32 */
+    const int o0 = base + (((0 + h4) ^ swz) << 3), o1 = base + (((1 + h4) ^ swz) << 3), o2 = base + (((2 + h4) ^ swz) << 3), o3 = base + (((3 + h4) ^ swz) << 3);
+    _Float16 *q0 = hi_plane + o0, *q1 = hi_plane + o1, *q2 = hi_plane + o2, *q3 = hi_plane + o3;
+    _Float16 *l0 = lo_plane + o0, *l1 = lo_plane + o1, *l2 = lo_plane + o2, *l3 = lo_plane + o3;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         _Float16 *q = (r & 3) == 0 ? q0 : ((r & 3) == 1 ? q1 : ((r & 3) == 2 ? q2 : q3));
+        _Float16 *l = (r & 3) == 0 ? l0 : ((r & 3) == 1 ? l1 : ((r & 3) == 2 ? l2 : l3));
         const float v = f(acc[r]);
         const _Float16 hv = (_Float16)v;
         q[(r >> 2) * 64] = hv;                                   /* +8 rows = 64 halves */
-        q[(r >> 2) * 64 + lo_off_halves] = (_Float16)(v - (float)hv);
+        l[(r >> 2) * 64] = (_Float16)(v - (float)hv);
     }
 }
 
@@ -66,19 +73,21 @@ __device__ __forceinline__ hh_h8 hhp_as_h8(const float4 &v) {
     return u.h;
 }
 
-/* NT tiles over KB 16-k blocks: acc += Ahi Bhi + Ahi Blo + Alo Bhi.  A fragments from the LDS planes, B fragments from global.
+/* NT column tiles x RH row halves over KB 16-k blocks: acc += Ahi Bhi + Ahi Blo + Alo Bhi.  A fragments from the LDS planes, B
+ * fragments from global: with RH = 2 a weight fragment serves two row halves from registers — half the weight stream per row.
  * Three register sets of weight fragments rotate BY NAME (the block loop is unrolled by three): block kb computes from set kb % 3
  * while the loads of block kb + 2 land in set (kb + 2) % 3.  Rotating by register moves instead would read the set that was just
- * requested and make the wave wait for it — a prefetch distance of one block (384 cycles) where an L2 round trip under load is
- * longer (measured: 37 % of the wave cycles waiting). */
+ * requested and make the wave wait for it — a prefetch distance of one block where an L2 round trip under load is longer
+ * (measured: 37 % of the wave cycles waiting). */
 template <int NT>
 struct HhpBSet {
     float4 h[NT], l[NT];
 };
-template <int NT>
+template <int NT, int RH>
 __device__ __forceinline__ void hhp_gemm_h(const float4 *__restrict__ a_hi, const float4 *__restrict__ a_lo, int kb0, int KB,
                                            const float4 *__restrict__ b_hi, const float4 *__restrict__ b_lo, int bkb0, int J, int j0, int lane,
-                                           hh_f32x16 (&acc)[NT]) {
+                                           hh_f32x16 (&acc)[RH][NT]) {
+    constexpr int R = 32 * RH;
     const int h = lane >> 5, i = lane & 31;
     const unsigned bstep = 2u * (unsigned)J;
     unsigned boff = (unsigned)((bkb0 * 2 + h) * J + j0 + i); /* fragment index from the (wave-uniform) plane bases: one 32-bit add per block */
@@ -91,7 +100,9 @@ __device__ __forceinline__ void hhp_gemm_h(const float4 *__restrict__ a_hi, cons
     }
     boff += 2u * bstep; /* block kb + 2 */
     int p0 = kb0 * 2 + h;
-    float4 ah = a_hi[p0 * 32 + (i ^ (p0 & 7))], al = a_lo[p0 * 32 + (i ^ (p0 & 7))];
+    float4 ah[RH], al[RH];
+#pragma unroll
+    for (int f = 0; f < RH; f++) { ah[f] = a_hi[p0 * R + f * 32 + (i ^ (p0 & 7))]; al[f] = a_lo[p0 * R + f * 32 + (i ^ (p0 & 7))]; }
 #pragma nounroll
     for (int base = 0; base < KB; base += 3) {
 #pragma unroll
@@ -104,22 +115,30 @@ __device__ __forceinline__ void hhp_gemm_h(const float4 *__restrict__ a_hi, cons
                     for (int t = 0; t < NT; t++) { far.h[t] = b_hi[boff + t * 32]; far.l[t] = b_lo[boff + t * 32]; }
                 }
                 boff += bstep;
-                float4 ahn = ah, aln = al;
+                float4 ahn[RH], aln[RH];
+#pragma unroll
+                for (int f = 0; f < RH; f++) { ahn[f] = ah[f]; aln[f] = al[f]; }
                 if (kb + 1 < KB) {
                     const int p = (kb0 + kb + 1) * 2 + h;
-                    ahn = a_hi[p * 32 + (i ^ (p & 7))];
-                    aln = a_lo[p * 32 + (i ^ (p & 7))];
+#pragma unroll
+                    for (int f = 0; f < RH; f++) { ahn[f] = a_hi[p * R + f * 32 + (i ^ (p & 7))]; aln[f] = a_lo[p * R + f * 32 + (i ^ (p & 7))]; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const hh_h8 fa_h = hhp_as_h8(ah), fa_l = hhp_as_h8(al);
 #pragma unroll
-                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h, hhp_as_h8(cur.h[t]), acc[t], 0, 0, 0);
+                for (int f = 0; f < RH; f++)
 #pragma unroll
-                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h, hhp_as_h8(cur.l[t]), acc[t], 0, 0, 0);
+                    for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(ah[f]), hhp_as_h8(cur.h[t]), acc[f][t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_l, hhp_as_h8(cur.h[t]), acc[t], 0, 0, 0);
+                for (int f = 0; f < RH; f++)
+#pragma unroll
+                    for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(ah[f]), hhp_as_h8(cur.l[t]), acc[f][t], 0, 0, 0);
+#pragma unroll
+                for (int f = 0; f < RH; f++)
+#pragma unroll
+                    for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(al[f]), hhp_as_h8(cur.h[t]), acc[f][t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                ah = ahn; al = aln;
+#pragma unroll
+                for (int f = 0; f < RH; f++) { ah[f] = ahn[f]; al[f] = aln[f]; }
             }
         }
     }
@@ -128,34 +147,37 @@ __device__ __forceinline__ void hhp_gemm_h(const float4 *__restrict__ a_hi, cons
 /* The short contractions (L1: K = 32, attention: K = 112, L3: K = 128 per wave) have too few MFMAs per block to hide a weight
  * fetch behind: all their weight fragments are requested up front (KB <= 8 blocks: at most 64 registers), so the wave pays ONE L2
  * round trip instead of one per block (phase timers: attention 21 %, L3 10 %, L1 8 % of a tile before this). */
-template <int NT, int KB>
-__device__ __forceinline__ void hhp_gemm_h_short(const float4 *__restrict__ a_hi, const float4 *__restrict__ a_lo, int kb0,
+template <int NT, int KB, int RH, int R>
+__device__ __forceinline__ void hhp_gemm_h_short(const float4 *__restrict__ a_hi, const float4 *__restrict__ a_lo, int kb0, int row0,
                                                  const float4 *__restrict__ b_hi, const float4 *__restrict__ b_lo, int bkb0, int J, int j0, int lane,
-                                                 hh_f32x16 (&acc)[NT]) {
+                                                 hh_f32x16 (&acc)[RH][NT]) {
     const int h = lane >> 5, i = lane & 31;
     const unsigned bstep = 2u * (unsigned)J, boff = (unsigned)((bkb0 * 2 + h) * J + j0 + i);
-    float4 bh[KB][NT], bl[KB][NT], ah[KB], al[KB];
+    float4 bh[KB][NT], bl[KB][NT];
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) {
 #pragma unroll
         for (int t = 0; t < NT; t++) { bh[kb][t] = b_hi[boff + kb * bstep + t * 32]; bl[kb][t] = b_lo[boff + kb * bstep + t * 32]; }
     }
-#pragma unroll
-    for (int kb = 0; kb < KB; kb++) {
-        const int p = (kb0 + kb) * 2 + h;
-        ah[kb] = a_hi[p * 32 + (i ^ (p & 7))];
-        al[kb] = a_lo[p * 32 + (i ^ (p & 7))];
-    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) {
-        const hh_h8 fa_h = hhp_as_h8(ah[kb]), fa_l = hhp_as_h8(al[kb]);
+        const int p = (kb0 + kb) * 2 + h;
+        float4 ah[RH], al[RH];
 #pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h, hhp_as_h8(bh[kb][t]), acc[t], 0, 0, 0);
+        for (int f = 0; f < RH; f++) { ah[f] = a_hi[p * R + row0 + f * 32 + (i ^ (p & 7))]; al[f] = a_lo[p * R + row0 + f * 32 + (i ^ (p & 7))]; }
 #pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h, hhp_as_h8(bl[kb][t]), acc[t], 0, 0, 0);
+        for (int f = 0; f < RH; f++)
 #pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_l, hhp_as_h8(bh[kb][t]), acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(ah[f]), hhp_as_h8(bh[kb][t]), acc[f][t], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < RH; f++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(ah[f]), hhp_as_h8(bl[kb][t]), acc[f][t], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < RH; f++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(al[f]), hhp_as_h8(bh[kb][t]), acc[f][t], 0, 0, 0);
     }
 }
 
@@ -180,163 +202,235 @@ __device__ unsigned long long hhp_prof[16];
 #define HHP_T0
 #endif
 
-/* LDS (bytes): Zh 32 KB | Zl 32 KB | Xh 2 KB | Xl 2 KB | L3 partials 16 KB alias Zh | logits 4 KB | rows, norm partials */
-#define HHPH_OFF_ZL 32768
-#define HHPH_OFF_XH 65536
-#define HHPH_OFF_XL 67584
-#define HHPH_OFF_LG 69632
-#define HHPH_OFF_ROWS 73728
-#define HHPH_OFF_NP 73856
-#define HHPH_LDS_BYTES (73856 + 512)
+/* LDS (bytes, x RH): Zh 32 KB | Zl 32 KB | Xh 2 KB | Xl 2 KB | L3 partials 16 KB alias Zh | logits 4 KB | rows x 2, norm partials */
+#define HHPH_OFF_ZL(RH) (32768 * (RH))
+#define HHPH_OFF_XH(RH) (65536 * (RH))
+#define HHPH_OFF_XL(RH) (67584 * (RH))
+#define HHPH_OFF_LG(RH) (69632 * (RH))
+#define HHPH_OFF_ROWS(RH) (73728 * (RH))
+#define HHPH_OFF_NP(RH) (73984 * (RH))
+#define HHPH_LDS_BYTES(RH) ((73984 + 512) * (RH))
 
-__global__ __launch_bounds__(256, 2) void hh_k_policy_h(HhpBank bank, HhpBankH bankh, int n_nets, const float *__restrict__ obs, int obs_stride,
-                                                        const int *__restrict__ counts, const int *__restrict__ lists, int max_rows,
-                                                        int8_t *__restrict__ actions, float *__restrict__ logits_out) {
-    extern __shared__ __align__(16) unsigned char ldsb[];
-    _Float16 *Zh = reinterpret_cast<_Float16 *>(ldsb);                  /* [32][2][32][8] hi plane of the activation tile */
-    _Float16 *Zl = reinterpret_cast<_Float16 *>(ldsb + HHPH_OFF_ZL);    /* lo plane */
-    _Float16 *Xh = reinterpret_cast<_Float16 *>(ldsb + HHPH_OFF_XH);    /* [2][2][32][8] observation tile */
-    _Float16 *Xl = reinterpret_cast<_Float16 *>(ldsb + HHPH_OFF_XL);
-    float *Pz = reinterpret_cast<float *>(ldsb);                        /* L3 split-K partials [4][32][32] (after S is dead) */
-    float *Lg = reinterpret_cast<float *>(ldsb + HHPH_OFF_LG);          /* [32][32] logits */
-    int *rows = reinterpret_cast<int *>(ldsb + HHPH_OFF_ROWS);          /* [32] */
-    float *npart = reinterpret_cast<float *>(ldsb + HHPH_OFF_NP);       /* [4][32] */
-
-    int cn[HH_POLICY_MAX_NETS];
-#pragma unroll
-    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? counts[n] : 0;
-    int net = -1, tile = blockIdx.x, cnt = 0;
+/* global tile index -> (network, tile of that network, rows of that network); false past the last tile */
+template <int R>
+__device__ __forceinline__ bool hhp_locate(const int (&cn)[HH_POLICY_MAX_NETS], int gt, int &net, int &tile, int &cnt) {
+    net = -1; tile = gt; cnt = 0;
 #pragma unroll
     for (int n = 0; n < HH_POLICY_MAX_NETS; n++) {
-        const int nt = (cn[n] + HHP_ROWS - 1) / HHP_ROWS;
+        const int nt = (cn[n] + R - 1) / R;
         if (net < 0) {
             if (tile < nt) { net = n; cnt = cn[n]; }
             else tile -= nt;
         }
     }
-    if (net < 0) return;
-    const HhpNet N = bank.net[net];
-    const HhpNetH H = bankh.net[net];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ci = lane & 31;
+    return net >= 0;
+}
+
+/* RH row halves per tile, 4 RH waves per workgroup.  RH = 1 (default): 32-row tiles, 256 threads, two workgroups per CU.
+ * RH = 2 (HH_POLICY_TILE=64): 64-row tiles, 512 threads = two waves per SIMD, 145 KB of LDS, one workgroup per CU: in L1 / L2 a
+ * wave owns 64 columns (2 MFMA tiles) of BOTH row halves, so every weight fragment it fetches serves two MFMA row blocks — half the
+ * weight stream per row; the attention block and the split-K logits give each wave one (column or k quarter, row half) pair.
+ * Persistent over tiles (grid-stride): the next tile's row list and observation rows are fetched while the current tile is in its
+ * later layers, so a tile starts with its X operand already in LDS.  Measured (`tools/policy_bench.py`, Fight1 + Fight2 rows): 84 us
+ * against 88 us per 32768 rows (back-to-back calls), 122 against 127 at 49152 — but workgroups of 145 KB come in whole rounds of
+ * 64 n_cu rows (24576 rows: 78 us against 70), the row count that carries a network is known on the device only (launching both
+ * widths and letting the binned counts choose costs the 2 us it gains), and `bench.py --workload rollout` / `hier --pilot net` come
+ * out level.  Kept as an A/B instance; what separates both forms from the matrix pipe's 30 k cycles per 64 rows is that a tile's
+ * epilogues (tanh, hi/lo split, 2-byte LDS scatter) and GEMMs alternate instead of overlapping. */
+template <int RH>
+__global__ __launch_bounds__(256 * RH, RH == 1 ? 2 : 1) void hh_k_policy_h(HhpBank bank, HhpBankH bankh, int n_nets, const float *__restrict__ obs, int obs_stride,
+                                                                           const int *__restrict__ counts, const int *__restrict__ lists, int max_rows,
+                                                                           int8_t *__restrict__ actions, float *__restrict__ logits_out) {
+    constexpr int R = 32 * RH, NTH = 256 * RH, NT = 4 / RH, WC = 32 * NT; /* rows per tile, threads, column tiles and columns per wave in L1 / L2 */
+    constexpr int XPT = R * HHP_XK / NTH;                                 /* observation elements per thread (8 / 4) */
+    extern __shared__ __align__(16) unsigned char ldsb[];
+    _Float16 *Zh = reinterpret_cast<_Float16 *>(ldsb);                      /* [32][2][R][8] hi plane of the activation tile */
+    _Float16 *Zl = reinterpret_cast<_Float16 *>(ldsb + HHPH_OFF_ZL(RH));    /* lo plane */
+    _Float16 *Xh = reinterpret_cast<_Float16 *>(ldsb + HHPH_OFF_XH(RH));    /* [2][2][R][8] observation tile */
+    _Float16 *Xl = reinterpret_cast<_Float16 *>(ldsb + HHPH_OFF_XL(RH));
+    float *Pz = reinterpret_cast<float *>(ldsb);                            /* L3 split-K partials [4][R][32] (after S is dead) */
+    float *Lg = reinterpret_cast<float *>(ldsb + HHPH_OFF_LG(RH));          /* [R][32] logits */
+    int *rowsb = reinterpret_cast<int *>(ldsb + HHPH_OFF_ROWS(RH));         /* [2][R] row lists of this tile and the next */
+    float *npart = reinterpret_cast<float *>(ldsb + HHPH_OFF_NP(RH));       /* [4][R] */
+
+    int cn[HH_POLICY_MAX_NETS];
+#pragma unroll
+    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? counts[n] : 0;
+    const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int wq = wave & 3, wrow0 = (wave >> 2) * 32; /* attention / L3: column or k quarter, row half of this wave */
+    int gt = blockIdx.x, net, tile, cnt;
+    if (!hhp_locate<R>(cn, gt, net, tile, cnt)) return;
     HHP_T0;
-    /* every bias this lane will add, requested now: a global round trip in front of each epilogue is ~1.4 k cycles */
-    float b1r[4], bsr[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) { b1r[t] = N.b1[wave * 128 + t * 32 + ci]; bsr[t] = N.bs[wave * 128 + t * 32 + ci]; }
-    const float bovr = N.bov[wave * 32 + ci], bar = N.ba[ci];
-
-    if (tid < HHP_ROWS) {
-        const int q = tile * HHP_ROWS + tid;
-        rows[tid] = q < cnt ? lists[(size_t)net * max_rows + q] : -1;
-    }
-    __syncthreads();
-    for (int e = tid; e < HHP_ROWS * HHP_XK; e += 256) {
-        const int i = e >> 5, c = e & 31, r = rows[i];
-        hhp_split_store(Xh, Xl, hhp_haidx(c, i), (r >= 0 && c < N.obs_dim) ? obs[(size_t)r * obs_stride + c] : 0.0f);
-    }
-    __syncthreads();
-    HHP_T(0);
-
-    /* ---- L1 ---- */
-    {
-        hh_f32x16 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = hhp_zero16();
-        hhp_gemm_h_short<4, HHP_XK / 16>(reinterpret_cast<const float4 *>(Xh), reinterpret_cast<const float4 *>(Xl), 0, H.w1h, H.w1l, 0, HHP_H, wave * 128, lane, acc);
-        HHP_T(1);
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int j = wave * 128 + t * 32 + ci;
-            const float bj = b1r[t];
-            hhp_store_tile(Zh, HHPH_OFF_ZL / 2, j, lane, acc[t], [bj](float a) { return hhp_tanh(a + bj); });
-        }
-    }
-    __syncthreads();
-    HHP_T(2);
-
-    /* ---- fight nets: x <- normalize(x + Wov x + bov) on columns 400..499 (K = 112: blocks 25..31 of the tile) ---- */
-    if (N.has_att) {
-        hh_f32x16 acc[1];
-        acc[0] = hhp_zero16();
-        hhp_gemm_h_short<1, 7>(reinterpret_cast<const float4 *>(Zh), reinterpret_cast<const float4 *>(Zl), 25, H.wovh, H.wovl, 0, HHP_ATT_J, wave * 32, lane, acc);
-        HHP_T(9);
-        const int j = wave * 32 + ci;
-        const float bj = bovr;
-        float y[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int ix = hhp_haidx(400 + (j < 100 ? j : 0), hhp_crow(r, lane));
-            const float x = (float)Zh[ix] + (float)Zl[ix];
-            y[r] = j < 100 ? x + (acc[0][r] + bj) : 0.0f;
-            const float s = hhp_sum32(y[r] * y[r]);
-            if (ci == 0) npart[wave * 32 + hhp_crow(r, lane)] = s;
-        }
-        HHP_T(10);
-        __syncthreads();
-        HHP_T(11);
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = hhp_crow(r, lane);
-            const float nn = ((npart[row] + npart[32 + row]) + npart[64 + row]) + npart[96 + row];
-            const float den = fmaxf(sqrtf(nn), 1e-12f);
-            if (j < 100) hhp_split_store(Zh, Zl, hhp_haidx(400 + j, row), y[r] / den);
+    { /* first tile: rows and observation in the open; later tiles find both prefetched */
+        const int tid = tid0;
+        if (tid < R) {
+            const int q = tile * R + tid;
+            rowsb[tid] = q < cnt ? lists[(size_t)net * max_rows + q] : -1;
         }
         __syncthreads();
-    }
-
-    HHP_T(3);
-    /* ---- L2 ---- */
-    {
-        hh_f32x16 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = hhp_zero16();
-        hhp_gemm_h<4>(reinterpret_cast<const float4 *>(Zh), reinterpret_cast<const float4 *>(Zl), 0, HHP_H / 16, H.wsh, H.wsl, 0, HHP_H, wave * 128, lane, acc);
-        HHP_T(4);
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const float bj = bsr[t];
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[t][r] = hhp_tanh(acc[t][r] + bj);
+        const int od = bank.net[net].obs_dim;
+        for (int e = tid; e < R * HHP_XK; e += NTH) {
+            const int i = e >> 5, c = e & 31, r = rowsb[i];
+            hhp_split_store<R>(Xh, Xl, hhp_haidx<R>(c, i), (r >= 0 && c < od) ? obs[(size_t)r * obs_stride + c] : 0.0f);
         }
-        HHP_T(5);
-        __syncthreads(); /* Z is dead */
-        HHP_T(6);
-#pragma unroll
-        for (int t = 0; t < 4; t++) hhp_store_tile(Zh, HHPH_OFF_ZL / 2, wave * 128 + t * 32 + ci, lane, acc[t], [](float a) { return a; });
+        __syncthreads();
+        HHP_T(0);
     }
-    __syncthreads();
 
-    HHP_T(7);
-    /* ---- L3: split-K, wave w contracts its own columns (blocks 8 w .. 8 w + 7) ---- */
-    hh_f32x16 lacc[1];
-    lacc[0] = hhp_zero16();
-    hhp_gemm_h_short<1, 8>(reinterpret_cast<const float4 *>(Zh), reinterpret_cast<const float4 *>(Zl), wave * 8, H.wah, H.wal, wave * 8, HHP_OUT, 0, lane, lacc);
-    __syncthreads(); /* every wave is done reading S: the hi plane now takes the four partials (16 KB) */
+    for (int it = 0;; it++) {
+        /* the lane index is laundered once per tile: otherwise the compiler hoists every lane-dependent LDS address of the body out of
+         * the tile loop (~150 loop-invariant registers, most of them spilled) */
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int tid = wave * 64 + lane, ci = lane & 31;
+        int *rows = rowsb + (it & 1) * R, *rows_next = rowsb + ((it + 1) & 1) * R;
+        const HhpNet N = bank.net[net];
+        const HhpNetH H = bankh.net[net];
+        /* every bias this lane will add, requested now: a global round trip in front of each epilogue is ~1.4 k cycles */
+        float b1r[NT], bsr[NT];
 #pragma unroll
-    for (int r = 0; r < 16; r++) Pz[wave * 1024 + hhp_crow(r, lane) * 32 + ci] = lacc[0][r];
-    __syncthreads();
-    for (int e = tid; e < HHP_ROWS * HHP_OUT; e += 256) {
-        const int i = e >> 5, c = e & 31;
-        const float v = (((Pz[e] + Pz[1024 + e]) + Pz[2048 + e]) + Pz[3072 + e]) + bar; /* c == tid & 31 == ci for every e of this thread */
-        Lg[e] = v;
-        if (logits_out && rows[i] >= 0) logits_out[(size_t)rows[i] * HH_POLICY_LOGITS + c] = c < N.n_out ? v : 0.0f;
+        for (int t = 0; t < NT; t++) { b1r[t] = N.b1[wave * WC + t * 32 + ci]; bsr[t] = N.bs[wave * WC + t * 32 + ci]; }
+        const float bovr = N.bov[wq * 32 + ci], bar = N.ba[ci];
+        /* the next tile of this workgroup: its row list is requested here and parked in LDS behind the L1 barrier */
+        int nnet, ntile, ncnt, nrow = -1;
+        const bool more = hhp_locate<R>(cn, gt + (int)gridDim.x, nnet, ntile, ncnt);
+        if (more && tid < R) {
+            const int q = ntile * R + tid;
+            nrow = q < ncnt ? lists[(size_t)nnet * max_rows + q] : -1;
+        }
+
+        /* ---- L1 ---- */
+        {
+            hh_f32x16 acc[RH][NT];
+#pragma unroll
+            for (int f = 0; f < RH; f++)
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[f][t] = hhp_zero16();
+            hhp_gemm_h_short<NT, HHP_XK / 16, RH, R>(reinterpret_cast<const float4 *>(Xh), reinterpret_cast<const float4 *>(Xl), 0, 0, H.w1h, H.w1l, 0, HHP_H, wave * WC, lane, acc);
+            HHP_T(1);
+#pragma unroll
+            for (int f = 0; f < RH; f++)
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const int j = wave * WC + t * 32 + ci;
+                    const float bj = b1r[t];
+                    hhp_store_tile<R>(Zh, Zl, j, f * 32, lane, acc[f][t], [bj](float a) { return hhp_tanh(a + bj); });
+                }
+        }
+        if (more && tid < R) rows_next[tid] = nrow;
+        __syncthreads();
+        HHP_T(2);
+
+        /* ---- fight nets: x <- normalize(x + Wov x + bov) on columns 400..499 (K = 112: blocks 25..31 of the tile) ---- */
+        if (N.has_att) {
+            hh_f32x16 acc[1][1];
+            acc[0][0] = hhp_zero16();
+            hhp_gemm_h_short<1, 7, 1, R>(reinterpret_cast<const float4 *>(Zh), reinterpret_cast<const float4 *>(Zl), 25, wrow0, H.wovh, H.wovl, 0, HHP_ATT_J, wq * 32, lane, acc);
+            HHP_T(9);
+            const int j = wq * 32 + ci;
+            const float bj = bovr;
+            float y[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = wrow0 + hhp_crow(r, lane);
+                const int ix = hhp_haidx<R>(400 + (j < 100 ? j : 0), row);
+                const float x = (float)Zh[ix] + (float)Zl[ix];
+                y[r] = j < 100 ? x + (acc[0][0][r] + bj) : 0.0f;
+                const float s = hhp_sum32(y[r] * y[r]);
+                if (ci == 0) npart[wq * R + row] = s;
+            }
+            HHP_T(10);
+            __syncthreads();
+            HHP_T(11);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = wrow0 + hhp_crow(r, lane);
+                const float nn = ((npart[row] + npart[R + row]) + npart[2 * R + row]) + npart[3 * R + row];
+                const float den = fmaxf(sqrtf(nn), 1e-12f);
+                if (j < 100) hhp_split_store<R>(Zh, Zl, hhp_haidx<R>(400 + j, row), y[r] / den);
+            }
+            __syncthreads();
+        }
+
+        HHP_T(3);
+        /* the next tile's observation rows: requested before the long GEMM, written to the (idle) X planes after it */
+        float xv[XPT];
+        if (more) {
+            const int od = bank.net[nnet].obs_dim;
+#pragma unroll
+            for (int u = 0; u < XPT; u++) {
+                const int e = tid + u * NTH, i = e >> 5, c = e & 31, r = rows_next[i];
+                xv[u] = (r >= 0 && c < od) ? obs[(size_t)r * obs_stride + c] : 0.0f;
+            }
+        }
+        /* ---- L2 ---- */
+        {
+            hh_f32x16 acc[RH][NT];
+#pragma unroll
+            for (int f = 0; f < RH; f++)
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[f][t] = hhp_zero16();
+            hhp_gemm_h<NT, RH>(reinterpret_cast<const float4 *>(Zh), reinterpret_cast<const float4 *>(Zl), 0, HHP_H / 16, H.wsh, H.wsl, 0, HHP_H, wave * WC, lane, acc);
+            HHP_T(4);
+#pragma unroll
+            for (int f = 0; f < RH; f++)
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const float bj = bsr[t];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[f][t][r] = hhp_tanh(acc[f][t][r] + bj);
+                }
+            HHP_T(5);
+            __syncthreads(); /* Z is dead */
+            HHP_T(6);
+#pragma unroll
+            for (int f = 0; f < RH; f++)
+#pragma unroll
+                for (int t = 0; t < NT; t++) hhp_store_tile<R>(Zh, Zl, wave * WC + t * 32 + ci, f * 32, lane, acc[f][t], [](float a) { return a; });
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < XPT; u++) {
+                const int e = tid + u * NTH;
+                hhp_split_store<R>(Xh, Xl, hhp_haidx<R>(e & 31, e >> 5), xv[u]);
+            }
+        }
+        __syncthreads();
+
+        HHP_T(7);
+        /* ---- L3: split-K, k quarter wq (blocks 8 wq .. 8 wq + 7) of row half wrow0 ---- */
+        hh_f32x16 lacc[1][1];
+        lacc[0][0] = hhp_zero16();
+        hhp_gemm_h_short<1, 8, 1, R>(reinterpret_cast<const float4 *>(Zh), reinterpret_cast<const float4 *>(Zl), wq * 8, wrow0, H.wah, H.wal, wq * 8, HHP_OUT, 0, lane, lacc);
+        __syncthreads(); /* every wave is done reading S: the hi plane now takes the four partials (16 KB x RH) */
+#pragma unroll
+        for (int r = 0; r < 16; r++) Pz[wq * (R * 32) + (wrow0 + hhp_crow(r, lane)) * 32 + ci] = lacc[0][0][r];
+        __syncthreads();
+        for (int e = tid; e < R * HHP_OUT; e += NTH) {
+            const int i = e >> 5, c = e & 31;
+            const float v = (((Pz[e] + Pz[R * 32 + e]) + Pz[2 * R * 32 + e]) + Pz[3 * R * 32 + e]) + bar; /* c == tid & 31 == ci for every e of this thread */
+            Lg[e] = v;
+            if (logits_out && rows[i] >= 0) logits_out[(size_t)rows[i] * HH_POLICY_LOGITS + c] = c < N.n_out ? v : 0.0f;
+        }
+        __syncthreads();
+        /* greedy decode (env_base.py:373-382), one thread per (row, MultiDiscrete component): first maximum of its segment */
+        if (tid < R * 4) {
+            const int row = tid >> 2, k = tid & 3;
+            const int lo = k == 0 ? 0 : (k == 1 ? 13 : (k == 2 ? 22 : 24)), hi = k == 0 ? 13 : (k == 1 ? 22 : (k == 2 ? 24 : 26));
+            const float *lg = Lg + row * 32;
+            int best = lo;
+            if (k < (N.n_out == 26 ? 4 : 3))
+                for (int c = lo + 1; c < hi; c++) if (lg[c] > lg[best]) best = c;
+            int a = (best - lo) << (8 * k);
+            a |= __builtin_amdgcn_mov_dpp(a, 0xB1, 0xf, 0xf, true); /* OR over the quad of the row's four components */
+            a |= __builtin_amdgcn_mov_dpp(a, 0x4E, 0xf, 0xf, true);
+            if (k == 0 && rows[row] >= 0) reinterpret_cast<int *>(actions)[rows[row]] = a;
+        }
+        HHP_T(8);
+        if (!more) break;
+        gt += (int)gridDim.x; net = nnet; tile = ntile; cnt = ncnt;
+        __syncthreads(); /* the partials (hi plane) and the logits are read: the next tile may write Z */
     }
-    __syncthreads();
-    /* greedy decode (env_base.py:373-382), one thread per (row, MultiDiscrete component): first maximum of its segment */
-    if (tid < HHP_ROWS * 4) {
-        const int row = tid >> 2, k = tid & 3;
-        const int lo = k == 0 ? 0 : (k == 1 ? 13 : (k == 2 ? 22 : 24)), hi = k == 0 ? 13 : (k == 1 ? 22 : (k == 2 ? 24 : 26));
-        const float *lg = Lg + row * 32;
-        int best = lo;
-        if (k < (N.n_out == 26 ? 4 : 3))
-            for (int c = lo + 1; c < hi; c++) if (lg[c] > lg[best]) best = c;
-        int a = (best - lo) << (8 * k);
-        a |= __builtin_amdgcn_mov_dpp(a, 0xB1, 0xf, 0xf, true); /* OR over the quad of the row's four components */
-        a |= __builtin_amdgcn_mov_dpp(a, 0x4E, 0xf, 0xf, true);
-        if (k == 0 && rows[row] >= 0) reinterpret_cast<int *>(actions)[rows[row]] = a;
-    }
-    HHP_T(8);
 }
 
 /* ---- host side: fp32 -> (hi, lo) fp16, round to nearest even, subnormals kept ---- */

@@ -202,3 +202,28 @@ def test_policy_abi_misuse_is_reported_through_status_codes():
     assert lib.hh_policy_act(bank.h, p(obs), 65, 30, p(sel), p(act), None, None) < 0      # more rows than max_rows
     assert lib.hh_policy_act(bank.h, p(obs), 64, 30, None, p(act), None, None) < 0        # sel == NULL before any binning call
     bank.act(obs, sel)                                                                      # the bank is still usable
+
+
+@pytest.mark.gpu
+def test_tile_instances_of_the_kernel_agree_bit_for_bit(monkeypatch):
+    """the 64-row-tile persistent instance (HH_POLICY_TILE=64, with and without the grid-stride walk) computes every row with the
+    same operation order as the default 32-row instance: identical logits and actions on a mixed batch larger than one round of
+    workgroups, and on a ragged small one"""
+    from hhmarl_2d_amd import pilots
+    rng = np.random.default_rng(5)
+    sels = np.array([0, pilots.SEL_FIGHT1, pilots.SEL_FIGHT2, pilots.SEL_ESC1, pilots.SEL_ESC2], dtype=np.uint8)
+    for R in (40003, 77):
+        obs = torch.from_numpy(rng.random((R, 30)).astype(np.float32)).cuda()
+        sel = torch.from_numpy(sels[rng.integers(0, len(sels), R)]).cuda()
+        res = []
+        for tile, persist in (("32", "1"), ("64", "1"), ("64", "0")):
+            monkeypatch.setenv("HH_POLICY_TILE", tile)
+            monkeypatch.setenv("HH_POLICY_PERSIST", persist)
+            bank = _bank(7, max_rows=R)
+            lg = torch.zeros((R, 32), device="cuda")
+            act = bank.act(obs, sel, logits=lg).clone()
+            torch.cuda.synchronize()
+            res.append((lg, act))
+            bank.close()
+        for lg, act in res[1:]:
+            assert torch.equal(lg, res[0][0]) and torch.equal(act, res[0][1])

@@ -23,10 +23,11 @@ n = 50
 for _ in range(n):
     bank.act(obs, sel)
 L.lib().hh_policy_prof_read(out, 0)
+TILE = int(os.environ.get("HH_POLICY_TILE", "32"))
 names = ["rows + obs gather", "L1 gemm", "L1 epilogue + barrier", "attention block", "L2 gemm", "L2 tanh", "barrier (Z dead)", "L2 store + barrier", "L3 + logits + decode"]
-print("attention detail: gemm", out[9] / (n * R / 32), "| y + row sums", out[10] / (n * R / 32), "| barrier", out[11] / (n * R / 32), "(the remainder of the block: normalise + store + barrier)")
+print("attention detail: gemm", out[9] / (n * R / TILE), "| y + row sums", out[10] / (n * R / TILE), "| barrier", out[11] / (n * R / TILE), "(the remainder of the block: normalise + store + barrier)")
 tot = sum(out[:9])
-tiles = n * R / 32
+tiles = n * R / TILE
 for k, nm in enumerate(names):
     print(f"{nm:24s} {out[k] / tiles:10.0f} ticks/tile  {100.0 * out[k] / tot:5.1f} %")
 print("total", tot / tiles, "s_memtime ticks per tile (100 MHz constant clock: x 10 ns)")

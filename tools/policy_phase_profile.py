@@ -1,5 +1,5 @@
 """per-phase cycle split of hh_k_policy_h (needs hhmarl_2d_amd/lib/prof_policy.so built with -DHHP_PROFILE:
-   hipcc <flags of __graft_entry__> -DHHP_PROFILE hhmarl_2d_amd/csrc/hh_world.hip -o hhmarl_2d_amd/lib/prof_policy.so;
+   hipcc <HIP_FLAGS of __graft_entry__.py> -DHHP_PROFILE hhmarl_2d_amd/csrc/hh_world.hip -o hhmarl_2d_amd/lib/prof_policy.so;
    run with HH_WORLD_LIB=hhmarl_2d_amd/lib/prof_policy.so)"""
 import ctypes as C
 import os

@@ -482,12 +482,15 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
  * from _action_assess to the commander observation; the pair table a tick leaves behind serves the next sub-step's act
  * phases; a workgroup leaves the sub-step loop as soon as none of its arenas is still inside its macro step
  * (13.2 of 16 sub-steps on average).  Same device functions as the phase kernel: bit-identical. ---- */
-template <int A, int B, int W>
-__global__ __launch_bounds__(B, W) void hh_k_hier_macro(DevPtrs P, DevCfg c, const int8_t *__restrict__ cmd, const int8_t *__restrict__ tape,
+template <int A, int B, int W, bool HLD>
+__global__ __launch_bounds__(B, W) void hh_k_hier_macro(DevPtrs P, DevCfg c_in, const int8_t *__restrict__ cmd, const int8_t *__restrict__ tape,
                                                      float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                      uint8_t *__restrict__ valid_out, uint8_t *__restrict__ done_out,
                                                      int *__restrict__ counters) {
     constexpr int GPB = B / A;
+    DevCfg c_hl = c_in;
+    hh_cfg_set_hl_default(c_hl); /* HLD: the default HighLevelEnv configuration as literals (hh_device.h) */
+    const DevCfg &c = HLD ? c_hl : c_in;
     __shared__ Shared<A, B> sh;
     const int tid = threadIdx.x;
     const int g = tid / A, s = tid % A;

@@ -528,10 +528,11 @@ extern "C" int hh_hl_rollout(hh_world *w, const int8_t *commander_actions, const
     const int grid = (c.N + GPB - 1) / GPB;
     const bool two = w->force_w == 2 || (w->force_w == 0 && grid > w->n_simd);
     hipStream_t st = (hipStream_t)stream;
-    if (two)
-        hipLaunchKernelGGL((hh_k_hier_macro<6, B, 2>), dim3(grid), dim3(B), 0, st, w->P, c, commander_actions, pilot_tape, obs, reward, reward_valid, done, w->counter);
-    else
-        hipLaunchKernelGGL((hh_k_hier_macro<6, B, 1>), dim3(grid), dim3(B), 0, st, w->P, c, commander_actions, pilot_tape, obs, reward, reward_valid, done, w->counter);
+    const bool hld = !w->no_spec && hh_cfg_is_hl_default(c); /* the instance compiled for the reference's default HighLevelEnv configuration */
+#define HH_MLAUNCH(Wv, Dv) hipLaunchKernelGGL((hh_k_hier_macro<6, B, Wv, Dv>), dim3(grid), dim3(B), 0, st, w->P, c, commander_actions, pilot_tape, obs, reward, reward_valid, done, w->counter)
+    if (two) { if (hld) HH_MLAUNCH(2, true); else HH_MLAUNCH(2, false); }
+    else { if (hld) HH_MLAUNCH(1, true); else HH_MLAUNCH(1, false); }
+#undef HH_MLAUNCH
     HIPCHK(hipGetLastError());
     return HH_OK;
 }

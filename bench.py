@@ -411,7 +411,7 @@ def main_hier(args):
     elif args.pilot == "random":
         pilot = RandomPilot(R.dev, args.seed + R.rank)
     elif args.pilot == "net":
-        pilot = NetPilot(w, seed=args.seed)
+        pilot = NetPilot(w, seed=args.seed, bind=os.environ.get("HH_BENCH_NO_BIND", "0") != "1")   # HH_BENCH_NO_BIND=1: binning pass per call (A/B)
     else:
         pilot = MLPPilot(R.dev, seed=args.seed)
     gen = torch.Generator(device=R.dev)

@@ -84,6 +84,11 @@ struct DevPtrs {
     float *trace;                                        /* [trace_cap][trace_K][A][HH_TRACE_F] or nullptr */
     int *trace_pos;                                      /* [trace_K] rows written so far (monotonic) */
     int trace_K, trace_cap;
+    /* optional policy bank bound with hh_hl_bind_policy: the HighLevelEnv phase kernels bin the pilot rows they emit by network
+     * themselves (selector byte -> slot through pol_lut), so hh_policy_act_binned needs no binning pass of its own */
+    const uint8_t *pol_lut;                              /* [256] or nullptr */
+    int *pol_counts, *pol_lists;                         /* rows per network [8] at stride HH_BIN_STRIDE (+ the bank's tickets), [8][pol_max_rows] */
+    int pol_max_rows;
 };
 
 
@@ -106,6 +111,30 @@ struct Arena {
 };
 
 __device__ __forceinline__ void arena_rekey(Arena &a) { a.tkey = hh_rng_tick_key(a.akey, (uint32_t)a.episode, (uint32_t)a.steps); }
+
+/* rows -> per-network lists, one atomic ROUND TRIP per wave (the scheme of hh_k_policy_bin): lane n - 1 carries the wave's count for
+ * network n, the (up to eight) atomics leave as one instruction, every row takes its slot from the base of its network plus its rank
+ * in that network's ballot.  Two halves so that the caller can put work (its output stores) between the request and the use of the
+ * returned base.  Call from wave-uniform control flow; slot = 0 for lanes without a row. */
+#define HH_BIN_STRIDE 32 /* ints between two counters: each on its own 128-byte line (atomics on one line serialise across addresses) */
+struct HhBinTicket { int base, rank; };
+__device__ __forceinline__ HhBinTicket hh_bin_rows_issue(int *__restrict__ counts, int slot) {
+    const int lane = threadIdx.x & 63;
+    int mine = 0;
+    HhBinTicket t{0, 0};
+#pragma unroll
+    for (int n = 1; n <= 8; n++) {
+        const unsigned long long m = __ballot(slot == n);
+        if (lane == n - 1) mine = __popcll(m);
+        if (slot == n) t.rank = __popcll(m & ((1ULL << lane) - 1ULL));
+    }
+    if (lane < 8 && mine) t.base = atomicAdd(&counts[lane * HH_BIN_STRIDE], mine);
+    return t;
+}
+__device__ __forceinline__ void hh_bin_rows_finish(const HhBinTicket &t, int *__restrict__ lists, int max_rows, int row, int slot) {
+    const int base = __shfl(t.base, slot > 0 ? slot - 1 : 0);
+    if (slot > 0 && base + t.rank < max_rows) lists[(size_t)(slot - 1) * max_rows + base + t.rank] = row;
+}
 
 /* one trace row of the lane's unit: lat, lon, heading, speed, alive, rocket lat, rocket lon, rocket alive + 16 * episode */
 __device__ __forceinline__ void trace_append(const DevPtrs &P, int A, int n, int s, const Unit &m, const Arena &ar, int &cursor) {

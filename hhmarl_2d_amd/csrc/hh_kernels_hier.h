@@ -377,13 +377,27 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
         __syncthreads();
     }
     int obs_side = -1; /* which side's pilot observations this launch emits */
+    /* a bound policy bank (hh_hl_bind_policy): this launch's pilot rows are binned by network here.  The selector of a row is known
+     * as soon as the phase body is through (policy type from the commander's / the opponent's own choice, env_hier.py:100-112) — for
+     * HL_AGENTS_ACT, which kills nobody, before it — so the list slot is REQUESTED there and used after the observation tile has
+     * left: all workgroups finish together, and the same-address atomics of 820 waves arriving at once are a ~5 us tail otherwise. */
+    int pslot = 0;
+    HhBinTicket bt{0, 0};
+    auto bin_issue = [&](int side) {
+        const bool mine_ = side == 0 ? agent : !agent;
+        const int sb = (active && ar.hl_run && m.alive && mine_) ? ((m.cmd_act != 0 ? 1 : 2) | (m.ac_type << 2)) : 0;
+        pslot = sb ? (int)P.pol_lut[sb] : 0;
+        bt = hh_bin_rows_issue(P.pol_counts, pslot);
+    };
 
     if (phase == HH_HL_BEGIN) {
         hl_do_begin<A, B>(c, sh, tid, base, s, n, active, L, cmd);
         obs_side = 0;
+        if (P.pol_lut && pilot_obs) bin_issue(0);
     } else if (phase == HH_HL_AGENTS_ACT) {
         int8_t act[4];
         hl_load_act(actions, u, active, act);
+        if (P.pol_lut && pilot_obs) bin_issue(1);
         hl_do_agents_act<A, B, W>(c, sh, tid, base, s, active, L, act);
         obs_side = 1;
     } else if (phase == HH_HL_TICK) {
@@ -396,7 +410,10 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
             if (rn && (tid & 63) == 0 && running_count) atomicAdd(reinterpret_cast<unsigned long long *>(running_count + 2), (unsigned long long)__popcll(rn));
         }
         obs_side = 0;
+        if (P.pol_lut && pilot_obs) bin_issue(0);
     } else { /* HH_HL_END, HH_HL_REFRESH, HH_HL_RESET */
+        /* a bound policy bank: rows the last tick binned and nobody consumed (the macro step is over) are dropped here */
+        if (P.pol_lut && blockIdx.x == 0 && tid <= 8) P.pol_counts[tid * HH_BIN_STRIDE] = 0;
         hl_do_end<A, B>(P, c, sh, tid, g, base, s, n, active, L, phase, reward_out, valid_out, done_out, mask);
         hl_store_commander_obs<A, B>(c, sh, tid, phase, obs_out, mask);
     }
@@ -427,6 +444,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
             } else {
                 for (int k = tid; k < cnt; k += B) dst[k] = ptile[k];
             }
+            if (P.pol_lut) hh_bin_rows_finish(bt, P.pol_lists, P.pol_max_rows, (int)u, pslot);
         } else {
             /* two workgroups per SIMD share the CU's 160 KB: only the acting side's rows are staged (in the tick's exchange
              * area), the other side's zeros are produced by the store loop; 8-byte stores (a side's 90 floats are even) */
@@ -459,6 +477,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
                     dst[k] = side == obs_side ? sh.u.obs[ar_ * (HALF * 30) + q] : 0.0f;
                 }
             }
+            if (P.pol_lut) hh_bin_rows_finish(bt, P.pol_lists, P.pol_max_rows, (int)u, pslot);
         }
     }
     if (active) {

@@ -86,14 +86,36 @@ __global__ __launch_bounds__(256) void hh_k_policy_bin(int n_rows, const uint8_t
         if (s == n) rank = __popcll(m & ((1ULL << lane) - 1ULL));
     }
     int base = 0;
-    if (lane < HH_POLICY_MAX_NETS && mine) base = atomicAdd(&counts[lane], mine);
+    if (lane < HH_POLICY_MAX_NETS && mine) base = atomicAdd(&counts[lane * HH_BIN_STRIDE], mine);
     base = __shfl(base, s > 0 ? s - 1 : 0);
     if (s > 0) lists[(size_t)(s - 1) * max_rows + base + rank] = r;
 }
 
 /* the counters are cleared by a kernel, not a memset node: the call sequence is replayed from HIP graphs */
 __global__ void hh_k_policy_clear(int *__restrict__ counts) {
-    if (threadIdx.x < HH_POLICY_MAX_NETS) counts[threadIdx.x] = 0;
+    if (threadIdx.x < HH_POLICY_MAX_NETS) counts[threadIdx.x * HH_BIN_STRIDE] = 0;
+}
+
+/* consume = 1 (hh_policy_act_binned: the row lists were written by the world's own kernels): a workgroup takes a ticket when it is
+ * done (it read the counters at its start), and the last one to do so clears the counters for the next binning pass — no clear
+ * kernel, and nothing that depends on how a HIP graph strings the calls together.  Tickets are sharded over 32 sub-counters with
+ * one top-level ticket per shard: ~500 workgroups finish together and same-address atomics serialise at ~13 ns each (a single
+ * ticket counter measured +5 us per launch).  counts[] in units of HH_BIN_STRIDE ints (every counter on its own 128-byte line):
+ * 0..7 rows per network, 8 top-level ticket, 9..40 shard tickets. */
+#define HHP_COUNTS_INTS (41 * HH_BIN_STRIDE)
+__device__ __forceinline__ void hhp_consume_counts(int *counts, int consume) {
+    if (consume && threadIdx.x == 0) {
+        const int j = blockIdx.x & 31;
+        const int nj = ((int)gridDim.x - j + 31) >> 5; /* workgroups of this shard */
+        if (atomicAdd(&counts[(9 + j) * HH_BIN_STRIDE], 1) == nj - 1) {
+            counts[(9 + j) * HH_BIN_STRIDE] = 0;
+            const int shards = min((int)gridDim.x, 32);
+            if (atomicAdd(&counts[HH_POLICY_MAX_NETS * HH_BIN_STRIDE], 1) == shards - 1) {
+#pragma unroll
+                for (int n = 0; n <= HH_POLICY_MAX_NETS; n++) counts[n * HH_BIN_STRIDE] = 0;
+            }
+        }
+    }
 }
 
 __device__ __forceinline__ hh_f32x16 hhp_zero16() {
@@ -154,8 +176,8 @@ __device__ __forceinline__ void hhp_gemm(const float4 *__restrict__ a_lds, int k
 #define HHP_LDS_BYTES (HHP_LDS_FLOATS * 4)
 
 __global__ __launch_bounds__(256, 2) void hh_k_policy(HhpBank bank, int n_nets, const float *__restrict__ obs, int obs_stride,
-                                                      const int *__restrict__ counts, const int *__restrict__ lists, int max_rows,
-                                                      int8_t *__restrict__ actions, float *__restrict__ logits_out) {
+                                                      int *counts, const int *__restrict__ lists, int max_rows,
+                                                      int8_t *__restrict__ actions, float *__restrict__ logits_out, int consume) {
     extern __shared__ __align__(16) float lds[];
     float *Zp = lds;                 /* [64][2][32][4]  activations after L1 (A operand of att and L2), then after L2 (A operand of
                                         L3: wave w reads only its own columns = planes [32 w, 32 w + 32)), then wave w's L3 partial */
@@ -167,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void hh_k_policy(HhpBank bank, int n_nets, 
     /* which (network, tile) is this workgroup's?  (all counters requested at once: one global round trip) */
     int cn[HH_POLICY_MAX_NETS];
 #pragma unroll
-    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? counts[n] : 0;
+    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? min(counts[n * HH_BIN_STRIDE], max_rows) : 0;
     int net = -1, tile = blockIdx.x, cnt = 0;
 #pragma unroll
     for (int n = 0; n < HH_POLICY_MAX_NETS; n++) {
@@ -177,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void hh_k_policy(HhpBank bank, int n_nets, 
             else tile -= nt;
         }
     }
-    if (net < 0) return;
+    if (net < 0) { hhp_consume_counts(counts, consume); return; }
     const HhpNet N = bank.net[net];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, ci = lane & 31;
@@ -288,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void hh_k_policy(HhpBank bank, int n_nets, 
         }
         reinterpret_cast<int *>(actions)[rows[tid]] = (a[0] & 0xff) | ((a[1] & 0xff) << 8) | ((a[2] & 0xff) << 16) | ((a[3] & 0xff) << 24);
     }
+    hhp_consume_counts(counts, consume);
 }
 
 #include "hh_policy_kernel_h16.h"
@@ -340,7 +363,8 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     p->lut = nullptr; p->counts = nullptr; p->lists = nullptr;
     hipError_t e = hipMalloc(&p->lut, 256);
     if (e == hipSuccess) e = hipMemset(p->lut, 0, 256);
-    if (e == hipSuccess) e = hipMalloc(&p->counts, HH_POLICY_MAX_NETS * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&p->counts, HHP_COUNTS_INTS * sizeof(int)); /* rows per network + the tickets of hhp_consume_counts */
+    if (e == hipSuccess) e = hipMemset(p->counts, 0, HHP_COUNTS_INTS * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&p->lists, (size_t)HH_POLICY_MAX_NETS * max_rows * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&p->slab, HHP_SLOT_BYTES * HH_POLICY_MAX_NETS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy), hipFuncAttributeMaxDynamicSharedMemorySize, HHP_LDS_BYTES);
@@ -453,6 +477,24 @@ extern "C" int hh_policy_set_lut(hh_policy *p, const uint8_t *lut) {
     return HH_OK;
 }
 
+/* the forward kernel over the current row lists; consume: the last workgroup to read the counters clears them */
+static int hhp_launch_forward(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, int8_t *actions, float *logits, int consume, hipStream_t st) {
+    const int grid = (n_rows + HHP_ROWS - 1) / HHP_ROWS + p->n_nets; /* upper bound of the tiles over all networks */
+    if (p->fp32) {
+        hipLaunchKernelGGL(hh_k_policy, dim3(grid), dim3(256), HHP_LDS_BYTES, st, p->bank, p->n_nets, obs, obs_stride, p->counts, p->lists, p->max_rows,
+                           actions, logits, consume);
+    } else if (p->tile_rows == 64) { /* persistent: one workgroup per CU walks the tiles grid-stride */
+        const int tiles = (n_rows + 63) / 64 + p->n_nets;
+        hipLaunchKernelGGL(hh_k_policy_h<2>, dim3(p->persist && tiles > p->n_cu ? p->n_cu : tiles), dim3(512), HHPH_LDS_BYTES(2), st, p->bank, p->bankh, p->n_nets,
+                           obs, obs_stride, p->counts, p->lists, p->max_rows, actions, logits, consume);
+    } else {
+        hipLaunchKernelGGL(hh_k_policy_h<1>, dim3(grid), dim3(256), HHPH_LDS_BYTES(1), st, p->bank, p->bankh, p->n_nets, obs, obs_stride, p->counts, p->lists,
+                           p->max_rows, actions, logits, consume);
+    }
+    HIPCHK(hipGetLastError());
+    return HH_OK;
+}
+
 extern "C" int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, const uint8_t *sel, int8_t *actions,
                              float *logits, void *stream) {
     if (!p || !obs || !actions || n_rows <= 0 || obs_stride <= 0) { g_err = "bad argument"; return HH_E_ARG; }
@@ -466,20 +508,30 @@ extern "C" int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int
         hipLaunchKernelGGL(hh_k_policy_bin, dim3((n_rows + 255) / 256), dim3(256), 0, st, n_rows, sel, p->lut, p->max_rows, p->counts, p->lists, actions);
         p->binned_rows = n_rows;
     }
-    const int grid = (n_rows + HHP_ROWS - 1) / HHP_ROWS + p->n_nets; /* upper bound of the tiles over all networks */
-    if (p->fp32) {
-        hipLaunchKernelGGL(hh_k_policy, dim3(grid), dim3(256), HHP_LDS_BYTES, st, p->bank, p->n_nets, obs, obs_stride, p->counts, p->lists, p->max_rows,
-                           actions, logits);
-    } else if (p->tile_rows == 64) { /* persistent: one workgroup per CU walks the tiles grid-stride */
-        const int tiles = (n_rows + 63) / 64 + p->n_nets;
-        hipLaunchKernelGGL(hh_k_policy_h<2>, dim3(p->persist && tiles > p->n_cu ? p->n_cu : tiles), dim3(512), HHPH_LDS_BYTES(2), st, p->bank, p->bankh, p->n_nets,
-                           obs, obs_stride, p->counts, p->lists, p->max_rows, actions, logits);
-    } else {
-        hipLaunchKernelGGL(hh_k_policy_h<1>, dim3(grid), dim3(256), HHPH_LDS_BYTES(1), st, p->bank, p->bankh, p->n_nets, obs, obs_stride, p->counts, p->lists,
-                           p->max_rows, actions, logits);
-    }
-    HIPCHK(hipGetLastError());
+    return hhp_launch_forward(p, obs, n_rows, obs_stride, actions, logits, 0, st);
+}
+
+/* HighLevelEnv: the world's phase kernels bin the pilot rows they emit into this bank's lists themselves */
+extern "C" int hh_hl_bind_policy(hh_world *w, hh_policy *p) {
+    if (!w) { g_err = "null argument"; return HH_E_ARG; }
+    if (w->cfg.env_kind != HH_ENV_HIGHLEVEL) { g_err = "hh_hl_bind_policy: not a HighLevelEnv world"; return HH_E_ARG; }
+    if (!p) { w->P.pol_lut = nullptr; w->P.pol_counts = nullptr; w->P.pol_lists = nullptr; w->P.pol_max_rows = 0; return HH_OK; }
+    if (p->device != w->device) { g_err = "hh_hl_bind_policy: world and policy bank live on different devices"; return HH_E_ARG; }
+    if ((long long)p->max_rows < (long long)w->dc.N * w->dc.A) { g_err = "hh_hl_bind_policy: the bank's max_rows is smaller than n_arenas x 6"; return HH_E_ARG; }
+    if (p->n_nets == 0) { g_err = "hh_hl_bind_policy: no network loaded"; return HH_E_ARG; }
+    HH_GUARD(w);
+    HIPCHK(hipMemset(p->counts, 0, HHP_COUNTS_INTS * sizeof(int)));
+    w->P.pol_lut = p->lut; w->P.pol_counts = p->counts; w->P.pol_lists = p->lists; w->P.pol_max_rows = p->max_rows;
+    p->binned_rows = 0; /* the lists now belong to the world's kernels: a later sel == NULL call of hh_policy_act must re-bin */
     return HH_OK;
+}
+
+extern "C" int hh_policy_act_binned(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, int8_t *actions, float *logits, void *stream) {
+    if (!p || !obs || !actions || n_rows <= 0 || obs_stride <= 0) { g_err = "bad argument"; return HH_E_ARG; }
+    if (n_rows > p->max_rows) { g_err = "hh_policy_act_binned: n_rows exceeds max_rows of hh_policy_create"; return HH_E_ARG; }
+    if (p->n_nets == 0) { g_err = "hh_policy_act_binned: no network loaded"; return HH_E_ARG; }
+    HH_GUARD(p);
+    return hhp_launch_forward(p, obs, n_rows, obs_stride, actions, logits, 1, (hipStream_t)stream);
 }
 
 #ifdef HHP_PROFILE

@@ -239,8 +239,8 @@ __device__ __forceinline__ bool hhp_locate(const int (&cn)[HH_POLICY_MAX_NETS], 
  * epilogues (tanh, hi/lo split, 2-byte LDS scatter) and GEMMs alternate instead of overlapping. */
 template <int RH>
 __global__ __launch_bounds__(256 * RH, RH == 1 ? 2 : 1) void hh_k_policy_h(HhpBank bank, HhpBankH bankh, int n_nets, const float *__restrict__ obs, int obs_stride,
-                                                                           const int *__restrict__ counts, const int *__restrict__ lists, int max_rows,
-                                                                           int8_t *__restrict__ actions, float *__restrict__ logits_out) {
+                                                                           int *counts, const int *__restrict__ lists, int max_rows,
+                                                                           int8_t *__restrict__ actions, float *__restrict__ logits_out, int consume) {
     constexpr int R = 32 * RH, NTH = 256 * RH, NT = 4 / RH, WC = 32 * NT; /* rows per tile, threads, column tiles and columns per wave in L1 / L2 */
     constexpr int XPT = R * HHP_XK / NTH;                                 /* observation elements per thread (8 / 4) */
     extern __shared__ __align__(16) unsigned char ldsb[];
@@ -255,11 +255,11 @@ __global__ __launch_bounds__(256 * RH, RH == 1 ? 2 : 1) void hh_k_policy_h(HhpBa
 
     int cn[HH_POLICY_MAX_NETS];
 #pragma unroll
-    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? counts[n] : 0;
+    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? min(counts[n * HH_BIN_STRIDE], max_rows) : 0;
     const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int wq = wave & 3, wrow0 = (wave >> 2) * 32; /* attention / L3: column or k quarter, row half of this wave */
     int gt = blockIdx.x, net, tile, cnt;
-    if (!hhp_locate<R>(cn, gt, net, tile, cnt)) return;
+    if (!hhp_locate<R>(cn, gt, net, tile, cnt)) { hhp_consume_counts(counts, consume); return; }
     HHP_T0;
     { /* first tile: rows and observation in the open; later tiles find both prefetched */
         const int tid = tid0;
@@ -431,6 +431,7 @@ __global__ __launch_bounds__(256 * RH, RH == 1 ? 2 : 1) void hh_k_policy_h(HhpBa
         gt += (int)gridDim.x; net = nnet; tile = ntile; cnt = ncnt;
         __syncthreads(); /* the partials (hi plane) and the logits are read: the next tile may write Z */
     }
+    hhp_consume_counts(counts, consume);
 }
 
 /* ---- host side: fp32 -> (hi, lo) fp16, round to nearest even, subnormals kept ---- */

@@ -110,6 +110,18 @@ class PolicyBank:
                                       C.c_void_p(actions.data_ptr()), lp, st))
         return actions
 
+    def act_binned(self, obs, actions, logits=None):
+        """the forward over row lists a bound world's kernels wrote (World.bind_policy): no binning pass, the kernel clears the
+        row counters behind itself"""
+        assert obs.dtype == torch.float32 and obs.is_contiguous() and actions.dtype == torch.int8 and actions.is_contiguous()
+        stride = obs.shape[-1]
+        n_rows = obs.numel() // stride
+        assert actions.numel() == n_rows * 4
+        st = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
+        lp = None if logits is None else C.c_void_p(logits.data_ptr())
+        L.check(L.lib().hh_policy_act_binned(self.h, C.c_void_p(obs.data_ptr()), n_rows, stride, C.c_void_p(actions.data_ptr()), lp, st))
+        return actions
+
     @staticmethod
     def flops_per_row(kind):
         return PN.flops_per_row(kind)
@@ -119,12 +131,25 @@ class NetPilot:
     """HighLevelEnv pilots (env_base.py:349-398): every live unit's lowlevel_state row through the network its selector
     byte names (fight / escape policy of its aircraft type), actions written into one static [N, A, 4] buffer."""
 
-    def __init__(self, world, bank=None, seed=0):
+    def __init__(self, world, bank=None, seed=0, bind=True):
         self.bank = bank if bank is not None else PolicyBank.random_init(world.device, seed=seed, max_rows=world.N * world.A)
         self.act = torch.zeros((world.N, world.A, 4), dtype=torch.int8, device=world.device)
+        # bound: the world's phase kernels write the bank's row lists themselves (hh_hl_bind_policy), every call is the forward only.
+        # The pilot must then be called exactly once after every hl_begin / hl_agents_act / hl_tick whose rows are wanted, which is
+        # what macro_step does; bind=False keeps the self-contained form (binning pass per call from pilot_mode).
+        self.world = world if bind else None
+        if bind:
+            world.bind_policy(self.bank)
 
     def __call__(self, pilot_obs, pilot_mode):
+        if self.world is not None:
+            return self.bank.act_binned(pilot_obs, self.act)
         return self.bank.act(pilot_obs, pilot_mode, self.act)
+
+    def close(self):
+        if self.world is not None:
+            self.world.bind_policy(None)
+            self.world = None
 
 
 class OpponentNets:

@@ -203,6 +203,12 @@ class World:
         L.check(L.lib().hh_arena_status(self.h, _p(out), self._stream()))
         return out
 
+    def bind_policy(self, bank):
+        """HighLevelEnv: let the phase kernels bin the pilot rows they emit into `bank`'s row lists (hh_hl_bind_policy); None unbinds.
+        The world keeps the bank alive while bound."""
+        L.check(L.lib().hh_hl_bind_policy(self.h, bank.h if bank is not None else None))
+        self._bound_bank = bank
+
     def trace_enable(self, n_arenas=1, capacity=1024):
         """device-side trajectory ring buffer for the first n_arenas arenas (0 turns it off)"""
         L.check(L.lib().hh_trace_enable(self.h, int(n_arenas), int(capacity)))

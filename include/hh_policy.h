@@ -66,6 +66,20 @@ int hh_policy_set_lut(hh_policy *p, const uint8_t *lut);
 int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, const uint8_t *sel, int8_t *actions,
                   float *logits, void *stream);
 
+/* HighLevelEnv with the networks in the loop (env_base.py:349-398 inside env_hier.py:114-140): bind a bank to a world and the
+ * phase kernels (hh_hl_begin / hh_hl_agents_act / hh_hl_tick) bin the pilot rows they emit by network themselves — through this
+ * bank's LUT into its row lists — while they still hold the selector in a register; hh_policy_act_binned then runs the forward
+ * over those lists with no binning pass, and the last workgroup to read the row counters clears them for the next phase
+ * (hh_hl_end / hh_reset drop rows nobody consumed).  Per policy call this replaces two launches (counter clear + binning: ~15 us of
+ * ~60 at 8192 arenas).  Contract: after binding, follow every hh_hl_begin / hh_hl_agents_act / hh_hl_tick whose rows are wanted
+ * with ONE hh_policy_act_binned (obs = the pilot_obs that phase wrote, n_rows = n_arenas x 6, obs_stride = 30) before the next
+ * phase launch; rows without a network keep whatever their action bytes held (the world ignores them).  The bank must have its
+ * networks and LUT loaded, live on the world's device, have max_rows >= n_arenas x 6, and outlive the binding:
+ * hh_hl_bind_policy(w, NULL) unbinds.  Mixing hh_policy_act (with selectors) on a bound bank is allowed between macro steps. */
+struct hh_world;
+int hh_hl_bind_policy(struct hh_world *w, hh_policy *p);
+int hh_policy_act_binned(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, int8_t *actions, float *logits, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

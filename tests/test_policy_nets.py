@@ -227,3 +227,54 @@ def test_tile_instances_of_the_kernel_agree_bit_for_bit(monkeypatch):
             bank.close()
         for lg, act in res[1:]:
             assert torch.equal(lg, res[0][0]) and torch.equal(act, res[0][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_w,nA,nO,N", [("0", 3, 3, 1003), ("2", 3, 3, 517), ("0", 2, 3, 300)], ids=["3v3", "3v3-W2", "2v3"])
+def test_rows_binned_by_the_world_kernels_give_the_same_macro_steps(monkeypatch, force_w, nA, nO, N):
+    """hh_hl_bind_policy: the phase kernels write the bank's row lists themselves and hh_policy_act_binned runs the forward only
+    (the last workgroup clears the counters; hh_hl_end drops what the last tick binned).  Same worlds, same weights: every macro
+    step's outputs, the pilots' actions of every sub-step and the final state equal the self-contained form (binning pass from
+    pilot_mode per call); afterwards the bank still serves selector calls, and unbinding restores the plain behaviour."""
+    from hhmarl_2d_amd import pilots
+    from hhmarl_2d_amd.env_hier import macro_step
+    from hhmarl_2d_amd.world import World, make_config
+    monkeypatch.setenv("HH_FORCE_W", force_w)
+    kw = dict(n_arenas=N, env_kind=1, n_agents=nA, n_opps=nO, seed=21, auto_reset=True, horizon=80)
+    a, b = World(make_config(**kw)), World(make_config(**kw))
+    assert torch.equal(a.reset(), b.reset())
+    pa, pb = pilots.NetPilot(a, seed=4, bind=False), pilots.NetPilot(b, seed=4, bind=True)
+    log_a, log_b = [], []
+
+    def tap(pilot, log):
+        def f(po, pm):
+            act = pilot(po, pm)
+            log.append((act.clone(), pm.clone()))
+            return act
+        return f
+    rng = np.random.default_rng(3)
+    dones = 0
+    for step in range(6):
+        cmd = torch.from_numpy(rng.integers(0, 3, (N, nA)).astype(np.int8)).cuda()
+        outs_a = macro_step(a, cmd, tap(pa, log_a))
+        outs_b = macro_step(b, cmd, tap(pb, log_b))
+        for x, y, name in zip(outs_a, outs_b, ("obs", "reward", "valid", "done")):
+            assert torch.equal(x, y), f"step {step}: {name}"
+        dones += int(outs_a[3].sum())
+    assert len(log_a) == len(log_b) == 6 * 32
+    for k, ((xa, ma), (xb, mb)) in enumerate(zip(log_a, log_b)):
+        assert torch.equal(ma, mb), f"call {k}: selector bytes"
+        live = ma != 0
+        assert torch.equal(xa[live], xb[live]), f"call {k}: pilots' actions"
+    sa, sb = a.get_state(), b.get_state()
+    for key in sa:
+        assert np.array_equal(sa[key], sb[key]), key
+    assert dones > 0
+    # the bound bank still answers a plain selector call, and an unbound pilot on the same world behaves like the other world's
+    obs = torch.rand((64, 30), device="cuda")
+    sel = torch.full((64,), pilots.SEL_FIGHT1, dtype=torch.uint8, device="cuda")
+    assert torch.equal(pb.bank.act(obs, sel), pa.bank.act(obs, sel))
+    pb.close()
+    cmd = torch.from_numpy(rng.integers(0, 3, (N, nA)).astype(np.int8)).cuda()
+    for x, y in zip(macro_step(a, cmd, pa), macro_step(b, cmd, pb)):
+        assert torch.equal(x, y)

@@ -332,8 +332,18 @@ struct hh_policy {
     char *slab;               /* ONE allocation for every network's weights (slot stride HHP_SLOT_BYTES): large, 2 MB-aligned mappings keep
                                  the weight stream on a handful of TLB entries instead of a fresh small allocation per network */
     uint8_t *lut;             /* [256] dev */
-    int *counts, *lists;      /* [MAX_NETS], [MAX_NETS][max_rows] dev */
+    int *counts, *lists;      /* counters (HHP_COUNTS_INTS), [MAX_NETS][max_rows] dev */
+    hh_world *bound;          /* hh_hl_bind_policy: the world whose kernels write the lists (one world per bank), or nullptr */
 };
+static void hhp_forget_world(hh_policy *p) { p->bound = nullptr; }
+static void hhp_unbind(hh_policy *p) {
+    if (p->bound) {
+        hh_world *w = p->bound;
+        w->P.pol_lut = nullptr; w->P.pol_counts = nullptr; w->P.pol_lists = nullptr; w->P.pol_max_rows = 0;
+        w->bound_policy = nullptr;
+        p->bound = nullptr;
+    }
+}
 
 static const int HHP_INPUTS[4][3][3] = {
     /* first column, last + 1, width: models/ac_models_hetero.py Fight1 214-231, Fight2 326-343, Esc1 46-63, Esc2 122-139 */
@@ -351,7 +361,7 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     DeviceGuard guard_(device);
     if (!guard_.ok) { g_err = "hipSetDevice failed"; return HH_E_HIP; }
     hh_policy *p = new hh_policy();
-    p->device = device; p->max_rows = max_rows; p->n_nets = 0; p->binned_rows = 0;
+    p->device = device; p->max_rows = max_rows; p->n_nets = 0; p->binned_rows = 0; p->bound = nullptr;
     memset(&p->bank, 0, sizeof(p->bank));
     memset(&p->bankh, 0, sizeof(p->bankh));
     { const char *e = getenv("HH_POLICY_FP32"); p->fp32 = e ? atoi(e) : 0; }
@@ -385,6 +395,7 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
 
 extern "C" int hh_policy_destroy(hh_policy *p) {
     if (!p) return HH_E_ARG;
+    hhp_unbind(p); /* a world still bound to this bank goes back to emitting selector bytes only */
     DeviceGuard guard_(p->device);
     (void)hipFree(p->slab);
     (void)hipFree(p->lut); (void)hipFree(p->counts); (void)hipFree(p->lists);
@@ -515,13 +526,16 @@ extern "C" int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int
 extern "C" int hh_hl_bind_policy(hh_world *w, hh_policy *p) {
     if (!w) { g_err = "null argument"; return HH_E_ARG; }
     if (w->cfg.env_kind != HH_ENV_HIGHLEVEL) { g_err = "hh_hl_bind_policy: not a HighLevelEnv world"; return HH_E_ARG; }
-    if (!p) { w->P.pol_lut = nullptr; w->P.pol_counts = nullptr; w->P.pol_lists = nullptr; w->P.pol_max_rows = 0; return HH_OK; }
+    if (w->bound_policy) hhp_unbind(w->bound_policy);
+    if (!p) return HH_OK;
+    if (p->bound) hhp_unbind(p); /* one world per bank: the row lists and counters are the bank's */
     if (p->device != w->device) { g_err = "hh_hl_bind_policy: world and policy bank live on different devices"; return HH_E_ARG; }
     if ((long long)p->max_rows < (long long)w->dc.N * w->dc.A) { g_err = "hh_hl_bind_policy: the bank's max_rows is smaller than n_arenas x 6"; return HH_E_ARG; }
     if (p->n_nets == 0) { g_err = "hh_hl_bind_policy: no network loaded"; return HH_E_ARG; }
     HH_GUARD(w);
     HIPCHK(hipMemset(p->counts, 0, HHP_COUNTS_INTS * sizeof(int)));
     w->P.pol_lut = p->lut; w->P.pol_counts = p->counts; w->P.pol_lists = p->lists; w->P.pol_max_rows = p->max_rows;
+    w->bound_policy = p; p->bound = w;
     p->binned_rows = 0; /* the lists now belong to the world's kernels: a later sel == NULL call of hh_policy_act must re-bin */
     return HH_OK;
 }

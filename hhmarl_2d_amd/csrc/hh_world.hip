@@ -60,6 +60,7 @@ struct hh_world {
     int no_spec;  /* HH_NO_SPEC=1: never pick the instance compiled for the default level-3 configuration */
     int no_two;   /* HH_NO_TWO=1: never pick the two-wave (simulation + output wave) form for small worlds */
     void *trace_mem; /* trajectory ring buffer + cursors (hh_trace_enable), separate allocation */
+    struct hh_policy *bound_policy; /* hh_hl_bind_policy: the bank whose row lists P.pol_* point into (it points back at this world) */
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -113,6 +114,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     d.seed = cfg->seed; d.arena_offset = cfg->arena_offset;
     w->block = HH_BLOCK;
     w->trace_mem = nullptr;
+    w->bound_policy = nullptr;
     { const char *fw = getenv("HH_FORCE_W"); w->force_w = fw ? atoi(fw) : 0; }
     { const char *nq = getenv("HH_NO_QUAD"); w->no_quad = nq ? atoi(nq) : 0; }
     { const char *ns = getenv("HH_NO_SPEC"); w->no_spec = ns ? atoi(ns) : 0; }
@@ -161,8 +163,11 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     return HH_OK;
 }
 
+static void hhp_forget_world(struct hh_policy *p); /* hh_policy_kernel.h */
+
 extern "C" int hh_world_destroy(hh_world *w) {
     if (!w) return HH_E_ARG;
+    if (w->bound_policy) hhp_forget_world(w->bound_policy);
     DeviceGuard guard_(w->device);
     (void)hipFree(w->slab);
     if (w->trace_mem) (void)hipFree(w->trace_mem);

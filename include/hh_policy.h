@@ -74,8 +74,8 @@ int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_st
  * ~60 at 8192 arenas).  Contract: after binding, follow every hh_hl_begin / hh_hl_agents_act / hh_hl_tick whose rows are wanted
  * with ONE hh_policy_act_binned (obs = the pilot_obs that phase wrote, n_rows = n_arenas x 6, obs_stride = 30) before the next
  * phase launch; rows without a network keep whatever their action bytes held (the world ignores them).  The bank must have its
- * networks and LUT loaded, live on the world's device, have max_rows >= n_arenas x 6, and outlive the binding:
- * hh_hl_bind_policy(w, NULL) unbinds.  Mixing hh_policy_act (with selectors) on a bound bank is allowed between macro steps. */
+ * networks and LUT loaded, live on the world's device and have max_rows >= n_arenas x 6; one world per bank (binding a second
+ * world moves the binding).  hh_hl_bind_policy(w, NULL) unbinds; destroying either side unbinds too.  Mixing hh_policy_act (with selectors) on a bound bank is allowed between macro steps. */
 struct hh_world;
 int hh_hl_bind_policy(struct hh_world *w, hh_policy *p);
 int hh_policy_act_binned(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, int8_t *actions, float *logits, void *stream);

@@ -278,3 +278,38 @@ def test_rows_binned_by_the_world_kernels_give_the_same_macro_steps(monkeypatch,
     cmd = torch.from_numpy(rng.integers(0, 3, (N, nA)).astype(np.int8)).cuda()
     for x, y in zip(macro_step(a, cmd, pa), macro_step(b, cmd, pb)):
         assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_binding_survives_either_side_going_away():
+    """hh_hl_bind_policy keeps raw device pointers of the bank inside the world: destroying the bank, rebinding it to another world or
+    destroying the world first must all leave both sides usable"""
+    from hhmarl_2d_amd import pilots
+    from hhmarl_2d_amd.env_hier import macro_step
+    from hhmarl_2d_amd.world import World, make_config
+    kw = dict(n_arenas=64, env_kind=1, seed=2, auto_reset=True)
+    w1, w2 = World(make_config(**kw)), World(make_config(**kw))
+    w1.reset(), w2.reset()
+    cmd = torch.ones((64, 3), dtype=torch.int8, device="cuda")
+    bank = pilots.PolicyBank.random_init(torch.device("cuda", 0), seed=1, max_rows=64 * 6)
+    p1 = pilots.NetPilot(w1, bank=bank)                  # bound to w1
+    ref = [t.clone() for t in macro_step(w1, cmd, p1)]
+    p2 = pilots.NetPilot(w2, bank=bank)                  # the binding moves to w2: w1 is back to emitting selector bytes only
+    out2 = macro_step(w2, cmd, p2)
+    for x, y in zip(ref, out2):
+        assert torch.equal(x, y)
+    p1.world = None                                       # w1's pilot falls back to the binning pass (its world is no longer bound)
+    macro_step(w1, cmd, p1)
+    bank.close()                                          # bank destroyed while bound to w2
+    tape = torch.zeros((16, 64, 6, 4), dtype=torch.int8, device="cuda")
+    w2.hl_rollout(cmd, tape)                              # w2 still steps (no dangling list pointers)
+    po, pm = w2.hl_begin(cmd)
+    torch.cuda.synchronize()
+    assert pm.any()
+    bank2 = pilots.PolicyBank.random_init(torch.device("cuda", 0), seed=1, max_rows=64 * 6)
+    w2.bind_policy(bank2)
+    w2.close()                                            # world destroyed while bound
+    obs = torch.rand((64, 30), device="cuda")
+    sel = torch.full((64,), pilots.SEL_FIGHT2, dtype=torch.uint8, device="cuda")
+    assert bank2.act(obs, sel).shape == (64, 4)           # the bank lives on
+    torch.cuda.synchronize()

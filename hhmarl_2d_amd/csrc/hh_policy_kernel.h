@@ -67,44 +67,55 @@ __device__ __forceinline__ float hhp_tanh(float x) {
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f); /* raw v_rcp_f32 (1 ulp): __frcp_rn expands to the ten-instruction IEEE division */
 }
 
-/* rows -> per-network lists.  One atomic ROUND TRIP per wave: a per-row atomic on two or four hot counters serialises (measured
- * 187 us for 32768 rows), and one returning atomic per network costs a memory round trip each; here lane n - 1 carries the wave's
- * count for network n, the (up to eight) atomics leave as one instruction, and every row takes its slot from the base of its
- * network plus its rank in that network's ballot. */
+/* rows -> per-network lists.  One atomic ROUND TRIP per WORKGROUP: a per-row atomic on two or four hot counters serialises (measured
+ * 187 us for 32768 rows; one returning atomic per wave and network 13.6 us, all of a wave's in one instruction 10.9 us — device-scope
+ * atomics on one address cost ~13 ns apiece however they are issued).  The four waves' ballots meet in LDS, lane n - 1 of wave 0
+ * carries the workgroup's count for network n, the (up to eight) atomics leave as one instruction, and every row takes its slot from
+ * the base of its network + the counts of the waves before its own + its rank in its wave's ballot.  The counters are found zero:
+ * the forward kernel that consumed the previous lists cleared them (hhp_consume_counts). */
 __global__ __launch_bounds__(256) void hh_k_policy_bin(int n_rows, const uint8_t *__restrict__ sel, const uint8_t *__restrict__ lut,
                                                        int max_rows, int *__restrict__ counts, int *__restrict__ lists,
                                                        int8_t *__restrict__ actions) {
+    __shared__ int wcnt[4][HH_POLICY_MAX_NETS], wbase[HH_POLICY_MAX_NETS];
     const int r = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = r < n_rows ? (int)lut[sel[r]] : 0;
     if (r < n_rows && s == 0) reinterpret_cast<int *>(actions)[r] = 0;
-    int mine = 0, rank = 0;
+    int rank = 0;
 #pragma unroll
     for (int n = 1; n <= HH_POLICY_MAX_NETS; n++) {
         const unsigned long long m = __ballot(s == n);
-        if (lane == n - 1) mine = __popcll(m);
+        if (lane == n - 1) wcnt[wave][n - 1] = __popcll(m);
         if (s == n) rank = __popcll(m & ((1ULL << lane) - 1ULL));
     }
-    int base = 0;
-    if (lane < HH_POLICY_MAX_NETS && mine) base = atomicAdd(&counts[lane * HH_BIN_STRIDE], mine);
-    base = __shfl(base, s > 0 ? s - 1 : 0);
-    if (s > 0) lists[(size_t)(s - 1) * max_rows + base + rank] = r;
+    __syncthreads();
+    if (threadIdx.x < HH_POLICY_MAX_NETS) {
+        const int tot = wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+        wbase[threadIdx.x] = tot ? atomicAdd(&counts[threadIdx.x * HH_BIN_STRIDE], tot) : 0;
+    }
+    __syncthreads();
+    if (s > 0) {
+        int at = wbase[s - 1] + rank;
+        for (int v = 0; v < wave; v++) at += wcnt[v][s - 1];
+        if (at < max_rows) lists[(size_t)(s - 1) * max_rows + at] = r;
+    }
 }
 
-/* the counters are cleared by a kernel, not a memset node: the call sequence is replayed from HIP graphs */
-__global__ void hh_k_policy_clear(int *__restrict__ counts) {
-    if (threadIdx.x < HH_POLICY_MAX_NETS) counts[threadIdx.x * HH_BIN_STRIDE] = 0;
+/* The forward kernel that runs over freshly binned lists clears the row counters behind itself (consume bit 0): a workgroup takes a
+ * ticket when it is done (it read the counters at its start), and the last one to do so saves the counts for later calls that re-use
+ * the lists (sel == NULL; they read the saved copy: consume bit 1) and clears the live ones for the next binning pass — no clear
+ * kernel, and nothing that depends on how a HIP graph strings the calls together.  Tickets are sharded over 32 sub-counters with one
+ * top-level ticket per shard: ~500 workgroups finish together and same-address atomics serialise (a single ticket counter measured
+ * +5 us per launch).  counts[] in units of HH_BIN_STRIDE ints (every counter on its own 128-byte line): 0..7 rows per network,
+ * 8 top-level ticket, 9..40 shard tickets, 41..48 saved rows per network. */
+#define HHP_COUNTS_INTS (49 * HH_BIN_STRIDE)
+#define HHP_CONSUME 1
+#define HHP_FROM_SAVED 2
+__device__ __forceinline__ int hhp_row_count(const int *counts, int n, int consume) {
+    return counts[((consume & HHP_FROM_SAVED) ? 41 + n : n) * HH_BIN_STRIDE];
 }
-
-/* consume = 1 (hh_policy_act_binned: the row lists were written by the world's own kernels): a workgroup takes a ticket when it is
- * done (it read the counters at its start), and the last one to do so clears the counters for the next binning pass — no clear
- * kernel, and nothing that depends on how a HIP graph strings the calls together.  Tickets are sharded over 32 sub-counters with
- * one top-level ticket per shard: ~500 workgroups finish together and same-address atomics serialise at ~13 ns each (a single
- * ticket counter measured +5 us per launch).  counts[] in units of HH_BIN_STRIDE ints (every counter on its own 128-byte line):
- * 0..7 rows per network, 8 top-level ticket, 9..40 shard tickets. */
-#define HHP_COUNTS_INTS (41 * HH_BIN_STRIDE)
 __device__ __forceinline__ void hhp_consume_counts(int *counts, int consume) {
-    if (consume && threadIdx.x == 0) {
+    if ((consume & HHP_CONSUME) && threadIdx.x == 0) {
         const int j = blockIdx.x & 31;
         const int nj = ((int)gridDim.x - j + 31) >> 5; /* workgroups of this shard */
         if (atomicAdd(&counts[(9 + j) * HH_BIN_STRIDE], 1) == nj - 1) {
@@ -112,7 +123,11 @@ __device__ __forceinline__ void hhp_consume_counts(int *counts, int consume) {
             const int shards = min((int)gridDim.x, 32);
             if (atomicAdd(&counts[HH_POLICY_MAX_NETS * HH_BIN_STRIDE], 1) == shards - 1) {
 #pragma unroll
-                for (int n = 0; n <= HH_POLICY_MAX_NETS; n++) counts[n * HH_BIN_STRIDE] = 0;
+                for (int n = 0; n < HH_POLICY_MAX_NETS; n++) {
+                    counts[(41 + n) * HH_BIN_STRIDE] = counts[n * HH_BIN_STRIDE];
+                    counts[n * HH_BIN_STRIDE] = 0;
+                }
+                counts[HH_POLICY_MAX_NETS * HH_BIN_STRIDE] = 0;
             }
         }
     }
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void hh_k_policy(HhpBank bank, int n_nets, 
     /* which (network, tile) is this workgroup's?  (all counters requested at once: one global round trip) */
     int cn[HH_POLICY_MAX_NETS];
 #pragma unroll
-    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? min(counts[n * HH_BIN_STRIDE], max_rows) : 0;
+    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? min(hhp_row_count(counts, n, consume), max_rows) : 0;
     int net = -1, tile = blockIdx.x, cnt = 0;
 #pragma unroll
     for (int n = 0; n < HH_POLICY_MAX_NETS; n++) {
@@ -515,11 +530,10 @@ extern "C" int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int
     HH_GUARD(p);
     hipStream_t st = (hipStream_t)stream;
     if (sel) { /* sel == NULL: the selectors are the ones of the previous call (a fixed network per unit slot): the lists stand */
-        hipLaunchKernelGGL(hh_k_policy_clear, dim3(1), dim3(64), 0, st, p->counts);
         hipLaunchKernelGGL(hh_k_policy_bin, dim3((n_rows + 255) / 256), dim3(256), 0, st, n_rows, sel, p->lut, p->max_rows, p->counts, p->lists, actions);
         p->binned_rows = n_rows;
     }
-    return hhp_launch_forward(p, obs, n_rows, obs_stride, actions, logits, 0, st);
+    return hhp_launch_forward(p, obs, n_rows, obs_stride, actions, logits, sel ? HHP_CONSUME : HHP_FROM_SAVED, st);
 }
 
 /* HighLevelEnv: the world's phase kernels bin the pilot rows they emit into this bank's lists themselves */
@@ -545,7 +559,7 @@ extern "C" int hh_policy_act_binned(hh_policy *p, const float *obs, int32_t n_ro
     if (n_rows > p->max_rows) { g_err = "hh_policy_act_binned: n_rows exceeds max_rows of hh_policy_create"; return HH_E_ARG; }
     if (p->n_nets == 0) { g_err = "hh_policy_act_binned: no network loaded"; return HH_E_ARG; }
     HH_GUARD(p);
-    return hhp_launch_forward(p, obs, n_rows, obs_stride, actions, logits, 1, (hipStream_t)stream);
+    return hhp_launch_forward(p, obs, n_rows, obs_stride, actions, logits, HHP_CONSUME, (hipStream_t)stream);
 }
 
 #ifdef HHP_PROFILE

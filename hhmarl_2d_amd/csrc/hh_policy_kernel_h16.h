@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256 * RH, RH == 1 ? 2 : 1) void hh_k_policy_h(HhpBa
 
     int cn[HH_POLICY_MAX_NETS];
 #pragma unroll
-    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? min(counts[n * HH_BIN_STRIDE], max_rows) : 0;
+    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? min(hhp_row_count(counts, n, consume), max_rows) : 0;
     const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int wq = wave & 3, wrow0 = (wave >> 2) * 32; /* attention / L3: column or k quarter, row half of this wave */
     int gt = blockIdx.x, net, tile, cnt;

@@ -70,8 +70,8 @@ int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_st
  * phase kernels (hh_hl_begin / hh_hl_agents_act / hh_hl_tick) bin the pilot rows they emit by network themselves — through this
  * bank's LUT into its row lists — while they still hold the selector in a register; hh_policy_act_binned then runs the forward
  * over those lists with no binning pass, and the last workgroup to read the row counters clears them for the next phase
- * (hh_hl_end / hh_reset drop rows nobody consumed).  Per policy call this replaces two launches (counter clear + binning: ~15 us of
- * ~60 at 8192 arenas).  Contract: after binding, follow every hh_hl_begin / hh_hl_agents_act / hh_hl_tick whose rows are wanted
+ * (hh_hl_end / hh_reset drop rows nobody consumed).  Per policy call this replaces the binning launch (~5 us of ~55 at 8192 arenas)
+ * by atomic traffic of about the same cost inside the phase kernels.  Contract: after binding, follow every hh_hl_begin / hh_hl_agents_act / hh_hl_tick whose rows are wanted
  * with ONE hh_policy_act_binned (obs = the pilot_obs that phase wrote, n_rows = n_arenas x 6, obs_stride = 30) before the next
  * phase launch; rows without a network keep whatever their action bytes held (the world ignores them).  The bank must have its
  * networks and LUT loaded, live on the world's device and have max_rows >= n_arenas x 6; one world per bank (binding a second

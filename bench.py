@@ -204,7 +204,7 @@ def load_json(name):
         return None
 
 
-def counter_evidence(kernel, n_arenas, ticks, units_per_s_per_gpu, arenas_per_wave):
+def counter_evidence(kernel, n_arenas, ticks, units_per_s_per_gpu, lanes_per_arena):
     """HBM bytes and instruction counts per launch from the PMC passes of a separate rocprofv3 run of this same command
     (tools/prof_pmc.sh -> profiles/latest_traffic.json, profiles/latest_pmc.json; counters cannot be read from inside the
     process).  Stored per arena-tick / per wave-tick, so they apply to any --chunk of the same kernel instance."""
@@ -216,8 +216,10 @@ def counter_evidence(kernel, n_arenas, ticks, units_per_s_per_gpu, arenas_per_wa
     pj = load_json("latest_pmc.json")
     if pj and pj.get("arenas") == n_arenas:
         valu = pj["insts_valu_per_wave_tick"]
-        lane_ops = valu * 64.0 / arenas_per_wave * units_per_s_per_gpu   # every VALU instruction counted as one issue slot per lane
-        fp64 = {"bound": "fp64 valu issue", "insts_valu_per_wave_tick": valu, "insts_salu_per_wave_tick": pj.get("insts_salu_per_wave_tick"),
+        # every VALU instruction of a wave counted as one issue slot for each lane that carries an aircraft (idle lanes of the
+        # 8-arenas-per-wave form are not work)
+        lane_ops = valu * lanes_per_arena * units_per_s_per_gpu
+        fp64 = {"bound": "fp64 valu issue", "wave_tick": pj.get("wave_tick"), "insts_valu_per_wave_tick": valu, "insts_salu_per_wave_tick": pj.get("insts_salu_per_wave_tick"),
                 "achieved_lane_ops_s": lane_ops, "peak": FP64_ISSUE_PEAK, "unit": "lane-ops/s", "frac": lane_ops / FP64_ISSUE_PEAK,
                 "source": pj.get("source", "profiles/latest_pmc.json")}
     return traffic, fp64
@@ -298,7 +300,7 @@ def main_low(args):
         bytes_per_launch = ALGO_BYTES_2V2_STEP * N * chunk
         achieved = bytes_per_launch / avg_launch_s / 1e9
         kname = w.kernel_name()
-        traffic, fp64 = counter_evidence(kname, N, chunk, N * chunk / avg_launch_s, 16)
+        traffic, fp64 = counter_evidence(kname, N, chunk, N * chunk / avg_launch_s, 4)   # 2-vs-2: four aircraft lanes per arena
         line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                             "traffic": traffic, "kernel": kname, "avg_launch_ms": avg_launch_s * 1e3,
                             "algorithmic_bytes_per_launch": bytes_per_launch, "fp64": fp64,

@@ -811,11 +811,15 @@ __device__ __forceinline__ void quad_target_refresh(const DevCfg &c, const QTab 
  * --level 3: fight mode, scripted opponents, friendly fire on, no friendly punishment, no escape shaping, glob_frac 0,
  * rew_scale 1) compiled with those values as constants: the other configurations' code and its scalar registers drop
  * out.  Every other configuration runs the L3 = false instance of the same source; both give the same results. */
-template <int W, bool L3, bool TWO>
+/* APW = arenas per simulation wave: 16 fills the 64 lanes; 8 (lanes 32..63 idle) is for worlds so small that half the SIMDs would
+ * otherwise sit empty: a wave's tick costs the instructions of every branch ANY of its arenas takes (rocket in flight, cannon
+ * burst, events, reset ...), so half the arenas per wave means fewer instructions per wave-tick at the same number of ticks. */
+template <int W, bool L3, bool TWO, int APW = 16>
 __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_eu(W, W))) void hh_k_world_quad(DevPtrs P, DevCfg c_in, int T, const int8_t *__restrict__ actions,
                                                                   float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                                   uint8_t *__restrict__ valid_out, uint8_t *__restrict__ done_out) {
-    constexpr int A = 4, B = 64, GPB = B / A;
+    constexpr int A = 4, B = 64, GPB = APW;
+    static_assert(APW == 16 || APW == 8, "arenas per wave");
     DevCfg c_l3 = c_in;
     c_l3.level = 3; c_l3.agent_mode = HH_MODE_FIGHT; c_l3.ext_opp = 0; c_l3.friendly_kill = 1; c_l3.friendly_punish = 0;
     c_l3.esc_dist_rew = 0; c_l3.glob_frac = 0.0; c_l3.rew_scale = 1.0; c_l3.D = HH_OBS_FIGHT_AC1; c_l3.n_ctrl = 2; c_l3.nA = 2; c_l3.nO = 2;
@@ -828,7 +832,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         if (threadIdx.x >= 64) { /* ---------------- the output wave ---------------- */
             const int g = tid >> 1, s = tid & 1; /* lanes 0..31: one agent row each */
             const int n = blockIdx.x * GPB + g;
-            const bool row = tid < 32 && n < c.N;
+            const bool row = tid < 2 * GPB && n < c.N;
             for (int t = 0; t < T; t++) {
                 __syncthreads(); /* mailbox t is posted */
                 const ObsMail &mb = mbx.mail[t & 1];
@@ -864,7 +868,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
     const int g = tid >> 2, s = tid & 3;
     const int base = g * A;
     const int n = blockIdx.x * GPB + g;
-    const bool active = n < c.N;
+    const bool active = g < GPB && n < c.N;
     const size_t U = (size_t)c.N * A;
     const size_t u = (size_t)n * A + s;
     HH_PROF_DECL;

@@ -59,6 +59,7 @@ struct hh_world {
     int no_quad;  /* HH_NO_QUAD=1: 2-vs-2 rollouts on the generic LDS-exchange kernel (A/B tests; same results) */
     int no_spec;  /* HH_NO_SPEC=1: never pick the instance compiled for the default level-3 configuration */
     int no_two;   /* HH_NO_TWO=1: never pick the two-wave (simulation + output wave) form for small worlds */
+    int apw;      /* HH_APW=16: never pick the 8-arenas-per-wave form of the two-wave kernel */
     void *trace_mem; /* trajectory ring buffer + cursors (hh_trace_enable), separate allocation */
     struct hh_policy *bound_policy; /* hh_hl_bind_policy: the bank whose row lists P.pol_* point into (it points back at this world) */
 };
@@ -116,6 +117,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     w->trace_mem = nullptr;
     w->bound_policy = nullptr;
     { const char *fw = getenv("HH_FORCE_W"); w->force_w = fw ? atoi(fw) : 0; }
+    { const char *e = getenv("HH_APW"); w->apw = e ? atoi(e) : 0; }
     { const char *nq = getenv("HH_NO_QUAD"); w->no_quad = nq ? atoi(nq) : 0; }
     { const char *ns = getenv("HH_NO_SPEC"); w->no_spec = ns ? atoi(ns) : 0; }
     { const char *nt = getenv("HH_NO_TWO"); w->no_two = nt ? atoi(nt) : 0; }
@@ -242,11 +244,17 @@ static int launch(hh_world *w, int run, int T, const int8_t *actions, const uint
                         !c.esc_dist_rew && c.glob_frac == 0.0 && c.rew_scale == 1.0;
         /* small worlds (every workgroup resident with a SIMD pair to itself): simulation wave + output wave per 16 arenas */
         const bool pair = !two && !w->no_two && waves <= w->n_simd / 2; /* 128-thread groups at one wave per SIMD: two per CU resident */
+        /* smaller still (the two-wave form of 8-arena groups fits one wave per SIMD): 8 arenas per simulation wave, hh_kernels_quad.h */
+        const int grid8 = (c.N + 7) / 8;
+        const bool half = pair && w->apw != 16 && 2 * grid8 <= w->n_simd;
 #define HH_QLAUNCH(Wv, L3v, TWOv) hipLaunchKernelGGL((hh_k_world_quad<Wv, L3v, TWOv>), dim3(grid), dim3(TWOv ? 128 : 64), 0, st, w->P, c, T, actions, obs, reward, valid, done)
+#define HH_QLAUNCH8(L3v) hipLaunchKernelGGL((hh_k_world_quad<1, L3v, true, 8>), dim3(grid8), dim3(128), 0, st, w->P, c, T, actions, obs, reward, valid, done)
         if (two) { if (l3) HH_QLAUNCH(2, true, false); else HH_QLAUNCH(2, false, false); }
+        else if (half) { if (l3) HH_QLAUNCH8(true); else HH_QLAUNCH8(false); }
         else if (pair) { if (l3) HH_QLAUNCH(1, true, true); else HH_QLAUNCH(1, false, true); }
         else { if (l3) HH_QLAUNCH(1, true, false); else HH_QLAUNCH(1, false, false); }
 #undef HH_QLAUNCH
+#undef HH_QLAUNCH8
     } else if (run >= HH_RUN_LL_BEGIN)
         hipLaunchKernelGGL((hh_k_world<4, B, 1, true>), dim3(grid), dim3(B), 0, st, w->P, c, run, T, actions, mask, obs, reward, valid, done);
     else if (two)
@@ -272,9 +280,10 @@ extern "C" int hh_rollout_kernel_name(hh_world *w, char *buf, int32_t len) {
     const bool l3 = !w->no_spec && c.level == 3 && c.agent_mode == HH_MODE_FIGHT && !c.ext_opp && c.friendly_kill == 1 && !c.friendly_punish &&
                     !c.esc_dist_rew && c.glob_frac == 0.0 && c.rew_scale == 1.0;
     const bool pair = !two && !w->no_two && waves <= w->n_simd / 2;
+    const bool half = pair && w->apw != 16 && 2 * ((c.N + 7) / 8) <= w->n_simd;
     if (w->no_quad) snprintf(buf, (size_t)len, "hh_k_world<4,64,%d,false>", two ? 2 : 1);
-    else snprintf(buf, (size_t)len, "hh_k_world_quad<W=%d,L3=%s,%s>", two ? 2 : 1, l3 ? "true" : "false",
-                  pair ? "simulation wave + output wave" : "single wave");
+    else snprintf(buf, (size_t)len, "hh_k_world_quad<W=%d,L3=%s,%s%s>", two ? 2 : 1, l3 ? "true" : "false",
+                  pair ? "simulation wave + output wave" : "single wave", half ? ",8 arenas per wave" : "");
     return HH_OK;
 }
 

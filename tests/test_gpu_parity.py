@@ -247,19 +247,23 @@ def test_register_exchange_kernel_equals_lds_kernel(monkeypatch, kw):
 @pytest.mark.parametrize("kw", [dict(level=3), dict(level=3, agent_mode=1, esc_dist_rew=1, glob_frac=0.0), dict(level=1)],
                          ids=["L3-fight", "L3-escape", "L1"])
 def test_two_wave_form_equals_single_wave(monkeypatch, kw):
-    """small worlds run a simulation wave + an output wave per 16 arenas (hh_kernels_quad.h); outputs and state must
-    equal the single-wave form and the LDS kernel bit for bit — sizes with a partial last workgroup included"""
+    """small worlds run a simulation wave + an output wave per 16 arenas — per 8 arenas when that still fits one wave per SIMD
+    (<= 4096 arenas on 256 CUs; HH_APW=16 keeps 16) — (hh_kernels_quad.h); outputs and state must equal the single-wave form and
+    the LDS kernel bit for bit — sizes with a partial last workgroup included"""
     import torch
     from hhmarl_2d_amd.world import World, make_config
-    for N, T in ((4096, 330), (8189, 90), (37, 200)):
+    for N, T in ((4096, 330), (8189, 90), (37, 200), (2045, 150)):
         cfg = dict(n_arenas=N, seed=99, auto_reset=True, **kw)
         worlds = []
-        for no_two, no_quad, no_spec in (("0", "0", "0"), ("1", "0", "0"), ("0", "0", "1"), ("1", "1", "0")):
+        for no_two, no_quad, no_spec, apw in (("0", "0", "0", "0"), ("0", "0", "0", "16"), ("1", "0", "0", "0"), ("0", "0", "1", "0"), ("1", "1", "0", "0")):
+            monkeypatch.setenv("HH_APW", apw)
             monkeypatch.setenv("HH_NO_TWO", no_two)
             monkeypatch.setenv("HH_NO_QUAD", no_quad)
             monkeypatch.setenv("HH_NO_SPEC", no_spec)
             monkeypatch.setenv("HH_FORCE_W", "0")
             worlds.append(World(make_config(**cfg)))
+        if N <= 4096:
+            assert "8 arenas per wave" in worlds[0].kernel_name() and "8 arenas per wave" not in worlds[1].kernel_name()
         obs0 = [w.reset() for w in worlds]
         assert all(torch.equal(obs0[0], o) for o in obs0[1:])
         rng = np.random.default_rng(N)

@@ -321,10 +321,9 @@ __device__ __forceinline__ void hl_do_end(const DevPtrs &P, const DevCfg &c, Sha
     __syncthreads();
 }
 
-template <int A, int B>
+template <int A, int B, int GPB = B / A>
 __device__ __forceinline__ void hl_store_commander_obs(const DevCfg &c, const Shared<A, B> &sh, int tid, int phase, float *__restrict__ obs_out,
                                                        const uint8_t *__restrict__ mask) {
-    constexpr int GPB = B / A;
     if (!obs_out) return;
     const int arenas = min(GPB, c.N - (int)blockIdx.x * GPB);
     const int per = c.nA * HH_OBS_HL, cnt = arenas * per;
@@ -501,12 +500,14 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
  * from _action_assess to the commander observation; the pair table a tick leaves behind serves the next sub-step's act
  * phases; a workgroup leaves the sub-step loop as soon as none of its arenas is still inside its macro step
  * (13.2 of 16 sub-steps on average).  Same device functions as the phase kernel: bit-identical. ---- */
-template <int A, int B, int W, bool HLD>
+template <int A, int B, int W, bool HLD, int APW = B / A>
 __global__ __launch_bounds__(B, W) void hh_k_hier_macro(DevPtrs P, DevCfg c_in, const int8_t *__restrict__ cmd, const int8_t *__restrict__ tape,
                                                      float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                      uint8_t *__restrict__ valid_out, uint8_t *__restrict__ done_out,
                                                      int *__restrict__ counters) {
-    constexpr int GPB = B / A;
+    constexpr int GPB = APW; /* arenas per wave: 10 fill 60 lanes; 8 when that still leaves every workgroup a SIMD of its own (a wave pays for
+                                every branch any of its arenas takes: hh_kernels_quad.h) */
+    static_assert(APW <= B / A, "arenas per wave");
     DevCfg c_hl = c_in;
     hh_cfg_set_hl_default(c_hl); /* HLD: the default HighLevelEnv configuration as literals (hh_device.h) */
     const DevCfg &c = HLD ? c_hl : c_in;
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier_macro(DevPtrs P, DevCfg c_in, 
         if (running) evm_last = L.evm;
     }
     hl_do_end<A, B>(P, c, sh, tid, g, base, s, n, active, L, HH_HL_END, reward_out, valid_out, done_out, nullptr);
-    hl_store_commander_obs<A, B>(c, sh, tid, HH_HL_END, obs_out, nullptr);
+    hl_store_commander_obs<A, B, GPB>(c, sh, tid, HH_HL_END, obs_out, nullptr);
     if (active) {
         unit_store(P, U, u, L.m);
         P.acc_rew[u] = L.acc;

@@ -543,9 +543,14 @@ extern "C" int hh_hl_rollout(hh_world *w, const int8_t *commander_actions, const
     const bool two = w->force_w == 2 || (w->force_w == 0 && grid > w->n_simd);
     hipStream_t st = (hipStream_t)stream;
     const bool hld = !w->no_spec && hh_cfg_is_hl_default(c); /* the instance compiled for the reference's default HighLevelEnv configuration */
+    const int grid8 = (c.N + 7) / 8;
+    const bool half = !two && w->apw != 16 && grid8 <= w->n_simd; /* 8 arenas per wave while every workgroup still has a SIMD of its own */
 #define HH_MLAUNCH(Wv, Dv) hipLaunchKernelGGL((hh_k_hier_macro<6, B, Wv, Dv>), dim3(grid), dim3(B), 0, st, w->P, c, commander_actions, pilot_tape, obs, reward, reward_valid, done, w->counter)
+#define HH_MLAUNCH8(Dv) hipLaunchKernelGGL((hh_k_hier_macro<6, B, 1, Dv, 8>), dim3(grid8), dim3(B), 0, st, w->P, c, commander_actions, pilot_tape, obs, reward, reward_valid, done, w->counter)
     if (two) { if (hld) HH_MLAUNCH(2, true); else HH_MLAUNCH(2, false); }
+    else if (half) { if (hld) HH_MLAUNCH8(true); else HH_MLAUNCH8(false); }
     else { if (hld) HH_MLAUNCH(1, true); else HH_MLAUNCH(1, false); }
+#undef HH_MLAUNCH8
 #undef HH_MLAUNCH
     HIPCHK(hipGetLastError());
     return HH_OK;

@@ -164,17 +164,21 @@ def test_n_vs_m_parity(oracle, nA, nO):
     assert dones > 0
 
 
-@pytest.mark.parametrize("N,force_w,horizon", [(170, "0", 60), (8192, "0", 60), (12003, "0", 60), (333, "2", 60), (170, "0", 500), (8192, "0", 500), (333, "2", 500)],
-                         ids=["170", "8192", "12003-W2", "333-forced-W2", "170-default-config", "configs3-8192-default-config", "333-forced-W2-default-config"])
-def test_persistent_macro_step_equals_phase_path(oracle, monkeypatch, N, force_w, horizon):
+@pytest.mark.parametrize("N,force_w,horizon,apw", [(170, "0", 60, "0"), (8192, "0", 60, "0"), (12003, "0", 60, "0"), (333, "2", 60, "0"), (170, "0", 500, "0"),
+                                                   (8192, "0", 500, "0"), (333, "2", 500, "0"), (170, "0", 60, "16"), (190, "0", 500, "16")],
+                         ids=["170", "8192", "12003-W2", "333-forced-W2", "170-default-config", "configs3-8192-default-config", "333-forced-W2-default-config",
+                              "170-ten-arenas-per-wave", "190-default-config-ten-arenas-per-wave"])
+def test_persistent_macro_step_equals_phase_path(oracle, monkeypatch, N, force_w, horizon, apw):
     """hh_hl_rollout (one launch per commander step, actions from a resident tape) against the phase-by-phase path with the same
     tape: outputs, final state, event masks, eval counters, episode statistics and tick counts bit for bit; at N = 170 also
     against the oracle.  horizon = 500 is the reference's default HighLevelEnv configuration, which runs the macro-step instance
-    compiled with that configuration as constants (hh_cfg_set_hl_default); any other horizon runs the general instance."""
+    compiled with that configuration as constants (hh_cfg_set_hl_default); any other horizon runs the general instance.  Worlds of up
+    to 8192 arenas run 8 arenas per wave unless HH_APW=16 keeps the 10 that fill a wave."""
     import torch
     from hhmarl_2d_amd.env_hier import macro_step
     from hhmarl_2d_amd.world import World, make_config
     monkeypatch.setenv("HH_FORCE_W", force_w)
+    monkeypatch.setenv("HH_APW", apw)
     base = dict(n_arenas=N, env_kind=1, seed=8, arena_offset=11, auto_reset=True, horizon=horizon)
     a, b = World(make_config(**base)), World(make_config(**base))
     o = oracle.OracleWorld(oracle.make_config(**base)) if N <= 200 else None

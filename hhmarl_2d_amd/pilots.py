@@ -161,6 +161,8 @@ class OpponentNets:
     def __init__(self, world, bank=None, seed=0):
         self.world = world
         n_opp = world.A - world.n_agents
+        self._private = bank is None     # nobody else re-bins a private bank: a fixed selector pattern needs one binning pass only
+        self._binned = False
         self.bank = bank if bank is not None else PolicyBank.random_init(world.device, seed=seed, max_rows=world.N * n_opp)
         self.act = torch.zeros((world.N, n_opp, 4), dtype=torch.int8, device=world.device)
         self.sel_fight = torch.tensor([SEL_FIGHT1, SEL_FIGHT2], dtype=torch.uint8, device=world.device).repeat(world.N, 1).contiguous()
@@ -171,6 +173,9 @@ class OpponentNets:
         if self.world.cfg.level == 5 and self.world.cfg.agent_mode == L.MODE_FIGHT:
             k = self.world.opp_policy(self.k)
             sel = (self.sel_fight + (16 * (k - 3) + (k == 5)).to(torch.uint8)[:, None]).contiguous()
+        elif self._private and self._binned:
+            sel = None                   # level 4: opponent 3 -> Fight1, opponent 4 -> Fight2 in every arena, the row lists stand
+        self._binned = True
         return self.bank.act(opp_obs.contiguous(), sel, self.act)
 
 

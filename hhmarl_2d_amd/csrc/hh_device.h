@@ -84,7 +84,7 @@ struct DevPtrs {
     float *trace;                                        /* [trace_cap][trace_K][A][HH_TRACE_F] or nullptr */
     int *trace_pos;                                      /* [trace_K] rows written so far (monotonic) */
     int trace_K, trace_cap;
-    /* optional policy bank bound with hh_hl_bind_policy: the HighLevelEnv phase kernels bin the pilot rows they emit by network
+    /* optional policy bank bound with hh_bind_policy: the HighLevelEnv phase kernels bin the pilot rows they emit by network
      * themselves (selector byte -> slot through pol_lut), so hh_policy_act_binned needs no binning pass of its own */
     const uint8_t *pol_lut;                              /* [256] or nullptr */
     int *pol_counts, *pol_lists;                         /* rows per network [8] at stride HH_BIN_STRIDE (+ the bank's tickets), [8][pol_max_rows] */

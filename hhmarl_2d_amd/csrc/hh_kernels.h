@@ -1118,6 +1118,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
         ar.done = 1;
     }
     sh.aux[tid] = 0;
+    if (run == HH_RUN_RESET && P.pol_lut && blockIdx.x == 0 && tid <= 8) P.pol_counts[tid * HH_BIN_STRIDE] = 0; /* rows nobody consumed */
     bool need_reset = run == HH_RUN_RESET && active && (mask == nullptr || mask[n]);
     uint32_t evm_last = 0;
     int tcur = (P.trace != nullptr && active && n < P.trace_K) ? P.trace_pos[n] : 0; /* trace cursor of the lane's arena */
@@ -1146,6 +1147,19 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
                 P.acc_rew[u] = pre;         /* escape-mode ammunition penalties (env_base.py:223-233) */
                 m.tgt_d1 = os0;             /* tgt_d1 is unused by LowLevelEnv: carries opp_stats[i][0] to LL_FINISH */
             }
+            /* a bound policy bank (hh_bind_policy): the opponents' rows [N, n_opps] are binned by network here — selector = policy type |
+             * aircraft type << 2, + 16 (k - 3) for the policy set k of the arena's level-5 draw (pilots.OpponentNets' encoding) */
+            int pslot = 0;
+            HhBinTicket bt{0, 0};
+            if (P.pol_lut && obs_out) {
+                int sb = 0;
+                if (running && m.alive && s >= c.nA) {
+                    const int k = c.level == 5 ? (T >= 0 ? (opp_mode == HH_MODE_ESCAPE ? 5 : 3) : hh_l5_policy_pick(ar.akey, (uint32_t)ar.episode)) : 3;
+                    sb = ((opp_mode == HH_MODE_ESCAPE ? 2 : 1) | (m.ac_type << 2)) + 16 * (k - 3);
+                }
+                pslot = sb ? (int)P.pol_lut[sb] : 0;
+                bt = hh_bin_rows_issue(P.pol_counts, pslot);
+            }
             /* observation of the frozen-policy opponents, after the agents acted (shot flags refreshed by act_phase) */
             __syncthreads(); /* the queue area of act_phase is free: stage the rows there, store them coalesced */
             if (active && s >= c.nA) {
@@ -1159,6 +1173,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
                 const int cnt = rows * c.nO * 30;
                 float *dst = obs_out + (size_t)blockIdx.x * GPB * c.nO * 30;
                 for (int q = tid; q < cnt; q += B) dst[q] = sh.u.obs[q];
+                if (P.pol_lut) hh_bin_rows_finish(bt, P.pol_lists, P.pol_max_rows, n * c.nO + (s - c.nA), pslot);
             }
             __syncthreads();
             T = 0; /* no tick in this launch */

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
         __syncthreads();
     }
     int obs_side = -1; /* which side's pilot observations this launch emits */
-    /* a bound policy bank (hh_hl_bind_policy): this launch's pilot rows are binned by network here.  The selector of a row is known
+    /* a bound policy bank (hh_bind_policy): this launch's pilot rows are binned by network here.  The selector of a row is known
      * as soon as the phase body is through (policy type from the commander's / the opponent's own choice, env_hier.py:100-112) — for
      * HL_AGENTS_ACT, which kills nobody, before it — so the list slot is REQUESTED there and used after the observation tile has
      * left: all workgroups finish together, and the same-address atomics of 820 waves arriving at once are a ~5 us tail otherwise. */

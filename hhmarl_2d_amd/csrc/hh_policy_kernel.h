@@ -348,7 +348,7 @@ struct hh_policy {
                                  the weight stream on a handful of TLB entries instead of a fresh small allocation per network */
     uint8_t *lut;             /* [256] dev */
     int *counts, *lists;      /* counters (HHP_COUNTS_INTS), [MAX_NETS][max_rows] dev */
-    hh_world *bound;          /* hh_hl_bind_policy: the world whose kernels write the lists (one world per bank), or nullptr */
+    hh_world *bound;          /* hh_bind_policy: the world whose kernels write the lists (one world per bank), or nullptr */
 };
 static void hhp_forget_world(hh_policy *p) { p->bound = nullptr; }
 static void hhp_unbind(hh_policy *p) {
@@ -375,7 +375,8 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     if (device < 0 || device >= ndev) { g_err = "bad device index"; return HH_E_ARG; }
     DeviceGuard guard_(device);
     if (!guard_.ok) { g_err = "hipSetDevice failed"; return HH_E_HIP; }
-    hh_policy *p = new hh_policy();
+    hh_policy *p = new (std::nothrow) hh_policy();
+    if (!p) { g_err = "hh_policy_create: out of host memory"; return HH_E_HIP; }
     p->device = device; p->max_rows = max_rows; p->n_nets = 0; p->binned_rows = 0; p->bound = nullptr;
     memset(&p->bank, 0, sizeof(p->bank));
     memset(&p->bankh, 0, sizeof(p->bankh));
@@ -418,7 +419,16 @@ extern "C" int hh_policy_destroy(hh_policy *p) {
     return HH_OK;
 }
 
+static int hhp_set_net(hh_policy *p, int32_t slot, const hh_net_weights *w);
 extern "C" int hh_policy_set_net(hh_policy *p, int32_t slot, const hh_net_weights *w) {
+    try { /* the repacking buffers are std::vectors: an allocation failure must not unwind through the C ABI */
+        return hhp_set_net(p, slot, w);
+    } catch (const std::exception &e) {
+        g_err = std::string("hh_policy_set_net: ") + e.what();
+        return HH_E_HIP;
+    }
+}
+static int hhp_set_net(hh_policy *p, int32_t slot, const hh_net_weights *w) {
     if (!p || !w || slot < 0 || slot >= HH_POLICY_MAX_NETS || w->kind < 0 || w->kind > 3) { g_err = "bad argument"; return HH_E_ARG; }
     const bool att = w->kind <= HH_NET_FIGHT2;
     if (!w->shared_w || !w->shared_b || !w->out_w || !w->out_b || (att && (!w->att_in_proj_w || !w->att_in_proj_b || !w->att_out_w || !w->att_out_b))) {
@@ -536,16 +546,17 @@ extern "C" int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int
     return hhp_launch_forward(p, obs, n_rows, obs_stride, actions, logits, sel ? HHP_CONSUME : HHP_FROM_SAVED, st);
 }
 
-/* HighLevelEnv: the world's phase kernels bin the pilot rows they emit into this bank's lists themselves */
-extern "C" int hh_hl_bind_policy(hh_world *w, hh_policy *p) {
+/* the world's kernels bin the policy rows they emit (HighLevelEnv pilots; LowLevelEnv levels 4-5 opponents) into this bank's lists themselves */
+extern "C" int hh_bind_policy(hh_world *w, hh_policy *p) {
     if (!w) { g_err = "null argument"; return HH_E_ARG; }
-    if (w->cfg.env_kind != HH_ENV_HIGHLEVEL) { g_err = "hh_hl_bind_policy: not a HighLevelEnv world"; return HH_E_ARG; }
+    if (w->cfg.env_kind != HH_ENV_HIGHLEVEL && !w->dc.ext_opp) { g_err = "hh_bind_policy: a LowLevelEnv world flies policies at levels 4-5 only (ext_opp_actions)"; return HH_E_ARG; }
     if (w->bound_policy) hhp_unbind(w->bound_policy);
     if (!p) return HH_OK;
     if (p->bound) hhp_unbind(p); /* one world per bank: the row lists and counters are the bank's */
-    if (p->device != w->device) { g_err = "hh_hl_bind_policy: world and policy bank live on different devices"; return HH_E_ARG; }
-    if ((long long)p->max_rows < (long long)w->dc.N * w->dc.A) { g_err = "hh_hl_bind_policy: the bank's max_rows is smaller than n_arenas x 6"; return HH_E_ARG; }
-    if (p->n_nets == 0) { g_err = "hh_hl_bind_policy: no network loaded"; return HH_E_ARG; }
+    if (p->device != w->device) { g_err = "hh_bind_policy: world and policy bank live on different devices"; return HH_E_ARG; }
+    const long long rows = (long long)w->dc.N * (w->cfg.env_kind == HH_ENV_HIGHLEVEL ? w->dc.A : w->dc.nO);
+    if ((long long)p->max_rows < rows) { g_err = "hh_bind_policy: the bank's max_rows is smaller than the rows of one policy call (n_arenas x 6, LowLevelEnv: x n_opps)"; return HH_E_ARG; }
+    if (p->n_nets == 0) { g_err = "hh_bind_policy: no network loaded"; return HH_E_ARG; }
     HH_GUARD(w);
     HIPCHK(hipMemset(p->counts, 0, HHP_COUNTS_INTS * sizeof(int)));
     w->P.pol_lut = p->lut; w->P.pol_counts = p->counts; w->P.pol_lists = p->lists; w->P.pol_max_rows = p->max_rows;

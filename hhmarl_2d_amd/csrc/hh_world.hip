@@ -61,7 +61,7 @@ struct hh_world {
     int no_two;   /* HH_NO_TWO=1: never pick the two-wave (simulation + output wave) form for small worlds */
     int apw;      /* HH_APW=16: never pick the 8-arenas-per-wave form of the two-wave kernel */
     void *trace_mem; /* trajectory ring buffer + cursors (hh_trace_enable), separate allocation */
-    struct hh_policy *bound_policy; /* hh_hl_bind_policy: the bank whose row lists P.pol_* point into (it points back at this world) */
+    struct hh_policy *bound_policy; /* hh_bind_policy: the bank whose row lists P.pol_* point into (it points back at this world) */
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -94,7 +94,8 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     if (!guard_.ok) { g_err = "hipSetDevice failed"; return HH_E_HIP; }
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
-    hh_world *w = new hh_world();
+    hh_world *w = new (std::nothrow) hh_world();
+    if (!w) { g_err = "hh_world_create: out of host memory"; return HH_E_HIP; }
     w->cfg = *cfg;
     w->device = device;
     w->n_simd = prop.multiProcessorCount * 4; /* 4 SIMDs per CU; follows the partition mode (SPX 256 CUs, CPX 32) */

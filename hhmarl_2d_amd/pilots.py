@@ -134,7 +134,7 @@ class NetPilot:
     def __init__(self, world, bank=None, seed=0, bind=True):
         self.bank = bank if bank is not None else PolicyBank.random_init(world.device, seed=seed, max_rows=world.N * world.A)
         self.act = torch.zeros((world.N, world.A, 4), dtype=torch.int8, device=world.device)
-        # bound: the world's phase kernels write the bank's row lists themselves (hh_hl_bind_policy), every call is the forward only.
+        # bound: the world's phase kernels write the bank's row lists themselves (hh_bind_policy), every call is the forward only.
         # The pilot must then be called exactly once after every hl_begin / hl_agents_act / hl_tick whose rows are wanted, which is
         # what macro_step does; bind=False keeps the self-contained form (binning pass per call from pilot_mode).
         self.world = world if bind else None
@@ -161,21 +161,24 @@ class OpponentNets:
     def __init__(self, world, bank=None, seed=0):
         self.world = world
         n_opp = world.A - world.n_agents
-        self._private = bank is None     # nobody else re-bins a private bank: a fixed selector pattern needs one binning pass only
-        self._binned = False
+        self._private = bank is None     # a private bank is bound to the world: hh_step_begin bins the opponents' rows itself
         self.bank = bank if bank is not None else PolicyBank.random_init(world.device, seed=seed, max_rows=world.N * n_opp)
+        self._skip = 0
+        if self._private:
+            world.bind_policy(self.bank)
+            self._skip = 1               # the step_begin that produced the first opp_obs may have run before the binding existed
         self.act = torch.zeros((world.N, n_opp, 4), dtype=torch.int8, device=world.device)
         self.sel_fight = torch.tensor([SEL_FIGHT1, SEL_FIGHT2], dtype=torch.uint8, device=world.device).repeat(world.N, 1).contiguous()
         self.k = torch.zeros((world.N,), dtype=torch.int8, device=world.device)
 
     def __call__(self, opp_obs, env=None):
+        if self._private and not self._skip:   # the rows of the step_begin that wrote opp_obs are already in the bank's lists
+            return self.bank.act_binned(opp_obs.contiguous(), self.act)
+        self._skip = 0
         sel = self.sel_fight
         if self.world.cfg.level == 5 and self.world.cfg.agent_mode == L.MODE_FIGHT:
             k = self.world.opp_policy(self.k)
             sel = (self.sel_fight + (16 * (k - 3) + (k == 5)).to(torch.uint8)[:, None]).contiguous()
-        elif self._private and self._binned:
-            sel = None                   # level 4: opponent 3 -> Fight1, opponent 4 -> Fight2 in every arena, the row lists stand
-        self._binned = True
         return self.bank.act(opp_obs.contiguous(), sel, self.act)
 
 

@@ -204,9 +204,9 @@ class World:
         return out
 
     def bind_policy(self, bank):
-        """HighLevelEnv: let the phase kernels bin the pilot rows they emit into `bank`'s row lists (hh_hl_bind_policy); None unbinds.
-        The world keeps the bank alive while bound."""
-        L.check(L.lib().hh_hl_bind_policy(self.h, bank.h if bank is not None else None))
+        """let the kernels that emit policy rows (HighLevelEnv phases; LowLevelEnv levels 4-5 step_begin) bin them into `bank`'s row
+        lists (hh_bind_policy); None unbinds.  The world keeps the bank alive while bound."""
+        L.check(L.lib().hh_bind_policy(self.h, bank.h if bank is not None else None))
         self._bound_bank = bank
 
     def trace_enable(self, n_arenas=1, capacity=1024):

@@ -66,18 +66,20 @@ int hh_policy_set_lut(hh_policy *p, const uint8_t *lut);
 int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, const uint8_t *sel, int8_t *actions,
                   float *logits, void *stream);
 
-/* HighLevelEnv with the networks in the loop (env_base.py:349-398 inside env_hier.py:114-140): bind a bank to a world and the
- * phase kernels (hh_hl_begin / hh_hl_agents_act / hh_hl_tick) bin the pilot rows they emit by network themselves — through this
- * bank's LUT into its row lists — while they still hold the selector in a register; hh_policy_act_binned then runs the forward
- * over those lists with no binning pass, and the last workgroup to read the row counters clears them for the next phase
- * (hh_hl_end / hh_reset drop rows nobody consumed).  Per policy call this replaces the binning launch (~5 us of ~55 at 8192 arenas)
- * by atomic traffic of about the same cost inside the phase kernels.  Contract: after binding, follow every hh_hl_begin / hh_hl_agents_act / hh_hl_tick whose rows are wanted
- * with ONE hh_policy_act_binned (obs = the pilot_obs that phase wrote, n_rows = n_arenas x 6, obs_stride = 30) before the next
- * phase launch; rows without a network keep whatever their action bytes held (the world ignores them).  The bank must have its
- * networks and LUT loaded, live on the world's device and have max_rows >= n_arenas x 6; one world per bank (binding a second
- * world moves the binding).  hh_hl_bind_policy(w, NULL) unbinds; destroying either side unbinds too.  Mixing hh_policy_act (with selectors) on a bound bank is allowed between macro steps. */
+/* The networks inside the env step (env_base.py:349-398 within env_hier.py:114-140 and env_hetero.py:160-172): bind a bank to a world
+ * and the kernels that emit policy rows bin them by network themselves — through this bank's LUT into its row lists — while they
+ * still hold the selector in a register: hh_hl_begin / hh_hl_agents_act / hh_hl_tick for the HighLevelEnv pilots (rows [N, 6]),
+ * hh_step_begin for the frozen opponents of LowLevelEnv levels 4-5 (rows [N, n_opps]; selector = policy type | aircraft type << 2,
+ * + 16 (k - 3) for the policy set k of the arena's level-5 draw, i.e. 5 / 9 at level 4 and 5 / 9, 21 / 25, 38 / 42 at level 5).
+ * hh_policy_act_binned then runs the forward over those lists with no binning pass, and the last workgroup to read the row counters
+ * clears them for the next phase (hh_hl_end / hh_reset drop rows nobody consumed).  Contract: after binding, follow every emitting
+ * launch whose rows are wanted with ONE hh_policy_act_binned (obs = the rows that launch wrote, n_rows = n_arenas x 6 | n_arenas x
+ * n_opps, obs_stride = 30) before the next emitting launch; rows without a network (dead units, finished arenas) keep whatever their
+ * action bytes held (the world ignores them).  The bank must have its networks and LUT loaded, live on the world's device and have
+ * max_rows >= the rows of one call; one world per bank (binding a second world moves the binding).  hh_bind_policy(w, NULL)
+ * unbinds; destroying either side unbinds too.  Mixing hh_policy_act (with selectors) on a bound bank is allowed between steps. */
 struct hh_world;
-int hh_hl_bind_policy(struct hh_world *w, hh_policy *p);
+int hh_bind_policy(struct hh_world *w, hh_policy *p);
 int hh_policy_act_binned(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, int8_t *actions, float *logits, void *stream);
 
 #ifdef __cplusplus

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+from helpers import random_actions
+
 from hhmarl_2d_amd import policy_nets as PN
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "policy_nets.npz")
@@ -150,12 +152,17 @@ def test_opponent_nets_drive_levels_4_5_through_the_facade(level):
     holder = {}
 
     def policy(opp_obs, env):
-        nets = holder.setdefault("nets", pilots.OpponentNets(env.world, seed=11))
+        if "nets" not in holder:   # created inside the first callback, i.e. after the first hh_step_begin already ran
+            holder["nets"] = pilots.OpponentNets(env.world, seed=11)
+        nets = holder["nets"]
         act = nets(opp_obs, env).clone()
         k = env.world.opp_policy().cpu().numpy()
         for slot, (fight, esc) in enumerate(((PN.FIGHT1, PN.ESC1), (PN.FIGHT2, PN.ESC2))):
             for kind, sel_rows in ((fight, k != 5), (esc, k == 5)):
                 idx = np.nonzero(sel_rows)[0]
+                if len(idx) == 0:
+                    continue
+                idx = idx[(opp_obs[idx, slot].abs().sum(dim=1) > 0).cpu().numpy()]   # live opponents of running arenas (others get no action)
                 if len(idx) == 0:
                     continue
                 ref = PN.torch_forward(kind, PN.random_weights(kind, 11), opp_obs[idx, slot].cpu())
@@ -232,7 +239,7 @@ def test_tile_instances_of_the_kernel_agree_bit_for_bit(monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("force_w,nA,nO,N", [("0", 3, 3, 1003), ("2", 3, 3, 517), ("0", 2, 3, 300)], ids=["3v3", "3v3-W2", "2v3"])
 def test_rows_binned_by_the_world_kernels_give_the_same_macro_steps(monkeypatch, force_w, nA, nO, N):
-    """hh_hl_bind_policy: the phase kernels write the bank's row lists themselves and hh_policy_act_binned runs the forward only
+    """hh_bind_policy: the phase kernels write the bank's row lists themselves and hh_policy_act_binned runs the forward only
     (the last workgroup clears the counters; hh_hl_end drops what the last tick binned).  Same worlds, same weights: every macro
     step's outputs, the pilots' actions of every sub-step and the final state equal the self-contained form (binning pass from
     pilot_mode per call); afterwards the bank still serves selector calls, and unbinding restores the plain behaviour."""
@@ -282,7 +289,7 @@ def test_rows_binned_by_the_world_kernels_give_the_same_macro_steps(monkeypatch,
 
 @pytest.mark.gpu
 def test_binding_survives_either_side_going_away():
-    """hh_hl_bind_policy keeps raw device pointers of the bank inside the world: destroying the bank, rebinding it to another world or
+    """hh_bind_policy keeps raw device pointers of the bank inside the world: destroying the bank, rebinding it to another world or
     destroying the world first must all leave both sides usable"""
     from hhmarl_2d_amd import pilots
     from hhmarl_2d_amd.env_hier import macro_step
@@ -313,3 +320,39 @@ def test_binding_survives_either_side_going_away():
     sel = torch.full((64,), pilots.SEL_FIGHT2, dtype=torch.uint8, device="cuda")
     assert bank2.act(obs, sel).shape == (64, 4)           # the bank lives on
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [4, 5])
+def test_opponent_rows_binned_by_step_begin_give_the_same_steps(level):
+    """hh_bind_policy on a LowLevelEnv world: hh_step_begin bins the frozen opponents' rows itself (selector from the aircraft type and
+    the arena's level-5 draw).  Same worlds and weights: every step equals the form that builds the selector bytes in torch and runs
+    the binning pass (a shared bank is never bound)"""
+    from hhmarl_2d_amd import pilots
+    from hhmarl_2d_amd.world import World, make_config
+    N = 3000
+    kw = dict(n_arenas=N, level=level, seed=17, auto_reset=True, ext_opp_actions=True, horizon=40)
+    a, b = World(make_config(**kw)), World(make_config(**kw))
+    assert torch.equal(a.reset(), b.reset())
+    shared = pilots.PolicyBank.random_init(torch.device("cuda", 0), seed=6, max_rows=N * 2)
+    na, nb = pilots.OpponentNets(a, bank=shared), pilots.OpponentNets(b, seed=6)      # selector bytes + binning pass | bound
+    rng = np.random.default_rng(2)
+    mode = -1 if level == 5 else 0
+    dones = 0
+    for t in range(60):
+        act = torch.from_numpy(random_actions(rng, (N,), 2)).cuda()
+        oa, ob = a.step_begin(act, mode), b.step_begin(act, mode)
+        assert torch.equal(oa, ob)
+        xa, xb = na(oa).clone(), nb(ob).clone()
+        live = oa.abs().sum(dim=2) > 0
+        assert torch.equal(xa[live], xb[live]), f"t={t}: opponents' actions"
+        outs_a, outs_b = a.step_finish(xa), b.step_finish(xb)
+        for x, y, name in zip(outs_a, outs_b, ("obs", "reward", "valid", "done")):
+            assert torch.equal(x, y), f"t={t}: {name}"
+        dones += int(outs_a[3].sum())
+    sa, sb = a.get_state(), b.get_state()
+    for key in sa:
+        assert np.array_equal(sa[key], sb[key]), key
+    assert dones > N // 4
+    if level == 5:
+        assert set(np.unique(a.opp_policy().cpu().numpy())) == {3, 4, 5}

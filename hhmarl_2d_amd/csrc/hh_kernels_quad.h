@@ -807,23 +807,40 @@ __device__ __forceinline__ void quad_target_refresh(const DevCfg &c, const QTab 
     if (m.alive && nb.n) { m.n_tgt = 1; m.tgt0 = nb.j0 + 1; m.tgt_d0 = nb.d0; }
 }
 
-/* L3 = the reference's default training configuration of the level the benchmark is quoted on (config.py:17-54 with
- * --level 3: fight mode, scripted opponents, friendly fire on, no friendly punishment, no escape shaping, glob_frac 0,
- * rew_scale 1) compiled with those values as constants: the other configurations' code and its scalar registers drop
- * out.  Every other configuration runs the L3 = false instance of the same source; both give the same results. */
+/* PRE = preset: the reference's default training configuration (config.py:17-54: scripted opponents, friendly fire on, no friendly
+ * punishment, no escape shaping, glob_frac 0, rew_scale 1) of one curriculum stage compiled with those values as constants — 1: level 3
+ * fight (the stage the benchmark is quoted on), 2: level 1 fight, 3: level 2 fight, 4: level 3 escape.  The other configurations'
+ * code (the other levels' opponent scripts, the other mode's observation and rewards) and its scalar registers drop out.  Every
+ * other configuration runs the PRE = 0 instance of the same source; all give the same results. */
+__host__ __device__ inline void hh_cfg_set_preset(DevCfg &c, int pre) {
+    c.level = pre == 2 ? 1 : (pre == 3 ? 2 : 3);
+    c.agent_mode = pre == 4 ? HH_MODE_ESCAPE : HH_MODE_FIGHT;
+    c.ext_opp = 0; c.friendly_kill = 1; c.friendly_punish = 0; c.esc_dist_rew = 0; c.glob_frac = 0.0; c.rew_scale = 1.0;
+    c.D = pre == 4 ? HH_OBS_ESC_AC1 : HH_OBS_FIGHT_AC1; c.n_ctrl = 2; c.nA = 2; c.nO = 2;
+}
+inline int hh_cfg_preset(const DevCfg &c) { /* which preset equals this configuration in every field it fixes (0: none) */
+    for (int pre = 1; pre <= 4; pre++) {
+        DevCfg d = c;
+        hh_cfg_set_preset(d, pre);
+        if (d.level == c.level && d.agent_mode == c.agent_mode && d.ext_opp == c.ext_opp && d.friendly_kill == c.friendly_kill &&
+            d.friendly_punish == c.friendly_punish && d.esc_dist_rew == c.esc_dist_rew && d.glob_frac == c.glob_frac && d.rew_scale == c.rew_scale &&
+            d.D == c.D && d.n_ctrl == c.n_ctrl && d.nA == c.nA && d.nO == c.nO)
+            return pre;
+    }
+    return 0;
+}
 /* APW = arenas per simulation wave: 16 fills the 64 lanes; 8 (lanes 32..63 idle) is for worlds so small that half the SIMDs would
  * otherwise sit empty: a wave's tick costs the instructions of every branch ANY of its arenas takes (rocket in flight, cannon
  * burst, events, reset ...), so half the arenas per wave means fewer instructions per wave-tick at the same number of ticks. */
-template <int W, bool L3, bool TWO, int APW = 16>
+template <int W, int PRE, bool TWO, int APW = 16>
 __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_eu(W, W))) void hh_k_world_quad(DevPtrs P, DevCfg c_in, int T, const int8_t *__restrict__ actions,
                                                                   float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                                   uint8_t *__restrict__ valid_out, uint8_t *__restrict__ done_out) {
     constexpr int A = 4, B = 64, GPB = APW;
     static_assert(APW == 16 || APW == 8, "arenas per wave");
-    DevCfg c_l3 = c_in;
-    c_l3.level = 3; c_l3.agent_mode = HH_MODE_FIGHT; c_l3.ext_opp = 0; c_l3.friendly_kill = 1; c_l3.friendly_punish = 0;
-    c_l3.esc_dist_rew = 0; c_l3.glob_frac = 0.0; c_l3.rew_scale = 1.0; c_l3.D = HH_OBS_FIGHT_AC1; c_l3.n_ctrl = 2; c_l3.nA = 2; c_l3.nO = 2;
-    const DevCfg &c = L3 ? c_l3 : c_in;
+    DevCfg c_pre = c_in;
+    hh_cfg_set_preset(c_pre, PRE);
+    const DevCfg &c = PRE ? c_pre : c_in;
     __shared__ Shared<A, B> sh;
     __shared__ QuadMailbox<TWO> mbx;
     const int tid = threadIdx.x & 63;

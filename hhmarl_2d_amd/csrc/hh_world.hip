@@ -241,19 +241,24 @@ static int launch(hh_world *w, int run, int T, const int8_t *actions, const uint
     const bool two = w->force_w == 2 || (w->force_w == 0 && waves > w->n_simd); /* more waves than SIMDs: hold two per SIMD */
     if (run == HH_RUN_ROLLOUT && !w->no_quad && !w->P.trace) { /* tracing runs on the generic kernel */
         static_assert(B == 64, "the register-exchange kernel is one wave per workgroup");
-        const bool l3 = !w->no_spec && c.level == 3 && c.agent_mode == HH_MODE_FIGHT && !c.ext_opp && c.friendly_kill == 1 && !c.friendly_punish &&
-                        !c.esc_dist_rew && c.glob_frac == 0.0 && c.rew_scale == 1.0;
+        const int pre = w->no_spec ? 0 : hh_cfg_preset(c); /* 1: level 3 fight, 2 / 3: levels 1 / 2 fight, 4: level 3 escape (hh_kernels_quad.h) */
         /* small worlds (every workgroup resident with a SIMD pair to itself): simulation wave + output wave per 16 arenas */
         const bool pair = !two && !w->no_two && waves <= w->n_simd / 2; /* 128-thread groups at one wave per SIMD: two per CU resident */
         /* smaller still (the two-wave form of 8-arena groups fits one wave per SIMD): 8 arenas per simulation wave, hh_kernels_quad.h */
         const int grid8 = (c.N + 7) / 8;
         const bool half = pair && w->apw != 16 && 2 * grid8 <= w->n_simd;
-#define HH_QLAUNCH(Wv, L3v, TWOv) hipLaunchKernelGGL((hh_k_world_quad<Wv, L3v, TWOv>), dim3(grid), dim3(TWOv ? 128 : 64), 0, st, w->P, c, T, actions, obs, reward, valid, done)
-#define HH_QLAUNCH8(L3v) hipLaunchKernelGGL((hh_k_world_quad<1, L3v, true, 8>), dim3(grid8), dim3(128), 0, st, w->P, c, T, actions, obs, reward, valid, done)
-        if (two) { if (l3) HH_QLAUNCH(2, true, false); else HH_QLAUNCH(2, false, false); }
-        else if (half) { if (l3) HH_QLAUNCH8(true); else HH_QLAUNCH8(false); }
-        else if (pair) { if (l3) HH_QLAUNCH(1, true, true); else HH_QLAUNCH(1, false, true); }
-        else { if (l3) HH_QLAUNCH(1, true, false); else HH_QLAUNCH(1, false, false); }
+#define HH_QLAUNCH(Wv, Pv, TWOv) hipLaunchKernelGGL((hh_k_world_quad<Wv, Pv, TWOv>), dim3(grid), dim3(TWOv ? 128 : 64), 0, st, w->P, c, T, actions, obs, reward, valid, done)
+#define HH_QLAUNCH8(Pv) hipLaunchKernelGGL((hh_k_world_quad<1, Pv, true, 8>), dim3(grid8), dim3(128), 0, st, w->P, c, T, actions, obs, reward, valid, done)
+#define HH_QPRE(LAUNCH) switch (pre) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; case 4: LAUNCH(4); break; default: LAUNCH(0); }
+#define HH_Q2(Pv) HH_QLAUNCH(2, Pv, false)
+#define HH_Q1(Pv) HH_QLAUNCH(1, Pv, false)
+        if (two) { HH_QPRE(HH_Q2) }
+        else if (half) { HH_QPRE(HH_QLAUNCH8) }
+        else if (pair) { if (pre == 1) HH_QLAUNCH(1, 1, true); else HH_QLAUNCH(1, 0, true); } /* 4097..8192 arenas: the benchmark's preset only */
+        else { HH_QPRE(HH_Q1) }
+#undef HH_Q2
+#undef HH_Q1
+#undef HH_QPRE
 #undef HH_QLAUNCH
 #undef HH_QLAUNCH8
     } else if (run >= HH_RUN_LL_BEGIN)
@@ -278,13 +283,16 @@ extern "C" int hh_rollout_kernel_name(hh_world *w, char *buf, int32_t len) {
     }
     const int waves = (c.N + 15) / 16;
     const bool two = w->force_w == 2 || (w->force_w == 0 && waves > w->n_simd);
-    const bool l3 = !w->no_spec && c.level == 3 && c.agent_mode == HH_MODE_FIGHT && !c.ext_opp && c.friendly_kill == 1 && !c.friendly_punish &&
-                    !c.esc_dist_rew && c.glob_frac == 0.0 && c.rew_scale == 1.0;
+    int pre = w->no_spec ? 0 : hh_cfg_preset(c);
     const bool pair = !two && !w->no_two && waves <= w->n_simd / 2;
     const bool half = pair && w->apw != 16 && 2 * ((c.N + 7) / 8) <= w->n_simd;
     if (w->no_quad) snprintf(buf, (size_t)len, "hh_k_world<4,64,%d,false>", two ? 2 : 1);
-    else snprintf(buf, (size_t)len, "hh_k_world_quad<W=%d,L3=%s,%s%s>", two ? 2 : 1, l3 ? "true" : "false",
-                  pair ? "simulation wave + output wave" : "single wave", half ? ",8 arenas per wave" : "");
+    else {
+        if (pair && !half && pre != 1) pre = 0;
+        static const char *names[5] = {"general", "L3 fight", "L1 fight", "L2 fight", "L3 escape"};
+        snprintf(buf, (size_t)len, "hh_k_world_quad<W=%d,preset=%s,%s%s>", two ? 2 : 1, names[pre],
+                 pair ? "simulation wave + output wave" : "single wave", half ? ",8 arenas per wave" : "");
+    }
     return HH_OK;
 }
 

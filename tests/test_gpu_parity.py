@@ -28,6 +28,7 @@ def _assert_same_state(a, b, what):
 CASES = [
     dict(level=1), dict(level=2), dict(level=3),
     dict(level=3, agent_mode=1, esc_dist_rew=True),
+    dict(level=3, agent_mode=1),     # the escape-mode default: its own compiled instance of the rollout kernel (hh_cfg_preset)
     dict(level=3, glob_frac=0.5, friendly_punish=True, rew_scale=2.0),
     dict(level=3, friendly_kill=False),
     dict(level=4, ext_opp_actions=True),
@@ -244,8 +245,8 @@ def test_register_exchange_kernel_equals_lds_kernel(monkeypatch, kw):
     assert int(outs[0][3].sum()) > N // 8   # episodes ended and were re-sampled inside the launch
 
 
-@pytest.mark.parametrize("kw", [dict(level=3), dict(level=3, agent_mode=1, esc_dist_rew=1, glob_frac=0.0), dict(level=1)],
-                         ids=["L3-fight", "L3-escape", "L1"])
+@pytest.mark.parametrize("kw", [dict(level=3), dict(level=3, agent_mode=1, esc_dist_rew=1, glob_frac=0.0), dict(level=1), dict(level=2), dict(level=3, agent_mode=1)],
+                         ids=["L3-fight", "L3-escape-shaping", "L1", "L2", "L3-escape"])
 def test_two_wave_form_equals_single_wave(monkeypatch, kw):
     """small worlds run a simulation wave + an output wave per 16 arenas — per 8 arenas when that still fits one wave per SIMD
     (<= 4096 arenas on 256 CUs; HH_APW=16 keeps 16) — (hh_kernels_quad.h); outputs and state must equal the single-wave form and

@@ -112,6 +112,22 @@ struct Arena {
 
 __device__ __forceinline__ void arena_rekey(Arena &a) { a.tkey = hh_rng_tick_key(a.akey, (uint32_t)a.episode, (uint32_t)a.steps); }
 
+/* Workgroup barrier for LDS hand-overs.  Every kernel of this path runs ONE wave per workgroup (B = 64): the LDS unit executes a
+ * wave's instructions in order, so a hand-over between lanes only needs the compiler kept from moving the accesses and the returned
+ * data waited for — s_waitcnt lgkmcnt(0).  __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: the vmcnt(0) also waits
+ * for every global load and store in flight (the action word requested a sub-step ahead, the output rows of the previous phase),
+ * once per barrier, ~25 times per tick.  Barriers that order GLOBAL accesses (ev_mask clear -> atomicOr) stay __syncthreads(). */
+template <int B>
+__device__ __forceinline__ void hh_wg_sync() {
+    if constexpr (B == 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else __syncthreads();
+}
+template <int B>
+__device__ __forceinline__ int hh_wg_sync_or(int x) {
+    if constexpr (B == 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return __any(x); }
+    else return __syncthreads_or(x);
+}
+
 /* rows -> per-network lists, one atomic ROUND TRIP per wave (the scheme of hh_k_policy_bin): lane n - 1 carries the wave's count for
  * network n, the (up to eight) atomics leave as one instruction, every row takes its slot from the base of its network plus its rank
  * in that network's ballot.  Two halves so that the caller can put work (its output stores) between the request and the use of the

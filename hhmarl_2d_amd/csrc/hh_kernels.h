@@ -698,7 +698,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     sh.res[tid] = 0;
     if (tid == 0) sh.u.t.q_count = 0;
     if (s == 0 && active) sh.g_tkey[g] = ar.tkey;
-    __syncthreads();
+    hh_wg_sync<B>();
 
     HH_PROF(1);
     /* ---------------- phase Q: enqueue every geodesic envelope test that survives the prefilter ---------------- */
@@ -755,12 +755,12 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
             if (nq > 7) sh.u.t.q_code[at + 7] = c7;
         }
     }
-    __syncthreads();
+    hh_wg_sync<B>();
 
     HH_PROF(2);
     /* ---------------- phase I: dense pass over the queue (estimate filter + out-of-line exact Karney) ---------------- */
     drain_envelope_queue<A, B, IX>(sh, tid, sh.u.t.q_count);
-    __syncthreads();
+    hh_wg_sync<B>();
 
     HH_PROF(3);
     /* ---------------- phase L: launch bookkeeping (env_base.py:227-236, ac1.py:76-79) ---------------- */
@@ -787,7 +787,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     if (want_launch && wait_after >= 0) m.missile_wait = wait_after;
     const int rk_at_start = m.rk_alive; /* rockets in do_tick's snapshot: in flight + launched this step */
     sh.aux[tid] = launched | ((fired ? (myres >> 1) & 0xff : 0) << 8);
-    __syncthreads();
+    hh_wg_sync<B>();
     {   /* launch order = unit id order (cmano_simulator.py:104-108): seq = running id counter */
         int before = 0, total = 0;
 #pragma unroll
@@ -807,7 +807,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     sh.res[tid] = rkw; /* res was consumed into myres above; reuse it for the rocket word */
 
     /* ---------------- phases C + D: id-ordered resolution by one lane per arena ---------------- */
-    __syncthreads();
+    hh_wg_sync<B>();
     if (s == 0 && active) {
         int alive = 0, nev = 0, dead = 0;
         int aux_[A], res_[A];
@@ -856,7 +856,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
         sh.g_nev[g] = nev;
         sh.g_rkdead[g] = dead;
     }
-    __syncthreads();
+    hh_wg_sync<B>();
     if (running && rk_at_start) {
         if ((sh.g_rkdead[g] >> s) & 1) {
             m.rk_alive = 0; m.rk_target = 0; m.rk_life = 0; m.rk_seq = 0;
@@ -924,7 +924,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     /* post-tick state + pair table: escape shaping now, observation next, pre-step lookups of the next tick */
     HH_PROF(5);
     publish_obs_hv(c, sh, tid, m, hv_c, hv_s);
-    __syncthreads();
+    hh_wg_sync<B>();
     HH_PROF(6);
     pair_tables(sh, tid, base, s, active);
     HH_PROF(7);
@@ -939,7 +939,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
         out.kill_event = kill;
         if (tmode == 0) ar.done = (ag <= 0 || op <= 0 || ar.steps >= c.horizon) ? 1 : 0;
     }
-    __syncthreads();
+    hh_wg_sync<B>();
     if (running && agent) {
         if (!hl && c.agent_mode == HH_MODE_ESCAPE && c.esc_dist_rew && m.alive) {
             /* env_hetero.py:198-214 */
@@ -966,7 +966,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
             }
         }
     }
-    __syncthreads(); /* all reads of rew/aux/g_* done before the caller reuses them */
+    hh_wg_sync<B>(); /* all reads of rew/aux/g_* done before the caller reuses them */
     HH_PROF(8);
 }
 
@@ -1026,15 +1026,15 @@ __device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int
     const bool try_launch = want_launch && !m.has_missile && m.missile_remain > 0;
     sh.res[tid] = 0;
     if (tid == 0) sh.u.t.q_count = 0;
-    __syncthreads();
+    hh_wg_sync<B>();
     const int launch_pre = !try_launch ? -1 : (TAB ? launch_planar(sh, tid, base, launch_tgt) : launch_planar_direct(sh, tid, base, launch_tgt));
     if (try_launch && launch_pre < 0) {
         int at = atomicAdd(&sh.u.t.q_count, 1);
         sh.u.t.q_code[at] = tid | (0 << 8) | (launch_tgt << 10);
     }
-    __syncthreads();
+    hh_wg_sync<B>();
     drain_envelope_queue<A, B, IX>(sh, tid, sh.u.t.q_count);
-    __syncthreads();
+    hh_wg_sync<B>();
     int launched = 0;
     if (try_launch && ((sh.res[tid] & 1) || launch_pre == 1)) { /* ac1.py:76-79 */
         launched = 1;
@@ -1053,7 +1053,7 @@ __device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int
         if (m.missile_wait > 0 && !m.has_missile) m.missile_wait -= 1;
     }
     sh.aux[tid] = launched;
-    __syncthreads();
+    hh_wg_sync<B>();
     {   /* rocket ids in unit id order (cmano_simulator.py:104-108) */
         int before = 0, total = 0;
 #pragma unroll
@@ -1068,7 +1068,7 @@ __device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int
     /* weapon flags other lanes observe (env_base.py:208-211) */
     int shot = m.burst > 0 || (m.ac_type == 1 && m.has_missile);
     sh.flags[tid] = (m.alive ? FL_ALIVE : 0) | ((m.ac_type & 3) << 1) | (shot ? FL_SHOT : 0);
-    __syncthreads();
+    hh_wg_sync<B>();
 }
 
 /* hh_opp_policy: k of every arena's current episode (level 5, fight mode) */
@@ -1124,9 +1124,9 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
     int tcur = (P.trace != nullptr && active && n < P.trace_K) ? P.trace_pos[n] : 0; /* trace cursor of the lane's arena */
     if (run == HH_RUN_ROLLOUT || run >= HH_RUN_LL_BEGIN) { /* pair table of the pre-tick state */
         publish_obs(c, sh, tid, m);
-        __syncthreads();
+        hh_wg_sync<B>();
         pair_tables(sh, tid, base, s, active);
-        __syncthreads();
+        hh_wg_sync<B>();
     }
     if constexpr (SPLIT) {
         if (run == HH_RUN_LL_BEGIN) {
@@ -1161,13 +1161,13 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
                 bt = hh_bin_rows_issue(P.pol_counts, pslot);
             }
             /* observation of the frozen-policy opponents, after the agents acted (shot flags refreshed by act_phase) */
-            __syncthreads(); /* the queue area of act_phase is free: stage the rows there, store them coalesced */
+            hh_wg_sync<B>(); /* the queue area of act_phase is free: stage the rows there, store them coalesced */
             if (active && s >= c.nA) {
                 float *row = &sh.u.obs[(g * c.nO + (s - c.nA)) * 30];
                 if (running && m.alive) lowlevel_obs<A, B>(c, sh, tid, base, s, opp_mode, m, row, 30);
                 else for (int q = 0; q < 30; q++) row[q] = 0.0f;
             }
-            __syncthreads();
+            hh_wg_sync<B>();
             if (obs_out) {
                 const int rows = min(GPB, c.N - (int)blockIdx.x * GPB);
                 const int cnt = rows * c.nO * 30;
@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
                 for (int q = tid; q < cnt; q += B) dst[q] = sh.u.obs[q];
                 if (P.pol_lut) hh_bin_rows_finish(bt, P.pol_lists, P.pol_max_rows, n * c.nO + (s - c.nA), pslot);
             }
-            __syncthreads();
+            hh_wg_sync<B>();
             T = 0; /* no tick in this launch */
         } else if (run == HH_RUN_LL_FINISH) {
             T = 1;
@@ -1233,7 +1233,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
             }
             /* episode statistics: one lane per arena, agent order */
             sh.rew[tid] = so.valid ? so.reward : 0.0;
-            __syncthreads();
+            hh_wg_sync<B>();
             if (active && s == 0 && was_running) {
                 for (int j = 0; j < c.nA; j++) ep_ret += sh.rew[base + j];
                 if (ar.done) {
@@ -1248,7 +1248,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
             if (was_running) trace_append(P, A, n, s, m, ar, tcur);
             need_reset = active && ar.done && c.auto_reset;
         }
-        const int any_reset = __syncthreads_or(need_reset ? 1 : 0);
+        const int any_reset = hh_wg_sync_or<B>(need_reset ? 1 : 0);
         if (need_reset) { /* K3 */
             reset_arena_scalars(ar);
             reset_unit<A>(c, s, m, ar);
@@ -1257,9 +1257,9 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
         }
         if (run != HH_RUN_ROLLOUT || any_reset) { /* state changed (or never published) */
             publish_obs(c, sh, tid, m);
-            __syncthreads();
+            hh_wg_sync<B>();
             pair_tables(sh, tid, base, s, active);
-            __syncthreads();
+            hh_wg_sync<B>();
         }
         need_reset = false;
         HH_PROF(9);
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
 #ifndef HH_ABL_NO_OBS
         if (active && s < c.nA) lowlevel_obs<A, B>(c, sh, tid, base, s, c.agent_mode, m, &sh.u.obs[(g * c.nA + s) * D], D);
 #endif
-        __syncthreads();
+        hh_wg_sync<B>();
         if (obs_out) {
             const int rows = min(GPB, c.N - (int)blockIdx.x * GPB);
             const int cnt = rows * c.nA * D;
@@ -1278,7 +1278,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
                 for (int k = tid; k < cnt; k += B) dst[k] = sh.u.obs[k];
             }
         }
-        __syncthreads();
+        hh_wg_sync<B>();
         HH_PROF(10);
     }
     HH_PROF_FLUSH;

@@ -252,7 +252,7 @@ __device__ __forceinline__ void hl_do_end(const DevPtrs &P, const DevCfg &c, Sha
     for (int j = 0; j < A; j++) { int al = sh_alive(sh, base + j); if (j < c.nA) ag += al; else op += al; }
     if (ending) ar.done = (ag <= 0 || op <= 0 || ar.steps >= c.horizon) ? 1 : 0;
     sh.rew[tid] = (ending && agent) ? L.acc : 0.0;
-    __syncthreads();
+    hh_wg_sync<B>();
     if (ending && s == 0) {
         for (int j = 0; j < c.nA; j++) L.ep_ret += sh.rew[base + j];
         if (ar.done) {
@@ -264,7 +264,7 @@ __device__ __forceinline__ void hl_do_end(const DevPtrs &P, const DevCfg &c, Sha
     if (phase == HH_HL_END) {
         /* eval_info of this commander step (env_base.py:91-107): units that still exist, by assessed commander action */
         sh.res[tid] = (ending && m.alive) ? (1 | ((m.cmd_act & 3) << 1)) : 0;
-        __syncthreads();
+        hh_wg_sync<B>();
         if (active && s == 0) {
             int e[HH_EVAL_K];
 #pragma unroll
@@ -298,7 +298,7 @@ __device__ __forceinline__ void hl_do_end(const DevPtrs &P, const DevCfg &c, Sha
     }
     bool need_reset = phase == HH_HL_END ? (active && ar.done && c.auto_reset)
                                          : (phase == HH_HL_RESET && active && (mask == nullptr || mask[n]));
-    const int any_reset = __syncthreads_or(need_reset ? 1 : 0);
+    const int any_reset = hh_wg_sync_or<B>(need_reset ? 1 : 0);
     if (need_reset) {
         reset_arena_scalars(ar);
         reset_unit<A>(c, s, m, ar);
@@ -309,16 +309,16 @@ __device__ __forceinline__ void hl_do_end(const DevPtrs &P, const DevCfg &c, Sha
     }
     if (any_reset) {
         publish_obs(c, sh, tid, m);
-        __syncthreads();
+        hh_wg_sync<B>();
         pair_tables(sh, tid, base, s, active);
-        __syncthreads();
+        hh_wg_sync<B>();
     }
-    __syncthreads();
+    hh_wg_sync<B>();
     if (active) { /* rows of the agents staged in LDS (opponents only refresh their stored target lists: nothing is written) */
         float *row = agent ? &sh.u.obs[(g * c.nA + s) * HH_OBS_HL] : &sh.u.obs[0];
         hl_commander_obs(c, sh, tid, base, s, m, row);
     }
-    __syncthreads();
+    hh_wg_sync<B>();
 }
 
 template <int A, int B, int GPB = B / A>
@@ -370,10 +370,10 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
     }
     sh.aux[tid] = 0;
     publish_obs(c, sh, tid, m);
-    __syncthreads();
+    hh_wg_sync<B>();
     if (phase != HH_HL_TICK) { /* HL_TICK builds its table after the tick; before it only a launch test may ask for an entry */
         pair_tables(sh, tid, base, s, active);
-        __syncthreads();
+        hh_wg_sync<B>();
     }
     int obs_side = -1; /* which side's pilot observations this launch emits */
     /* a bound policy bank (hh_bind_policy): this launch's pilot rows are binned by network here.  The selector of a row is known
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
     /* pilot observations: every unit's row is staged in LDS (the tick's exchange area is free by now) and the workgroup's
      * rows, contiguous in [N, A, 30], leave with unit-stride 16-byte stores */
     if (obs_side >= 0 && pilot_obs) {
-        __syncthreads(); /* all reads of the tick's LDS area are done */
+        hh_wg_sync<B>(); /* all reads of the tick's LDS area are done */
         constexpr int HALF = A / 2; /* units per side */
         const bool mine = obs_side == 0 ? agent : !agent;
         const int arenas = min(GPB, c.N - (int)blockIdx.x * GPB);
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
                 else for (int k = 0; k < 30; k++) row[k] = 0.0f;
                 if (pilot_mode) pilot_mode[u] = (uint8_t)(mode ? (mode | (m.ac_type << 2)) : 0); /* policy type | aircraft type: selects the network */
             }
-            __syncthreads();
+            hh_wg_sync<B>();
             const int cnt = arenas * A * 30;
             if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0) {
                 const float4 *src4 = reinterpret_cast<const float4 *>(ptile);
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
                 }
                 if (pilot_mode) pilot_mode[u] = (uint8_t)(mode ? (mode | (m.ac_type << 2)) : 0); /* policy type | aircraft type: selects the network */
             }
-            __syncthreads();
+            hh_wg_sync<B>();
             const int cnt2 = arenas * A * 15; /* float2 elements */
             const float2 *src2 = reinterpret_cast<const float2 *>(sh.u.obs);
             if ((reinterpret_cast<uintptr_t>(dst) & 7) == 0) {
@@ -533,16 +533,16 @@ __global__ __launch_bounds__(B, W) void hh_k_hier_macro(DevPtrs P, DevCfg c_in, 
     }
     sh.aux[tid] = 0;
     publish_obs(c, sh, tid, L.m);
-    __syncthreads();
+    hh_wg_sync<B>();
     pair_tables(sh, tid, base, s, active);
-    __syncthreads();
+    hh_wg_sync<B>();
     hl_do_begin<A, B>(c, sh, tid, base, s, n, active, L, cmd);
     int ticks = 0;
     uint32_t evm_last = 0;
     /* the action word of the next sub-step is requested a sub-step ahead (one wave per SIMD cannot hide the round trip) */
     int act_next = active ? *reinterpret_cast<const int *>(tape + u * 4) : 0;
     for (int sub = 0; sub < 16; sub++) {
-        if (!__syncthreads_or(L.ar.hl_run)) break; /* nobody in this workgroup is inside a macro step any more */
+        if (!hh_wg_sync_or<B>(L.ar.hl_run)) break; /* nobody in this workgroup is inside a macro step any more */
         const int w = act_next;
         if (active && sub + 1 < 16) act_next = *reinterpret_cast<const int *>(tape + ((size_t)(sub + 1) * U + u) * 4);
         int8_t act[4];

@@ -501,6 +501,8 @@ def main_hier(args):
 
 def main():
     args = parse_args()
+    if args.dry_run and args.workload != "low":
+        sys.exit("--dry-run exercises the rank plumbing of the default workload on a CPU box (gloo); the other workloads need the GPU")
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args))
     if args.workload == "hier":

@@ -44,11 +44,25 @@ def _bank(seed, max_rows=1 << 16):
     return PolicyBank.random_init(torch.device("cuda", 0), seed=seed, max_rows=max_rows)
 
 
+FORMS = {"split-fp16": {}, "fp32-mfma": {"HH_POLICY_FP32": "1"}, "split-fp16-64-row-tiles": {"HH_POLICY_TILE": "64"}}
+
+
+def _form(monkeypatch, form):
+    """the kernel form a bank created from now on runs (read at hh_policy_create)"""
+    for k in ("HH_POLICY_FP32", "HH_POLICY_TILE"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in FORMS[form].items():
+        monkeypatch.setenv(k, v)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", list(FORMS))
 @pytest.mark.parametrize("kind", [PN.FIGHT1, PN.FIGHT2, PN.ESC1, PN.ESC2], ids=lambda k: PN.KIND_NAMES[k])
-def test_hip_kernel_matches_reference_vectors(kind):
-    """hh_policy_act against the vectors recorded from the reference's own model classes: logits 1e-5, actions exact"""
+def test_hip_kernel_matches_reference_vectors(monkeypatch, kind, form):
+    """hh_policy_act (every form of the forward kernel) against the vectors recorded from the reference's own model classes: logits
+    1e-5, actions exact"""
     from hhmarl_2d_amd import pilots
+    _form(monkeypatch, form)
     g = np.load(GOLD)
     name = PN.KIND_NAMES[kind].lower()
     bank = _bank(int(g["seed"]))
@@ -237,8 +251,10 @@ def test_tile_instances_of_the_kernel_agree_bit_for_bit(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("force_w,nA,nO,N", [("0", 3, 3, 1003), ("2", 3, 3, 517), ("0", 2, 3, 300)], ids=["3v3", "3v3-W2", "2v3"])
-def test_rows_binned_by_the_world_kernels_give_the_same_macro_steps(monkeypatch, force_w, nA, nO, N):
+@pytest.mark.parametrize("force_w,nA,nO,N,form", [("0", 3, 3, 1003, "split-fp16"), ("2", 3, 3, 517, "split-fp16"), ("0", 2, 3, 300, "split-fp16"),
+                                                  ("0", 3, 3, 700, "fp32-mfma"), ("0", 3, 3, 900, "split-fp16-64-row-tiles")],
+                         ids=["3v3", "3v3-W2", "2v3", "3v3-fp32-mfma", "3v3-64-row-tiles"])
+def test_rows_binned_by_the_world_kernels_give_the_same_macro_steps(monkeypatch, force_w, nA, nO, N, form):
     """hh_bind_policy: the phase kernels write the bank's row lists themselves and hh_policy_act_binned runs the forward only
     (the last workgroup clears the counters; hh_hl_end drops what the last tick binned).  Same worlds, same weights: every macro
     step's outputs, the pilots' actions of every sub-step and the final state equal the self-contained form (binning pass from
@@ -247,6 +263,7 @@ def test_rows_binned_by_the_world_kernels_give_the_same_macro_steps(monkeypatch,
     from hhmarl_2d_amd.env_hier import macro_step
     from hhmarl_2d_amd.world import World, make_config
     monkeypatch.setenv("HH_FORCE_W", force_w)
+    _form(monkeypatch, form)
     kw = dict(n_arenas=N, env_kind=1, n_agents=nA, n_opps=nO, seed=21, auto_reset=True, horizon=80)
     a, b = World(make_config(**kw)), World(make_config(**kw))
     assert torch.equal(a.reset(), b.reset())

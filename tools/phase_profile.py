@@ -18,7 +18,8 @@ L = _lib.lib(); L.hh_prof_read(buf, 1)
 for _ in range(4): w.rollout(act, out=out)
 L.hh_prof_read(buf, 0)
 names = ["A2 level-3 script (opponents)", "B kinematics+move", "Q enqueue", "I drain (estimate)", "L+C+D launch/resolve/rocket move", "E rewards", "publish", "pair tables", "finish (shaping, done)", "stats/outputs/reset", "K2 observe+store", "A1 rekey + agents' action decode"]
-waves = (N + 15) // 16
+APW = 8 if N <= 4096 and os.environ.get("HH_APW") != "16" else 16   # the form small worlds run (hh_kernels_quad.h)
+waves = (N + APW - 1) // APW
 tot = sum(buf[:12])
 for k, nm in enumerate(names):
     print(f"{nm:36s} {buf[k] / (waves * 4 * T):9.0f} cycles/wave-tick  {100.0 * buf[k] / tot:5.1f} %")

@@ -345,6 +345,12 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
     constexpr int GPB = B / A;
     __shared__ Shared<A, B> sh;
     __shared__ alignas(16) float ptile[W == 1 ? GPB * A * 30 : 4]; /* every unit's pilot row (W = 1 only, see below) */
+#ifdef HH_PROFILE_PHASES /* tuning builds: where a phase launch spends its cycles (tools/phase_cost.py) */
+    unsigned long long ht0_ = __builtin_readcyclecounter(), hacc_[8] = {0};
+#define HH_HPROF(k) do { unsigned long long t_ = __builtin_readcyclecounter(); hacc_[k] += t_ - ht0_; ht0_ = t_; } while (0)
+#else
+#define HH_HPROF(k)
+#endif
     const int tid = threadIdx.x;
     const int g = tid / A, s = tid % A;
     const int base = g * A;
@@ -369,12 +375,15 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
         ar.done = 1;
     }
     sh.aux[tid] = 0;
+    HH_HPROF(0); /* loads requested */
     publish_obs(c, sh, tid, m);
     hh_wg_sync<B>();
+    HH_HPROF(1); /* state arrived, published */
     if (phase != HH_HL_TICK) { /* HL_TICK builds its table after the tick; before it only a launch test may ask for an entry */
         pair_tables(sh, tid, base, s, active);
         hh_wg_sync<B>();
     }
+    HH_HPROF(2); /* pair table */
     int obs_side = -1; /* which side's pilot observations this launch emits */
     /* a bound policy bank (hh_bind_policy): this launch's pilot rows are binned by network here.  The selector of a row is known
      * as soon as the phase body is through (policy type from the commander's / the opponent's own choice, env_hier.py:100-112) — for
@@ -416,6 +425,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
         hl_do_end<A, B>(P, c, sh, tid, g, base, s, n, active, L, phase, reward_out, valid_out, done_out, mask);
         hl_store_commander_obs<A, B>(c, sh, tid, phase, obs_out, mask);
     }
+    HH_HPROF(3); /* phase body */
     /* pilot observations: every unit's row is staged in LDS (the tick's exchange area is free by now) and the workgroup's
      * rows, contiguous in [N, A, 30], leave with unit-stride 16-byte stores */
     if (obs_side >= 0 && pilot_obs) {
@@ -479,6 +489,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
             if (P.pol_lut) hh_bin_rows_finish(bt, P.pol_lists, P.pol_max_rows, (int)u, pslot);
         }
     }
+    HH_HPROF(4); /* pilot rows staged and stored */
     if (active) {
         unit_store(P, U, u, m);
         P.acc_rew[u] = L.acc;
@@ -488,6 +499,10 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
             P.ep_ret[n] = L.ep_ret;
         }
     }
+    HH_HPROF(5); /* state stores issued */
+#ifdef HH_PROFILE_PHASES
+    if ((tid & 63) == 0) { for (int k_ = 0; k_ < 6; k_++) atomicAdd(&hh_prof_cycles[k_], hacc_[k_]); atomicAdd(&hh_prof_cycles[6 + (phase == HH_HL_TICK)], 1ULL); }
+#endif
     if (phase == HH_HL_AGENTS_ACT || phase == HH_HL_TICK) {
         if (active && s == 0 && phase == HH_HL_AGENTS_ACT && ar.hl_run) P.ev_mask[n] = 0;
         __syncthreads();

@@ -39,3 +39,14 @@ for with_obs in (True, False):
     for _ in range(50): g.replay()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
     print(f"phase path, pilot observations {'written' if with_obs else 'not requested'}: {dt * 1e6:.0f} us per commander step = {dt * 1e6 / 34:.1f} us per launch")
+
+if os.environ.get("HH_WORLD_LIB", "").endswith("prof_phases.so"):   # -DHH_PROFILE_PHASES build: the markers of hh_k_hier
+    buf = (C.c_ulonglong * 16)()
+    lib.hh_prof_read(buf, 1)
+    g.replay(); torch.cuda.synchronize()
+    lib.hh_prof_read(buf, 0)
+    launches = buf[6] + buf[7]
+    names = ["loads requested", "state arrived + published", "pair table (not in HL_TICK)", "phase body", "pilot rows staged + stored", "state stores issued"]
+    for k, nm in enumerate(names):
+        print(f"  {nm:32s} {buf[k] / launches:9.0f} cycles per wave-launch")
+    print(f"  {'sum':32s} {sum(buf[:6]) / launches:9.0f} cycles per wave-launch ({launches} wave-launches)")

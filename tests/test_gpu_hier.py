@@ -255,3 +255,41 @@ def test_reference_traces_on_gpu(path):
         assert np.array_equal(val, g["valid"][r]) and done == g["done"][r], f"row {r}"
         assert np.abs(st["ac_f"][0][:nU] - g["ac_f"][r]).max() <= 1e-9 and np.abs(obs - g["obs"][r]).max() <= 1e-6, f"row {r}"
         assert np.abs(rew - g["reward"][r]).max() <= 1e-6, f"row {r}"
+
+
+@pytest.mark.gpu
+def test_random_highlevel_configurations_parity(oracle):
+    """configuration fuzz for HighLevelEnv: 14 seeded random combinations of side sizes (n-vs-m), reward sharing, action assessment,
+    opponents' fight ratio, horizon and arena count; the one-launch macro step (whatever instance the configuration selects) against
+    the oracle stepping the same tape phase by phase: outputs, eval counters, event masks and the final state bit for bit"""
+    import torch
+    from hhmarl_2d_amd.world import World, make_config
+    rng = np.random.default_rng(424242)
+    for trial in range(14):
+        nA, nO = (3, 3) if trial % 2 == 0 else (int(rng.integers(1, 4)), int(rng.integers(1, 4)))
+        kw = dict(n_arenas=int(rng.choice([1, 9, 10, 11, 170, 1001])), env_kind=1, n_agents=nA, n_opps=nO, horizon=int(rng.choice([40, 120, 500])),
+                  glob_frac=float(rng.choice([0.0, 0.0, 0.3])), hier_action_assess=bool(rng.integers(0, 2)),
+                  hier_opp_fight_ratio=int(rng.choice([0, 50, 75, 100])), friendly_kill=bool(rng.integers(0, 4)),
+                  seed=int(rng.integers(0, 1 << 30)), arena_offset=int(rng.integers(0, 1 << 20)), auto_reset=True)
+        if trial % 4 == 0:   # the reference's default HighLevelEnv configuration: its own compiled instance
+            kw.update(horizon=500, glob_frac=0.0, hier_action_assess=True, hier_opp_fight_ratio=75, friendly_kill=True)
+        g, o = World(make_config(**kw)), oracle.OracleWorld(oracle.make_config(**kw))
+        assert np.array_equal(g.reset().cpu().numpy(), o.reset()), (trial, kw)
+        N, nU = kw["n_arenas"], nA + nO
+        for step in range(4):
+            cmd = rng.integers(0, 3, (N, nA)).astype(np.int8)
+            tape = random_actions(rng, (16, N), 6)
+            tape[..., 2] |= step % 2
+            outs = [x.cpu().numpy() for x in g.hl_rollout(torch.from_numpy(cmd).cuda(), torch.from_numpy(tape).cuda())]
+            o.hl_begin(cmd)
+            for k in range(16):
+                o.hl_agents_act(np.ascontiguousarray(tape[k][:, :nU]))
+                o.hl_tick(np.ascontiguousarray(tape[k][:, :nU]))
+            for a, b, name in zip(outs, o.hl_end(), ("obs", "reward", "valid", "done")):
+                assert np.array_equal(a, b), (trial, step, name, kw)
+            for a, b in zip([x.cpu().numpy() for x in g.eval_info()], o.eval_info()):
+                assert np.array_equal(a, b), (trial, step, "eval counters", kw)
+            assert np.array_equal(g.event_masks(), o.event_masks()), (trial, step, kw)
+        sg, so = g.get_state(), o.get_state()
+        for k in sg:   # the world keeps six unit slots, the oracle exactly n + m units
+            assert np.array_equal(sg[k] if k == "ar_i" else sg[k][:, :nU], so[k]), (trial, k, kw)

@@ -407,3 +407,35 @@ def test_error_codes_instead_of_exceptions():
         L.check(lib.hh_step(ll.h, None, None, None, None, None, None))
     ll.reset()
     ll.step(torch.zeros((8, 2, 4), dtype=torch.int8, device="cuda"))              # the worlds are still usable
+
+
+@pytest.mark.gpu
+def test_random_configurations_parity(oracle):
+    """configuration fuzz: 24 seeded random combinations of level, mode, reward options, horizon, map size and arena count (every
+    preset and the general instance of the rollout kernel, partial last workgroups, auto-reset on and off) — rollout outputs, event
+    masks, episode statistics and the final state against the oracle, bit for bit"""
+    import torch
+    rng = np.random.default_rng(20260927)
+    for trial in range(24):
+        level = int(rng.integers(1, 4))
+        kw = dict(n_arenas=int(rng.choice([1, 7, 16, 33, 250, 1000, 2049])), level=level, agent_mode=int(rng.integers(0, 2)),
+                  horizon=int(rng.integers(15, 120)), friendly_kill=bool(rng.integers(0, 2)), friendly_punish=bool(rng.integers(0, 2)),
+                  esc_dist_rew=bool(rng.integers(0, 2)), glob_frac=float(rng.choice([0.0, 0.0, 0.3])), rew_scale=float(rng.choice([1.0, 1.0, 2.0])),
+                  map_size=float(rng.choice([0.3, 0.3, 0.4])), seed=int(rng.integers(0, 1 << 30)), arena_offset=int(rng.integers(0, 1 << 20)),
+                  auto_reset=bool(rng.integers(0, 4)))
+        if trial % 4 == 0:   # a share of pure presets (the reference's defaults of a curriculum stage)
+            kw.update(friendly_kill=True, friendly_punish=False, esc_dist_rew=False, glob_frac=0.0, rew_scale=1.0)
+        g, o = _worlds(oracle, **kw)
+        assert np.array_equal(g.reset().cpu().numpy(), o.reset()), (trial, kw)
+        N, T = kw["n_arenas"], 70
+        act = random_actions(rng, (T, N), g.n_ctrl)
+        if trial % 3 == 0:
+            act[..., 2] = 1      # triggers pulled: more cannon events
+        got = [x.cpu().numpy() for x in g.rollout(torch.from_numpy(act).cuda())]
+        want = o.rollout(act)
+        for a, b, name in zip(got, want, ("obs", "reward", "valid", "done")):
+            assert np.array_equal(a, b), (trial, name, kw, g.kernel_name())
+        assert np.array_equal(g.event_masks(), o.event_masks()), (trial, kw)
+        _assert_same_state(g.get_state(), o.get_state(), f"trial {trial} {kw}")
+        for a, b in zip([x.cpu().numpy() for x in g.episode_stats()], o.episode_stats()):
+            assert np.array_equal(a, b), (trial, "episode statistics", kw)

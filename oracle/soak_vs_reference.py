@@ -42,6 +42,8 @@ def replay(fn, oracle_lib, path, tight):
 def main():
     ap = argparse.ArgumentParser(description=__doc__)
     ap.add_argument("--arenas", type=int, default=6, help="fresh (seed, arena) pairs per scenario")
+    ap.add_argument("--fuzz", type=int, default=0, help="additionally: this many random configurations per env kind (levels, modes, reward "
+                    "options, map size, horizon, n-vs-m, opponents' fight ratio ...) recorded from the reference and replayed")
     ap.add_argument("--report", default=os.path.join(ROOT, "profiles", "oracle_soak_report.json"))
     a = ap.parse_args()
     import gen_env_golden as G
@@ -72,6 +74,35 @@ def main():
                 report["scenarios"].append(dict(name=name, seed=seed, arena=arena + 5, rows=rows, ok=True, state_float_tol=tol))
                 total_rows += rows
                 total_traces += 1
+        rng = np.random.default_rng(987654321)
+        for k in range(a.fuzz):   # configuration fuzz on the REAL reference: nothing here is a committed scenario
+            seed, arena = 555000 + 17 * k, 3000 + 11 * k
+            level = int(rng.integers(1, 6))
+            kw = dict(level=level, agent_mode=str(rng.choice(["fight", "escape"])) if level <= 3 else "fight", friendly_kill=bool(rng.integers(0, 2)),
+                      friendly_punish=bool(rng.integers(0, 2)), esc_dist_rew=bool(rng.integers(0, 2)), glob_frac=float(rng.choice([0.0, 0.3, 0.5])),
+                      rew_scale=int(rng.choice([1, 2])), map_size=float(rng.choice([0.3, 0.3, 0.4])), horizon=int(rng.integers(40, 200)))
+            policy = G.pursuit_actions if rng.integers(0, 2) else G.random_actions
+            name = f"fuzz_low_{k}"
+            G.record(name, "low", kw, policy, 3, 300, seed=seed, arena=arena)
+            path = os.path.join(tmp, f"env_{name}.npz")
+            tol = replay(T.replay_low, oracle_lib, path, T.FLOAT_TOL)
+            rows = int(len(np.load(path)["kind"]))
+            report["scenarios"].append(dict(name=name, args=kw, policy=policy.__name__, seed=seed, arena=arena, rows=rows, ok=True, state_float_tol=tol))
+            total_rows += rows
+            total_traces += 1
+            nA, nO = (3, 3) if k % 2 == 0 else (int(rng.integers(1, 4)), int(rng.integers(1, 4)))
+            kw = dict(mode=1, num_agents=nA, num_opps=nO, glob_frac=float(rng.choice([0.0, 0.3])), hier_action_assess=bool(rng.integers(0, 2)),
+                      hier_opp_fight_ratio=int(rng.choice([0, 50, 75, 100])), friendly_kill=bool(rng.integers(0, 4)), eval_info=bool(rng.integers(0, 2)),
+                      horizon=int(rng.choice([120, 300, 500])))
+            style = str(rng.choice(["random", "pursuit"]))
+            name = f"fuzz_hl_{k}"
+            G.record_hl(name, kw, style, 3, 40, seed=seed, arena=arena + 5)
+            path = os.path.join(tmp, f"env_{name}.npz")
+            tol = replay(T.replay_high, oracle_lib, path, T.FLOAT_TOL)
+            rows = int(len(np.load(path)["kind"]))
+            report["scenarios"].append(dict(name=name, args=kw, pilots=style, seed=seed, arena=arena + 5, rows=rows, ok=True, state_float_tol=tol))
+            total_rows += rows
+            total_traces += 1
     report["traces"], report["rows"], report["seconds"] = total_traces, total_rows, round(time.time() - t0, 1)
     report["traces_needing_1e-7"] = sum(1 for s in report["scenarios"] if s["state_float_tol"] > T.FLOAT_TOL)
     with open(a.report, "w") as f:

@@ -373,3 +373,59 @@ def test_opponent_rows_binned_by_step_begin_give_the_same_steps(level):
     assert dones > N // 4
     if level == 5:
         assert set(np.unique(a.opp_policy().cpu().numpy())) == {3, 4, 5}
+
+
+def _stub_reference_module(kind, seed):
+    """a torch module with the parameter names of the reference's exported policies (SlimFC wraps nn.Linear as `_model.0`,
+    models/ac_models_hetero.py), value branch included, filled with the synthetic weights"""
+    import torch.nn as nn
+
+    class SlimFC(nn.Module):
+        def __init__(self, i, o):
+            super().__init__()
+            self._model = nn.Sequential(nn.Linear(i, o))
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            (a0, a1, w1), (b0, b1, w2), (c0, c1, w3) = PN.INPUTS[kind]
+            self.inp1, self.inp2, self.inp3 = SlimFC(a1 - a0, w1), SlimFC(b1 - b0, w2), SlimFC(c1 - c0, w3)
+            if PN.HAS_ATT[kind]:
+                self.att_act = nn.MultiheadAttention(100, 2, batch_first=True)
+            self.shared_layer, self.act_out = SlimFC(500, 500), SlimFC(500, PN.N_OUT[kind])
+            self.v1, self.val_out = SlimFC(60, 500), SlimFC(500, 1)      # the centralised-critic branch: ignored by the actor kernel
+    net = Net()
+    sd = PN.random_weights(kind, seed)
+    with torch.no_grad():
+        for k, v in sd.items():
+            dict(net.named_parameters())[k].copy_(torch.from_numpy(v))
+    return net, sd
+
+
+@pytest.mark.parametrize("kind", [PN.FIGHT1, PN.FIGHT2, PN.ESC1, PN.ESC2], ids=lambda k: PN.KIND_NAMES[k])
+def test_weights_of_a_loaded_reference_module_are_recognised(kind):
+    """PolicyBank.from_modules takes what the reference torch.load()s (env_base.py:312-347): architecture from the parameter shapes,
+    actor tensors by their state_dict() names"""
+    net, sd = _stub_reference_module(kind, 5)
+    got_kind, got = PN.from_torch_module(net)
+    assert got_kind == kind and set(got) == set(PN.actor_keys(kind))
+    for k in sd:
+        assert np.array_equal(got[k], sd[k])
+
+
+@pytest.mark.gpu
+def test_bank_from_loaded_modules_acts_like_the_torch_forward():
+    from hhmarl_2d_amd import pilots
+    mods = {s: _stub_reference_module(kind, 8)[0] for s, kind in enumerate((PN.FIGHT1, PN.FIGHT2, PN.ESC1, PN.ESC2))}
+    bank = pilots.PolicyBank.from_modules(torch.device("cuda", 0), mods, max_rows=4096)
+    bank.set_lut({pilots.SEL_FIGHT1: 0, pilots.SEL_FIGHT2: 1, pilots.SEL_ESC1: 2, pilots.SEL_ESC2: 3})
+    rng = np.random.default_rng(1)
+    obs = torch.from_numpy(rng.random((4096, 30)).astype(np.float32)).cuda()
+    sels = np.array([pilots.SEL_FIGHT1, pilots.SEL_FIGHT2, pilots.SEL_ESC1, pilots.SEL_ESC2], dtype=np.uint8)
+    sel = torch.from_numpy(sels[rng.integers(0, 4, 4096)]).cuda()
+    logits = torch.zeros((4096, 32), device="cuda")
+    bank.act(obs, sel, logits=logits)
+    for byte, kind in zip(sels, (PN.FIGHT1, PN.FIGHT2, PN.ESC1, PN.ESC2)):
+        idx = (sel == int(byte)).nonzero().flatten()
+        ref = PN.torch_forward(kind, PN.random_weights(kind, 8), obs[idx].cpu())
+        assert (logits[idx, : PN.N_OUT[kind]].cpu() - ref).abs().max() <= LOGIT_TOL

@@ -112,11 +112,17 @@ class LowLevelEnv(_Base):
         self.opp_mode = "fight"
         self.opp_k = None
         self._l5_draw = self.args.level == 5 and self.agent_mode == "fight"
-        if self.args.level >= 4 and self.opponent_policy is None:
-            raise ValueError("levels 4-5 fly frozen opponent policies (envs/env_base.py:312-398); pass env_config["
-                             "'opponent_policy'] = callable(opp_obs f32 [N,2,30], env) -> int8 actions [N,2,4] for units 3,4")
+        policy_dir = env_config.get("policy_dir", None)
+        if self.args.level >= 4 and self.opponent_policy is None and policy_dir is None:
+            raise ValueError("levels 4-5 fly frozen opponent policies (envs/env_base.py:312-398); pass env_config['policy_dir'] = the "
+                             "directory of the exported L*_AC*_{fight,escape}.pt files, or env_config['opponent_policy'] = "
+                             "callable(opp_obs f32 [N,2,30], env) -> int8 actions [N,2,4] for units 3,4")
         cfg = config_from_args(self.args, L.ENV_LOWLEVEL, self.num_envs, int(env_config.get("seed", 0)))
         self.world = World(cfg, device=int(env_config.get("device", 0)))
+        if self.args.level >= 4 and self.opponent_policy is None:   # _get_policies("LowLevel"), env_base.py:312-332
+            from .pilots import OpponentNets, PolicyBank
+            bank = PolicyBank.from_reference_dir(self.world.device, policy_dir, "LowLevel", self.args, max_rows=self.num_envs * 2)
+            self.opponent_policy = OpponentNets(self.world, bank=bank, bind=True)
         self._act = torch.zeros((self.num_envs, self.world.n_ctrl, 4), dtype=torch.int8, device=self.world.device)
         self._act_host = np.zeros((self.num_envs, self.world.n_ctrl, 4), dtype=np.int8)
         self._out = self.world.alloc_outputs()

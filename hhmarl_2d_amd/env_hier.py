@@ -50,11 +50,17 @@ class HighLevelEnv(_Base):
         self.map_size = self.args.map_size
         self.num_envs = int(env_config.get("num_envs", 1))
         self.pilot = env_config.get("pilot", None)
-        if self.pilot is None:
-            raise ValueError("HighLevelEnv flies frozen low-level pilot policies (envs/env_base.py:312-398); pass "
-                             "env_config['pilot'] = callable(pilot_obs, pilot_mode) -> int8 actions [N, 6, 4]")
+        policy_dir = env_config.get("policy_dir", None)
+        if self.pilot is None and policy_dir is None:
+            raise ValueError("HighLevelEnv flies frozen low-level pilot policies (envs/env_base.py:312-398); pass env_config['policy_dir'] "
+                             "= the directory of the exported L*_AC*_{fight,escape}.pt files, or env_config['pilot'] = "
+                             "callable(pilot_obs, pilot_mode) -> int8 actions [N, 6, 4]")
         cfg = config_from_args(self.args, L.ENV_HIGHLEVEL, self.num_envs, int(env_config.get("seed", 0)))
         self.world = World(cfg, device=int(env_config.get("device", 0)))
+        if self.pilot is None:   # _get_policies("HighLevel"), env_base.py:333-343
+            from .pilots import NetPilot, PolicyBank
+            bank = PolicyBank.from_reference_dir(self.world.device, policy_dir, "HighLevel", self.args, max_rows=self.num_envs * 6)
+            self.pilot = NetPilot(self.world, bank=bank)
         self._cmd = torch.zeros((self.num_envs, self.args.num_agents), dtype=torch.int8, device=self.world.device)
         self.commander_actions = None
         self.rewards = {}

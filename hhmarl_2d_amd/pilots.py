@@ -94,6 +94,45 @@ class PolicyBank:
             b.set_net(slot, kind, sd)
         return b
 
+    @classmethod
+    def from_reference_dir(cls, device, policy_dir, env, args, max_rows=1 << 20, load=None):
+        """The reference's `_get_policies` (envs/env_base.py:312-347): which exported policies an environment flies, by file name
+        in `policy_dir` (the reference keeps them in <repo>/policies; torch.load needs the reference's model classes importable).
+        env = "LowLevel" | "HighLevel".  Selector bytes as the world kernels emit them (policy type | aircraft type << 2, + 16 (k - 3)
+        for the policy set k of a level-5 arena):
+          LowLevel level 4 (fight):   L3_AC{1,2}_fight                                              -> 5, 9
+          LowLevel level 5 (fight):   policies[3] = L3 fights, [4] = L4 fights, [5] = L3 escapes    -> 5, 9 | 21, 25 | 38, 42
+          LowLevel level 5 (escape):  L5_AC{1,2}_fight                                              -> 5, 9
+          HighLevel:                  L{eval_level_ag}_AC{1,2}_fight, L5 escapes (L3 escapes when absent)  -> 5, 9, 6, 10
+        (HighLevel with eval_hl = False flies other fight policies on the opponents' side: the selector byte does not carry the side;
+        load those into a second bank.)"""
+        import os
+        if load is None:
+            load = lambda path: torch.load(path, weights_only=False)
+        f = lambda name: load(os.path.join(policy_dir, name))
+        plan = []   # (selector byte, file)
+        if env == "LowLevel":
+            if args.agent_mode == "fight" and args.level == 4:
+                plan = [(SEL_FIGHT1, "L3_AC1_fight.pt"), (SEL_FIGHT2, "L3_AC2_fight.pt")]
+            elif args.agent_mode == "fight":
+                plan = [(SEL_FIGHT1, "L3_AC1_fight.pt"), (SEL_FIGHT2, "L3_AC2_fight.pt"), (SEL_FIGHT1 + 16, "L4_AC1_fight.pt"),
+                        (SEL_FIGHT2 + 16, "L4_AC2_fight.pt"), (SEL_ESC1 + 32, "L3_AC1_escape.pt"), (SEL_ESC2 + 32, "L3_AC2_escape.pt")]
+            else:
+                plan = [(SEL_FIGHT1, "L5_AC1_fight.pt"), (SEL_FIGHT2, "L5_AC2_fight.pt")]
+        else:
+            lv = int(getattr(args, "eval_level_ag", 5))
+            esc = "L5" if os.path.exists(os.path.join(policy_dir, "L5_AC1_escape.pt")) else "L3"   # env_base.py:337-343
+            plan = [(SEL_FIGHT1, f"L{lv}_AC1_fight.pt"), (SEL_FIGHT2, f"L{lv}_AC2_fight.pt"), (SEL_ESC1, f"{esc}_AC1_escape.pt"),
+                    (SEL_ESC2, f"{esc}_AC2_escape.pt")]
+        b = cls(device, max_rows)
+        lut = {}
+        for slot, (byte, name) in enumerate(plan):
+            kind, sd = PN.from_torch_module(f(name))
+            b.set_net(slot, kind, sd)
+            lut[byte] = slot
+        b.set_lut(lut)
+        return b
+
     def act(self, obs, sel, actions=None, logits=None):
         """obs f32 [..., D] (rows = all leading dims), sel u8 [...] selector bytes -> int8 actions [..., 4]"""
         assert obs.dtype == torch.float32 and obs.is_contiguous()
@@ -158,10 +197,11 @@ class OpponentNets:
     arena and episode (env_hetero.py:55-59): selector = fight selector + 16 (k - 3), + 1 when k == 5 (escape), so a bank
     loaded with policies[3], policies[4] (fight sets) and policies[5] (escape set) maps 5/9, 21/25 and 38/42 to them."""
 
-    def __init__(self, world, bank=None, seed=0):
+    def __init__(self, world, bank=None, seed=0, bind=None):
         self.world = world
         n_opp = world.A - world.n_agents
-        self._private = bank is None     # a private bank is bound to the world: hh_step_begin bins the opponents' rows itself
+        # bound (default for a bank nobody else uses): hh_step_begin bins the opponents' rows into the bank's lists itself
+        self._private = (bank is None) if bind is None else bool(bind)
         self.bank = bank if bank is not None else PolicyBank.random_init(world.device, seed=seed, max_rows=world.N * n_opp)
         self._skip = 0
         if self._private:

@@ -84,3 +84,44 @@ def pursuit_actions(rng, state, n_agents, n_ctrl):
         act[:, i, 2] = 1
         act[:, i, 3] = rng.random(N) < 0.5
     return act
+
+
+# ---- picklable stand-ins for the reference's exported policy modules (torch.save / torch.load round trip in tests)
+def _stub_classes():
+    import torch.nn as nn
+
+    class StubSlimFC(nn.Module):      # ray's SlimFC keeps its nn.Linear in self._model[0]
+        def __init__(self, i, o):
+            super().__init__()
+            self._model = nn.Sequential(nn.Linear(i, o))
+
+    class StubPolicyNet(nn.Module):   # parameter names of models/ac_models_hetero.py (actor half + a value branch the kernel ignores)
+        def __init__(self, inputs, n_out, att):
+            super().__init__()
+            (a0, a1, w1), (b0, b1, w2), (c0, c1, w3) = inputs
+            self.inp1, self.inp2, self.inp3 = StubSlimFC(a1 - a0, w1), StubSlimFC(b1 - b0, w2), StubSlimFC(c1 - c0, w3)
+            if att:
+                self.att_act = nn.MultiheadAttention(100, 2, batch_first=True)
+            self.shared_layer, self.act_out = StubSlimFC(500, 500), StubSlimFC(500, n_out)
+            self.v1, self.val_out = StubSlimFC(60, 500), StubSlimFC(500, 1)
+    return StubSlimFC, StubPolicyNet
+
+
+try:
+    StubSlimFC, StubPolicyNet = _stub_classes()
+    StubSlimFC.__qualname__, StubPolicyNet.__qualname__ = "StubSlimFC", "StubPolicyNet"
+except ImportError:   # torch-less environments never reach the tests that use them
+    pass
+
+
+def stub_reference_module(kind, seed):
+    """(module, actor state dict) of one synthetic policy with the reference's parameter names"""
+    import torch
+    from hhmarl_2d_amd import policy_nets as PN
+    net = StubPolicyNet(PN.INPUTS[kind], PN.N_OUT[kind], PN.HAS_ATT[kind])
+    sd = PN.random_weights(kind, seed)
+    params = dict(net.named_parameters())
+    with torch.no_grad():
+        for k, v in sd.items():
+            params[k].copy_(torch.from_numpy(v))
+    return net, sd

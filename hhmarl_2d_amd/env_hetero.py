@@ -124,8 +124,12 @@ class LowLevelEnv(_Base):
             bank = PolicyBank.from_reference_dir(self.world.device, policy_dir, "LowLevel", self.args, max_rows=self.num_envs * 2)
             self.opponent_policy = OpponentNets(self.world, bank=bank, bind=True)
         self._act = torch.zeros((self.num_envs, self.world.n_ctrl, 4), dtype=torch.int8, device=self.world.device)
-        self._act_host = np.zeros((self.num_envs, self.world.n_ctrl, 4), dtype=np.int8)
         self._out = self.world.alloc_outputs()
+        # pinned host mirrors: one asynchronous copy per array and ONE stream synchronisation per step() instead of a blocking
+        # .cpu() per array (the dict protocol hands host arrays both ways on every call)
+        self._act_pin = torch.zeros((self.num_envs, self.world.n_ctrl, 4), dtype=torch.int8).pin_memory()
+        self._act_host = self._act_pin.numpy()
+        self._out_pin = [torch.zeros(t.shape, dtype=t.dtype).pin_memory() for t in self._out]
         self.steps = 0
         self.rewards = {}
         self.record_trace = bool(env_config.get("record_trace", False))
@@ -133,8 +137,15 @@ class LowLevelEnv(_Base):
         super().__init__()
 
     # -- helpers
+    def _to_host(self, outs):
+        """device (obs, reward, valid, done) -> their pinned host mirrors as numpy arrays, one synchronisation"""
+        for src, dst in zip(outs, self._out_pin):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.current_stream(self.world.device).synchronize()
+        return [t.numpy() for t in self._out_pin]
+
     def _obs_dict(self, obs):
-        o = obs.cpu().numpy()
+        o = obs if isinstance(obs, np.ndarray) else obs.cpu().numpy()
         if self.num_envs == 1:
             return {i: o[0, i - 1, : self.obs_dim_map[i]].copy() for i in sorted(self._agent_ids)}
         return {i: o[:, i - 1, : self.obs_dim_map[i]].copy() for i in sorted(self._agent_ids)}
@@ -166,7 +177,7 @@ class LowLevelEnv(_Base):
                     a[0, k - 1, : v.shape[-1]] = v
                 else:
                     a[:, k - 1, : v.shape[-1]] = v
-            self._act.copy_(torch.from_numpy(a))
+            self._act.copy_(self._act_pin, non_blocking=True)
             if self.opponent_policy is not None:
                 # env_hetero.py:160-172: agents act, then each frozen-policy opponent observes and acts
                 mode = L.OPP_MODE_EPISODE if self._l5_draw else (0 if self.opp_mode == "fight" else 1)
@@ -176,7 +187,7 @@ class LowLevelEnv(_Base):
             else:
                 obs, rew, val, done = self.world.step(self._act, out=self._out)
             self.steps += 1
-            rew, val, done = rew.cpu().numpy(), val.cpu().numpy(), done.cpu().numpy()
+            obs, rew, val, done = self._to_host((obs, rew, val, done))
             if self.num_envs == 1:
                 self.rewards = {i: float(rew[0, i - 1]) for i in range(1, n_ag + 1) if val[0, i - 1]}
                 d = bool(done[0])

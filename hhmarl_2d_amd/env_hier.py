@@ -103,7 +103,9 @@ class HighLevelEnv(_Base):
                 if k <= nA:
                     c[:, k - 1] = np.asarray(v)
             self._cmd.copy_(torch.from_numpy(c))
-            obs, rew, val, done = macro_step(self.world, self._cmd, self.pilot, early_exit=True)
+            # leaving the sub-step loop early costs a host synchronisation per tick: worth it for a few arenas (RLlib's one env per
+            # worker), pointless for a large batch, where some arena is practically always still inside its macro step
+            obs, rew, val, done = macro_step(self.world, self._cmd, self.pilot, early_exit=self.num_envs <= 64)
             rew, val, done = rew.cpu().numpy(), val.cpu().numpy(), done.cpu().numpy()
             if getattr(self.args, "eval_info", False):
                 info = self._eval_info()

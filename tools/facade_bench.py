@@ -23,3 +23,27 @@ for k in range(S):
         pass   # RLlib would reset the finished sub-environments here; the rate below is the step path alone
 dt = (time.perf_counter() - t0) / S
 print(f"LowLevelEnv(num_envs={N}).step(dict): {dt * 1e6:.0f} us per call -> {N / dt / 1e6:.2f} M env-steps/s (host arrays in and out)")
+
+if len(sys.argv) > 2 and sys.argv[2] == "hier":   # HighLevelEnv.step(dict) with the Fight / Esc networks as pilots (synthetic weights)
+    import torch
+    from hhmarl_2d_amd.env_hier import HighLevelEnv
+    from hhmarl_2d_amd.pilots import NetPilot
+    from hhmarl_2d_amd.world import World
+    holder = {}
+
+    class LazyPilot:            # the pilot needs the env's world: built on first use
+        def __call__(self, po, pm):
+            if "p" not in holder:
+                holder["p"] = NetPilot(hl.world, seed=1, bind=False)
+            return holder["p"](po, pm)
+    hl = HighLevelEnv({"args": make_args(1), "num_envs": N, "seed": 1, "pilot": LazyPilot()})
+    hl.reset()
+    cmds = [{i: rng.integers(0, 3, N) for i in (1, 2, 3)} for _ in range(8)]
+    for k in range(5):
+        hl.step(cmds[k % 8])
+    S = 40
+    t0 = time.perf_counter()
+    for k in range(S):
+        hl.step(cmds[k % 8])
+    dt = (time.perf_counter() - t0) / S
+    print(f"HighLevelEnv(num_envs={N}).step(dict), networks in the loop: {dt * 1e3:.2f} ms per call -> {N / dt:.3g} commander-steps/s")

@@ -1,5 +1,5 @@
 """One-off soak: the GPU world against the CPU oracle over tens of millions of arena-steps (rare-event coverage for
-the staged envelope predicates).  Usage: soak.py [arenas] [ticks] [level] [agent_mode]"""
+the staged envelope predicates).  Usage: soak.py [arenas] [ticks] [level] [agent_mode] [esc_dist_rew, default = agent_mode]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,7 +12,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
 level = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-kw = dict(n_arenas=N, level=level, agent_mode=mode, esc_dist_rew=bool(mode), seed=20260927, auto_reset=True, ext_opp_actions=level >= 4)
+shaping = bool(int(sys.argv[5])) if len(sys.argv) > 5 else bool(mode)
+kw = dict(n_arenas=N, level=level, agent_mode=mode, esc_dist_rew=shaping, seed=20260927, auto_reset=True, ext_opp_actions=level >= 4)
 g = World(make_config(**kw))
 o = O.OracleWorld(O.make_config(**kw))
 assert np.array_equal(g.reset().cpu().numpy(), o.reset())

@@ -92,6 +92,29 @@ class HighLevelEnv(_Base):
             return {k: int(last[0, i]) for i, k in enumerate(L.EVAL_KEYS)}
         return {k: last[:, i].copy() for i, k in enumerate(L.EVAL_KEYS)}
 
+    def _macro_step_batched(self):
+        """large batches: no early exit (some arena is practically always still inside its macro step), and with the library's
+        own NetPilot — launches only, nothing the host has to see in between — the 66 launches of a commander step are captured
+        once in a HIP graph and replayed"""
+        from .pilots import NetPilot
+        if not isinstance(self.pilot, NetPilot):
+            return macro_step(self.world, self._cmd, self.pilot, early_exit=False)
+        if getattr(self, "_graph", None) is None:
+            self._g_out, self._g_pilot = self.world.alloc_outputs(), self.world.alloc_pilot()
+            # the forward kernels' first launch must not happen inside a capture: one call on rows without a network
+            self.pilot.bank.act(torch.zeros((64, 30), device=self.world.device), torch.zeros((64,), dtype=torch.uint8, device=self.world.device))
+            torch.cuda.synchronize(self.world.device)
+            side = torch.cuda.Stream(device=self.world.device)
+            side.wait_stream(torch.cuda.current_stream(self.world.device))
+            with torch.cuda.stream(side):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    macro_step(self.world, self._cmd, self.pilot, out=self._g_out, pilot_buf=self._g_pilot, early_exit=False)
+            torch.cuda.current_stream(self.world.device).wait_stream(side)
+            self._graph = graph
+        self._graph.replay()
+        return self._g_out
+
     def step(self, action):
         self.rewards = {}
         info = {}
@@ -105,7 +128,10 @@ class HighLevelEnv(_Base):
             self._cmd.copy_(torch.from_numpy(c))
             # leaving the sub-step loop early costs a host synchronisation per tick: worth it for a few arenas (RLlib's one env per
             # worker), pointless for a large batch, where some arena is practically always still inside its macro step
-            obs, rew, val, done = macro_step(self.world, self._cmd, self.pilot, early_exit=self.num_envs <= 64)
+            if self.num_envs <= 64:
+                obs, rew, val, done = macro_step(self.world, self._cmd, self.pilot, early_exit=True)
+            else:
+                obs, rew, val, done = self._macro_step_batched()
             rew, val, done = rew.cpu().numpy(), val.cpu().numpy(), done.cpu().numpy()
             if getattr(self.args, "eval_info", False):
                 info = self._eval_info()

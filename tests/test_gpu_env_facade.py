@@ -263,3 +263,46 @@ def test_trace_ring_buffer_wraps_and_spans_episodes_in_hier():
         assert np.allclose(rows[-1, :, :2], st["ac_f"][k, :, :2].astype(np.float32))   # the newest row is the current state
     w.trace_enable(0, 0)                                              # off again
     w.hl_rollout(cmd, tape)
+
+
+@pytest.mark.gpu
+def test_highlevel_facade_batched_graph_path_equals_the_eager_loop():
+    """HighLevelEnv with more than 64 arenas replays its commander step from a HIP graph (no early exit, NetPilot launches only):
+    same observations, rewards, done flags and info as the same world stepped through macro_step eagerly"""
+    import torch
+    from hhmarl_2d_amd import pilots
+    from hhmarl_2d_amd.config import make_args
+    from hhmarl_2d_amd.env_hier import HighLevelEnv, macro_step
+    from hhmarl_2d_amd.world import World
+    n = 200
+    holder = {}
+
+    class Lazy:   # HighLevelEnv wants its pilot at construction, the pilot wants the env's world
+        def __call__(self, po, pm):
+            return holder["pilot"](po, pm)
+    env = HighLevelEnv({"args": make_args(1, horizon=60), "num_envs": n, "seed": 6, "pilot": Lazy()})
+    env.pilot = holder["pilot"] = pilots.NetPilot(env.world, seed=2)            # the graph path needs the library's own NetPilot
+    from hhmarl_2d_amd.env_hetero import config_from_args
+    from hhmarl_2d_amd import _lib as L
+    ref = World(config_from_args(env.args, L.ENV_HIGHLEVEL, n, 6))
+    rp = pilots.NetPilot(ref, seed=2, bind=False)
+    obs0, _ = env.reset()
+    assert np.array_equal(obs0[1], ref.reset().cpu().numpy()[:, 0])
+    rng = np.random.default_rng(3)
+    dones = 0
+    for t in range(12):
+        cmd = {i: rng.integers(0, 3, n) for i in (1, 2, 3)}
+        obs, rew, term, trunc, info = env.step(cmd)
+        c = torch.from_numpy(np.stack([cmd[1], cmd[2], cmd[3]], axis=1).astype(np.int8)).cuda()
+        o, r, v, d = [x.cpu().numpy() for x in macro_step(ref, c, rp)]
+        for i in (1, 2, 3):
+            assert np.array_equal(obs[i], o[:, i - 1]), (t, i)
+            assert np.array_equal(rew[i], r[:, i - 1]), (t, i)
+        assert np.array_equal(term["__all__"], d.astype(bool))
+        dones += int(d.sum())
+        fin = np.nonzero(d)[0]
+        if len(fin):      # the facade leaves resets to the caller (RLlib's protocol): reset the same arenas on both sides
+            m = np.zeros(n, dtype=np.uint8); m[fin] = 1
+            env.world.reset(mask=torch.from_numpy(m).cuda()); ref.reset(mask=torch.from_numpy(m).cuda())
+    assert dones > 0 and env._graph is not None
+    env.close()

@@ -37,6 +37,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "hier":   # HighLevelEnv.step(dict) with
                 holder["p"] = NetPilot(hl.world, seed=1, bind=False)
             return holder["p"](po, pm)
     hl = HighLevelEnv({"args": make_args(1), "num_envs": N, "seed": 1, "pilot": LazyPilot()})
+    hl.pilot = holder["p"] = NetPilot(hl.world, seed=1)   # the library's own pilot: batches above 64 arenas replay a HIP graph
     hl.reset()
     cmds = [{i: rng.integers(0, 3, N) for i in (1, 2, 3)} for _ in range(8)]
     for k in range(5):

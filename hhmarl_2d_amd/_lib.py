@@ -21,6 +21,7 @@ class HHConfig(C.Structure):
         ("level", C.c_int32), ("agent_mode", C.c_int32), ("horizon", C.c_int32), ("friendly_kill", C.c_int32),
         ("friendly_punish", C.c_int32), ("esc_dist_rew", C.c_int32), ("hier_action_assess", C.c_int32),
         ("hier_opp_fight_ratio", C.c_int32), ("auto_reset", C.c_int32), ("ext_opp_actions", C.c_int32),
+        ("opp_side_selector", C.c_int32), ("reserved0", C.c_int32),
         ("map_size", C.c_double), ("glob_frac", C.c_double), ("rew_scale", C.c_double),
         ("seed", C.c_uint64), ("arena_offset", C.c_uint64),
     ]

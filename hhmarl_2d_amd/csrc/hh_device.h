@@ -37,6 +37,7 @@ struct DevCfg {
     int N, env_kind, nA, nO, A, level, agent_mode, horizon;
     int friendly_kill, friendly_punish, esc_dist_rew, hier_action_assess, hier_opp_fight_ratio;
     int auto_reset, ext_opp, D, n_ctrl;
+    int sel_side; /* hh_config.opp_side_selector: an opponent's fight row selects "fight_*_opp" (env_base.py:387-390) */
     double glob_frac, rew_scale, ext_lat, ext_lon, inv_ext_lat, inv_ext_lon, lat_hi, lon_hi, inv_diag;
     uint64_t seed, arena_offset;
 };
@@ -49,7 +50,7 @@ struct DevCfg {
 __host__ __device__ inline void hh_cfg_set_hl_default(DevCfg &c) {
     c.env_kind = 1; c.nA = 3; c.nO = 3; c.A = 6; c.horizon = 500;
     c.friendly_kill = 1; c.friendly_punish = 0; c.esc_dist_rew = 0; c.hier_action_assess = 1; c.hier_opp_fight_ratio = 75;
-    c.ext_opp = 0; c.D = 34; c.n_ctrl = 3;
+    c.ext_opp = 0; c.D = 34; c.n_ctrl = 3; c.sel_side = 0;
     c.glob_frac = 0.0; c.rew_scale = 1.0;
     c.ext_lat = 0.5; c.ext_lon = 0.5; c.inv_ext_lat = 2.0; c.inv_ext_lon = 2.0; c.lat_hi = 5.5; c.lon_hi = 7.5;
     c.inv_diag = 1.0 / __builtin_sqrt(0.5);
@@ -59,7 +60,7 @@ inline bool hh_cfg_is_hl_default(const DevCfg &c) {
     hh_cfg_set_hl_default(d);
     return d.env_kind == c.env_kind && d.nA == c.nA && d.nO == c.nO && d.A == c.A && d.horizon == c.horizon && d.friendly_kill == c.friendly_kill &&
            d.friendly_punish == c.friendly_punish && d.esc_dist_rew == c.esc_dist_rew && d.hier_action_assess == c.hier_action_assess &&
-           d.hier_opp_fight_ratio == c.hier_opp_fight_ratio && d.ext_opp == c.ext_opp && d.D == c.D && d.n_ctrl == c.n_ctrl &&
+           d.hier_opp_fight_ratio == c.hier_opp_fight_ratio && d.ext_opp == c.ext_opp && d.sel_side == c.sel_side && d.D == c.D && d.n_ctrl == c.n_ctrl &&
            d.glob_frac == c.glob_frac && d.rew_scale == c.rew_scale && d.ext_lat == c.ext_lat && d.ext_lon == c.ext_lon &&
            d.inv_ext_lat == c.inv_ext_lat && d.inv_ext_lon == c.inv_ext_lon && d.lat_hi == c.lat_hi && d.lon_hi == c.lon_hi && d.inv_diag == c.inv_diag;
 }

@@ -106,6 +106,12 @@ __device__ __forceinline__ void hl_commander_obs(const DevCfg &c, const Shared<A
     }
 }
 
+/* pilot_mode byte of a unit that flies a policy: policy type (1 fight / 2 escape) | aircraft type << 2, and with
+ * hh_config.opp_side_selector the side bit on an opponent's fight row (env_base.py:387-390: "fight_{type}_opp") */
+__device__ __forceinline__ int hl_selector(const DevCfg &c, int mode, int ac_type, bool agent) {
+    return mode | (ac_type << 2) | ((c.sel_side && !agent && mode == 1) ? HH_SEL_OPP_SIDE : 0);
+}
+
 __device__ __forceinline__ int hl_gcd(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
 /* env_hier.py:142-190 _action_assess for the lane's unit; returns the shaping reward of an agent */
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
     HhBinTicket bt{0, 0};
     auto bin_issue = [&](int side) {
         const bool mine_ = side == 0 ? agent : !agent;
-        const int sb = (active && ar.hl_run && m.alive && mine_) ? ((m.cmd_act != 0 ? 1 : 2) | (m.ac_type << 2)) : 0;
+        const int sb = (active && ar.hl_run && m.alive && mine_) ? hl_selector(c, m.cmd_act != 0 ? 1 : 2, m.ac_type, agent) : 0;
         pslot = sb ? (int)P.pol_lut[sb] : 0;
         bt = hh_bin_rows_issue(P.pol_counts, pslot);
     };
@@ -442,7 +448,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
                 int mode = 0;
                 if (ar.hl_run && m.alive && mine) mode = hl_pilot_obs(c, sh, tid, base, s, m, row);
                 else for (int k = 0; k < 30; k++) row[k] = 0.0f;
-                if (pilot_mode) pilot_mode[u] = (uint8_t)(mode ? (mode | (m.ac_type << 2)) : 0); /* policy type | aircraft type: selects the network */
+                if (pilot_mode) pilot_mode[u] = (uint8_t)(mode ? hl_selector(c, mode, m.ac_type, agent) : 0); /* policy type | aircraft type: selects the network */
             }
             hh_wg_sync<B>();
             const int cnt = arenas * A * 30;
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
                     if (ar.hl_run && m.alive) mode = hl_pilot_obs(c, sh, tid, base, s, m, row);
                     else for (int k = 0; k < 30; k++) row[k] = 0.0f;
                 }
-                if (pilot_mode) pilot_mode[u] = (uint8_t)(mode ? (mode | (m.ac_type << 2)) : 0); /* policy type | aircraft type: selects the network */
+                if (pilot_mode) pilot_mode[u] = (uint8_t)(mode ? hl_selector(c, mode, m.ac_type, agent) : 0); /* policy type | aircraft type: selects the network */
             }
             hh_wg_sync<B>();
             const int cnt2 = arenas * A * 15; /* float2 elements */

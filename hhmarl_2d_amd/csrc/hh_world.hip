@@ -105,6 +105,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     d.friendly_kill = cfg->friendly_kill; d.friendly_punish = cfg->friendly_punish; d.esc_dist_rew = cfg->esc_dist_rew;
     d.hier_action_assess = cfg->hier_action_assess; d.hier_opp_fight_ratio = cfg->hier_opp_fight_ratio;
     d.auto_reset = cfg->auto_reset; d.ext_opp = cfg->ext_opp_actions;
+    d.sel_side = (cfg->env_kind == HH_ENV_HIGHLEVEL && cfg->opp_side_selector) ? 1 : 0;
     d.D = cfg->env_kind == HH_ENV_HIGHLEVEL ? HH_OBS_HL : (cfg->agent_mode == HH_MODE_FIGHT ? HH_OBS_FIGHT_AC1 : HH_OBS_ESC_AC1);
     d.n_ctrl = cfg->ext_opp_actions ? A : cfg->n_agents;
     d.glob_frac = cfg->glob_frac; d.rew_scale = cfg->rew_scale;

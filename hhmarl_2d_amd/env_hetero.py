@@ -42,7 +42,9 @@ def config_from_args(args, env_kind, num_envs, seed, auto_reset=False, arena_off
         hier_action_assess=getattr(args, "hier_action_assess", True),
         hier_opp_fight_ratio=getattr(args, "hier_opp_fight_ratio", 75), auto_reset=auto_reset,
         ext_opp_actions=(env_kind == L.ENV_LOWLEVEL and args.level >= 4), map_size=args.map_size,
-        glob_frac=args.glob_frac, rew_scale=float(args.rew_scale), seed=seed, arena_offset=arena_offset)
+        glob_frac=args.glob_frac, rew_scale=float(args.rew_scale), seed=seed, arena_offset=arena_offset,
+        # evaluation.py's low-level-vs-low-level mode: the opponents fly L{eval_level_opp} fight policies (env_base.py:343-346,387-390)
+        opp_side_selector=(env_kind == L.ENV_HIGHLEVEL and not getattr(args, "eval_hl", True)))
 
 
 def _enable_trace(env):
@@ -122,7 +124,7 @@ class LowLevelEnv(_Base):
         if self.args.level >= 4 and self.opponent_policy is None:   # _get_policies("LowLevel"), env_base.py:312-332
             from .pilots import OpponentNets, PolicyBank
             bank = PolicyBank.from_reference_dir(self.world.device, policy_dir, "LowLevel", self.args, max_rows=self.num_envs * 2)
-            self.opponent_policy = OpponentNets(self.world, bank=bank, bind=True)
+            self.opponent_policy = OpponentNets(self.world, bank=bank, bind=True, skip_first=False)   # bound before any step_begin
         self._act = torch.zeros((self.num_envs, self.world.n_ctrl, 4), dtype=torch.int8, device=self.world.device)
         self._out = self.world.alloc_outputs()
         # pinned host mirrors: one asynchronous copy per array and ONE stream synchronisation per step() instead of a blocking

@@ -99,6 +99,10 @@ class HighLevelEnv(_Base):
         from .pilots import NetPilot
         if not isinstance(self.pilot, NetPilot):
             return macro_step(self.world, self._cmd, self.pilot, early_exit=False)
+        # the captured graph holds the world's device pointers (trace ring, bound bank's row lists) by value: re-capture whenever
+        # World.trace_enable / bind_policy changed them since
+        if getattr(self, "_graph", None) is not None and self._graph_gen != getattr(self.world, "ptr_generation", 0):
+            self._graph = None
         if getattr(self, "_graph", None) is None:
             self._g_out, self._g_pilot = self.world.alloc_outputs(), self.world.alloc_pilot()
             # the forward kernels' first launch must not happen inside a capture: one call on rows without a network
@@ -112,6 +116,7 @@ class HighLevelEnv(_Base):
                     macro_step(self.world, self._cmd, self.pilot, out=self._g_out, pilot_buf=self._g_pilot, early_exit=False)
             torch.cuda.current_stream(self.world.device).wait_stream(side)
             self._graph = graph
+            self._graph_gen = getattr(self.world, "ptr_generation", 0)
         self._graph.replay()
         return self._g_out
 

@@ -20,6 +20,7 @@ from . import policy_nets as PN
 
 # selector byte the world kernels emit as pilot_mode: (1 fight | 2 escape) | (aircraft type << 2)
 SEL_FIGHT1, SEL_ESC1, SEL_FIGHT2, SEL_ESC2 = 5, 6, 9, 10
+SEL_OPP_SIDE = 64   # HH_SEL_OPP_SIDE: an opponent's fight row of a world created with opp_side_selector (eval_hl = False)
 
 
 class PolicyBank:
@@ -103,9 +104,11 @@ class PolicyBank:
           LowLevel level 4 (fight):   L3_AC{1,2}_fight                                              -> 5, 9
           LowLevel level 5 (fight):   policies[3] = L3 fights, [4] = L4 fights, [5] = L3 escapes    -> 5, 9 | 21, 25 | 38, 42
           LowLevel level 5 (escape):  L5_AC{1,2}_fight                                              -> 5, 9
-          HighLevel:                  L{eval_level_ag}_AC{1,2}_fight, L5 escapes (L3 escapes when absent)  -> 5, 9, 6, 10
-        (HighLevel with eval_hl = False flies other fight policies on the opponents' side: the selector byte does not carry the side;
-        load those into a second bank.)"""
+          HighLevel:                  L{eval_level_ag}_AC{1,2}_fight, L5 escapes (L3 escapes when EITHER is absent)  -> 5, 9, 6, 10
+          HighLevel, eval_hl = False: additionally "fight_{1,2}_opp" = L{eval_level_opp}_AC{1,2}_fight for the opponents' fight rows, whose
+                                      selector carries the side bit (hh_config.opp_side_selector)                      -> 69, 73
+        LowLevel escape mode below level 5 loads nothing in the reference (env_base.py:328-330) and its _policy_actions would fail
+        on the empty dict: refused here with a clear error."""
         import os
         if load is None:
             load = lambda path: torch.load(path, weights_only=False)
@@ -117,17 +120,28 @@ class PolicyBank:
             elif args.agent_mode == "fight":
                 plan = [(SEL_FIGHT1, "L3_AC1_fight.pt"), (SEL_FIGHT2, "L3_AC2_fight.pt"), (SEL_FIGHT1 + 16, "L4_AC1_fight.pt"),
                         (SEL_FIGHT2 + 16, "L4_AC2_fight.pt"), (SEL_ESC1 + 32, "L3_AC1_escape.pt"), (SEL_ESC2 + 32, "L3_AC2_escape.pt")]
-            else:
+            elif args.level == 5:
                 plan = [(SEL_FIGHT1, "L5_AC1_fight.pt"), (SEL_FIGHT2, "L5_AC2_fight.pt")]
+            else:
+                raise ValueError("LowLevelEnv in escape mode flies frozen opponents at level 5 only (the reference loads no policy for "
+                                 f"escape mode at level {args.level}: envs/env_base.py:328-330)")
         else:
             lv = int(getattr(args, "eval_level_ag", 5))
-            esc = "L5" if os.path.exists(os.path.join(policy_dir, "L5_AC1_escape.pt")) else "L3"   # env_base.py:337-343
-            plan = [(SEL_FIGHT1, f"L{lv}_AC1_fight.pt"), (SEL_FIGHT2, f"L{lv}_AC2_fight.pt"), (SEL_ESC1, f"{esc}_AC1_escape.pt"),
-                    (SEL_ESC2, f"{esc}_AC2_escape.pt")]
+            plan = [(SEL_FIGHT1, f"L{lv}_AC1_fight.pt"), (SEL_FIGHT2, f"L{lv}_AC2_fight.pt")]
+            try:   # env_base.py:336-342: BOTH L5 escape policies, or (if either load fails) both L3 ones
+                loaded = {n: f(n) for n in ("L5_AC1_escape.pt", "L5_AC2_escape.pt")}
+                plan += [(SEL_ESC1, "L5_AC1_escape.pt"), (SEL_ESC2, "L5_AC2_escape.pt")]
+            except Exception:   # noqa: BLE001 — the reference's bare except
+                loaded = {}
+                plan += [(SEL_ESC1, "L3_AC1_escape.pt"), (SEL_ESC2, "L3_AC2_escape.pt")]
+            if not getattr(args, "eval_hl", True):   # env_base.py:343-346
+                lo = int(getattr(args, "eval_level_opp", 4))
+                plan += [(SEL_FIGHT1 + SEL_OPP_SIDE, f"L{lo}_AC1_fight.pt"), (SEL_FIGHT2 + SEL_OPP_SIDE, f"L{lo}_AC2_fight.pt")]
         b = cls(device, max_rows)
         lut = {}
+        loaded = locals().get("loaded", {})
         for slot, (byte, name) in enumerate(plan):
-            kind, sd = PN.from_torch_module(f(name))
+            kind, sd = PN.from_torch_module(loaded[name] if name in loaded else f(name))
             b.set_net(slot, kind, sd)
             lut[byte] = slot
         b.set_lut(lut)
@@ -197,7 +211,10 @@ class OpponentNets:
     arena and episode (env_hetero.py:55-59): selector = fight selector + 16 (k - 3), + 1 when k == 5 (escape), so a bank
     loaded with policies[3], policies[4] (fight sets) and policies[5] (escape set) maps 5/9, 21/25 and 38/42 to them."""
 
-    def __init__(self, world, bank=None, seed=0, bind=None):
+    def __init__(self, world, bank=None, seed=0, bind=None, skip_first=True):
+        """skip_first: the binding is made AFTER a hh_step_begin already produced the opp_obs of the first call (a callable built
+        lazily inside its first invocation): that call bins the rows itself.  A facade that binds before any step passes False —
+        its first step_begin already filled the row lists, and binning them a second time would list every row twice."""
         self.world = world
         n_opp = world.A - world.n_agents
         # bound (default for a bank nobody else uses): hh_step_begin bins the opponents' rows into the bank's lists itself
@@ -206,7 +223,7 @@ class OpponentNets:
         self._skip = 0
         if self._private:
             world.bind_policy(self.bank)
-            self._skip = 1               # the step_begin that produced the first opp_obs may have run before the binding existed
+            self._skip = 1 if skip_first else 0
         self.act = torch.zeros((world.N, n_opp, 4), dtype=torch.int8, device=world.device)
         self.sel_fight = torch.tensor([SEL_FIGHT1, SEL_FIGHT2], dtype=torch.uint8, device=world.device).repeat(world.N, 1).contiguous()
         self.k = torch.zeros((world.N,), dtype=torch.int8, device=world.device)

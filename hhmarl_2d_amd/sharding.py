@@ -78,4 +78,15 @@ class ShardedWorld:
             self.last_stats = gather_stats(self._blocks[k], self.world_size)
             self._events[k] = torch.cuda.Event()
             self._events[k].record(side_stream)
+        # the gathered tensor was allocated and is being written on the side stream: whoever reads it from the stepping stream
+        # must wait for the gather (stats_ready) and the allocator must not recycle the block under a reader on that stream
+        self.last_stats.record_stream(cur)
+        self.stats_ready = self._events[k]
+        return self.last_stats
+
+    def wait_stats(self):
+        """last_stats, safe to read from the current stream (orders it after the side-stream all-gather that produces it)"""
+        ev = getattr(self, "stats_ready", None)
+        if ev is not None:
+            torch.cuda.current_stream(self.world.device).wait_event(ev)
         return self.last_stats

@@ -13,7 +13,7 @@ from . import _lib as L
 def make_config(n_arenas=1, env_kind=L.ENV_LOWLEVEL, level=1, agent_mode=L.MODE_FIGHT, n_agents=None, n_opps=None,
                 horizon=None, friendly_kill=True, friendly_punish=False, esc_dist_rew=False, hier_action_assess=True,
                 hier_opp_fight_ratio=75, auto_reset=False, ext_opp_actions=False, map_size=None, glob_frac=0.0,
-                rew_scale=1.0, seed=0, arena_offset=0):
+                rew_scale=1.0, seed=0, arena_offset=0, opp_side_selector=False):
     """Defaults follow the reference's config.py:17-54 and horizons config.py:94-98."""
     hl = env_kind == L.ENV_HIGHLEVEL
     if n_agents is None:
@@ -26,7 +26,7 @@ def make_config(n_arenas=1, env_kind=L.ENV_LOWLEVEL, level=1, agent_mode=L.MODE_
         map_size = 0.5 if hl else 0.3
     return L.HHConfig(n_arenas, env_kind, n_agents, n_opps, level, agent_mode, horizon, int(friendly_kill),
                       int(friendly_punish), int(esc_dist_rew), int(hier_action_assess), hier_opp_fight_ratio,
-                      int(auto_reset), int(ext_opp_actions), map_size, glob_frac, rew_scale, seed, arena_offset)
+                      int(auto_reset), int(ext_opp_actions), int(opp_side_selector), 0, map_size, glob_frac, rew_scale, seed, arena_offset)
 
 
 def _p(t):
@@ -208,10 +208,12 @@ class World:
         lists (hh_bind_policy); None unbinds.  The world keeps the bank alive while bound."""
         L.check(L.lib().hh_bind_policy(self.h, bank.h if bank is not None else None))
         self._bound_bank = bank
+        self.ptr_generation = getattr(self, "ptr_generation", 0) + 1   # captured HIP graphs hold the old pointers by value
 
     def trace_enable(self, n_arenas=1, capacity=1024):
         """device-side trajectory ring buffer for the first n_arenas arenas (0 turns it off)"""
         L.check(L.lib().hh_trace_enable(self.h, int(n_arenas), int(capacity)))
+        self.ptr_generation = getattr(self, "ptr_generation", 0) + 1   # the old ring buffer was freed: captured graphs are stale
         self._trace_shape = (int(capacity), min(int(n_arenas), self.N), self.A, 8) if n_arenas and capacity else None
 
     def trace_read(self):

@@ -47,6 +47,10 @@ typedef struct hh_config {
     int32_t hier_opp_fight_ratio; /* args.hier_opp_fight_ratio [%] */
     int32_t auto_reset;       /* 1: a finished arena is re-sampled inside hh_step */
     int32_t ext_opp_actions;  /* 1: opponents take actions from the caller (levels 4-5 frozen policies) */
+    int32_t opp_side_selector; /* HighLevelEnv, evaluation.py with eval_hl = False: the opponents fly their OWN fight policies
+                                  ("fight_{1,2}_opp" = L{eval_level_opp}, env_base.py:343-346,387-390): pilot_mode of an opponent's
+                                  fight row carries HH_SEL_OPP_SIDE on top of policy type | aircraft type << 2 */
+    int32_t reserved0;        /* keeps the doubles 8-byte aligned; must be 0 */
     double map_size;          /* args.map_size */
     double glob_frac;         /* args.glob_frac */
     double rew_scale;         /* args.rew_scale */
@@ -72,6 +76,8 @@ typedef struct hh_state_view {
     int32_t *tgt_id; /* [N, A, HH_TGT_K]  (0 = none) */
     double *tgt_d;   /* [N, A, HH_TGT_K] */
 } hh_state_view;
+
+#define HH_SEL_OPP_SIDE 64 /* selector bit of an opponent's fight row when hh_config.opp_side_selector is set */
 
 typedef struct hh_world hh_world;
 

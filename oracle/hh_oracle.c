@@ -1340,7 +1340,11 @@ API int hho_hl_pilot_obs(void *h, int side, float *obs /* [N, A, 30] */, uint8_t
             float *o = obs + ((size_t)n * A + (i - 1)) * 30;
             int md = 0;
             int mine = side == 0 ? i <= w->cfg.n_agents : i > w->cfg.n_agents;
-            if (a->hl_running && a->ac[i - 1].alive && mine) md = hl_pilot_obs_one(w, a, i, o) | (a->ac[i - 1].ac_type << 2); /* policy type | aircraft type */
+            if (a->hl_running && a->ac[i - 1].alive && mine) {
+                md = hl_pilot_obs_one(w, a, i, o);
+                if (w->cfg.opp_side_selector && i > w->cfg.n_agents && md == 1) md |= HH_SEL_OPP_SIDE; /* "fight_*_opp", env_base.py:387-390 */
+                md |= a->ac[i - 1].ac_type << 2; /* policy type | aircraft type */
+            }
             else for (int k = 0; k < 30; k++) o[k] = 0.0f;
             mode[(size_t)n * A + (i - 1)] = (uint8_t)md;
         }

@@ -22,6 +22,7 @@ class HHConfig(C.Structure):
         ("level", C.c_int32), ("agent_mode", C.c_int32), ("horizon", C.c_int32), ("friendly_kill", C.c_int32),
         ("friendly_punish", C.c_int32), ("esc_dist_rew", C.c_int32), ("hier_action_assess", C.c_int32),
         ("hier_opp_fight_ratio", C.c_int32), ("auto_reset", C.c_int32), ("ext_opp_actions", C.c_int32),
+        ("opp_side_selector", C.c_int32), ("reserved0", C.c_int32),
         ("map_size", C.c_double), ("glob_frac", C.c_double), ("rew_scale", C.c_double),
         ("seed", C.c_uint64), ("arena_offset", C.c_uint64),
     ]
@@ -41,7 +42,7 @@ ACF_K, ACI_K, RKF_K, RKI_K, ARI_K, TGT_K = 6, 10, 4, 4, 6, 3
 def make_config(n_arenas=1, env_kind=ENV_LOWLEVEL, level=1, agent_mode=MODE_FIGHT, n_agents=None, n_opps=None,
                 horizon=None, friendly_kill=True, friendly_punish=False, esc_dist_rew=False, hier_action_assess=True,
                 hier_opp_fight_ratio=75, auto_reset=False, ext_opp_actions=False, map_size=None, glob_frac=0.0,
-                rew_scale=1.0, seed=0, arena_offset=0):
+                rew_scale=1.0, seed=0, arena_offset=0, opp_side_selector=False):
     """Defaults follow config.py:17-54,94-98 of the reference."""
     hl = env_kind == ENV_HIGHLEVEL
     if n_agents is None:
@@ -54,7 +55,7 @@ def make_config(n_arenas=1, env_kind=ENV_LOWLEVEL, level=1, agent_mode=MODE_FIGH
         map_size = 0.5 if hl else 0.3
     return HHConfig(n_arenas, env_kind, n_agents, n_opps, level, agent_mode, horizon, int(friendly_kill),
                     int(friendly_punish), int(esc_dist_rew), int(hier_action_assess), hier_opp_fight_ratio,
-                    int(auto_reset), int(ext_opp_actions), map_size, glob_frac, rew_scale, seed, arena_offset)
+                    int(auto_reset), int(ext_opp_actions), int(opp_side_selector), 0, map_size, glob_frac, rew_scale, seed, arena_offset)
 
 
 def alloc_state(n, a):

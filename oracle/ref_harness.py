@@ -356,7 +356,7 @@ def dump_state(env, n_units):
 class RefEnv:
     """One reference arena driven through the keyed tape."""
 
-    def __init__(self, kind, args, seed, arena):
+    def __init__(self, kind, args, seed, arena, keep_policies=False):
         ref = load_reference()
         self.kind = kind
         self.args = args
@@ -366,7 +366,8 @@ class RefEnv:
             self.env = ref["env_hetero"].LowLevelEnv({"args": args})
         else:
             cls = ref["env_hier"].HighLevelEnv
-            cls._get_policies = lambda self_, mode: None
+            if not keep_policies:   # taped pilots: nothing to load (the exported policies are not shipped)
+                cls._get_policies = lambda self_, mode: None
             self.env = cls({"args": args})
         self.tape.env = self.env
         self.n_units = args.total_num

@@ -15,6 +15,23 @@ def golden_files(kind="low"):
     return hl if kind == "high" else [f for f in allf if f not in hl]
 
 
+def frozen_opponent_files():
+    """LowLevelEnv traces of levels 4-5 (frozen-policy opponents): the taped ones and the ones recorded with the reference's own
+    networks in the loop (env_*_nets.npz)"""
+    return [f for f in golden_files() if json.loads(str(np.load(f)["meta"]))["args"]["level"] >= 4]
+
+
+def nets_in_loop_files(kind="low"):
+    """traces recorded with the reference's own _get_policies / _policy_actions running (oracle/gen_env_golden.py: record_nets)"""
+    return [f for f in golden_files(kind) if json.loads(str(np.load(f)["meta"])).get("nets_in_loop")]
+
+
+def draws_opponent_policy(meta):
+    """env_hetero.py:55-59: only level 5 in FIGHT mode draws k = randint(3,5) per episode (escape-mode level 5 flies the L5 fight
+    policies, opp_mode stays "fight": env_hetero.py:50)"""
+    return meta["args"]["level"] == 5 and meta["args"]["agent_mode"] == "fight"
+
+
 def load_golden(path):
     g = np.load(path)
     meta = json.loads(str(g["meta"]))
@@ -47,7 +64,8 @@ def cfg_kwargs_from_meta(meta, **over):
         esc_dist_rew=a["esc_dist_rew"], hier_action_assess=a["hier_action_assess"],
         hier_opp_fight_ratio=a["hier_opp_fight_ratio"], map_size=a["map_size"], glob_frac=a["glob_frac"],
         rew_scale=a["rew_scale"], seed=meta["seed"], arena_offset=meta["arena"],
-        ext_opp_actions=(meta["env"] == "low" and a["level"] >= 4))
+        ext_opp_actions=(meta["env"] == "low" and a["level"] >= 4),
+        opp_side_selector=(meta["env"] == "high" and not a.get("eval_hl", True)))
     kw.update(over)
     return kw
 

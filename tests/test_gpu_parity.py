@@ -6,7 +6,8 @@ masks, float64 kinematics, float32 observations and rewards."""
 import numpy as np
 import pytest
 
-from helpers import cfg_kwargs_from_meta, edge_cases, golden_files, load_golden, pursuit_actions, random_actions
+from helpers import (cfg_kwargs_from_meta, draws_opponent_policy, edge_cases, frozen_opponent_files, golden_files, load_golden, pursuit_actions,
+                     random_actions)
 
 pytestmark = pytest.mark.gpu
 
@@ -105,7 +106,7 @@ def test_no_auto_reset_freezes_done_arenas_and_masked_reset(oracle):
     _assert_same_state(g.get_state(), o.get_state(), "after masked reset")
 
 
-@pytest.mark.parametrize("path", [p for p in golden_files() if "frozen" not in p], ids=lambda p: p.split("env_")[-1][:-4])
+@pytest.mark.parametrize("path", [p for p in golden_files() if p not in frozen_opponent_files()], ids=lambda p: p.split("env_")[-1][:-4])
 def test_golden_traces_on_gpu(path):
     """the committed reference traces replayed directly on the HIP world"""
     import torch
@@ -309,7 +310,7 @@ def test_split_step_parity_levels_4_5(oracle, level, opp_mode):
     assert dones > 0
 
 
-@pytest.mark.parametrize("path", [p for p in golden_files() if "frozen" in p], ids=lambda p: p.split("env_")[-1][:-4])
+@pytest.mark.parametrize("path", frozen_opponent_files(), ids=lambda p: p.split("env_")[-1][:-4])
 def test_frozen_opponent_traces_on_gpu(path):
     import torch
     from hhmarl_2d_amd.world import World, make_config
@@ -321,7 +322,7 @@ def test_frozen_opponent_traces_on_gpu(path):
             continue
         a = g["actions"][r]
         mode = int(g["opp_mode"][r])
-        if meta["args"]["level"] == 5:   # the world draws the episode's policy set itself (env_hetero.py:55-59), never fed the recorded mode
+        if draws_opponent_policy(meta):   # the world draws the episode's policy set itself (env_hetero.py:55-59), never fed the recorded mode
             assert (int(w.opp_policy().cpu()[0]) == 5) == (mode == 1), f"row {r}: level-5 policy draw"
             mode = -1
         oo = w.step_begin(torch.from_numpy(np.ascontiguousarray(a[None, :2])).cuda(), mode).cpu().numpy()[0]

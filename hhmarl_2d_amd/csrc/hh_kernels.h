@@ -386,8 +386,10 @@ struct StepOut {
 /* phase I of the tick: dense pass over the workgroup's envelope queue.  Every entry is decided by the
  * filtered exact predicate (mid-latitude estimate with proven error bounds; the Karney solution for
  * the undecided sliver) and its verdict is OR-ed into the requesting lane's result word. */
-template <int A, int B, bool INLINE_EXACT = false>
-__device__ __forceinline__ void drain_envelope_queue(Shared<A, B> &sh, int tid, int count) {
+/* GS = lanes per arena group (A: aircraft packed; 8: the two-quads-of-three layout of hh_kernels_oct.h, where lane position 0..2
+ * = agents, 4..6 = opponents and `opp_id0` = unit id of the first opponent: the cannon draw is keyed by unit ids) */
+template <int GS, int B, bool INLINE_EXACT, class SH>
+__device__ __forceinline__ void drain_envelope_queue_t(SH &sh, int tid, int count, int opp_id0) {
 #ifdef HH_ABL_NO_ENVELOPE
     count = 0;
 #endif
@@ -395,7 +397,7 @@ __device__ __forceinline__ void drain_envelope_queue(Shared<A, B> &sh, int tid, 
     for (int q = tid; q < count; q += B) {
         int code = sh.u.t.q_code[q];
         int src = code & 0xff, kind = (code >> 8) & 3, j = (code >> 10) & 7;
-        int ss = src % A, sb = src - ss;
+        int ss = src % GS, sb = src - ss;
         double la1, lo1, la2, lo2;
         if (kind <= 1) { la1 = sh.lat0[src]; lo1 = sh.lon0[src]; }
         else { la1 = sh.u.t.rk_lat[src]; lo1 = sh.u.t.rk_lon[src]; }
@@ -404,7 +406,7 @@ __device__ __forceinline__ void drain_envelope_queue(Shared<A, B> &sh, int tid, 
         lo2 = moved ? sh.u.t.lon1[sb + j] : sh.lon0[sb + j];
         /* filtered exact predicate: decide from the mid-latitude estimate when it is farther from every
          * threshold than its proven error bound; otherwise redo the test with the Karney solution */
-        const int t = sh_type(sh, src);
+        const int t = (sh.flags[src] >> 1) & 3;
         const double hdg_src = kind == 0 ? sh.hdg[src] : sh.u.t.hdg1[src];
         const double sep = hh_max(hh_fabs(la2 - la1), hh_fabs(lo2 - lo1));
         const bool dom = hh_fabs(la1) <= HH_GEO_EST_MAX_LAT && hh_fabs(la2) <= HH_GEO_EST_MAX_LAT &&
@@ -441,12 +443,18 @@ __device__ __forceinline__ void drain_envelope_queue(Shared<A, B> &sh, int tid, 
         if (verdict) {
             if (kind == 0) bit = 1;
             else if (kind == 1) { /* ac1.py:112-113 Bernoulli hit, drawn only when in the cone */
-                double u = hh_rng_u01(sh.g_tkey[src / A], (uint32_t)(ss + 1), HH_SITE_CANNON, (uint32_t)(j + 1));
+                const int id_src = GS == 8 ? (ss < 4 ? ss + 1 : opp_id0 + (ss - 4)) : ss + 1;
+                const int id_tgt = GS == 8 ? (j < 4 ? j + 1 : opp_id0 + (j - 4)) : j + 1;
+                double u = hh_rng_u01(sh.g_tkey[src / GS], (uint32_t)id_src, HH_SITE_CANNON, (uint32_t)id_tgt);
                 if (u < HH_AC_HIT_PROB(t)) bit = 2 << j;
             } else bit = kind == 2 ? (1 << 9) : (1 << 10);
         }
         if (bit) atomicOr(&sh.res[src], bit);
     }
+}
+template <int A, int B, bool INLINE_EXACT = false>
+__device__ __forceinline__ void drain_envelope_queue(Shared<A, B> &sh, int tid, int count) {
+    drain_envelope_queue_t<A, B, INLINE_EXACT>(sh, tid, count, 0);
 }
 
 __device__ __forceinline__ void arm_cannon(Unit &m) { /* ac1.py:69-70 / ac2.py:65-66 fire_cannon */

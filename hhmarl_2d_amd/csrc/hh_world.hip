@@ -12,6 +12,7 @@
 
 #include "hh_kernels_hier.h"
 #include "hh_kernels_quad.h"
+#include "hh_kernels_oct.h"
 #include "hh_gae.h"
 
 /* ===================================================================== host side */
@@ -59,6 +60,7 @@ struct hh_world {
     int no_quad;  /* HH_NO_QUAD=1: 2-vs-2 rollouts on the generic LDS-exchange kernel (A/B tests; same results) */
     int no_spec;  /* HH_NO_SPEC=1: never pick the instance compiled for the default level-3 configuration */
     int no_two;   /* HH_NO_TWO=1: never pick the two-wave (simulation + output wave) form for small worlds */
+    int no_oct;   /* HH_NO_OCT=1: HighLevelEnv macro steps on the LDS-exchange kernel instead of the register-exchange one (A/B) */
     int apw;      /* HH_APW=16: never pick the 8-arenas-per-wave form of the two-wave kernel */
     void *trace_mem; /* trajectory ring buffer + cursors (hh_trace_enable), separate allocation */
     struct hh_policy *bound_policy; /* hh_bind_policy: the bank whose row lists P.pol_* point into (it points back at this world) */
@@ -123,6 +125,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     { const char *nq = getenv("HH_NO_QUAD"); w->no_quad = nq ? atoi(nq) : 0; }
     { const char *ns = getenv("HH_NO_SPEC"); w->no_spec = ns ? atoi(ns) : 0; }
     { const char *nt = getenv("HH_NO_TWO"); w->no_two = nt ? atoi(nt) : 0; }
+    { const char *no = getenv("HH_NO_OCT"); w->no_oct = no ? atoi(no) : 0; }
     /* one slab, 256-byte aligned sub-arrays */
     size_t U = (size_t)d.N * A, N = (size_t)d.N;
     size_t off = 0;
@@ -555,6 +558,15 @@ extern "C" int hh_hl_rollout(hh_world *w, const int8_t *commander_actions, const
     const bool hld = !w->no_spec && hh_cfg_is_hl_default(c); /* the instance compiled for the reference's default HighLevelEnv configuration */
     const int grid8 = (c.N + 7) / 8;
     const bool half = !two && w->apw != 16 && grid8 <= w->n_simd; /* 8 arenas per wave while every workgroup still has a SIMD of its own */
+    if (!w->no_oct) { /* register-exchange form (hh_kernels_oct.h): one arena per 8-lane group */
+        const bool two8 = w->force_w == 2 || (w->force_w == 0 && grid8 > w->n_simd);
+#define HH_OLAUNCH(Wv, Dv) hipLaunchKernelGGL((hh_k_hier_macro_oct<Wv, Dv>), dim3(grid8), dim3(64), 0, st, w->P, c, commander_actions, pilot_tape, obs, reward, reward_valid, done, w->counter)
+        if (two8) { if (hld) HH_OLAUNCH(2, true); else HH_OLAUNCH(2, false); }
+        else { if (hld) HH_OLAUNCH(1, true); else HH_OLAUNCH(1, false); }
+#undef HH_OLAUNCH
+        HIPCHK(hipGetLastError());
+        return HH_OK;
+    }
 #define HH_MLAUNCH(Wv, Dv) hipLaunchKernelGGL((hh_k_hier_macro<6, B, Wv, Dv>), dim3(grid), dim3(B), 0, st, w->P, c, commander_actions, pilot_tape, obs, reward, reward_valid, done, w->counter)
 #define HH_MLAUNCH8(Dv) hipLaunchKernelGGL((hh_k_hier_macro<6, B, 1, Dv, 8>), dim3(grid8), dim3(B), 0, st, w->P, c, commander_actions, pilot_tape, obs, reward, reward_valid, done, w->counter)
     if (two) { if (hld) HH_MLAUNCH(2, true); else HH_MLAUNCH(2, false); }

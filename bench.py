@@ -34,6 +34,8 @@ ALGO_BYTES_2V2_STEP = 1113       # state r/w 2*448 + actions 8
 ALGO_BYTES_3V3_TICK = 2056       # 656 + 656 + pilot obs 720 + pilot actions 24
 ALGO_BYTES_3V3_CMD_FIXED = 424   # commander obs 408 + actions 3 + rewards 12 + done 1
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F16_PEAK_TFLOPS = 2500.0    # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md; AMD's headline figure includes 2:1 sparsity)
+MFMA_F32_PEAK_TFLOPS = 157.3     # fp32-in MFMA runs at the vector rate
 FP64_ISSUE_PEAK = 3.93e13        # lane-operations/s: 78.6 TFLOP/s vector FP64 / 2 flop per FMA (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz)
 
 
@@ -60,6 +62,8 @@ def parse_args():
                          "MLP stand-ins in torch, or the reference's Fight/Esc architectures in the fused HIP kernel (net)")
     ap.add_argument("--no-graph", action="store_true", help="hier/rollout: launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--phases", action="store_true", help="hier with --pilot tape: the 34-launch phase path instead of the one-launch macro step")
+    ap.add_argument("--no-extra", action="store_true", help="default workload at 1 GPU: skip the short runs of the other single-GPU configurations "
+                                                             "(BASELINE configs[2], configs[3] tape / networks) that fill line['extra']")
     return ap.parse_args()
 
 
@@ -204,30 +208,41 @@ def load_json(name):
         return None
 
 
-def counter_evidence(kernel, n_arenas, ticks, units_per_s_per_gpu, lanes_per_arena):
+def counter_evidence(instance, n_arenas, ticks, units_per_s_per_gpu, lanes_per_arena):
     """HBM bytes and instruction counts per launch from the PMC passes of a separate rocprofv3 run of this same command
     (tools/prof_pmc.sh -> profiles/latest_traffic.json, profiles/latest_pmc.json; counters cannot be read from inside the
-    process).  Stored per arena-tick / per wave-tick, so they apply to any --chunk of the same kernel instance."""
+    process).  Stored per arena-tick / per wave-tick, so they apply to any --chunk of the same kernel instance — and ONLY to that
+    instance: evidence whose profiled kernel name does not contain `instance` (hh_kernel_instance: the template instance this world
+    launches, as a profiler prints it) is stale and is not quoted (traffic / fp64 stay null)."""
     traffic, fp64 = None, None
     tj = load_json("latest_traffic.json")
-    if tj and tj.get("arenas") == n_arenas and tj.get("hbm_bytes_per_launch"):
+    if tj and tj.get("arenas") == n_arenas and tj.get("hbm_bytes_per_launch") and instance in str(tj.get("kernel_full", tj.get("kernel", ""))):
         per = tj.get("hbm_bytes_per_arena_tick") or tj["hbm_bytes_per_launch"] / (tj["arenas"] * tj["ticks_per_launch"])
         traffic = int(per * n_arenas * ticks)
     pj = load_json("latest_pmc.json")
-    if pj and pj.get("arenas") == n_arenas:
+    if pj and pj.get("arenas") == n_arenas and instance in str(pj.get("kernel", "")):
         valu = pj["insts_valu_per_wave_tick"]
         # every VALU instruction of a wave counted as one issue slot for each lane that carries an aircraft (idle lanes of the
         # 8-arenas-per-wave form are not work)
         lane_ops = valu * lanes_per_arena * units_per_s_per_gpu
         fp64 = {"bound": "fp64 valu issue", "wave_tick": pj.get("wave_tick"), "insts_valu_per_wave_tick": valu, "insts_salu_per_wave_tick": pj.get("insts_salu_per_wave_tick"),
                 "achieved_lane_ops_s": lane_ops, "peak": FP64_ISSUE_PEAK, "unit": "lane-ops/s", "frac": lane_ops / FP64_ISSUE_PEAK,
+                "frac_note": "every VALU instruction counted as an FP64 issue slot (upper bound on the pipe's use)",
                 "source": pj.get("source", "profiles/latest_pmc.json")}
+        f64 = pj.get("insts_f64_per_wave_tick")   # SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64: the instructions that are FP64 arithmetic
+        if f64:
+            n64 = sum(f64.values())
+            fp64["insts_f64_per_wave_tick"] = f64
+            fp64["f64_share_of_valu"] = n64 / valu if valu else None
+            fp64["true_frac"] = n64 * lanes_per_arena * units_per_s_per_gpu / FP64_ISSUE_PEAK
+            fp64["true_frac_note"] = "only ADD/MUL/FMA/TRANS_F64 instructions counted (an FMA as ONE issue slot): the FP64 pipe's arithmetic use"
     return traffic, fp64
 
 
 # ------------------------------------------------------------------------------------------------ configs[1]: the headline
-def main_low(args):
-    R = Ranks(args)
+def main_low(args, R=None):
+    own = R is None
+    R = R or Ranks(args)
     torch = R.torch
     from hhmarl_2d_amd.sharding import ShardedWorld
     N = args.arenas or 4096
@@ -300,26 +315,29 @@ def main_low(args):
         bytes_per_launch = ALGO_BYTES_2V2_STEP * N * chunk
         achieved = bytes_per_launch / avg_launch_s / 1e9
         kname = w.kernel_name()
-        traffic, fp64 = counter_evidence(kname, N, chunk, N * chunk / avg_launch_s, 4)   # 2-vs-2: four aircraft lanes per arena
+        traffic, fp64 = counter_evidence(w.kernel_instance(), N, chunk, N * chunk / avg_launch_s, 4)   # 2-vs-2: four aircraft lanes per arena
         line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                            "traffic": traffic, "kernel": kname, "avg_launch_ms": avg_launch_s * 1e3,
+                            "traffic": traffic, "kernel": kname, "kernel_instance": w.kernel_instance(), "avg_launch_ms": avg_launch_s * 1e3,
                             "algorithmic_bytes_per_launch": bytes_per_launch, "fp64": fp64,
                             "note": "FP64-VALU issue bound, not HBM bound (DESIGN.md section 4): `fp64.frac` is the fraction of the "
                                     "vector-FP64 issue slots the measured rate uses; HBM traffic is far below the algorithmic bytes "
                                     "because state stays in registers across the ticks of a launch"}
         if R.rank == 0 and R.world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, args.level, args.seed)
+    if not own:
+        return line
     if R.rank == 0:
         print(json.dumps(line), flush=True)
     R.close()
 
 
 # ------------------------------------------------------------------------------------------------ configs[2]: policy in the loop
-def main_policy_rollout(args):
+def main_policy_rollout(args, R=None):
     """BASELINE configs[2]: N arenas x 2-vs-2 fight L3 driven by a policy in the loop — per tick: observations [N, 2, 26|24]
     -> fight networks with the reference's architecture (models/ac_models_hetero.py Fight1 for agent 1, Fight2 for agent 2, actor
     half, greedy decode as env_base.py:373-382) in the fused HIP kernel -> int8 actions -> hh_step.  A step is one tick of all arenas."""
-    R = Ranks(args)
+    own = R is None
+    R = R or Ranks(args)
     torch = R.torch
     from hhmarl_2d_amd.pilots import SEL_FIGHT1, SEL_FIGHT2, PolicyBank
     from hhmarl_2d_amd.sharding import ShardedWorld
@@ -386,6 +404,26 @@ def main_policy_rollout(args):
                      "kernel": f"{w.kernel_name()} (T = 1 per launch) + hh_k_policy, " + ("one HIP graph per tick" if graph is not None else "eager"),
                      "policy_flops_per_s": bank.flops_per_row(PolicyBank.FIGHT1) * N * 2 * args.steps / gpu_s},
     }
+    # the two kernels of a tick on their own (HIP events, eager launches): which one dominates and its own roofline
+    def timed(fn, n=60):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn(); a.record()
+        for _ in range(n):
+            fn()
+        b.record(); b.synchronize()
+        return a.elapsed_time(b) / n
+    pol_ms = timed(lambda: bank.act(out[0], None, act))
+    world_ms = timed(lambda: w.step(act, out=out))
+    flops3 = 3.0 * (bank.flops_per_row(PolicyBank.FIGHT1) + bank.flops_per_row(PolicyBank.FIGHT2)) * N   # split-fp16: three MFMA passes per product
+    fp32_form = os.environ.get("HH_POLICY_FP32", "0") == "1"
+    line["kernels_ms"] = {"hh_k_policy_h" if not fp32_form else "hh_k_policy": pol_ms, w.kernel_instance(): world_ms}
+    line["roofline"]["dominant"] = {"kernel": "hh_k_policy_h (split-fp16: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16)" if not fp32_form else "hh_k_policy (fp32 MFMA)",
+                                    "bound": "mfma", "avg_launch_ms": pol_ms,
+                                    "achieved": (flops3 if not fp32_form else flops3 / 3.0) / (pol_ms * 1e-3) / 1e12,
+                                    "peak": MFMA_F16_PEAK_TFLOPS if not fp32_form else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s"}
+    line["roofline"]["dominant"]["frac"] = line["roofline"]["dominant"]["achieved"] / line["roofline"]["dominant"]["peak"]
+    if not own:
+        return line
     if R.rank == 0:
         print(json.dumps(line), flush=True)
     R.close()
@@ -396,10 +434,11 @@ PILOT_DESC = {"tape": "uniform action tape resident in HBM", "random": "uniform 
               "mlp": "random-init MLP stand-ins (torch)", "net": "random-init Fight1/Fight2/Esc1/Esc2 actors (reference architecture) in the fused HIP kernel"}
 
 
-def main_hier(args):
+def main_hier(args, R=None):
     """BASELINE configs[3]/[4]: N arenas x 3-vs-3 HighLevelEnv (map 0.5, horizon 500, N_OPPS_HL=2), commander actions uniform
     {0,1,2}; a step is one commander step (HighLevelEnv.step) of every arena = up to 16 sub-steps with pilot actions."""
-    R = Ranks(args)
+    own = R is None
+    R = R or Ranks(args)
     torch = R.torch
     from hhmarl_2d_amd.env_hier import macro_step
     from hhmarl_2d_amd.pilots import MLPPilot, NetPilot, RandomPilot, TapePilot
@@ -489,11 +528,18 @@ def main_hier(args):
                                f"pilots = {PILOT_DESC[args.pilot]}, auto-reset (BASELINE configs[3])", "arenas_per_gpu": N,
                    "parallelism": f"arena-sharded x{R.world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": ("hh_k_hier_macro (one persistent launch per commander step)" if one_launch else
+                     "traffic": None, "kernel": (f"{w.kernel_instance(1)} (one persistent launch per commander step)" if one_launch else
                                                  f"{w.kernel_name()} (every phase launch of the macro step, plus the pilots' kernels if any)"),
                      "algorithmic_bytes": algo_bytes,
                      "note": "2056 B per arena-tick actually run + 424 B per commander step (SURVEY.md 8d)"},
     }
+    line["gpu_ms_per_step"] = gpu_s / steps * 1e3
+    if not one_launch:
+        line["launches_per_step"] = 2 + 16 * (4 if args.pilot in ("net", "mlp", "random") else 2)
+    if hasattr(pilot, "close"):
+        pilot.close()
+    if not own:
+        return line
     if R.rank == 0:
         print(json.dumps(line), flush=True)
     R.close()
@@ -509,7 +555,45 @@ def main():
         return main_hier(args)
     if args.workload == "rollout":
         return main_policy_rollout(args)
-    return main_low(args)
+    single = args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1
+    if args.dry_run or args.no_extra or not single:
+        return main_low(args)
+    # the driver's line: configs[1] is the headline; the other single-GPU configurations of BASELINE.json ride along as short runs
+    R = Ranks(args)
+    line = main_low(args, R)
+    line["extra"] = extra_configs(args, R)
+    print(json.dumps(line), flush=True)
+    R.close()
+
+
+def extra_configs(args, R):
+    """BASELINE configs[2] (16384 arenas, fight networks in the loop every tick) and configs[3] (8192 arenas x 3-vs-3 HighLevelEnv:
+    pilot actions from a tape = one persistent launch per commander step, and with the reference's pilot networks in the loop),
+    each measured like its own `--workload` run but shorter; a failure of one does not cost the headline its line."""
+    import copy
+
+    def brief(line):
+        keys = ("metric", "value", "unit", "steps", "ms_per_step", "gpu_ms_per_step", "dtype", "kernels_ms", "launches_per_step", "sim_ticks_per_s",
+                "ticks_per_commander_step")
+        out = {k: line[k] for k in keys if k in line}
+        out["workload"] = line["config"]["workload"]
+        out["roofline"] = line["roofline"]
+        return out
+
+    extra = {}
+    for name, fn, kw in (("configs2", main_policy_rollout, dict(workload="rollout", steps=300, warmup=30)),
+                         ("configs3", main_hier, dict(workload="hier", pilot="tape", steps=40, warmup=8)),
+                         ("configs3_networks_in_loop", main_hier, dict(workload="hier", pilot="net", steps=12, warmup=3))):
+        a = copy.copy(args)
+        a.arenas, a.spinup, a.no_graph, a.phases = None, 0.3, False, False
+        for k, v in kw.items():
+            setattr(a, k, v)
+        try:
+            extra[name] = brief(fn(a, R))
+        except Exception as e:   # noqa: BLE001 — reported, never silently dropped
+            extra[name] = {"error": f"{type(e).__name__}: {e}"}
+        R.torch.cuda.synchronize()
+    return extra
 
 
 if __name__ == "__main__":

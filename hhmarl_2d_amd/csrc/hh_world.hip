@@ -300,6 +300,42 @@ extern "C" int hh_rollout_kernel_name(hh_world *w, char *buf, int32_t len) {
     return HH_OK;
 }
 
+/* the same instance the way a profiler prints it (demangled template arguments): what bench.py matches the committed rocprofv3
+ * counter evidence against.  which = 0: hh_rollout / hh_step (LowLevelEnv) or the hh_hl_* phase launches; 1: hh_hl_rollout */
+extern "C" int hh_kernel_instance(hh_world *w, int32_t which, char *buf, int32_t len) {
+    if (!w || !buf || len <= 0) return HH_E_ARG;
+    const DevCfg &c = w->dc;
+    if (w->cfg.env_kind != HH_ENV_LOWLEVEL) {
+        const int grid = (c.N + 9) / 10, grid8 = (c.N + 7) / 8;
+        if (which == 0) {
+            const bool two = (w->force_w == 2 || (w->force_w == 0 && grid > w->n_simd)) && c.nA == 3 && c.nO == 3;
+            snprintf(buf, (size_t)len, "hh_k_hier<6, 64, %d>", two ? 2 : 1);
+            return HH_OK;
+        }
+        const bool hld = !w->no_spec && hh_cfg_is_hl_default(c);
+        if (!w->no_oct) {
+            const bool two8 = w->force_w == 2 || (w->force_w == 0 && grid8 > w->n_simd);
+            snprintf(buf, (size_t)len, "hh_k_hier_macro_oct<%d, %s>", two8 ? 2 : 1, hld ? "true" : "false");
+            return HH_OK;
+        }
+        const bool two = w->force_w == 2 || (w->force_w == 0 && grid > w->n_simd);
+        const bool half = !two && w->apw != 16 && grid8 <= w->n_simd;
+        snprintf(buf, (size_t)len, "hh_k_hier_macro<6, 64, %d, %s, %d>", two ? 2 : 1, hld ? "true" : "false", half ? 8 : 10);
+        return HH_OK;
+    }
+    const int waves = (c.N + 15) / 16;
+    const bool two = w->force_w == 2 || (w->force_w == 0 && waves > w->n_simd);
+    int pre = w->no_spec ? 0 : hh_cfg_preset(c);
+    const bool pair = !two && !w->no_two && waves <= w->n_simd / 2;
+    const bool half = pair && w->apw != 16 && 2 * ((c.N + 7) / 8) <= w->n_simd;
+    if (w->no_quad || w->P.trace) snprintf(buf, (size_t)len, "hh_k_world<4, 64, %d, false>", two ? 2 : 1);
+    else {
+        if (pair && !half && pre != 1) pre = 0;
+        snprintf(buf, (size_t)len, "hh_k_world_quad<%d, %d, %s, %d>", two ? 2 : 1, pre, pair ? "true" : "false", half ? 8 : 16);
+    }
+    return HH_OK;
+}
+
 /* cumulative number of arena-ticks HighLevelEnv macro steps have run on this world (sub-steps of arenas that were
  * still inside their macro step) — the honest numerator of a ticks/s figure, since arenas leave a macro step early */
 extern "C" int hh_hl_tick_count(hh_world *w, uint64_t *out /* [host] */, void *stream) {

@@ -244,6 +244,12 @@ class World:
         L.check(L.lib().hh_rollout_kernel_name(self.h, buf, 128))
         return buf.value.decode()
 
+    def kernel_instance(self, which=0):
+        """the launched instance as a profiler prints it (hh_kernel_instance); which = 1: the hh_hl_rollout kernel"""
+        buf = C.create_string_buffer(128)
+        L.check(L.lib().hh_kernel_instance(self.h, int(which), buf, 128))
+        return buf.value.decode()
+
     # ---- host snapshots (parity tests, checkpointing) ----
     def _alloc_state(self):
         n, a = self.N, self.A

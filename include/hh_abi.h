@@ -169,6 +169,11 @@ int hh_hl_tick_count(hh_world *w, uint64_t *out, void *stream);
 /* name of the kernel instance hh_rollout / hh_step (or the hh_hl_* phases) launch for this world on this device */
 int hh_rollout_kernel_name(hh_world *w, char *buf, int32_t len);
 
+/* the same instance as a profiler prints it (demangled template arguments, e.g. "hh_k_world_quad<1, 1, true, 8>"): bench.py only
+ * quotes counter evidence (profiles/latest_*.json) whose kernel name contains this string.  which = 0: the kernel of hh_rollout /
+ * hh_step (LowLevelEnv) or of the hh_hl_* phase launches (HighLevelEnv); 1: the kernel of hh_hl_rollout */
+int hh_kernel_instance(hh_world *w, int32_t which, char *buf, int32_t len);
+
 /* Evaluation counters of HighLevelEnv.step (envs/env_base.py:91-107, read by evaluation.py:66-82), computed on the device
  * for every arena inside hh_hl_end: columns = agents_win, opps_win, draw (flags of the step that ended the episode),
  * agent_fight, agent_escape, opp_fight, opp_escape, agent_steps, opp_steps, opp1, opp2, opp3 (units that still exist after

@@ -54,18 +54,23 @@ def traffic_json(fetch_db, write_db, kernel, min_us, arenas, ticks):
         rows = list(db.execute("select kernel_name, avg(value), max(value) from counters_collection where counter_name=? group by kernel_name", (name,)))
         rows = sorted((r for r in rows if kernel in str(r[0])), key=lambda r: -r[2])
         vals[name] = rows[0][2] if rows else None   # the dominant matching kernel; max over dispatches = a full-length launch
-    b = None if None in vals.values() else int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
-    print(json.dumps({"arenas": arenas, "ticks_per_launch": ticks, "kernel": kernel, "fetch_size_kb": vals["FETCH_SIZE"],
+        if rows:
+            vals["full"] = str(rows[0][0])[:60]
+    b = None if None in (vals["FETCH_SIZE"], vals["WRITE_SIZE"]) else int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+    print(json.dumps({"arenas": arenas, "ticks_per_launch": ticks, "kernel": kernel, "kernel_full": vals.get("full"), "fetch_size_kb": vals["FETCH_SIZE"],
                       "write_size_kb": vals["WRITE_SIZE"], "hbm_bytes_per_launch": b,
                       "hbm_bytes_per_arena_tick": None if b is None else b / (arenas * ticks),
                       "note": "2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate passes"}))
 
 
-def pmc_json(db_path, kernel, arenas, ticks, arenas_per_wave):
-    """instruction counters per wave-tick (one wave-tick = `arenas_per_wave` arenas x 1 tick) for bench.py's fp64 roofline block"""
+def pmc_json(db_path, kernel, arenas, ticks, arenas_per_wave, f64_db=None):
+    """instruction counters per wave-tick (one wave-tick = `arenas_per_wave` arenas x 1 tick) for bench.py's fp64 roofline block;
+    f64_db: the pass with SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 (the instructions that are FP64 arithmetic)"""
     import json
     db = sqlite3.connect(db_path)
     rows = list(db.execute("select kernel_name, counter_name, max(value) from counters_collection group by kernel_name, counter_name"))
+    if f64_db:
+        rows += list(sqlite3.connect(f64_db).execute("select kernel_name, counter_name, max(value) from counters_collection group by kernel_name, counter_name"))
     rows = [r for r in rows if kernel in str(r[0])]
     if not rows:
         print(json.dumps({"error": "kernel not found"}))
@@ -73,7 +78,8 @@ def pmc_json(db_path, kernel, arenas, ticks, arenas_per_wave):
     top = max(rows, key=lambda r: r[2] if r[1] == "SQ_INSTS_VALU" else -1)[0]   # the instance doing the most work
     v = {r[1]: r[2] for r in rows if r[0] == top}
     wt = (arenas + arenas_per_wave - 1) // arenas_per_wave * ticks
-    print(json.dumps({"arenas": arenas, "ticks_per_launch": ticks, "kernel": str(top)[:60],
+    f64 = {k[len("SQ_INSTS_VALU_"):]: v[k] / wt for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64") if k in v}
+    print(json.dumps({"arenas": arenas, "ticks_per_launch": ticks, "kernel": str(top)[:60], "insts_f64_per_wave_tick": f64 or None,
                       "insts_valu_per_wave_tick": v.get("SQ_INSTS_VALU", 0) / wt, "insts_salu_per_wave_tick": v.get("SQ_INSTS_SALU", 0) / wt,
                       "insts_lds_per_wave_tick": v.get("SQ_INSTS_LDS", 0) / wt, "sq_waves": v.get("SQ_WAVES"),
                       "wave_cycles_per_wave_tick": v.get("SQ_WAVE_CYCLES", 0) * 4 / wt,
@@ -84,6 +90,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--traffic":
         traffic_json(sys.argv[2], sys.argv[3], sys.argv[4], 0, int(sys.argv[5]), int(sys.argv[6]))
     elif len(sys.argv) > 1 and sys.argv[1] == "--pmcjson":
-        pmc_json(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]))
+        pmc_json(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7] if len(sys.argv) > 7 else None)
     else:
         main()

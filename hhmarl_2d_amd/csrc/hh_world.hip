@@ -655,6 +655,16 @@ extern "C" int hh_gae(int32_t T, int32_t N, int32_t n_agents, const float *rewar
     return HH_OK;
 }
 
+extern "C" int hh_gae_rllib(int32_t T, int32_t N, int32_t n_agents, const float *reward, const float *value, const uint8_t *done, double gamma,
+                            double lam, float *adv, float *ret, void *stream) {
+    if (T <= 0 || N <= 0 || n_agents <= 0 || !reward || !value || !done || !adv || !ret) { g_err = "bad argument"; return HH_E_ARG; }
+    size_t cols = (size_t)N * n_agents;
+    int grid = (int)((cols + 255) / 256);
+    hipLaunchKernelGGL(hh_k_gae_rllib, dim3(grid), dim3(256), 0, (hipStream_t)stream, T, N, n_agents, reward, value, done, gamma, lam, adv, ret);
+    HIPCHK(hipGetLastError());
+    return HH_OK;
+}
+
 /* commander_actions after _action_assess expanded them (agents: validated action, opponents: drawn fight target /
  * escape; env_hier.py:142-190) — what evaluation.py's eval_info counters read (env_base.py:91-107) */
 extern "C" int hh_hl_commands(hh_world *w, int8_t *out /* [host] [N, A] */) {

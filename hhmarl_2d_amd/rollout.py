@@ -25,6 +25,21 @@ def gae(reward, value, valid, done, gamma=0.99, lam=0.95):
     return adv, ret
 
 
+def gae_rllib(reward, value, done, gamma=0.99, lam=0.95):
+    """Advantages / value targets the way RLlib 2.4 computes them for the reference's step stream (hh_gae_rllib): rows of agents
+    without a reward key stay in with reward 0.0 (nothing is masked), last_r = 0.0 at every episode end, float64 discounted sum.
+    train_hetero.py:216 uses lam = 0.95, train_hier.py:186 RLlib's default lam = 1.0.
+    reward [T,N,nA] (0.0 where the world reported reward_valid = 0); value [T+1,N,nA]; done [T,N] -> (advantages, value targets)"""
+    T, N, nA = reward.shape
+    assert value.shape == (T + 1, N, nA) and done.shape == (T, N)
+    reward, value = reward.contiguous().float(), value.contiguous().float()
+    done = done.contiguous().to(torch.uint8)
+    adv, ret = torch.empty_like(reward), torch.empty_like(reward)
+    st = C.c_void_p(torch.cuda.current_stream(reward.device).cuda_stream)
+    L.check(L.lib().hh_gae_rllib(T, N, nA, _p(reward), _p(value), _p(done), float(gamma), float(lam), _p(adv), _p(ret), st))
+    return adv, ret
+
+
 def central_critic_inputs(obs, actions):
     """The four blocks the reference's centralised critic sees per agent (central_critic_observer +
     on_postprocess_trajectory, train_hetero.py:113-181), for the 2-vs-2 low-level setting:
@@ -35,8 +50,10 @@ def central_critic_inputs(obs, actions):
     Returns a dict per agent of float32 tensors with the reference's widths."""
     d1 = obs.shape[-1]
     d2 = d1 - 2 if d1 == 26 else d1 - 1          # 26/24 fight, 30/29 escape
-    a = actions.float()
-    scaled = torch.stack([a[..., 0] / 12.0, a[..., 1] / 8.0, a[..., 2], a[..., 3]], dim=-1)
+    # the reference divides the integer actions in float64 and stores into the float32 batch (train_hetero.py:143-160): the same here
+    # on any device (a float32 division on the GPU is not correctly rounded in every PyTorch build, the float64 one is)
+    a = actions.double()
+    scaled = torch.stack([a[..., 0] / 12.0, a[..., 1] / 8.0, a[..., 2], a[..., 3]], dim=-1).float()
     o1, o2 = obs[..., 0, :d1], obs[..., 1, :d2]
     a1, a2 = scaled[..., 0, :ACTION_DIM_AC1], scaled[..., 1, :ACTION_DIM_AC2]
     return {1: {"obs_1_own": o1, "obs_2": o2, "act_1_own": a1, "act_2": a2},
@@ -61,7 +78,7 @@ def central_critic_rows_hl(obs, actions, agent):
     actions int8 [..., 3] -> float32 [..., 105]."""
     others = [i for i in (1, 2, 3) if i != agent]
     order = [agent] + others
-    a = torch.stack([actions[..., i - 1].float() / 2.0 for i in order], dim=-1)
+    a = torch.stack([actions[..., i - 1].double() / 2.0 for i in order], dim=-1).float()
     return torch.cat([a] + [obs[..., i - 1, :].float() for i in order], dim=-1)
 
 

@@ -211,6 +211,15 @@ int hh_episode_stats_packed(hh_world *w, float *out, void *stream);
 int hh_gae(int32_t T, int32_t N, int32_t n_agents, const float *reward, const float *value, const uint8_t *valid,
            const uint8_t *done, float gamma, float lam, float *adv, float *ret, void *stream);
 
+/* The same scan with the semantics RLlib 2.4 gives the reference's step stream (what train_hetero.py / train_hier.py actually
+ * train on): no reward key = reward 0.0 and the row stays in the trajectory (the reference returns observations for dead agents,
+ * env_hetero.py:65-103,217-223, and RLlib's sampler reads rewards[env_id].get(agent_id, 0.0)); last_r = 0.0 after every episode
+ * end; delta and the discounted sum in float64 (np.concatenate with last_r promotes, scipy.signal.lfilter inside discount_cumsum
+ * (ray/rllib/evaluation/postprocessing.py).  `reward` must hold 0.0 where hh_rollout reported reward_valid = 0 (it does).
+ * train_hetero.py:216: gamma 0.99, lambda 0.95; train_hier.py:186: gamma 0.99 and RLlib's default lambda 1.0. */
+int hh_gae_rllib(int32_t T, int32_t N, int32_t n_agents, const float *reward, const float *value, const uint8_t *done, double gamma,
+                 double lam, float *adv, float *ret, void *stream);
+
 /* host snapshot in / out (synchronises the stream) */
 int hh_get_state(hh_world *w, hh_state_view *view);
 int hh_set_state(hh_world *w, const hh_state_view *view);

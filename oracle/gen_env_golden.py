@@ -747,6 +747,64 @@ def record_edge(seed=20240917):
               f"rockets {out['rk_i'][sel][:, :, 0].sum(axis=1).tolist()} wait {out['ac_i'][sel][:, 0, 7].tolist()}")
 
 
+# ---------------------------------------------------------------- the reference's own per-tick unit trace
+def record_unit_trace(name="l3_fight_random", seed=20240917, arena=7):
+    """tests/golden/unit_trace_l3.npz: what the reference's simulator RECORDS for rendering — CmanoSimulator.trace_record_units
+    (cmano_simulator.py:82,125-130,147-150,159-162: one (utc_time, position, heading, speed) tuple per recorded unit at reset and
+    after every tick while the unit exists; reset_sim / env_base.py:581 record every aircraft; rockets enter through add_unit,
+    which records nothing, so `ep*_rockets` stays empty) — dumped
+    at the end of each episode of the `l3_fight_random` scenario (same seed, arena and action stream as env_l3_fight_random.npz,
+    so a replay of that trace must leave the same trajectory in the device-side ring buffer of hh_trace_enable)."""
+    sc = [x for x in SCENARIOS if x[0] == name][0]
+    _, kind, kw, policy, episodes, max_rows = sc
+    args = H.make_args(**kw)
+    env = H.RefEnv(kind, args, seed=seed, arena=arena)
+    A = args.total_num
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    eps = []
+    rows = 0
+
+    def dump():
+        sim = env.env.sim
+        t0 = min(t for u in range(1, A + 1) for t, _, _, _ in sim.trace_record_units[u])
+        T = max(len(v) for v in sim.trace_record_units.values())
+        ac = np.full((T, A, 4), np.nan)
+        for u in range(1, A + 1):
+            for t, pos, hdg, spd in sim.trace_record_units[u]:
+                ac[int((t - t0).total_seconds()), u - 1] = (pos.lat, pos.lon, hdg, spd)
+        rk = []   # rocket id, source unit, tick, lat, lon
+        for uid, tr in sim.trace_record_units.items():
+            if uid > A:
+                src = env.env._hh_rocket_src[uid]
+                for t, pos, hdg, spd in tr:
+                    rk.append((uid - A, src, int((t - t0).total_seconds()), pos.lat, pos.lon))
+        return ac, np.asarray(rk, dtype=np.float64).reshape(-1, 5)
+
+    for ep in range(episodes):
+        env.reset()
+        rows += 1
+        env.env._hh_rocket_src = {}
+        done = False
+        while not done and rows < max_rows:
+            act = policy(rng, env)
+            obs, rew, term, trunc, info = env.step(act)
+            for uid, r in env.env.sim.active_units.items():
+                if uid > A:
+                    env.env._hh_rocket_src[uid] = r.source.id
+            rows += 1
+            done = term["__all__"]
+        eps.append(dump())
+        if rows >= max_rows:
+            break
+    out = {"meta": np.array(json.dumps(dict(name=name, seed=seed, arena=arena, episodes=len(eps))))}
+    for k, (ac, rk) in enumerate(eps):
+        out[f"ep{k}_aircraft"] = ac
+        out[f"ep{k}_rockets"] = rk
+    path = os.path.join(OUT, "unit_trace_l3.npz")
+    np.savez_compressed(path, **out)
+    print(f"unit_trace_l3: episodes={len(eps)} ticks={[len(a) - 1 for a, _ in eps]} rocket points={[len(r) for _, r in eps]} size={os.path.getsize(path)}")
+
+
 def generate(out_dir, only=()):
     global OUT
     OUT = out_dir
@@ -771,6 +829,8 @@ def generate(out_dir, only=()):
             record_hl_nets(*sc)
     if not only or "edge_cases" in only:
         record_edge()
+    if not only or "unit_trace" in only:
+        record_unit_trace()
 
 
 def check(committed_dir):
@@ -781,7 +841,7 @@ def check(committed_dir):
     with tempfile.TemporaryDirectory() as tmp:
         generate(tmp)
         new = sorted(os.path.basename(f) for f in glob.glob(os.path.join(tmp, "*.npz")))
-        old = sorted(os.path.basename(f) for f in glob.glob(os.path.join(committed_dir, "env_*.npz")) + glob.glob(os.path.join(committed_dir, "edge_*.npz")))
+        old = sorted(os.path.basename(f) for f in glob.glob(os.path.join(committed_dir, "env_*.npz")) + glob.glob(os.path.join(committed_dir, "edge_*.npz")) + glob.glob(os.path.join(committed_dir, "unit_trace_*.npz")))
         if new != old:
             bad.append(f"file sets differ: generated {new} vs committed {old}")
         for f in new:

@@ -1,6 +1,8 @@
 """The drop-in boundary: hhmarl_2d_amd.env_hetero.LowLevelEnv driven exactly like RLlib drives the
 reference's LowLevelEnv (dict in / dict out), checked against the golden traces recorded from the
 reference: same keys, same shapes/dtypes, same values."""
+import os
+
 import numpy as np
 import pytest
 
@@ -236,6 +238,48 @@ def test_plot_writes_a_png(tmp_path):
     st = env.world.get_state()
     assert np.allclose(rows[-1, :, :4], st["ac_f"][0, :, :4].astype(np.float32)) and np.array_equal(rows[-1, :, 4], st["ac_i"][0, :, 0])
     assert np.array_equal(rows[-1, :, 7], st["rk_i"][0, :, 0])
+    env.close()
+
+
+def test_trace_ring_equals_the_reference_simulators_own_unit_trace():
+    """SURVEY.md 8 f-4 against the reference itself: tests/golden/unit_trace_l3.npz is CmanoSimulator.trace_record_units
+    (cmano_simulator.py:125-130,147-150,159-162: (utc_time, position, heading, speed) per aircraft at reset and after every tick
+    while it exists) dumped at the end of each episode of the `l3_fight_random` scenario.  Replaying that scenario's recorded
+    actions through the facade with record_trace must leave the same trajectory in the device-side ring buffer: same number of
+    points per aircraft, same values (float32 ring), and the ring's alive flag drops exactly where the reference stops recording
+    (a unit that leaves the map is still recorded at the tick it left: do_tick stores, then the env removes it)."""
+    from hhmarl_2d_amd import env_hetero
+    g, meta = load_golden([p for p in golden_files() if p.endswith("env_l3_fight_random.npz")][0])
+    ref = np.load(os.path.join(os.path.dirname(golden_files()[0]), "unit_trace_l3.npz"))
+    orig = env_hetero.config_from_args
+    env_hetero.config_from_args = lambda *a, **k: orig(*a, **{**k, "arena_offset": meta["arena"]})
+    try:
+        env, args = _env_from_meta(meta, record_trace=True)
+    finally:
+        env_hetero.config_from_args = orig
+    ep, checked = -1, 0
+    for r in range(len(g["kind"])):
+        if g["kind"][r] == 0:
+            env.reset()
+            ep += 1
+            continue
+        _, _, term, _, _ = env.step({1: g["actions"][r][0, :4].tolist(), 2: g["actions"][r][1, :3].tolist()})
+        if term["__all__"]:
+            rows, eps = env.world.trace_read()[0]
+            rows = rows[eps == eps[-1]]                       # this episode: reset row + one row per tick
+            want = ref[f"ep{ep}_aircraft"]
+            assert len(ref[f"ep{ep}_rockets"]) == 0           # the reference never records rockets (add_unit does not)
+            assert rows.shape[0] == want.shape[0], (ep, rows.shape, want.shape)
+            for u in range(4):
+                rec = ~np.isnan(want[:, u, 0])
+                n = int(rec.sum())
+                assert rec[:n].all(), "the reference records a unit without gaps until it is gone"
+                assert np.allclose(rows[:n, u, :4], want[:n, u].astype(np.float32), rtol=0, atol=1e-5), (ep, u)
+                alive = rows[:, u, 4] > 0
+                # alive while recorded; the last recorded point may already carry alive = 0 (left the map in that tick)
+                assert alive[: n - 1].all() and not alive[n:].any(), (ep, u, n)
+                checked += n
+    assert ep == 1 and checked > 500
     env.close()
 
 

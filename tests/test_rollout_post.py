@@ -47,3 +47,46 @@ def test_complete_episode_slicing():
                 k += 1
                 last_done = t
         assert bool(complete[: last_done + 1, n].all()) and not bool(complete[last_done + 1:, n].any())
+
+
+# ---- GAE with RLlib 2.4's semantics for the reference's step stream (oracle/gae_ref.py)
+def test_rllib_postprocessing_restatement_on_hand_computed_vectors():
+    """ray/rllib/evaluation/postprocessing.py compute_advantages, by hand with exactly representable numbers:
+    rewards [1, 0, 2], values [0.5, 0.25, -1], last_r = 0, gamma = lambda = 0.5:
+      delta = [1 + .5*.25 - .5, 0 + .5*(-1) - .25, 2 + .5*0 + 1] = [0.625, -0.75, 3]
+      A     = [0.625 + .25*0, -0.75 + .25*3, 3]                   = [0.625, 0, 3];   targets = A + V = [1.125, 0.25, 2]"""
+    import gae_ref
+    adv, tgt = gae_ref.compute_advantages(np.array([1, 0, 2], dtype=np.float32), np.array([0.5, 0.25, -1], dtype=np.float32), 0.0, 0.5, 0.5)
+    assert adv.dtype == np.float32 and np.array_equal(adv, [0.625, 0.0, 3.0]) and np.array_equal(tgt, [1.125, 0.25, 2.0])
+    # truncated trajectory: last_r = V(last obs) = 4 enters the last delta only: delta_2 = 2 + .5*4 + 1 = 5 -> A = [0.625 + .25*.5, -0.75 + .25*5, 5]
+    adv, tgt = gae_ref.compute_advantages(np.array([1, 0, 2], dtype=np.float32), np.array([0.5, 0.25, -1], dtype=np.float32), 4.0, 0.5, 0.5)
+    assert np.array_equal(adv, [0.75, 0.5, 5.0]) and np.array_equal(tgt, [1.25, 0.75, 4.0])
+
+
+def test_rllib_stream_keeps_the_rows_of_dead_agents_and_restarts_at_episode_ends():
+    """the reference returns observations for dead agents but no reward key: RLlib's sampler gives those rows reward 0.0 and keeps
+    them, so the critic's predictions on them still shape the advantages before AND after the death; hh_gae's masked convention
+    cuts there.  One arena, one agent, two episodes (done after rows 2 and 4), the agent dies after row 0 of the first."""
+    import gae_ref
+    r = np.array([1, 9, 9, 2, 0], dtype=np.float32).reshape(5, 1, 1)          # the 9s sit on rows without a reward key: ignored
+    valid = np.array([1, 0, 0, 1, 1], dtype=np.uint8).reshape(5, 1, 1)
+    done = np.array([0, 0, 1, 0, 1], dtype=np.uint8).reshape(5, 1)
+    v = np.array([0.5, 0.25, -1, 2, 1, 7], dtype=np.float32).reshape(6, 1, 1)
+    adv, tgt = gae_ref.rllib_stream(r, valid, v, done, 0.5, 0.5)
+    # episode 1: rewards [1, 0, 0], values [.5, .25, -1], last_r 0: delta = [0.625, -0.75, 1], A = [0.625 + .25*(-0.5), -0.75 + .25*1, 1]
+    # episode 2: rewards [2, 0], values [2, 1]: delta = [2 + .5 - 2, 0 - 1] = [0.5, -1], A = [0.5 - .25, -1]
+    assert np.array_equal(adv[:, 0, 0], [0.5, -0.5, 1.0, 0.25, -1.0])
+    assert np.array_equal(tgt[:, 0, 0], [1.0, -0.25, 0.0, 2.25, 0.0])
+    adv_m, ret_m = gae_ref.masked_stream(np.where(valid > 0, r, 0).astype(np.float32), valid, v, done, 0.5, 0.5)
+    assert np.array_equal(adv_m[:, 0, 0], [0.625, 0.0, 0.0, 0.25, -1.0]) and np.array_equal(ret_m[:, 0, 0], [1.125, 0.0, 0.0, 2.25, 0.0])
+
+
+def test_gae_fixtures_regenerate_from_the_committed_traces():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "oracle", "gen_gae_golden.py"), "--check"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    g = np.load(os.path.join(root, "tests", "golden", "gae_vectors.npz"))
+    # the streams contain what the test is about: rows without a reward key inside episodes that complete
+    assert int((g["l3_fight_pursuit_share/valid"] == 0).sum()) > 100 and int(g["l3_escape_shaping/done"].sum()) == 3

@@ -237,6 +237,7 @@ struct OctShared {
             int q_code[64 * 8];
         } t;
         float obs[8 * 3 * HH_OBS_HL];
+        float prow[8 * 6 * 30]; /* every unit's pilot row of the wave's eight arenas, contiguous like [N, 6, 30] */
     } u;
 };
 
@@ -764,12 +765,12 @@ __device__ __forceinline__ int oct_do_tick(const DevPtrs &P, const DevCfg &c, Oc
 /* HL_END: done, rewards out, episode statistics, eval counters, auto-reset, commander observation + stored target lists
  * (env_hier.py:49-98, env_base.py:91-107); the agents' rows are left staged in sh.u.obs.  `tb` must hold the full table. */
 __device__ __forceinline__ void oct_do_end(const DevPtrs &P, const DevCfg &c, OctShared &sh, int tid, const OLane &L, int n, bool active, HlLane &H,
-                                           OTab &tb, OPub &pub, float *__restrict__ reward_out, uint8_t *__restrict__ valid_out,
-                                           uint8_t *__restrict__ done_out) {
+                                           OTab &tb, OPub &pub, int phase, float *__restrict__ reward_out, uint8_t *__restrict__ valid_out,
+                                           uint8_t *__restrict__ done_out, const uint8_t *__restrict__ mask) {
     const bool agent = L.q == 0;
     Unit &m = H.m;
     Arena &ar = H.ar;
-    const bool ending = active && !ar.done; /* arena took part in this macro step */
+    const bool ending = phase == HH_HL_END && active && !ar.done; /* arena took part in this macro step */
     const int ag = __popc(tb.amask & 0x07), op = __popc(tb.amask & 0x70);
     if (ending) ar.done = (ag <= 0 || op <= 0 || ar.steps >= c.horizon) ? 1 : 0;
     {   /* episode return: the agents' accumulated rewards in id order (every lane of the agents' quad keeps the same sum) */
@@ -786,7 +787,7 @@ __device__ __forceinline__ void oct_do_end(const DevPtrs &P, const DevCfg &c, Oc
             }
         }
     }
-    {   /* eval_info of this commander step (env_base.py:91-107): units that still exist, by assessed commander action */
+    if (phase == HH_HL_END) { /* eval_info of this commander step (env_base.py:91-107): units that still exist, by assessed commander action */
         const bool ex = ending && L.exists && m.alive;
         const int al = oct_arena_bits(__ballot(ex), L);
         const int b1 = oct_arena_bits(__ballot(ex && (m.cmd_act & 1)), L), b2 = oct_arena_bits(__ballot(ex && (m.cmd_act & 2)), L);
@@ -816,14 +817,17 @@ __device__ __forceinline__ void oct_do_end(const DevPtrs &P, const DevCfg &c, Oc
             }
         }
     }
-    ar.hl_run = 0;
-    if (active && agent && L.exists) {
-        const size_t o = (size_t)n * c.nA + L.s;
-        if (reward_out) reward_out[o] = ending ? (float)H.acc : 0.0f;
-        if (valid_out) valid_out[o] = ending ? 1 : 0; /* every agent id has a reward key (env_hier.py:154,188) */
+    if (phase == HH_HL_END) {
+        ar.hl_run = 0;
+        if (active && agent && L.exists) {
+            const size_t o = (size_t)n * c.nA + L.s;
+            if (reward_out) reward_out[o] = ending ? (float)H.acc : 0.0f;
+            if (valid_out) valid_out[o] = ending ? 1 : 0; /* every agent id has a reward key (env_hier.py:154,188) */
+        }
+        if (active && L.p == 0 && done_out) done_out[n] = (uint8_t)ar.done;
     }
-    if (active && L.p == 0 && done_out) done_out[n] = (uint8_t)ar.done;
-    const bool need_reset = active && ar.done && c.auto_reset;
+    const bool need_reset = phase == HH_HL_END ? (active && ar.done && c.auto_reset)
+                                               : (phase == HH_HL_RESET && active && (mask == nullptr || mask[n]));
     if (__ballot(need_reset)) { /* wave-uniform */
         if (need_reset) {
             reset_arena_scalars(ar);
@@ -915,7 +919,7 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_macro_oct(DevPtrs P, DevCfg c
     }
     oct_publish_norm(c, H.m, pub);
     oct_tables<true>(H.m, pub, L, tb);
-    oct_do_end(P, c, sh, tid, L, n, active, H, tb, pub, reward_out, valid_out, done_out);
+    oct_do_end(P, c, sh, tid, L, n, active, H, tb, pub, HH_HL_END, reward_out, valid_out, done_out, nullptr);
     if (obs_out) { /* the workgroup's agent rows are contiguous in [N, nA, 34] */
         const int arenas = min(8, c.N - (int)blockIdx.x * 8);
         const int cnt = arenas * c.nA * HH_OBS_HL;
@@ -940,6 +944,190 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_macro_oct(DevPtrs P, DevCfg c
     if (active && L.p == 0 && ticks) P.ev_mask[n] = 0;
     __syncthreads();
     if (L.exists && ticks && evm_last) atomicOr(&P.ev_mask[n], evm_last);
+}
+
+/* env_hier.py:100-112 lowlevel_state of the lane's unit -> 30 floats (zero padded) + policy type (hl_pilot_obs of hh_kernels_hier.h) */
+__device__ __forceinline__ int oct_pilot_obs(const DevCfg &c, const OTab &t, const OPub &p, const OLane &L, const Unit &m, float *out) {
+    for (int k = 0; k < 30; k++) out[k] = 0.0f;
+    Near3 fr;
+    oct_nearby(c, t, L, true, fr);
+    int n = 0;
+    out[n++] = p.nlat;
+    out[n++] = p.nlon;
+    out[n++] = p.nspd;
+    out[n++] = p.nhdg;
+    int mode;
+    const int cmd_act = m.cmd_act, n_tgt = m.n_tgt, t0 = m.tgt0, t1 = m.tgt1, t2 = m.tgt2;
+    const double d0 = m.tgt_d0, d1 = m.tgt_d1, d2 = m.tgt_d2;
+    const int r0 = t0 ? o_pos_rel(L, o_slot_pos(c, t0 - 1)) : 2, r1 = t1 ? o_pos_rel(L, o_slot_pos(c, t1 - 1)) : 2;
+    if (cmd_act != 0) { /* fight the commander-chosen target, with the stale stored distance */
+        mode = 1;
+        double dist = d0;
+        int r = r0;
+        if (cmd_act == 2) { dist = d1; r = r1; }
+        if (cmd_act >= 3) { dist = d2; r = t2 ? o_pos_rel(L, o_slot_pos(c, t2 - 1)) : 2; }
+        out[n++] = (float)norm180(o_sel5(t.foc, r));
+        out[n++] = (float)aspect(o_sel5(t.focr, r));
+        out[n++] = (float)o_sel3v(t.hd[0], t.hd[1], t.hd[2], r - 2);
+        out[n++] = (float)dist;
+        out[n++] = (float)hh_clip((double)m.cannon_remain / (double)m.cannon_max, 0.0, 1.0);
+        if (m.ac_type == 1) {
+            out[n++] = (float)hh_clip((double)m.missile_remain / (double)m.rocket_max, 0.0, 1.0);
+            out[n++] = m.missile_wait == 0 ? 1.0f : 0.0f;
+            out[n++] = (m.has_missile || m.burst > 0) ? 1.0f : 0.0f;
+        } else {
+            out[n++] = m.burst > 0 ? 1.0f : 0.0f;
+        }
+        n += oct_opp_block(t, 0, r, dist, out + n);
+    } else {
+        mode = 2;
+        out[n++] = (float)hh_clip((double)m.cannon_remain / (double)m.cannon_max, 0.0, 1.0);
+        if (m.ac_type == 1) out[n++] = (float)hh_clip((double)m.missile_remain / (double)m.rocket_max, 0.0, 1.0);
+        out[n++] = (p.flags & FL_SHOT) ? 1.0f : 0.0f;
+        if (n_tgt >= 1) oct_opp_block(t, 1, r0, d0, out + n);
+        if (n_tgt >= 2) oct_opp_block(t, 1, r1, d1, out + n + 9);
+        n += 18;
+    }
+    if (fr.n) oct_friend_block(c, t, fr.i0, out + n);
+    return mode;
+}
+
+/* ---- the phases one launch each, for callers whose pilot networks run BETWEEN them (hh_k_hier of hh_kernels_hier.h on the
+ * register table): HL_BEGIN / HL_AGENTS_ACT / HL_TICK / HL_END.  Same results, bit for bit; HL_REFRESH / HL_RESET stay on the
+ * generic kernel (the state in HBM is the same). ---- */
+template <int W>
+__global__ __launch_bounds__(64, W) void hh_k_hier_oct(DevPtrs P, DevCfg c, int phase, const int8_t *__restrict__ cmd, const int8_t *__restrict__ actions,
+                                                     float *__restrict__ pilot_obs, uint8_t *__restrict__ pilot_mode, float *__restrict__ obs_out,
+                                                     float *__restrict__ reward_out, uint8_t *__restrict__ valid_out, uint8_t *__restrict__ done_out,
+                                                     int *__restrict__ running_count) {
+    __shared__ OctShared sh;
+    const int tid = threadIdx.x;
+    OLane L;
+    L.g = tid >> 3; L.p = tid & 7; L.q = (tid >> 2) & 1; L.i = tid & 3;
+    L.base = tid & ~7;
+    const int n = blockIdx.x * 8 + L.g;
+    const bool active = n < c.N;
+    L.exists = active && L.i < (L.q ? c.nO : c.nA);
+    L.s = L.q ? c.nA + L.i : L.i;
+    const bool agent = L.q == 0;
+    const size_t U = (size_t)c.N * 6;
+    const size_t u = (size_t)n * 6 + L.s;
+    HlLane H;
+    H.m = Unit{};
+    H.m.ac_type = 2; H.m.cannon_max = 1;
+    H.ar = Arena{};
+    H.acc = 0.0; H.ep_ret = 0.0; H.evm = 0;
+    H.tcur = (P.trace != nullptr && active && n < P.trace_K) ? P.trace_pos[n] : 0;
+    Unit &m = H.m;
+    Arena &ar = H.ar;
+    if (L.exists) { unit_load(P, U, u, m); H.acc = P.acc_rew[u]; }
+    if (active) {
+        arena_load(P, c, n, ar);
+        if (L.p == 0) H.ep_ret = P.ep_ret[n];
+    } else {
+        ar.done = 1;
+    }
+    {
+        const double speed_table[11] = HH_ROCKET_SPEED_TABLE;
+        if (tid < 11) sh.rk_speed[tid] = speed_table[tid];
+    }
+    OPub pub;
+    OTab tb;
+    oct_publish_vec(m, pub);
+    oct_publish_norm(c, m, pub);
+    oct_publish_flags(m, pub);
+    if (phase == HH_HL_TICK) oct_positions(m, L, tb); /* the tick builds its table afterwards; before it only a launch test may ask for an entry */
+    else oct_tables<true>(m, pub, L, tb);
+    o_wave_sync();
+    int obs_side = -1; /* which side's pilot observations this launch emits */
+    /* a bound policy bank (hh_bind_policy): this launch's pilot rows are binned by network here (see hh_k_hier) */
+    int pslot = 0;
+    HhBinTicket bt{0, 0};
+    auto bin_issue = [&](int side) {
+        const bool mine_ = side == 0 ? agent : !agent;
+        const int sb = (L.exists && ar.hl_run && m.alive && mine_) ? hl_selector(c, m.cmd_act != 0 ? 1 : 2, m.ac_type, agent) : 0;
+        pslot = sb ? (int)P.pol_lut[sb] : 0;
+        bt = hh_bin_rows_issue(P.pol_counts, pslot);
+    };
+    if (phase == HH_HL_BEGIN) {
+        oct_do_begin(c, tb, L, n, active, H, cmd);
+        obs_side = 0;
+        if (P.pol_lut && pilot_obs) bin_issue(0);
+    } else if (phase == HH_HL_AGENTS_ACT) {
+        int8_t act[4];
+        hl_load_act(actions, u, L.exists, act);
+        if (P.pol_lut && pilot_obs) bin_issue(1);
+        const bool running = active && ar.hl_run;
+        act_oct<(W >= 2), true>(c, sh, tid, L, running, m, ar, act, agent, tb, pub, H.evm);
+        HH_O_FETCH5(i, tb.fl, pub.flags); /* the opponents observe the agents' weapon flags of this sub-step (env_base.py:208-211) */
+        obs_side = 1;
+    } else if (phase == HH_HL_TICK) {
+        int8_t act[4];
+        hl_load_act(actions, u, L.exists, act);
+        const bool running = active && ar.hl_run;
+        act_oct<(W >= 2), false>(c, sh, tid, L, running, m, ar, act, !agent, tb, pub, H.evm);
+        const int ran = oct_do_tick<(W >= 2), true>(P, c, sh, tid, L, n, active, H, tb, pub);
+        if (L.p == 0 && ran && ar.hl_run && running_count) atomicAdd(running_count, 1);
+        {   /* cumulative arena-ticks of this world (hh_hl_tick_count): one atomic per wave */
+            const unsigned long long rn = __ballot(ran && L.p == 0);
+            if (rn && tid == 0 && running_count) atomicAdd(reinterpret_cast<unsigned long long *>(running_count + 2), (unsigned long long)__popcll(rn));
+        }
+        obs_side = 0;
+        if (P.pol_lut && pilot_obs) bin_issue(0);
+    } else { /* HH_HL_END */
+        if (P.pol_lut && blockIdx.x == 0 && tid <= 8) P.pol_counts[tid * HH_BIN_STRIDE] = 0; /* rows the last tick binned and nobody consumed */
+        oct_do_end(P, c, sh, tid, L, n, active, H, tb, pub, HH_HL_END, reward_out, valid_out, done_out, nullptr);
+        if (obs_out) {
+            const int arenas = min(8, c.N - (int)blockIdx.x * 8);
+            const int cnt = arenas * c.nA * HH_OBS_HL;
+            float *dst = obs_out + (size_t)blockIdx.x * 8 * c.nA * HH_OBS_HL;
+            for (int k = tid; k < cnt; k += 64) dst[k] = sh.u.obs[k];
+        }
+    }
+    if (obs_side >= 0 && pilot_obs) {
+        const bool mine = obs_side == 0 ? agent : !agent;
+        o_wave_sync(); /* the queue's exchange area (same LDS) is free */
+        if (c.nA + c.nO < 6) { /* n-vs-m: the rows of the slots without an aircraft */
+            for (int k = tid; k < 8 * 6 * 30; k += 64) sh.u.prow[k] = 0.0f;
+            o_wave_sync();
+        }
+        if (L.exists) {
+            float *row = &sh.u.prow[(L.g * 6 + L.s) * 30];
+            int mode = 0;
+            if (ar.hl_run && m.alive && mine) mode = oct_pilot_obs(c, tb, pub, L, m, row);
+            else for (int k = 0; k < 30; k++) row[k] = 0.0f;
+            if (pilot_mode) pilot_mode[u] = (uint8_t)(mode ? hl_selector(c, mode, m.ac_type, agent) : 0);
+        }
+        if (active && pilot_mode && c.nA + c.nO < 6 && L.p == 3) { /* the bytes of the slots without an aircraft */
+            for (int sl = c.nA + c.nO; sl < 6; sl++) pilot_mode[(size_t)n * 6 + sl] = 0;
+        }
+        o_wave_sync();
+        const int arenas = min(8, c.N - (int)blockIdx.x * 8);
+        const int cnt = arenas * 6 * 30;
+        float *dst = pilot_obs + (size_t)blockIdx.x * 8 * 6 * 30;
+        if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0) {
+            const float4 *src4 = reinterpret_cast<const float4 *>(sh.u.prow);
+            float4 *dst4 = reinterpret_cast<float4 *>(dst);
+            for (int k = tid; k < (cnt >> 2); k += 64) dst4[k] = src4[k];
+        } else {
+            for (int k = tid; k < cnt; k += 64) dst[k] = sh.u.prow[k];
+        }
+        if (P.pol_lut) hh_bin_rows_finish(bt, P.pol_lists, P.pol_max_rows, (int)u, pslot);
+    }
+    if (L.exists) {
+        unit_store(P, U, u, m);
+        P.acc_rew[u] = H.acc;
+    }
+    if (active && L.p == 0) {
+        if (P.trace != nullptr && n < P.trace_K) P.trace_pos[n] = H.tcur;
+        arena_store(P, n, ar);
+        P.ep_ret[n] = H.ep_ret;
+    }
+    if (phase == HH_HL_AGENTS_ACT || phase == HH_HL_TICK) {
+        if (active && L.p == 0 && phase == HH_HL_AGENTS_ACT && ar.hl_run) P.ev_mask[n] = 0;
+        __syncthreads();
+        if (L.exists && H.evm) atomicOr(&P.ev_mask[n], H.evm);
+    }
 }
 
 #endif /* HH_KERNELS_OCT_H */

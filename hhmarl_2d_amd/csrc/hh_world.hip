@@ -216,6 +216,15 @@ static int launch_hier(hh_world *w, int phase, const int8_t *cmd, const int8_t *
     const DevCfg &c = w->dc;
     if (w->cfg.env_kind != HH_ENV_HIGHLEVEL || c.A != 6) { g_err = "not a HighLevelEnv (3-vs-3) world"; return HH_E_ARG; }
     HH_GUARD(w);
+    if (!w->no_oct && phase <= HH_HL_END) { /* register-exchange form (hh_kernels_oct.h): one arena per 8-lane group */
+        const int grid8 = (c.N + 7) / 8;
+        if (w->force_w == 2 || (w->force_w == 0 && grid8 > w->n_simd))
+            hipLaunchKernelGGL((hh_k_hier_oct<2>), dim3(grid8), dim3(64), 0, st, w->P, c, phase, cmd, actions, pilot_obs, pilot_mode, obs, reward, valid, done, w->counter);
+        else
+            hipLaunchKernelGGL((hh_k_hier_oct<1>), dim3(grid8), dim3(64), 0, st, w->P, c, phase, cmd, actions, pilot_obs, pilot_mode, obs, reward, valid, done, w->counter);
+        HIPCHK(hipGetLastError());
+        return HH_OK;
+    }
     constexpr int B = HH_BLOCK, GPB = B / 6;
     int grid = (c.N + GPB - 1) / GPB;
     /* the W = 2 instance stages the pilot rows per SIDE (three slots each): n-vs-m arenas use the W = 1 instance */
@@ -309,7 +318,8 @@ extern "C" int hh_kernel_instance(hh_world *w, int32_t which, char *buf, int32_t
         const int grid = (c.N + 9) / 10, grid8 = (c.N + 7) / 8;
         if (which == 0) {
             const bool two = (w->force_w == 2 || (w->force_w == 0 && grid > w->n_simd)) && c.nA == 3 && c.nO == 3;
-            snprintf(buf, (size_t)len, "hh_k_hier<6, 64, %d>", two ? 2 : 1);
+            if (!w->no_oct) snprintf(buf, (size_t)len, "hh_k_hier_oct<%d>", (w->force_w == 2 || (w->force_w == 0 && grid8 > w->n_simd)) ? 2 : 1);
+            else snprintf(buf, (size_t)len, "hh_k_hier<6, 64, %d>", two ? 2 : 1);
             return HH_OK;
         }
         const bool hld = !w->no_spec && hh_cfg_is_hl_default(c);

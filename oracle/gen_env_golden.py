@@ -852,7 +852,8 @@ def check(committed_dir):
                 bad.append(f"{f}: keys differ {sorted(set(a.files) ^ set(b.files))}")
                 continue
             for k in a.files:
-                if a[k].shape != b[k].shape or not np.array_equal(a[k], b[k]):
+                same = a[k].shape == b[k].shape and (np.array_equal(a[k], b[k], equal_nan=True) if a[k].dtype.kind == "f" else np.array_equal(a[k], b[k]))
+                if not same:
                     bad.append(f"{f}: array {k} differs")
     return bad
 

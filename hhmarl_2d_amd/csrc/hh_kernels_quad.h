@@ -48,6 +48,13 @@ template <int J> __device__ __forceinline__ double q_bc_d(double v) { return q_p
 /* the other aircraft of the same side (slot s ^ 1) */
 __device__ __forceinline__ double q_mate_d(double v) { return q_perm_d<HH_QP(1, 0, 3, 2)>(v); }
 
+/* lanes 32..63 of a wave that carries 8 arenas in lanes 0..31 (the small-world form) are HELPERS of lane - 32: one
+ * v_permlane32_swap_b32 hands a word down (main -> helper, main keeps its own) or up (helper -> main, helper keeps its own) */
+__device__ __forceinline__ int q_down_i(int v) { return __builtin_amdgcn_permlane32_swap(v, v, false, false)[0]; }
+__device__ __forceinline__ int q_up_i(int v) { return __builtin_amdgcn_permlane32_swap(v, v, false, false)[1]; }
+__device__ __forceinline__ double q_down_d(double v) { return __hiloint2double(q_down_i(__double2hiint(v)), q_down_i(__double2loint(v))); }
+__device__ __forceinline__ double q_up_d(double v) { return __hiloint2double(q_up_i(__double2hiint(v)), q_up_i(__double2loint(v))); }
+
 /* table lookup by relative slot k in 1..3 (k outside -> entry 3).  Operands by VALUE: a select between array
  * addresses would pin the table in scratch memory. */
 template <class T>
@@ -96,13 +103,19 @@ __device__ __forceinline__ void quad_publish(const DevCfg &c, const Unit &m, QPu
     quad_publish_flags(m, p);
 }
 
-/* the pair table of pair_tables() in registers.  WAVE-UNIFORM control flow only. */
-__device__ __forceinline__ void quad_tables(const Unit &m, const QPub &p, int s, QTab &t) {
-    const double c1 = p.uc, s1 = p.us, n1 = p.un;
+/* the pair table of pair_tables() in registers.  WAVE-UNIFORM control flow only.
+ * DUAL (8 arenas in lanes 0..31, helpers in lanes 32..63): the helper of a lane receives its position and heading vector, the DPP
+ * fetches then deliver the same neighbours to both halves, and the four acos chains of a lane are split two and two — the main lane
+ * computes the focus towards slots +1 and +2, its helper the focus towards slot +3 and the heading difference — the same expressions
+ * on the same operands, handed up afterwards: half the table's arithmetic per lane for 14 lane swaps. */
+template <bool DUAL>
+__device__ __forceinline__ void quad_tables(const Unit &m, const QPub &p, int s, bool helper, QTab &t) {
+    double lat = m.lat, lon = m.lon, c1 = p.uc, s1 = p.us, n1 = p.un;
+    if (DUAL) { lat = q_down_d(lat); lon = q_down_d(lon); c1 = q_down_d(c1); s1 = q_down_d(s1); n1 = q_down_d(n1); }
     double ouc[3], ous[3], oun[3];
 #define HH_QFETCH(K)                                                                  \
-    t.lat[K - 1] = q_rot_d<K>(m.lat); t.lon[K - 1] = q_rot_d<K>(m.lon);                   \
-    ouc[K - 1] = q_rot_d<K>(p.uc); ous[K - 1] = q_rot_d<K>(p.us); oun[K - 1] = q_rot_d<K>(p.un); \
+    t.lat[K - 1] = q_rot_d<K>(lat); t.lon[K - 1] = q_rot_d<K>(lon);                       \
+    ouc[K - 1] = q_rot_d<K>(c1); ous[K - 1] = q_rot_d<K>(s1); oun[K - 1] = q_rot_d<K>(n1); \
     t.nlat[K - 1] = q_rot_f<K>(p.nlat); t.nlon[K - 1] = q_rot_f<K>(p.nlon);               \
     t.nspd[K - 1] = q_rot_f<K>(p.nspd); t.nhdg[K - 1] = q_rot_f<K>(p.nhdg);               \
     t.fl[K - 1] = q_rot_i<K>(p.flags);
@@ -110,36 +123,56 @@ __device__ __forceinline__ void quad_tables(const Unit &m, const QPub &p, int s,
     HH_QFETCH(2)
     HH_QFETCH(3)
 #undef HH_QFETCH
-    /* planar distances: the pair (s, s+3) is the pair (s', s'+1) of lane s' = s+3, and dx*dx + dy*dy does not
-     * change when both differences flip sign, so two square roots per lane cover the six pairs */
-    {
-        double dx0 = t.lon[0] - m.lon, dy0 = t.lat[0] - m.lat;
-        double dx1 = t.lon[1] - m.lon, dy1 = t.lat[1] - m.lat;
-        t.dist[0] = hh_sqrt(dx0 * dx0 + dy0 * dy0);
-        t.dist[1] = hh_sqrt(dx1 * dx1 + dy1 * dy1);
-        t.dist[2] = q_rot_d<3>(t.dist[0]);
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        double dx = t.lon[k] - m.lon, dy = t.lat[k] - m.lat;
-        double n2 = t.dist[k];
-        double dot = c1 * dx + s1 * dy;
-        double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
-        t.foc[k] = hh_acos(x) * (180.0 / HH_PI);
-    }
     /* heading difference (env_base.py:448-456): read only by agents about opponents (observation), so the four
      * agent-opponent pairs are split one per lane — (0,2) (1,3) (2,1) (3,0) — and handed over; the expression is
      * symmetric in its operands, so either end computes the same bits */
-    {
-        const int kh = s < 2 ? 2 : (s == 2 ? 3 : 1);
-        const double c2 = q_sel(ouc, kh), s2 = q_sel(ous, kh), n2 = q_sel(oun, kh);
-        double dot = c1 * c2 + s1 * s2;
-        double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
-        const double hx = hh_clip(HH_DIVC(hh_acos(x) * (180.0 / HH_PI), 180.0), 0.0, 1.0);
-        t.hd[0] = q_rot_d<1>(hx); /* used by slot 1 about slot 2 */
-        t.hd[1] = hx;             /* agents: the opponent two slots up */
-        t.hd[2] = q_rot_d<3>(hx); /* used by slot 0 about slot 3 */
+    const int kh = s < 2 ? 2 : (s == 2 ? 3 : 1);
+    const double c2 = q_sel(ouc, kh), s2 = q_sel(ous, kh), n2 = q_sel(oun, kh);
+    double hx;
+    if (!DUAL) {
+        /* planar distances: the pair (s, s+3) is the pair (s', s'+1) of lane s' = s+3, and dx*dx + dy*dy does not
+         * change when both differences flip sign, so two square roots per lane cover the six pairs */
+        {
+            double dx0 = t.lon[0] - lon, dy0 = t.lat[0] - lat;
+            double dx1 = t.lon[1] - lon, dy1 = t.lat[1] - lat;
+            t.dist[0] = hh_sqrt(dx0 * dx0 + dy0 * dy0);
+            t.dist[1] = hh_sqrt(dx1 * dx1 + dy1 * dy1);
+            t.dist[2] = q_rot_d<3>(t.dist[0]);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double dx = t.lon[k] - lon, dy = t.lat[k] - lat;
+            double nn = t.dist[k];
+            double dot = c1 * dx + s1 * dy;
+            double x = hh_clip(dot / (n1 * nn + 1e-10), -1.0, 1.0);
+            t.foc[k] = hh_acos(x) * (180.0 / HH_PI);
+        }
+        {
+            double dot = c1 * c2 + s1 * s2;
+            double x = hh_clip(dot / (n1 * n2 + 1e-10), -1.0, 1.0);
+            hx = hh_clip(HH_DIVC(hh_acos(x) * (180.0 / HH_PI), 180.0), 0.0, 1.0);
+        }
+    } else {
+        /* chain A: main = focus towards slot +1, helper = focus towards slot +3 (its distance is the same bits from either end) */
+        const double dxA = (helper ? t.lon[2] : t.lon[0]) - lon, dyA = (helper ? t.lat[2] : t.lat[0]) - lat;
+        const double nA = hh_sqrt(dxA * dxA + dyA * dyA);
+        const double xA = hh_clip((c1 * dxA + s1 * dyA) / (n1 * nA + 1e-10), -1.0, 1.0);
+        const double focA = hh_acos(xA) * (180.0 / HH_PI);
+        /* chain B: main = focus towards slot +2, helper = the heading difference */
+        const double dxB = t.lon[1] - lon, dyB = t.lat[1] - lat;
+        const double nBm = hh_sqrt(dxB * dxB + dyB * dyB);
+        const double dotBm = c1 * dxB + s1 * dyB, dotBh = c1 * c2 + s1 * s2;
+        const double xB = hh_clip((helper ? dotBh : dotBm) / (n1 * (helper ? n2 : nBm) + 1e-10), -1.0, 1.0);
+        const double angB = hh_acos(xB) * (180.0 / HH_PI);
+        t.dist[0] = nA; t.dist[1] = nBm;
+        t.dist[2] = q_rot_d<3>(t.dist[0]);
+        t.foc[0] = focA; t.foc[1] = angB;
+        t.foc[2] = q_up_d(focA);
+        hx = q_up_d(hh_clip(HH_DIVC(angB, 180.0), 0.0, 1.0));
     }
+    t.hd[0] = q_rot_d<1>(hx); /* used by slot 1 about slot 2 */
+    t.hd[1] = hx;             /* agents: the opponent two slots up */
+    t.hd[2] = q_rot_d<3>(hx); /* used by slot 0 about slot 3 */
     /* focus of slot s+k at me = that lane's entry for ITS relative slot 4-k */
     t.focr[0] = q_rot_d<1>(t.foc[2]);
     t.focr[1] = q_rot_d<2>(t.foc[1]);
@@ -249,8 +282,8 @@ __device__ __forceinline__ void q_wave_sync() { asm volatile("s_waitcnt lgkmcnt(
 
 /* one fused LowLevelEnv step of the lane's arena; `tb`/`pub` hold the pre-tick table on entry and the post-tick
  * table on return.  Line-by-line counterpart of tick<4, 64>(tmode 0) in hh_kernels.h. */
-template <bool IX>
-__device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, int tid, int g, int s, int base, bool active, Unit &m,
+template <bool IX, bool DUAL>
+__device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, int tid, int g, int s, int base, bool active, bool helper, Unit &m,
                                           Arena &ar, const int8_t *act, QTab &tb, QPub &pub, StepOut &out,
                                           uint32_t &ev_mask_out HH_PROF_ARGS) {
     constexpr int A = 4;
@@ -426,9 +459,10 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     {
         const bool mv_a = snap && m.spd > 0.0;
         const bool any_rk = __ballot(rk_spec) != 0ULL;
+        double r_lat = 5.0, r_lon = 7.0, r_hdg = 0.0;
         if (any_rk) {
-            double r_lat = rk_pre ? m.rk_lat : lat_old, r_lon = rk_pre ? m.rk_lon : lon_old;
-            double r_hdg = rk_pre ? m.rk_hdg : hdg_old;
+            r_lat = rk_pre ? m.rk_lat : lat_old; r_lon = rk_pre ? m.rk_lon : lon_old;
+            r_hdg = rk_pre ? m.rk_hdg : hdg_old;
             rk_ncmd = rk_pre ? m.rk_cmd
                              : hh_clip(hdg_old * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
             if (r_hdg != rk_ncmd) {
@@ -437,6 +471,21 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                 else r_hdg += delta >= 0.0 ? HH_ROCKET_TURN_RATE : -HH_ROCKET_TURN_RATE;
             }
             rk_nhdg = r_hdg;
+        }
+        if (DUAL) {
+            /* ONE chain per lane: the main lane moves the aircraft, its helper the rocket (d_geo_move2's two interleaved chains give
+             * the same bits as d_geo_move of each argument set) */
+            double x_lat = m.lat, x_lon = m.lon, x_hdg = m.hdg, x_s = mv_a ? m.spd * HH_KNOTS_TO_MS * 1.0 : 0.0;
+            if (any_rk) {
+                const double h_lat = q_down_d(rk_spec ? r_lat : 5.0), h_lon = q_down_d(rk_spec ? r_lon : 7.0);
+                const double h_hdg = q_down_d(r_hdg), h_s = q_down_d(rk_speed0 * HH_KNOTS_TO_MS * 1.0);
+                x_lat = helper ? h_lat : x_lat; x_lon = helper ? h_lon : x_lon; x_hdg = helper ? h_hdg : x_hdg; x_s = helper ? h_s : x_s;
+            }
+            double o_lat, o_lon;
+            d_geo_move(x_lat, x_lon, x_hdg, x_s, o_lat, o_lon);
+            if (mv_a) { m.lat = o_lat; m.lon = o_lon; }
+            if (any_rk) { rk_nlat = q_up_d(o_lat); rk_nlon = q_up_d(o_lon); }
+        } else if (any_rk) {
             const double r_spd = rk_speed0;
             double a_lat, a_lon;
             d_geo_move2(m.lat, m.lon, m.hdg, mv_a ? m.spd * HH_KNOTS_TO_MS * 1.0 : 0.0, a_lat, a_lon,
@@ -529,7 +578,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         sh.u.t.lat1[tid] = m.lat; sh.u.t.lon1[tid] = m.lon; sh.u.t.hdg1[tid] = m.hdg;
         sh.u.t.rk_lat[tid] = rk0_lat; sh.u.t.rk_lon[tid] = rk0_lon;
         sh.res[tid] = 0;
-        if (s == 0) sh.g_tkey[g] = ar.tkey;
+        if (s == 0 && !helper) sh.g_tkey[g] = ar.tkey;
         q_wave_sync();
         drain_envelope_queue<4, 64, IX>(sh, tid, q_total);
         q_wave_sync();
@@ -713,7 +762,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     quad_publish_flags(m, pn);
     pub = pn;
     HH_PROF(6);
-    quad_tables(m, pub, s, tb);
+    quad_tables<DUAL>(m, pub, s, helper, tb);
     HH_PROF(7);
     if (running) {
         out.kill_event = nev > 0 || oobm != 0;
@@ -832,12 +881,13 @@ inline int hh_cfg_preset(const DevCfg &c) { /* which preset equals this configur
 /* APW = arenas per simulation wave: 16 fills the 64 lanes; 8 (lanes 32..63 idle) is for worlds so small that half the SIMDs would
  * otherwise sit empty: a wave's tick costs the instructions of every branch ANY of its arenas takes (rocket in flight, cannon
  * burst, events, reset ...), so half the arenas per wave means fewer instructions per wave-tick at the same number of ticks. */
-template <int W, int PRE, bool TWO, int APW = 16>
+template <int W, int PRE, bool TWO, int APW = 16, bool DUAL = false>
 __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_eu(W, W))) void hh_k_world_quad(DevPtrs P, DevCfg c_in, int T, const int8_t *__restrict__ actions,
                                                                   float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                                   uint8_t *__restrict__ valid_out, uint8_t *__restrict__ done_out) {
     constexpr int A = 4, B = 64, GPB = APW;
     static_assert(APW == 16 || APW == 8, "arenas per wave");
+    static_assert(!DUAL || APW == 8, "helper lanes exist only where half the wave is idle");
     DevCfg c_pre = c_in;
     hh_cfg_set_preset(c_pre, PRE);
     const DevCfg &c = PRE ? c_pre : c_in;
@@ -882,10 +932,12 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         }
     }
     /* ---------------- the simulation wave (the only wave when !TWO) ---------------- */
-    const int g = tid >> 2, s = tid & 3;
+    const bool helper = DUAL && tid >= 32;              /* lanes 32..63: helpers of lane - 32 (quad_tables, the moves) */
+    const int mt = DUAL ? (tid & 31) : tid;
+    const int g = mt >> 2, s = mt & 3;
     const int base = g * A;
     const int n = blockIdx.x * GPB + g;
-    const bool active = g < GPB && n < c.N;
+    const bool active = !helper && g < GPB && n < c.N;
     const size_t U = (size_t)c.N * A;
     const size_t u = (size_t)n * A + s;
     HH_PROF_DECL;
@@ -907,7 +959,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
     QPub pub;
     QTab tb;
     quad_publish(c, m, pub);
-    quad_tables(m, pub, s, tb);
+    quad_tables<DUAL>(m, pub, s, helper, tb);
     /* Action words: vmcnt is one in-order counter for loads AND stores, so waiting for a load also waits for the
      * write acknowledgements of every store issued before it.  The word of tick t+1 is therefore taken (waited
      * for) right after tick t's compute and BEFORE tick t's output stores, when the load is a whole tick old and
@@ -923,10 +975,10 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         int8_t act[4];
         act[0] = (int8_t)(act_cur & 0xff); act[1] = (int8_t)((act_cur >> 8) & 0xff); act[2] = (int8_t)((act_cur >> 16) & 0xff); act[3] = (int8_t)((act_cur >> 24) & 0xff);
         const bool was_running = active && !ar.done;
-        tick_quad<(W >= 2)>(c, sh, tid, g, s, base, active, m, ar, act, tb, pub, so, evm_last HH_PROF_PASS);
+        tick_quad<(W >= 2), DUAL>(c, sh, tid, g, s, base, active, helper, m, ar, act, tb, pub, so, evm_last HH_PROF_PASS);
         const int done_now = ar.done;
         if constexpr (TWO) { /* post the agents' rows as early as they exist: the LDS stores drain behind the work below */
-            if (s < 2) mail_post(mbx.mail[t & 1], g * 2 + s, tb, pub, m, so, done_now);
+            if (!helper && s < 2) mail_post(mbx.mail[t & 1], g * 2 + s, tb, pub, m, so, done_now);
         }
         asm volatile("" : "+v"(act_next)); /* take the word of tick t+1 HERE (see above) ... */
         act_cur = act_next;
@@ -960,9 +1012,9 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                 ep_ret = 0.0;
             }
             quad_publish(c, m, pub);
-            quad_tables(m, pub, s, tb);
+            quad_tables<DUAL>(m, pub, s, helper, tb);
             if constexpr (TWO) { /* the first observation of the new episode replaces the posted rows */
-                if (s < 2) mail_post(mbx.mail[t & 1], g * 2 + s, tb, pub, m, so, done_now);
+                if (!helper && s < 2) mail_post(mbx.mail[t & 1], g * 2 + s, tb, pub, m, so, done_now);
             }
         }
         HH_PROF(9);

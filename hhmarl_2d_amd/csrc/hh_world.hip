@@ -60,6 +60,7 @@ struct hh_world {
     int no_quad;  /* HH_NO_QUAD=1: 2-vs-2 rollouts on the generic LDS-exchange kernel (A/B tests; same results) */
     int no_spec;  /* HH_NO_SPEC=1: never pick the instance compiled for the default level-3 configuration */
     int no_two;   /* HH_NO_TWO=1: never pick the two-wave (simulation + output wave) form for small worlds */
+    int no_dual;  /* HH_NO_DUAL=1: the 8-arenas-per-wave 2-vs-2 form without helper lanes (A/B) */
     int no_oct;   /* HH_NO_OCT=1: HighLevelEnv macro steps on the LDS-exchange kernel instead of the register-exchange one (A/B) */
     int apw;      /* HH_APW=16: never pick the 8-arenas-per-wave form of the two-wave kernel */
     void *trace_mem; /* trajectory ring buffer + cursors (hh_trace_enable), separate allocation */
@@ -126,6 +127,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     { const char *ns = getenv("HH_NO_SPEC"); w->no_spec = ns ? atoi(ns) : 0; }
     { const char *nt = getenv("HH_NO_TWO"); w->no_two = nt ? atoi(nt) : 0; }
     { const char *no = getenv("HH_NO_OCT"); w->no_oct = no ? atoi(no) : 0; }
+    { const char *nd = getenv("HH_NO_DUAL"); w->no_dual = nd ? atoi(nd) : 0; }
     /* one slab, 256-byte aligned sub-arrays */
     size_t U = (size_t)d.N * A, N = (size_t)d.N;
     size_t off = 0;
@@ -261,7 +263,8 @@ static int launch(hh_world *w, int run, int T, const int8_t *actions, const uint
         const int grid8 = (c.N + 7) / 8;
         const bool half = pair && w->apw != 16 && 2 * grid8 <= w->n_simd;
 #define HH_QLAUNCH(Wv, Pv, TWOv) hipLaunchKernelGGL((hh_k_world_quad<Wv, Pv, TWOv>), dim3(grid), dim3(TWOv ? 128 : 64), 0, st, w->P, c, T, actions, obs, reward, valid, done)
-#define HH_QLAUNCH8(Pv) hipLaunchKernelGGL((hh_k_world_quad<1, Pv, true, 8>), dim3(grid8), dim3(128), 0, st, w->P, c, T, actions, obs, reward, valid, done)
+#define HH_QLAUNCH8(Pv) do { if (w->no_dual) hipLaunchKernelGGL((hh_k_world_quad<1, Pv, true, 8>), dim3(grid8), dim3(128), 0, st, w->P, c, T, actions, obs, reward, valid, done); \
+                            else hipLaunchKernelGGL((hh_k_world_quad<1, Pv, true, 8, true>), dim3(grid8), dim3(128), 0, st, w->P, c, T, actions, obs, reward, valid, done); } while (0)
 #define HH_QPRE(LAUNCH) switch (pre) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; case 4: LAUNCH(4); break; default: LAUNCH(0); }
 #define HH_Q2(Pv) HH_QLAUNCH(2, Pv, false)
 #define HH_Q1(Pv) HH_QLAUNCH(1, Pv, false)
@@ -304,7 +307,7 @@ extern "C" int hh_rollout_kernel_name(hh_world *w, char *buf, int32_t len) {
         if (pair && !half && pre != 1) pre = 0;
         static const char *names[5] = {"general", "L3 fight", "L1 fight", "L2 fight", "L3 escape"};
         snprintf(buf, (size_t)len, "hh_k_world_quad<W=%d,preset=%s,%s%s>", two ? 2 : 1, names[pre],
-                 pair ? "simulation wave + output wave" : "single wave", half ? ",8 arenas per wave" : "");
+                 pair ? "simulation wave + output wave" : "single wave", half ? (w->no_dual ? ",8 arenas per wave" : ",8 arenas per wave + helper lanes") : "");
     }
     return HH_OK;
 }
@@ -341,7 +344,8 @@ extern "C" int hh_kernel_instance(hh_world *w, int32_t which, char *buf, int32_t
     if (w->no_quad || w->P.trace) snprintf(buf, (size_t)len, "hh_k_world<4, 64, %d, false>", two ? 2 : 1);
     else {
         if (pair && !half && pre != 1) pre = 0;
-        snprintf(buf, (size_t)len, "hh_k_world_quad<%d, %d, %s, %d>", two ? 2 : 1, pre, pair ? "true" : "false", half ? 8 : 16);
+        if (half && !w->no_dual) snprintf(buf, (size_t)len, "hh_k_world_quad<1, %d, true, 8, true>", pre);
+        else snprintf(buf, (size_t)len, "hh_k_world_quad<%d, %d, %s, %d, false>", two ? 2 : 1, pre, pair ? "true" : "false", half ? 8 : 16);
     }
     return HH_OK;
 }

@@ -62,6 +62,8 @@ def parse_args():
                          "MLP stand-ins in torch, or the reference's Fight/Esc architectures in the fused HIP kernel (net)")
     ap.add_argument("--no-graph", action="store_true", help="hier/rollout: launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--phases", action="store_true", help="hier with --pilot tape: the 34-launch phase path instead of the one-launch macro step")
+    ap.add_argument("--coop", action="store_true", help="hier with --pilot net: the whole commander step as ONE cooperative launch (hh_hl_step_nets: world phases + policy "
+                                                         "tiles behind grid barriers) instead of the 66-launch graph — correct (tests/test_gpu_hier_nets.py) but 3x slower: A/B only")
     ap.add_argument("--no-extra", action="store_true", help="default workload at 1 GPU: skip the short runs of the other single-GPU configurations "
                                                              "(BASELINE configs[2], configs[3] tape / networks) that fill line['extra']")
     return ap.parse_args()
@@ -451,6 +453,10 @@ def main_hier(args, R=None):
         pilot = TapePilot(R.dev, N, 6, seed=args.seed + R.rank)
     elif args.pilot == "random":
         pilot = RandomPilot(R.dev, args.seed + R.rank)
+    elif args.pilot == "net" and args.coop:
+        from hhmarl_2d_amd.pilots import PolicyBank
+        pilot = None
+        coop_bank = PolicyBank.random_init(R.dev, seed=args.seed, max_rows=N * 6)   # the whole commander step is ONE cooperative launch
     elif args.pilot == "net":
         pilot = NetPilot(w, seed=args.seed, bind=os.environ.get("HH_BENCH_NO_BIND", "0") != "1")   # HH_BENCH_NO_BIND=1: binning pass per call (A/B)
     else:
@@ -465,7 +471,8 @@ def main_hier(args, R=None):
     # actions from a resident tape: the whole commander step is ONE persistent launch (hh_hl_rollout).
     cmd_static = cmds[0].clone()
     graph = None
-    one_launch = args.pilot == "tape" and not args.phases
+    coop = args.pilot == "net" and getattr(args, "coop", False)
+    one_launch = (args.pilot == "tape" and not args.phases) or coop
     if not args.no_graph and not one_launch:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -482,6 +489,12 @@ def main_hier(args, R=None):
     def run(n):
         for _ in range(n):
             k = state["k"]
+            if coop:
+                w.hl_step_nets(coop_bank, cmds[k % 64], out=out)
+                state["k"] = k + 1
+                if state["k"] % 16 == 0:
+                    sw.log_episode_stats(log_side)
+                continue
             if one_launch:
                 w.hl_rollout(cmds[k % 64], pilot.bank[k % pilot.bank.shape[0]], out=out)
                 state["k"] = k + 1
@@ -528,7 +541,8 @@ def main_hier(args, R=None):
                                f"pilots = {PILOT_DESC[args.pilot]}, auto-reset (BASELINE configs[3])", "arenas_per_gpu": N,
                    "parallelism": f"arena-sharded x{R.world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": (f"{w.kernel_instance(1)} (one persistent launch per commander step)" if one_launch else
+                     "traffic": None, "kernel": ("hh_k_hier_nets (one cooperative launch per commander step: world phases + policy tiles behind grid barriers)" if coop else
+                                                 f"{w.kernel_instance(1)} (one persistent launch per commander step)" if one_launch else
                                                  f"{w.kernel_name()} (every phase launch of the macro step, plus the pilots' kernels if any)"),
                      "algorithmic_bytes": algo_bytes,
                      "note": "2056 B per arena-tick actually run + 424 B per commander step (SURVEY.md 8d)"},
@@ -536,6 +550,10 @@ def main_hier(args, R=None):
     line["gpu_ms_per_step"] = gpu_s / steps * 1e3
     if not one_launch:
         line["launches_per_step"] = 2 + 16 * (4 if args.pilot in ("net", "mlp", "random") else 2)
+    if coop:
+        assert w.hl_step_nets_ok(), "a grid barrier of the cooperative step timed out"
+        line["launches_per_step"] = 1
+        coop_bank.close()
     if hasattr(pilot, "close"):
         pilot.close()
     if not own:
@@ -585,7 +603,7 @@ def extra_configs(args, R):
                          ("configs3", main_hier, dict(workload="hier", pilot="tape", steps=40, warmup=8)),
                          ("configs3_networks_in_loop", main_hier, dict(workload="hier", pilot="net", steps=12, warmup=3))):
         a = copy.copy(args)
-        a.arenas, a.spinup, a.no_graph, a.phases = None, 0.3, False, False
+        a.arenas, a.spinup, a.no_graph, a.phases, a.coop = None, 0.3, False, False, False
         for k, v in kw.items():
             setattr(a, k, v)
         try:

@@ -995,17 +995,18 @@ __device__ __forceinline__ int oct_pilot_obs(const DevCfg &c, const OTab &t, con
 /* ---- the phases one launch each, for callers whose pilot networks run BETWEEN them (hh_k_hier of hh_kernels_hier.h on the
  * register table): HL_BEGIN / HL_AGENTS_ACT / HL_TICK / HL_END.  Same results, bit for bit; HL_REFRESH / HL_RESET stay on the
  * generic kernel (the state in HBM is the same). ---- */
+/* one phase for the eight arenas grp * 8 .. grp * 8 + 7, executed by ONE wave (tid = lane): the body of hh_k_hier_oct, also called by the
+ * one-launch commander step with the networks inside (hh_kernels_coop.h), where several waves of a workgroup run it side by side */
 template <int W>
-__global__ __launch_bounds__(64, W) void hh_k_hier_oct(DevPtrs P, DevCfg c, int phase, const int8_t *__restrict__ cmd, const int8_t *__restrict__ actions,
-                                                     float *__restrict__ pilot_obs, uint8_t *__restrict__ pilot_mode, float *__restrict__ obs_out,
-                                                     float *__restrict__ reward_out, uint8_t *__restrict__ valid_out, uint8_t *__restrict__ done_out,
-                                                     int *__restrict__ running_count) {
-    __shared__ OctShared sh;
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c, int phase, int grp, int tid, OctShared &sh, const int8_t *__restrict__ cmd,
+                                               const int8_t *__restrict__ actions, float *__restrict__ pilot_obs, uint8_t *__restrict__ pilot_mode,
+                                               float *__restrict__ obs_out, float *__restrict__ reward_out, uint8_t *__restrict__ valid_out,
+                                               uint8_t *__restrict__ done_out, int *__restrict__ running_count,
+                                               unsigned long long *__restrict__ tick_total) {
     OLane L;
     L.g = tid >> 3; L.p = tid & 7; L.q = (tid >> 2) & 1; L.i = tid & 3;
     L.base = tid & ~7;
-    const int n = blockIdx.x * 8 + L.g;
+    const int n = grp * 8 + L.g;
     const bool active = n < c.N;
     L.exists = active && L.i < (L.q ? c.nO : c.nA);
     L.s = L.q ? c.nA + L.i : L.i;
@@ -1070,17 +1071,17 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_oct(DevPtrs P, DevCfg c, int 
         if (L.p == 0 && ran && ar.hl_run && running_count) atomicAdd(running_count, 1);
         {   /* cumulative arena-ticks of this world (hh_hl_tick_count): one atomic per wave */
             const unsigned long long rn = __ballot(ran && L.p == 0);
-            if (rn && tid == 0 && running_count) atomicAdd(reinterpret_cast<unsigned long long *>(running_count + 2), (unsigned long long)__popcll(rn));
+            if (rn && tid == 0 && tick_total) atomicAdd(tick_total, (unsigned long long)__popcll(rn));
         }
         obs_side = 0;
         if (P.pol_lut && pilot_obs) bin_issue(0);
     } else { /* HH_HL_END */
-        if (P.pol_lut && blockIdx.x == 0 && tid <= 8) P.pol_counts[tid * HH_BIN_STRIDE] = 0; /* rows the last tick binned and nobody consumed */
+        if (P.pol_lut && grp == 0 && tid <= 8) P.pol_counts[tid * HH_BIN_STRIDE] = 0; /* rows the last tick binned and nobody consumed */
         oct_do_end(P, c, sh, tid, L, n, active, H, tb, pub, HH_HL_END, reward_out, valid_out, done_out, nullptr);
         if (obs_out) {
-            const int arenas = min(8, c.N - (int)blockIdx.x * 8);
+            const int arenas = min(8, c.N - grp * 8);
             const int cnt = arenas * c.nA * HH_OBS_HL;
-            float *dst = obs_out + (size_t)blockIdx.x * 8 * c.nA * HH_OBS_HL;
+            float *dst = obs_out + (size_t)grp * 8 * c.nA * HH_OBS_HL;
             for (int k = tid; k < cnt; k += 64) dst[k] = sh.u.obs[k];
         }
     }
@@ -1102,9 +1103,9 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_oct(DevPtrs P, DevCfg c, int 
             for (int sl = c.nA + c.nO; sl < 6; sl++) pilot_mode[(size_t)n * 6 + sl] = 0;
         }
         o_wave_sync();
-        const int arenas = min(8, c.N - (int)blockIdx.x * 8);
+        const int arenas = min(8, c.N - grp * 8);
         const int cnt = arenas * 6 * 30;
-        float *dst = pilot_obs + (size_t)blockIdx.x * 8 * 6 * 30;
+        float *dst = pilot_obs + (size_t)grp * 8 * 6 * 30;
         if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0) {
             const float4 *src4 = reinterpret_cast<const float4 *>(sh.u.prow);
             float4 *dst4 = reinterpret_cast<float4 *>(dst);
@@ -1125,9 +1126,19 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_oct(DevPtrs P, DevCfg c, int 
     }
     if (phase == HH_HL_AGENTS_ACT || phase == HH_HL_TICK) {
         if (active && L.p == 0 && phase == HH_HL_AGENTS_ACT && ar.hl_run) P.ev_mask[n] = 0;
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the clear is acknowledged before this wave's atomics leave (one wave per arena group) */
         if (L.exists && H.evm) atomicOr(&P.ev_mask[n], H.evm);
     }
+}
+
+template <int W>
+__global__ __launch_bounds__(64, W) void hh_k_hier_oct(DevPtrs P, DevCfg c, int phase, const int8_t *__restrict__ cmd, const int8_t *__restrict__ actions,
+                                                     float *__restrict__ pilot_obs, uint8_t *__restrict__ pilot_mode, float *__restrict__ obs_out,
+                                                     float *__restrict__ reward_out, uint8_t *__restrict__ valid_out, uint8_t *__restrict__ done_out,
+                                                     int *__restrict__ running_count) {
+    __shared__ OctShared sh;
+    oct_phase_body<W>(P, c, phase, (int)blockIdx.x, (int)threadIdx.x, sh, cmd, actions, pilot_obs, pilot_mode, obs_out, reward_out, valid_out, done_out,
+                      running_count, running_count ? reinterpret_cast<unsigned long long *>(running_count + 2) : nullptr);
 }
 
 #endif /* HH_KERNELS_OCT_H */

@@ -237,13 +237,14 @@ __device__ __forceinline__ bool hhp_locate(const int (&cn)[HH_POLICY_MAX_NETS], 
  * widths and letting the binned counts choose costs the 2 us it gains), and `bench.py --workload rollout` / `hier --pilot net` come
  * out level.  Kept as an A/B instance; what separates both forms from the matrix pipe's 30 k cycles per 64 rows is that a tile's
  * epilogues (tanh, hi/lo split, 2-byte LDS scatter) and GEMMs alternate instead of overlapping. */
+/* the forward over the tiles first_tile, first_tile + tile_stride, ... of the row lists (cn = rows per network): the body of
+ * hh_k_policy_h, also called by the one-launch commander step (hh_kernels_coop.h) between two grid barriers */
 template <int RH>
-__global__ __launch_bounds__(256 * RH, RH == 1 ? 2 : 1) void hh_k_policy_h(HhpBank bank, HhpBankH bankh, int n_nets, const float *__restrict__ obs, int obs_stride,
-                                                                           int *counts, const int *__restrict__ lists, int max_rows,
-                                                                           int8_t *__restrict__ actions, float *__restrict__ logits_out, int consume) {
+__device__ __forceinline__ void hhp_forward_tiles(const HhpBank &bank, const HhpBankH &bankh, const int (&cn)[HH_POLICY_MAX_NETS], const float *__restrict__ obs,
+                                                  int obs_stride, const int *__restrict__ lists, int max_rows, int8_t *__restrict__ actions,
+                                                  float *__restrict__ logits_out, unsigned char *ldsb, int first_tile, int tile_stride) {
     constexpr int R = 32 * RH, NTH = 256 * RH, NT = 4 / RH, WC = 32 * NT; /* rows per tile, threads, column tiles and columns per wave in L1 / L2 */
     constexpr int XPT = R * HHP_XK / NTH;                                 /* observation elements per thread (8 / 4) */
-    extern __shared__ __align__(16) unsigned char ldsb[];
     _Float16 *Zh = reinterpret_cast<_Float16 *>(ldsb);                      /* [32][2][R][8] hi plane of the activation tile */
     _Float16 *Zl = reinterpret_cast<_Float16 *>(ldsb + HHPH_OFF_ZL(RH));    /* lo plane */
     _Float16 *Xh = reinterpret_cast<_Float16 *>(ldsb + HHPH_OFF_XH(RH));    /* [2][2][R][8] observation tile */
@@ -253,13 +254,10 @@ __global__ __launch_bounds__(256 * RH, RH == 1 ? 2 : 1) void hh_k_policy_h(HhpBa
     int *rowsb = reinterpret_cast<int *>(ldsb + HHPH_OFF_ROWS(RH));         /* [2][R] row lists of this tile and the next */
     float *npart = reinterpret_cast<float *>(ldsb + HHPH_OFF_NP(RH));       /* [4][R] */
 
-    int cn[HH_POLICY_MAX_NETS];
-#pragma unroll
-    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? min(hhp_row_count(counts, n, consume), max_rows) : 0;
     const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int wq = wave & 3, wrow0 = (wave >> 2) * 32; /* attention / L3: column or k quarter, row half of this wave */
-    int gt = blockIdx.x, net, tile, cnt;
-    if (!hhp_locate<R>(cn, gt, net, tile, cnt)) { hhp_consume_counts(counts, consume); return; }
+    int gt = first_tile, net, tile, cnt;
+    if (!hhp_locate<R>(cn, gt, net, tile, cnt)) return;
     HHP_T0;
     { /* first tile: rows and observation in the open; later tiles find both prefetched */
         const int tid = tid0;
@@ -293,7 +291,7 @@ __global__ __launch_bounds__(256 * RH, RH == 1 ? 2 : 1) void hh_k_policy_h(HhpBa
         const float bovr = N.bov[wq * 32 + ci], bar = N.ba[ci];
         /* the next tile of this workgroup: its row list is requested here and parked in LDS behind the L1 barrier */
         int nnet, ntile, ncnt, nrow = -1;
-        const bool more = hhp_locate<R>(cn, gt + (int)gridDim.x, nnet, ntile, ncnt);
+        const bool more = hhp_locate<R>(cn, gt + tile_stride, nnet, ntile, ncnt);
         if (more && tid < R) {
             const int q = ntile * R + tid;
             nrow = q < ncnt ? lists[(size_t)nnet * max_rows + q] : -1;
@@ -428,9 +426,20 @@ __global__ __launch_bounds__(256 * RH, RH == 1 ? 2 : 1) void hh_k_policy_h(HhpBa
         }
         HHP_T(8);
         if (!more) break;
-        gt += (int)gridDim.x; net = nnet; tile = ntile; cnt = ncnt;
+        gt += tile_stride; net = nnet; tile = ntile; cnt = ncnt;
         __syncthreads(); /* the partials (hi plane) and the logits are read: the next tile may write Z */
     }
+}
+
+template <int RH>
+__global__ __launch_bounds__(256 * RH, RH == 1 ? 2 : 1) void hh_k_policy_h(HhpBank bank, HhpBankH bankh, int n_nets, const float *__restrict__ obs, int obs_stride,
+                                                                           int *counts, const int *__restrict__ lists, int max_rows,
+                                                                           int8_t *__restrict__ actions, float *__restrict__ logits_out, int consume) {
+    extern __shared__ __align__(16) unsigned char ldsb[];
+    int cn[HH_POLICY_MAX_NETS];
+#pragma unroll
+    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? min(hhp_row_count(counts, n, consume), max_rows) : 0;
+    hhp_forward_tiles<RH>(bank, bankh, cn, obs, obs_stride, lists, max_rows, actions, logits_out, ldsb, (int)blockIdx.x, (int)gridDim.x);
     hhp_consume_counts(counts, consume);
 }
 

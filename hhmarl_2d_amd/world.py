@@ -233,6 +233,20 @@ class World:
             out.append((r, ep))
         return out
 
+    def hl_step_nets(self, bank, commander_actions, out=None):
+        """HighLevelEnv.step with the pilot networks inside, ONE cooperative launch (hh_hl_step_nets): commander_actions int8
+        [N, n_agents], bank = pilots.PolicyBank with the Fight / Esc networks and selector LUT -> (obs, reward, valid, done)"""
+        assert commander_actions.dtype == torch.int8 and commander_actions.is_contiguous()
+        obs, rew, val, done = out if out is not None else self.alloc_outputs()
+        L.check(L.lib().hh_hl_step_nets(self.h, bank.h, _p(commander_actions), _p(obs), _p(rew), _p(val), _p(done), self._stream()))
+        return obs, rew, val, done
+
+    def hl_step_nets_ok(self):
+        """False if a grid barrier of a cooperative step ever timed out (synchronises the current stream)"""
+        e = C.c_int32(0)
+        L.check(L.lib().hh_hl_step_nets_status(self.h, C.byref(e), self._stream()))
+        return e.value == 0
+
     def hl_tick_count(self):
         """cumulative arena-ticks run by macro steps on this world (synchronises the current stream)"""
         v = C.c_uint64(0)

@@ -192,6 +192,7 @@ def cpu_baseline(n_arenas, level, seed, budget_s=12.0):
         steps += T
     dt = time.perf_counter() - t0
     out = {"value": n_arenas * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "note": "unoptimised scalar C restatement (statement order of the reference, no SIMD): a reported baseline, not a tuned CPU implementation",
            "sample": f"{n_arenas} arenas x {steps} ticks, same config/seed/action distribution, one OpenMP team, arenas outer / ticks inner"}
     ref = load_json("reference_cpu_rate.json")
     if ref:
@@ -239,6 +240,15 @@ def counter_evidence(instance, n_arenas, ticks, units_per_s_per_gpu, lanes_per_a
             fp64["true_frac"] = n64 * lanes_per_arena * units_per_s_per_gpu / FP64_ISSUE_PEAK
             fp64["true_frac_note"] = "only ADD/MUL/FMA/TRANS_F64 instructions counted (an FMA as ONE issue slot): the FP64 pipe's arithmetic use"
     return traffic, fp64
+
+
+def launch_traffic(fname, instance, n_arenas):
+    """HBM bytes per launch of a profiled kernel (2*FETCH_SIZE + WRITE_SIZE, tools/prof_pmc.sh) from profiles/<fname>, or None when
+    the file was made for another kernel instance or arena count"""
+    tj = load_json(fname)
+    if tj and tj.get("arenas") == n_arenas and tj.get("hbm_bytes_per_launch") and instance in str(tj.get("kernel_full", "")):
+        return int(tj["hbm_bytes_per_launch"])
+    return None
 
 
 # ------------------------------------------------------------------------------------------------ configs[1]: the headline
@@ -424,6 +434,7 @@ def main_policy_rollout(args, R=None):
                                     "achieved": (flops3 if not fp32_form else flops3 / 3.0) / (pol_ms * 1e-3) / 1e12,
                                     "peak": MFMA_F16_PEAK_TFLOPS if not fp32_form else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s"}
     line["roofline"]["dominant"]["frac"] = line["roofline"]["dominant"]["achieved"] / line["roofline"]["dominant"]["peak"]
+    line["roofline"]["dominant"]["traffic"] = launch_traffic("r03_policy16384_traffic.json", "hh_k_policy_h<1>", N) if not fp32_form else None
     if not own:
         return line
     if R.rank == 0:
@@ -548,6 +559,8 @@ def main_hier(args, R=None):
                      "note": "2056 B per arena-tick actually run + 424 B per commander step (SURVEY.md 8d)"},
     }
     line["gpu_ms_per_step"] = gpu_s / steps * 1e3
+    if one_launch and not coop:   # HBM bytes per commander step of the one-launch kernel, from the committed PMC passes
+        line["roofline"]["traffic"] = launch_traffic("r03_hier8192_traffic.json", w.kernel_instance(1), N)
     if not one_launch:
         line["launches_per_step"] = 2 + 16 * (4 if args.pilot in ("net", "mlp", "random") else 2)
     if coop:

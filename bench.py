@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_2V2_STEP = 1113       # state r/w 2*448 + actions 8 + obs 200 + reward 8 + done 1
 ALGO_BYTES_3V3_TICK = 2056       # 656 + 656 + pilot obs 720 + pilot actions 24
 ALGO_BYTES_3V3_CMD_FIXED = 424   # commander obs 408 + actions 3 + rewards 12 + done 1
+DEFAULT_STREAMS = {"rollout": 1, "hier_net": 2}   # sub-worlds / streams of the policy-in-the-loop workloads (--streams)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F16_PEAK_TFLOPS = 2500.0    # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md; AMD's headline figure includes 2:1 sparsity)
 MFMA_F32_PEAK_TFLOPS = 157.3     # fp32-in MFMA runs at the vector rate
@@ -64,6 +65,9 @@ def parse_args():
     ap.add_argument("--phases", action="store_true", help="hier with --pilot tape: the 34-launch phase path instead of the one-launch macro step")
     ap.add_argument("--coop", action="store_true", help="hier with --pilot net: the whole commander step as ONE cooperative launch (hh_hl_step_nets: world phases + policy "
                                                          "tiles behind grid barriers) instead of the 66-launch graph — correct (tests/test_gpu_hier_nets.py) but 3x slower: A/B only")
+    ap.add_argument("--streams", type=int, default=0, help="rollout / hier --pilot net: split the arenas into this many sub-worlds (disjoint global arena ids, "
+                                                                 "bit-identical to one world) stepped on as many HIP streams inside the one graph, so that one sub-world's world "
+                                                                 "launches run under another's policy kernel (0 = the workload's default)")
     ap.add_argument("--no-extra", action="store_true", help="default workload at 1 GPU: skip the short runs of the other single-GPU configurations "
                                                              "(BASELINE configs[2], configs[3] tape / networks) that fill line['extra']")
     return ap.parse_args()
@@ -354,21 +358,40 @@ def main_policy_rollout(args, R=None):
     from hhmarl_2d_amd.pilots import SEL_FIGHT1, SEL_FIGHT2, PolicyBank
     from hhmarl_2d_amd.sharding import ShardedWorld
     N = args.arenas or 16384
-    sw = ShardedWorld(dict(n_arenas=N, level=args.level, seed=args.seed, auto_reset=True), rank=R.rank, world_size=R.world, device=R.local_rank)
-    w = sw.world
-    obs = w.reset()
-    bank = PolicyBank.random_init(R.dev, seed=args.seed, max_rows=N * 2)
-    out = w.alloc_outputs()
-    out[0].copy_(obs)
-    act = torch.zeros((N, 2, 4), dtype=torch.int8, device=R.dev)
+    K = args.streams or DEFAULT_STREAMS["rollout"]
+    assert N % K == 0, "--streams must divide the arena count"
+    n = N // K
+    # sub-world k of rank r holds the global arenas [r N + k n, r N + (k + 1) n): the same arenas as one world of N (keyed RNG by global id)
+    sws = [ShardedWorld(dict(n_arenas=n, level=args.level, seed=args.seed, auto_reset=True, arena_offset=k * n + R.rank * (N - n)), rank=R.rank,
+                        world_size=R.world, device=R.local_rank) for k in range(K)]
+    sw, w = sws[0], sws[0].world
+    banks = [PolicyBank.random_init(R.dev, seed=args.seed, max_rows=n * 2) for _ in range(K)]
+    bank = banks[0]
+    outs, acts = [], []
     # agent 1 is a type-1 aircraft (Fight1), agent 2 a type-2 (Fight2): env_base.py:560-561 fixes the first two slots
-    net_id = torch.tensor([SEL_FIGHT1, SEL_FIGHT2], dtype=torch.uint8, device=R.dev).repeat(N, 1).contiguous()
-
-    bank.act(out[0], net_id, act)     # builds the row lists once: agent 1 -> Fight1, agent 2 -> Fight2 never changes
+    net_id = torch.tensor([SEL_FIGHT1, SEL_FIGHT2], dtype=torch.uint8, device=R.dev).repeat(n, 1).contiguous()
+    for k in range(K):
+        o = sws[k].world.alloc_outputs()
+        o[0].copy_(sws[k].world.reset())
+        outs.append(o)
+        acts.append(torch.zeros((n, 2, 4), dtype=torch.int8, device=R.dev))
+        banks[k].act(o[0], net_id, acts[k])     # builds the row lists once: agent 1 -> Fight1, agent 2 -> Fight2 never changes
+    out, act = outs[0], acts[0]
+    streams = [torch.cuda.Stream() for _ in range(K)] if K > 1 else []
 
     def tick():
-        bank.act(out[0], None, act)   # same selectors as before: no binning pass
-        w.step(act, out=out)
+        if K == 1:
+            bank.act(out[0], None, act)   # same selectors as before: no binning pass
+            w.step(act, out=out)
+            return
+        cur = torch.cuda.current_stream()
+        for k in range(K):
+            streams[k].wait_stream(cur)
+            with torch.cuda.stream(streams[k]):
+                banks[k].act(outs[k][0], None, acts[k])
+                sws[k].world.step(acts[k], out=outs[k])
+        for k in range(K):
+            cur.wait_stream(streams[k])
 
     graph = None
     if not args.no_graph:
@@ -407,7 +430,7 @@ def main_policy_rollout(args, R=None):
     line = {
         "metric": "env-steps/sec (2v2, policy in the loop)", "value": value, "unit": "env-steps/s", "n_gpus": R.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64 world + f32 policy", "data": "synthetic", "agent_steps_per_s": value * 2,
+        "dtype": "f64 world + f32 policy", "data": "synthetic", "agent_steps_per_s": value * 2, "streams": K,
         "config": {"workload": f"{N} arenas/GPU x 2-vs-2 fight L{args.level}, actions from random-init Fight1/Fight2 actors (reference "
                                f"architecture, fp32, fused HIP kernel, greedy decode) evaluated every tick on the same GPU, auto-reset "
                                f"(BASELINE configs[2])",
@@ -426,15 +449,15 @@ def main_policy_rollout(args, R=None):
         return a.elapsed_time(b) / n
     pol_ms = timed(lambda: bank.act(out[0], None, act))
     world_ms = timed(lambda: w.step(act, out=out))
-    flops3 = 3.0 * (bank.flops_per_row(PolicyBank.FIGHT1) + bank.flops_per_row(PolicyBank.FIGHT2)) * N   # split-fp16: three MFMA passes per product
+    flops3 = 3.0 * (bank.flops_per_row(PolicyBank.FIGHT1) + bank.flops_per_row(PolicyBank.FIGHT2)) * n   # split-fp16: three MFMA passes per product; one sub-world's rows
     fp32_form = os.environ.get("HH_POLICY_FP32", "0") == "1"
-    line["kernels_ms"] = {"hh_k_policy_h" if not fp32_form else "hh_k_policy": pol_ms, w.kernel_instance(): world_ms}
+    line["kernels_ms"] = {"hh_k_policy_h" if not fp32_form else "hh_k_policy": pol_ms, w.kernel_instance(): world_ms, "arenas_per_launch": n}
     line["roofline"]["dominant"] = {"kernel": "hh_k_policy_h (split-fp16: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16)" if not fp32_form else "hh_k_policy (fp32 MFMA)",
                                     "bound": "mfma", "avg_launch_ms": pol_ms,
                                     "achieved": (flops3 if not fp32_form else flops3 / 3.0) / (pol_ms * 1e-3) / 1e12,
                                     "peak": MFMA_F16_PEAK_TFLOPS if not fp32_form else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s"}
     line["roofline"]["dominant"]["frac"] = line["roofline"]["dominant"]["achieved"] / line["roofline"]["dominant"]["peak"]
-    line["roofline"]["dominant"]["traffic"] = launch_traffic("r03_policy16384_traffic.json", "hh_k_policy_h<1>", N) if not fp32_form else None
+    line["roofline"]["dominant"]["traffic"] = launch_traffic("r03_policy16384_traffic.json", "hh_k_policy_h<1>", n) if not fp32_form else None
     if not own:
         return line
     if R.rank == 0:
@@ -457,6 +480,11 @@ def main_hier(args, R=None):
     from hhmarl_2d_amd.pilots import MLPPilot, NetPilot, RandomPilot, TapePilot
     from hhmarl_2d_amd.sharding import ShardedWorld
     N = args.arenas or 8192
+    K = (args.streams or DEFAULT_STREAMS["hier_net"]) if (args.pilot == "net" and not getattr(args, "coop", False)) else 1
+    assert N % K == 0, "--streams must divide the arena count"
+    n_sub = N // K
+    if K > 1:
+        return main_hier_split(args, R, own, N, K)
     sw = ShardedWorld(dict(n_arenas=N, env_kind=1, seed=args.seed, auto_reset=True), rank=R.rank, world_size=R.world, device=R.local_rank)
     w = sw.world
     w.reset()
@@ -576,6 +604,100 @@ def main_hier(args, R=None):
     R.close()
 
 
+def main_hier_split(args, R, own, N, K):
+    """configs[3] with the pilot networks in the loop, the arenas split into K sub-worlds (disjoint global arena ids: the same arenas
+    as one world of N) whose 66-launch commander steps run on K streams inside ONE HIP graph: a sub-world's world-phase launches
+    (single-pass, latency-bound) run under another sub-world's policy kernel"""
+    torch = R.torch
+    from hhmarl_2d_amd.env_hier import macro_step
+    from hhmarl_2d_amd.pilots import NetPilot
+    from hhmarl_2d_amd.sharding import ShardedWorld
+    n = N // K
+    sws = [ShardedWorld(dict(n_arenas=n, env_kind=1, seed=args.seed, auto_reset=True, arena_offset=k * n + R.rank * (N - n)), rank=R.rank, world_size=R.world,
+                        device=R.local_rank) for k in range(K)]
+    worlds = [x.world for x in sws]
+    for w in worlds:
+        w.reset()
+    pilots_ = [NetPilot(w, seed=args.seed) for w in worlds]
+    gen = torch.Generator(device=R.dev)
+    gen.manual_seed(args.seed + 17 + R.rank)
+    cmds = (torch.rand((64, N, 3), device=R.dev, generator=gen) * 3).to(torch.int8).contiguous()
+    cmd_static = [cmds[0, k * n:(k + 1) * n].clone() for k in range(K)]
+    outs = [w.alloc_outputs() for w in worlds]
+    pbufs = [w.alloc_pilot() for w in worlds]
+    streams = [torch.cuda.Stream() for _ in range(K)]
+
+    def step():
+        cur = torch.cuda.current_stream()
+        for k in range(K):
+            streams[k].wait_stream(cur)
+            with torch.cuda.stream(streams[k]):
+                macro_step(worlds[k], cmd_static[k], pilots_[k], out=outs[k], pilot_buf=pbufs[k])
+        for k in range(K):
+            cur.wait_stream(streams[k])
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    state = {"k": 0}
+
+    def run(m):
+        for _ in range(m):
+            k = state["k"]
+            for j in range(K):
+                cmd_static[j].copy_(cmds[k % 64, j * n:(j + 1) * n])
+            graph.replay()
+            state["k"] = k + 1
+
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup:
+        run(1)
+        torch.cuda.synchronize()
+    run(args.warmup)
+    R.barrier()
+    ticks0 = sum(w.hl_tick_count() for w in worlds)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    run(args.steps)
+    e1.record()
+    R.barrier()
+    dt = R.max_over_ranks(time.perf_counter() - t0)
+    ticks = sum(w.hl_tick_count() for w in worlds) - ticks0
+    gpu_s = e0.elapsed_time(e1) * 1e-3
+    steps = args.steps
+    value = N * R.world * steps / dt
+    algo_bytes = ALGO_BYTES_3V3_TICK * ticks + ALGO_BYTES_3V3_CMD_FIXED * N * steps
+    achieved = algo_bytes / gpu_s / 1e9
+    line = {
+        "metric": "commander-steps/sec (3v3 HighLevelEnv)", "value": value, "unit": "env-steps/s", "n_gpus": R.world, "steps": steps,
+        "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic", "agent_steps_per_s": value * 3, "streams": K,
+        "sim_ticks_per_s": ticks * R.world / dt, "ticks_per_commander_step": ticks / float(N * steps),
+        "config": {"workload": f"{N} arenas/GPU x 3-vs-3 HighLevelEnv commander steps (<= 16 sub-steps each), uniform commander actions, "
+                               f"pilots = {PILOT_DESC['net']}, auto-reset (BASELINE configs[3])", "arenas_per_gpu": N,
+                   "parallelism": f"arena-sharded x{R.world}, no data-path collective; {K} sub-worlds on {K} streams inside one HIP graph"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": f"{worlds[0].kernel_instance(0)} (every phase launch of the macro step) + hh_k_policy_h", "algorithmic_bytes": algo_bytes,
+                     "note": "2056 B per arena-tick actually run + 424 B per commander step (SURVEY.md 8d)"},
+        "gpu_ms_per_step": gpu_s / steps * 1e3, "launches_per_step": 66 * K,
+    }
+    for p in pilots_:
+        p.close()
+    if not own:
+        return line
+    if R.rank == 0:
+        print(json.dumps(line), flush=True)
+    R.close()
+
+
 def main():
     args = parse_args()
     if args.dry_run and args.workload != "low":
@@ -600,30 +722,32 @@ def main():
 def extra_configs(args, R):
     """BASELINE configs[2] (16384 arenas, fight networks in the loop every tick) and configs[3] (8192 arenas x 3-vs-3 HighLevelEnv:
     pilot actions from a tape = one persistent launch per commander step, and with the reference's pilot networks in the loop),
-    each measured like its own `--workload` run but shorter; a failure of one does not cost the headline its line."""
-    import copy
-
+    each measured by its own `--workload` run of this script in a CHILD process (shorter than a stand-alone run): whatever happens
+    there — an exception, a crash — costs the headline nothing but an `error` entry."""
     def brief(line):
         keys = ("metric", "value", "unit", "steps", "ms_per_step", "gpu_ms_per_step", "dtype", "kernels_ms", "launches_per_step", "sim_ticks_per_s",
-                "ticks_per_commander_step")
+                "ticks_per_commander_step", "streams")
         out = {k: line[k] for k in keys if k in line}
         out["workload"] = line["config"]["workload"]
         out["roofline"] = line["roofline"]
         return out
 
     extra = {}
-    for name, fn, kw in (("configs2", main_policy_rollout, dict(workload="rollout", steps=300, warmup=30)),
-                         ("configs3", main_hier, dict(workload="hier", pilot="tape", steps=40, warmup=8)),
-                         ("configs3_networks_in_loop", main_hier, dict(workload="hier", pilot="net", steps=12, warmup=3))):
-        a = copy.copy(args)
-        a.arenas, a.spinup, a.no_graph, a.phases, a.coop = None, 0.3, False, False, False
-        for k, v in kw.items():
-            setattr(a, k, v)
+    R.torch.cuda.synchronize()
+    for name, flags in (("configs2", ["--workload", "rollout", "--steps", "300", "--warmup", "30"]),
+                        ("configs3", ["--workload", "hier", "--pilot", "tape", "--steps", "40", "--warmup", "8"]),
+                        ("configs3_networks_in_loop", ["--workload", "hier", "--pilot", "net", "--steps", "12", "--warmup", "3"])):
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--spinup", "0.3", "--seed", str(args.seed), "--no-cpu-baseline"] + flags
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
         try:
-            extra[name] = brief(fn(a, R))
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=env)
+            lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not lines:
+                extra[name] = {"error": f"child exited with {p.returncode}: {(p.stderr or '')[-300:]}"}
+            else:
+                extra[name] = brief(json.loads(lines[-1]))
         except Exception as e:   # noqa: BLE001 — reported, never silently dropped
             extra[name] = {"error": f"{type(e).__name__}: {e}"}
-        R.torch.cuda.synchronize()
     return extra
 
 

@@ -97,7 +97,7 @@ __device__ __forceinline__ int sh_type(const Shared<A, B> &sh, int idx) { return
 
 /* heading unit vector (east, north) of env_base.py:428 */
 __device__ __forceinline__ void heading_vec(double hdg, double &c, double &s) {
-    hh_sincos(hh_pymod(90.0 - hdg, 360.0) * (HH_PI / 180.0), &s, &c);
+    hh_sincos(hh_pymod360(90.0 - hdg) * (HH_PI / 180.0), &s, &c);
 }
 /* publish the state other lanes read */
 template <int A, int B>
@@ -126,7 +126,7 @@ __device__ __forceinline__ void publish_obs_hv(const DevCfg &c, Shared<A, B> &sh
     sh.nlat[tid] = (float)hh_clip(hh_div_known(m.lat - HH_MAP_LAT0, c.ext_lat, c.inv_ext_lat), 0.0, 1.0);
     sh.nlon[tid] = (float)hh_clip(hh_div_known(m.lon - HH_MAP_LON0, c.ext_lon, c.inv_ext_lon), 0.0, 1.0);
     sh.nspd[tid] = (float)hh_clip(hh_div_known(m.spd, HH_AC_MAX_SPEED(m.ac_type), HH_AC_INV_MAX_SPEED(m.ac_type)), 0.0, 1.0);
-    sh.nhdg[tid] = (float)hh_clip(HH_DIVC(hh_pymod(m.hdg, 359.0), 359.0), 0.0, 1.0);
+    sh.nhdg[tid] = (float)hh_clip(HH_DIVC(hh_pymod359(m.hdg), 359.0), 0.0, 1.0);
 }
 template <int A, int B>
 __device__ __forceinline__ void publish_obs(const DevCfg &c, Shared<A, B> &sh, int tid, const Unit &m) {
@@ -518,7 +518,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
                 if (t && sh_alive(sh, base + t - 1)) opp_stat0 = norm180(sh.p_foc[s][base + t - 1]); /* env_hetero.py:169-170 */
             }
             /* env_base.py:214-238 _take_base_action */
-            double nh = hh_pymod(m.hdg + (double)(((int)act[0] - 6) * 15), 360.0);
+            double nh = hh_pymod360(m.hdg + (double)(((int)act[0] - 6) * 15));
             if (nh >= 360.0 || nh < 0.0) nh = 0.0;
             m.cmd_hdg = nh;
             double mx = HH_AC_MAX_SPEED(m.ac_type);
@@ -543,7 +543,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
                 if (!man) man = (ar.steps % hh_rng_randint(d_rng(ar, id, HH_SITE_L2_PERIOD, 0), 35, 45)) <= 5;
                 if (man) {
                     int r = hh_rng_randint(d_rng(ar, id, HH_SITE_L2_TURN, 0), 0, 1);
-                    m.cmd_hdg = hh_pymod(m.hdg + (r ? -90.0 : 90.0), 360.0);
+                    m.cmd_hdg = hh_pymod360(m.hdg + (r ? -90.0 : 90.0));
                     m.cmd_spd = (double)(100 + hh_rng_randint(d_rng(ar, id, HH_SITE_L2_SPEED, 0), 0, 4) * 75);
                 }
             }
@@ -600,13 +600,13 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
                     int ag = base + nb.i0;
                     /* env_base.py:464-487 _correct_angle_sign */
                     double sn, cs;
-                    hh_sincos(hh_pymod(m.hdg, 360.0) * (HH_PI / 180.0), &sn, &cs);
+                    hh_sincos(hh_pymod360(m.hdg) * (HH_PI / 180.0), &sn, &cs);
                     double x1 = m.lon + hh_round3(sn), y1 = m.lat + hh_round3(cs);
                     double val = (x1 - m.lon) * (sh.lat0[ag] - m.lat) - (sh.lon0[ag] - m.lon) * (y1 - m.lat);
                     double sign = val < 0.0 ? 1.0 : -1.0;
                     double r = hh_rng_uniform(d_rng(ar, id, HH_SITE_HC_R, 0), 0.7, 1.3);
                     double focus = sh.p_foc[nb.i0][tid];
-                    if (nb.d0 > 0.008 && focus > 4.0) heading = hh_pymod(heading + r * sign * focus, 360.0);
+                    if (nb.d0 > 0.008 && focus > 4.0) heading = hh_pymod360(heading + r * sign * focus);
                     if (nb.d0 > 0.05) {
                         double us = d_rng(ar, id, HH_SITE_HC_SPEED2, 0);
                         speed = focus < 30.0 ? (double)(int)hh_rng_uniform(us, 500.0, 800.0) : (double)(int)hh_rng_uniform(us, 100.0, 500.0);
@@ -640,7 +640,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
             double delta = d_signed_heading_diff(m.hdg, m.cmd_hdg);
             double max_deg = HH_AC_TURN_RATE(t) * 1.0;
             if (hh_fabs(delta) <= max_deg) m.hdg = m.cmd_hdg;
-            else { m.hdg += delta >= 0.0 ? max_deg : -max_deg; m.hdg = hh_pymod(m.hdg, 360.0); }
+            else { m.hdg += delta >= 0.0 ? max_deg : -max_deg; m.hdg = hh_pymod360(m.hdg); }
         }
         if (m.spd != m.cmd_spd) {
             double delta = m.cmd_spd - m.spd;
@@ -1013,7 +1013,7 @@ __device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int
             valid = 1;
             if (t && sh_alive(sh, base + t - 1)) opp_stat0 = norm180(sh.p_foc[s][base + t - 1]);
         }
-        double nh = hh_pymod(m.hdg + (double)(((int)act[0] - 6) * 15), 360.0);
+        double nh = hh_pymod360(m.hdg + (double)(((int)act[0] - 6) * 15));
         if (nh >= 360.0 || nh < 0.0) nh = 0.0;
         m.cmd_hdg = nh;
         double mx = HH_AC_MAX_SPEED(m.ac_type);

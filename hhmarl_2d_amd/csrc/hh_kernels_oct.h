@@ -135,7 +135,7 @@ struct OTab {
 
 __device__ __forceinline__ void oct_publish_vec(const Unit &m, OPub &p) {
     double sn, cs;
-    hh_sincos(hh_pymod(90.0 - m.hdg, 360.0) * (HH_PI / 180.0), &sn, &cs);
+    hh_sincos(hh_pymod360(90.0 - m.hdg) * (HH_PI / 180.0), &sn, &cs);
     p.uc = cs;
     p.us = sn;
     p.un = hh_sqrt(cs * cs + sn * sn);
@@ -144,7 +144,7 @@ __device__ __forceinline__ void oct_publish_norm(const DevCfg &c, const Unit &m,
     p.nlat = (float)hh_clip(hh_div_known(m.lat - HH_MAP_LAT0, c.ext_lat, c.inv_ext_lat), 0.0, 1.0);
     p.nlon = (float)hh_clip(hh_div_known(m.lon - HH_MAP_LON0, c.ext_lon, c.inv_ext_lon), 0.0, 1.0);
     p.nspd = (float)hh_clip(hh_div_known(m.spd, HH_AC_MAX_SPEED(m.ac_type), HH_AC_INV_MAX_SPEED(m.ac_type)), 0.0, 1.0);
-    p.nhdg = (float)hh_clip(HH_DIVC(hh_pymod(m.hdg, 359.0), 359.0), 0.0, 1.0);
+    p.nhdg = (float)hh_clip(HH_DIVC(hh_pymod359(m.hdg), 359.0), 0.0, 1.0);
 }
 __device__ __forceinline__ void oct_publish_flags(const Unit &m, OPub &p) {
     const int shot = m.burst > 0 || (m.ac_type == 1 && m.has_missile);
@@ -402,7 +402,7 @@ __device__ __forceinline__ void act_oct(const DevCfg &c, OctShared &sh, int tid,
     if (snap) {
         double dd;
         const int t = hl_target_slot(m, dd);
-        double nh = hh_pymod(m.hdg + (double)(((int)act[0] - 6) * 15), 360.0);
+        double nh = hh_pymod360(m.hdg + (double)(((int)act[0] - 6) * 15));
         if (nh >= 360.0 || nh < 0.0) nh = 0.0;
         m.cmd_hdg = nh;
         const double mx = HH_AC_MAX_SPEED(m.ac_type);
@@ -485,7 +485,7 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
             const double delta = d_signed_heading_diff(m.hdg, m.cmd_hdg);
             const double max_deg = HH_AC_TURN_RATE(t) * 1.0;
             if (hh_fabs(delta) <= max_deg) m.hdg = m.cmd_hdg;
-            else { m.hdg += delta >= 0.0 ? max_deg : -max_deg; m.hdg = hh_pymod(m.hdg, 360.0); }
+            else { m.hdg += delta >= 0.0 ? max_deg : -max_deg; m.hdg = hh_pymod360(m.hdg); }
         }
         if (m.spd != m.cmd_spd) {
             const double delta = m.cmd_spd - m.spd;

@@ -85,14 +85,14 @@ struct QTab {
 /* position / speed / heading part (final once the aircraft has moved) and the status flags (final at the end of the tick) */
 __device__ __forceinline__ void quad_publish_motion(const DevCfg &c, const Unit &m, QPub &p) {
     double sn, cs;
-    hh_sincos(hh_pymod(90.0 - m.hdg, 360.0) * (HH_PI / 180.0), &sn, &cs);
+    hh_sincos(hh_pymod360(90.0 - m.hdg) * (HH_PI / 180.0), &sn, &cs);
     p.uc = cs;
     p.us = sn;
     p.un = hh_sqrt(cs * cs + sn * sn);
     p.nlat = (float)hh_clip(hh_div_known(m.lat - HH_MAP_LAT0, c.ext_lat, c.inv_ext_lat), 0.0, 1.0);
     p.nlon = (float)hh_clip(hh_div_known(m.lon - HH_MAP_LON0, c.ext_lon, c.inv_ext_lon), 0.0, 1.0);
     p.nspd = (float)hh_clip(hh_div_known(m.spd, HH_AC_MAX_SPEED(m.ac_type), HH_AC_INV_MAX_SPEED(m.ac_type)), 0.0, 1.0);
-    p.nhdg = (float)hh_clip(HH_DIVC(hh_pymod(m.hdg, 359.0), 359.0), 0.0, 1.0);
+    p.nhdg = (float)hh_clip(HH_DIVC(hh_pymod359(m.hdg), 359.0), 0.0, 1.0);
 }
 __device__ __forceinline__ void quad_publish_flags(const Unit &m, QPub &p) {
     int shot = m.burst > 0 || (m.ac_type == 1 && m.has_missile);
@@ -320,7 +320,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                 if (t && ((amask0 >> (t - 1)) & 1)) opp_stat0 = norm180(q_sel(tb.focr, (t - 1 - s) & 3)); /* env_hetero.py:169-170 */
             }
             /* env_base.py:214-238 _take_base_action */
-            double nh = hh_pymod(m.hdg + (double)(((int)act[0] - 6) * 15), 360.0);
+            double nh = hh_pymod360(m.hdg + (double)(((int)act[0] - 6) * 15));
             if (nh >= 360.0 || nh < 0.0) nh = 0.0;
             m.cmd_hdg = nh;
             double mx = HH_AC_MAX_SPEED(m.ac_type);
@@ -343,7 +343,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                 if (!man) man = (ar.steps % hh_rng_randint(d_rng(ar, id, HH_SITE_L2_PERIOD, 0), 35, 45)) <= 5;
                 if (man) {
                     int r = hh_rng_randint(d_rng(ar, id, HH_SITE_L2_TURN, 0), 0, 1);
-                    m.cmd_hdg = hh_pymod(m.hdg + (r ? -90.0 : 90.0), 360.0);
+                    m.cmd_hdg = hh_pymod360(m.hdg + (r ? -90.0 : 90.0));
                     m.cmd_spd = (double)(100 + hh_rng_randint(d_rng(ar, id, HH_SITE_L2_SPEED, 0), 0, 4) * 75);
                 }
             }
@@ -395,13 +395,13 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                     const double ag_lat = q_sel(tb.lat, nb.k0), ag_lon = q_sel(tb.lon, nb.k0);
                     /* env_base.py:464-487 _correct_angle_sign */
                     double sn, cs;
-                    hh_sincos(hh_pymod(m.hdg, 360.0) * (HH_PI / 180.0), &sn, &cs);
+                    hh_sincos(hh_pymod360(m.hdg) * (HH_PI / 180.0), &sn, &cs);
                     double x1 = m.lon + hh_round3(sn), y1 = m.lat + hh_round3(cs);
                     double val = (x1 - m.lon) * (ag_lat - m.lat) - (ag_lon - m.lon) * (y1 - m.lat);
                     double sign = val < 0.0 ? 1.0 : -1.0;
                     double r = hh_rng_uniform(d_rng(ar, id, HH_SITE_HC_R, 0), 0.7, 1.3);
                     double focus = q_sel(tb.foc, nb.k0);
-                    if (nb.d0 > 0.008 && focus > 4.0) heading = hh_pymod(heading + r * sign * focus, 360.0);
+                    if (nb.d0 > 0.008 && focus > 4.0) heading = hh_pymod360(heading + r * sign * focus);
                     if (nb.d0 > 0.05) {
                         double us = d_rng(ar, id, HH_SITE_HC_SPEED2, 0);
                         speed = focus < 30.0 ? (double)(int)hh_rng_uniform(us, 500.0, 800.0) : (double)(int)hh_rng_uniform(us, 100.0, 500.0);
@@ -435,7 +435,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
             double delta = d_signed_heading_diff(m.hdg, m.cmd_hdg);
             double max_deg = HH_AC_TURN_RATE(t) * 1.0;
             if (hh_fabs(delta) <= max_deg) m.hdg = m.cmd_hdg;
-            else { m.hdg += delta >= 0.0 ? max_deg : -max_deg; m.hdg = hh_pymod(m.hdg, 360.0); }
+            else { m.hdg += delta >= 0.0 ? max_deg : -max_deg; m.hdg = hh_pymod360(m.hdg); }
         }
         if (m.spd != m.cmd_spd) {
             double delta = m.cmd_spd - m.spd;
@@ -522,7 +522,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     }
     int q_total = 0;
     {
-        bool push[6];
+        int push[6];
         int code[6];
         push[0] = try_launch && launch_pre < 0;
         code[0] = tid | (0 << 8) | (launch_tgt << 10);
@@ -535,32 +535,35 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
             /* target already moved iff its id is lower (cmano_simulator.py:142) */
             const double tl = j < s ? lat1[k - 1] : tb.lat[k - 1];
             const double to = j < s ? lon1[k - 1] : tb.lon[k - 1];
-            push[k] = fired && snap_j && (c.friendly_kill || enemy) && d_maybe_within_km(lat_old, lon_old, tl, to, HH_AC_CANNON_KM(t)) &&
-                      !hh_cannon_cone_planar_outside(lat_old, lon_old, tl, to, pn.uc, pn.us, t);
+            /* every clause is a handful of compares and products and almost every tick SOME lane of the wave has fired: evaluated
+             * unconditionally (&, not &&) — at one wave per SIMD an exec-mask region costs ~45 cycles whether or not it is entered */
+            push[k] = (int)fired & (int)snap_j & ((int)(c.friendly_kill != 0) | (int)enemy) & (int)d_maybe_within_km(lat_old, lon_old, tl, to, HH_AC_CANNON_KM(t)) &
+                      (int)!hh_cannon_cone_planar_outside(lat_old, lon_old, tl, to, pn.uc, pn.us, t);
             code[k] = tid | (1 << 8) | (j << 10);
         }
         {
             const int kt = (rk_tgt - s) & 3;
             const double tl = kt ? q_sel(lat1, kt) : m.lat, to = kt ? q_sel(lon1, kt) : m.lon;
-            push[4] = rk_maybe && d_maybe_within_km(rk0_lat, rk0_lon, tl, to, HH_ROCKET_FUSE_KM);
+            push[4] = (int)rk_maybe & (int)d_maybe_within_km(rk0_lat, rk0_lon, tl, to, HH_ROCKET_FUSE_KM);
             code[4] = tid | (2 << 8) | (rk_tgt << 10);
             const int fid = s == 1 ? 0 : 1; /* rocket_unit.py:46: 1 if source.id == 2 else 2 */
             const int kf = (fid - s) & 3;
             const double fl_ = kf ? q_sel(lat1, kf) : m.lat, fo_ = kf ? q_sel(lon1, kf) : m.lon;
-            push[5] = rk_maybe && c.friendly_kill && d_maybe_within_km(rk0_lat, rk0_lon, fl_, fo_, HH_ROCKET_FUSE_KM);
+            push[5] = (int)rk_maybe & (int)(c.friendly_kill != 0) & (int)d_maybe_within_km(rk0_lat, rk0_lon, fl_, fo_, HH_ROCKET_FUSE_KM);
             code[5] = tid | (3 << 8) | (fid << 10);
         }
+        /* one wave-uniform test for the whole group (87 % of the wave-ticks queue nothing), then slots by ballot prefix */
+        if (__ballot(push[0] | push[1] | push[2] | push[3] | push[4] | push[5])) {
 #pragma unroll
-        for (int e = 0; e < 6; e++) {
-            const unsigned long long bm = __ballot(push[e]);
-            if (bm) { /* wave-uniform */
+            for (int e = 0; e < 6; e++) {
+                const unsigned long long bm = __ballot(push[e]);
                 if (push[e]) {
                     int pos = q_total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
                     sh.u.t.q_code[pos] = code[e];
                 }
                 q_total += __popcll(bm);
 #ifdef HH_PROFILE_PHASES
-                if (tid == 0) atomicAdd(&hh_prof_cycles[e == 0 ? 13 : (e < 4 ? 14 : 15)], (unsigned long long)__popcll(bm));
+                if (tid == 0 && bm) atomicAdd(&hh_prof_cycles[e == 0 ? 13 : (e < 4 ? 14 : 15)], (unsigned long long)__popcll(bm));
 #endif
             }
         }

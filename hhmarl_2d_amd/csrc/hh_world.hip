@@ -510,6 +510,10 @@ extern "C" int hh_set_state(hh_world *w, const hh_state_view *v) {
     std::vector<int2> rkp(U);
     for (int k = 0; k < 6; k++) f[k].resize(U);
     for (int k = 0; k < 4; k++) rk[k].resize(U);
+    for (size_t u = 0; u < U; u++) { /* the step keeps headings in [0, 360) (ac1.py:94, env_base.py:219-221) and its modulo relies on it */
+        const double h = v->ac_f[u * HH_ACF_K + 2], ch = v->ac_f[u * HH_ACF_K + 4];
+        if (!(h >= 0.0 && h < 360.0 && ch >= 0.0 && ch < 360.0)) { g_err = "hh_set_state: heading / commanded heading outside [0, 360)"; return HH_E_ARG; }
+    }
     for (size_t u = 0; u < U; u++) {
         for (int k = 0; k < 6; k++) f[k][u] = v->ac_f[u * HH_ACF_K + k];
         const int32_t *q = v->ac_i + u * HH_ACI_K;

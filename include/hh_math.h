@@ -56,7 +56,8 @@ HH_HD double hh_hypot(double x, double y) { return hh_sqrt(x * x + y * y); }
  * literal moduli 360 / 359 this code uses; |x| / |m| < 2^50). */
 HH_HD double hh_fmod(double x, double m) {
     double ax = hh_fabs(x), am = hh_fabs(m);
-    if (ax < am) return x;
+    /* no early return for |x| < |m|: the general path gives x back there (q = 0, or q = 1 undone by the first fix-up; the sign
+     * of a zero survives the copysign), and on the GPU a skipped branch costs more than these five instructions */
     double q = hh_floor(ax * (1.0 / am));
     double r = hh_fma(-q, am, ax);
     if (r < 0.0) r += am;
@@ -86,6 +87,20 @@ HH_HD double hh_pymod(double x, double m) {
     }
     return r;
 }
+
+/* x % 360.0 / x % 359.0 where the operand is a heading plus or minus less than a turn — every call of the step.  Inside
+ * [-m, 2m) the value of hh_pymod is one exact subtraction (x - m for m <= x < 2m: Sterbenz), the same rounded addition CPython
+ * makes (x + m for x < 0), or x itself (+ 0.0 turns the -0.0 of an empty remainder into CPython's +0.0): ~10 instructions
+ * instead of ~37, no branch.  PRECONDITION -m <= x < 2m: headings are kept in [0, 360) by the step itself (every write goes through
+ * a modulo or the 0 <= h < 360 guard of _take_base_action, hh_set_state refuses others) and the operands here are a heading plus
+ * or minus less than a turn; tests/test_math.py compares the two forms over the interval, its end points included, and the oracle
+ * keeps calling the general form, so every parity run cross-checks the kernels' use of this one. */
+HH_HD double hh_pymod_turn(double x, double m) /* m > 0, -m <= x < 2 m */ {
+    const double lo = x + (x < 0.0 ? m : 0.0);
+    return x >= m ? x - m : lo;
+}
+HH_HD double hh_pymod360(double x) { return hh_pymod_turn(x, 360.0); }
+HH_HD double hh_pymod359(double x) { return hh_pymod_turn(x, 359.0); }
 
 /* IEEE remainder(x, m): x - n*m with n = nearest integer to x/m, ties to even */
 HH_HD double hh_remainder(double x, double m) {

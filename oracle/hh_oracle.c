@@ -1437,6 +1437,7 @@ API void hho_math_eval(int fn, int n, const double *a, const double *b, double *
             case 7: o0[i] = hh_fmod(a[i], b[i]); break;
             case 8: o0[i] = hh_round3(a[i]); break;
             case 9: o0[i] = hh_div_known(a[i], b[i], 1.0 / b[i]); break;
+            case 10: o0[i] = hh_pymod_turn(a[i], b[i]); break;
             default: break;
         }
     }

@@ -62,6 +62,13 @@ def test_modulo_family_exact(oracle):
         b = np.full(a.size, m)
         assert np.array_equal(oracle.math_eval(5, a, b)[0], np.array([u % m for u in a]))
         assert np.array_equal(oracle.math_eval(7, a, b)[0], np.fmod(a, m))
+        # the one-turn form the kernels call on headings: same value for every operand, -0.0 / +0.0 included
+        edge = np.array([-m, -m + 1e-13, np.nextafter(-m, 0), -1e-300, -5e-324, 5e-324, 0.0, -0.0, m, np.nextafter(m, 0), np.nextafter(m, 1e9),
+                         np.nextafter(2 * m, 0), 2 * m - 1e-9])
+        aa = np.concatenate([a[(a >= -m) & (a < 2 * m)], edge, rng.uniform(-m, 2 * m, 200000)])   # its precondition: -m <= x < 2m
+        got = oracle.math_eval(10, aa, np.full(aa.size, m))[0]
+        want = np.array([u % m for u in aa])
+        assert np.array_equal(got, want) and np.array_equal(np.signbit(got), np.signbit(want))
     b = np.full(a.size, 360.0)
     assert np.array_equal(oracle.math_eval(6, a, b)[0], np.array([math.remainder(u, 360.0) for u in a]))
     t = np.array([180.0, -180, 540, 900, -540])

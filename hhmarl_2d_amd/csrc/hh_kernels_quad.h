@@ -307,6 +307,10 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     bool base_gate = false;
 
     /* ---------------- phase A: commands (env_hetero.py:160-182) ---------------- */
+    /* Control flow of the tick: at one wave per SIMD a region under the exec mask costs ~45 cycles entered and ~55 skipped
+     * (tools/ubench/issue.hip) — more than a dozen instructions.  Short bodies are therefore written as selects on values computed
+     * unconditionally (named locals first, so that the front end emits a select and not a branch), nested tests are merged into one
+     * region, and rare bodies sit behind ONE wave-uniform ballot test.  Same expressions, same bits. */
     if (snap) {
         if (agent || c.ext_opp) {
             int t = m.n_tgt ? m.tgt0 : 0;
@@ -315,9 +319,13 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                 quad_nearby(c, tb, s, nb);
                 m.n_tgt = nb.n ? 1 : 0; m.tgt0 = nb.n ? nb.j0 + 1 : 0; m.tgt_d0 = nb.n ? nb.d0 : 0.0;
                 t = m.tgt0;
-            } else {
-                out.valid = 1;
-                if (t && ((amask0 >> (t - 1)) & 1)) opp_stat0 = norm180(q_sel(tb.focr, (t - 1 - s) & 3)); /* env_hetero.py:169-170 */
+            }
+            {
+                const int t1 = t ? t - 1 : 0;
+                const double os = norm180(q_sel(tb.focr, (t1 - s) & 3)); /* env_hetero.py:169-170 */
+                const bool os_ok = agent & (t != 0) & (((amask0 >> t1) & 1) != 0);
+                out.valid = agent ? 1 : out.valid;
+                opp_stat0 = os_ok ? os : opp_stat0;
             }
             /* env_base.py:214-238 _take_base_action */
             double nh = hh_pymod360(m.hdg + (double)(((int)act[0] - 6) * 15));
@@ -329,12 +337,11 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                 arm_cannon(m);
                 if (agent && c.agent_mode == HH_MODE_ESCAPE && m.cannon_remain < 90) out.reward -= 0.1;
             }
-            if (m.ac_type == 1 && act[3]) {
-                if (t && m.missile_remain > 0 && !m.has_missile && m.missile_wait == 0) {
-                    base_gate = true;
-                    want_launch = 1;
-                    launch_tgt = t - 1;
-                }
+            {
+                const bool gate = (m.ac_type == 1) & (act[3] != 0) & (t != 0) & (m.missile_remain > 0) & (m.has_missile == 0) & (m.missile_wait == 0);
+                base_gate = gate;
+                want_launch = gate ? 1 : want_launch;
+                launch_tgt = gate ? t - 1 : launch_tgt;
             }
         } else if (c.level <= 2) { /* env_hetero.py:118-136 levels 1-2 */
             if (c.level == 2) {
@@ -360,18 +367,22 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     if (running && !c.ext_opp && c.level >= 3) {
         int esc = ar.escaping, esc_t = ar.escaping_time;
         bool my_escaping = false;
+        const bool draw_tick = ar.steps % 60 == 0; /* one tick in sixty per arena: the draws sit behind a wave-uniform test */
 #pragma unroll
         for (int j = 2; j < A; j++) {
-            if (!((amask0 >> j) & 1)) continue;
-            if (ar.steps % 60 == 0 && !esc) {
-                esc = hh_rng_randint(d_rng(ar, j + 1, HH_SITE_L3_ESC_COIN, 0), 0, 1);
-                if (esc) esc_t = (int)hh_rng_uniform(d_rng(ar, j + 1, HH_SITE_L3_ESC_TIME, 0), 20.0, 30.0);
+            const bool aj = ((amask0 >> j) & 1) != 0;
+            const bool draws = aj & draw_tick & (esc == 0);
+            if (__ballot(draws)) {
+                if (draws) {
+                    esc = hh_rng_randint(d_rng(ar, j + 1, HH_SITE_L3_ESC_COIN, 0), 0, 1);
+                    if (esc) esc_t = (int)hh_rng_uniform(d_rng(ar, j + 1, HH_SITE_L3_ESC_TIME, 0), 20.0, 30.0);
+                }
             }
-            if (j == s) my_escaping = esc != 0;
-            if (esc) {
-                esc_t -= 1;
-                if (esc_t <= 0) esc = 0;
-            }
+            const bool mine = aj & (j == s), upd = aj & (esc != 0);
+            my_escaping = mine ? (esc != 0) : my_escaping;
+            const int esc_t1 = esc_t - 1;
+            esc_t = upd ? esc_t1 : esc_t;
+            esc = (upd & (esc_t <= 0)) ? 0 : esc;
         }
         ar.escaping = esc;
         ar.escaping_time = esc_t;
@@ -401,11 +412,12 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                     double sign = val < 0.0 ? 1.0 : -1.0;
                     double r = hh_rng_uniform(d_rng(ar, id, HH_SITE_HC_R, 0), 0.7, 1.3);
                     double focus = q_sel(tb.foc, nb.k0);
-                    if (nb.d0 > 0.008 && focus > 4.0) heading = hh_pymod360(heading + r * sign * focus);
-                    if (nb.d0 > 0.05) {
-                        double us = d_rng(ar, id, HH_SITE_HC_SPEED2, 0);
-                        speed = focus < 30.0 ? (double)(int)hh_rng_uniform(us, 500.0, 800.0) : (double)(int)hh_rng_uniform(us, 100.0, 500.0);
-                    }
+                    const double turned = hh_pymod360(heading + r * sign * focus);
+                    heading = ((nb.d0 > 0.008) & (focus > 4.0)) ? turned : heading;
+                    const double us = d_rng(ar, id, HH_SITE_HC_SPEED2, 0);
+                    const double sp_near = (double)(int)hh_rng_uniform(us, 500.0, 800.0), sp_far = (double)(int)hh_rng_uniform(us, 100.0, 500.0);
+                    const double sp2 = focus < 30.0 ? sp_near : sp_far;
+                    speed = nb.d0 > 0.05 ? sp2 : speed;
                     fire = nb.d0 < 0.03 && focus < 10.0;
                     fire_m = nb.d0 < 0.09 && focus < 5.0;
                     opp = nb.j0;
@@ -431,26 +443,29 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     const bool try_launch = want_launch && !m.has_missile && m.missile_remain > 0; /* ac1.py:73 */
     if (snap) {
         int t = m.ac_type;
-        if (m.hdg != m.cmd_hdg) {
-            double delta = d_signed_heading_diff(m.hdg, m.cmd_hdg);
-            double max_deg = HH_AC_TURN_RATE(t) * 1.0;
-            if (hh_fabs(delta) <= max_deg) m.hdg = m.cmd_hdg;
-            else { m.hdg += delta >= 0.0 ? max_deg : -max_deg; m.hdg = hh_pymod360(m.hdg); }
+        {
+            const double delta = d_signed_heading_diff(m.hdg, m.cmd_hdg);
+            const double max_deg = HH_AC_TURN_RATE(t) * 1.0;
+            const double stepped = hh_pymod360(m.hdg + (delta >= 0.0 ? max_deg : -max_deg));
+            const double nh = hh_fabs(delta) <= max_deg ? m.cmd_hdg : stepped;
+            m.hdg = m.hdg != m.cmd_hdg ? nh : m.hdg;
         }
-        if (m.spd != m.cmd_spd) {
-            double delta = m.cmd_spd - m.spd;
-            double max_delta = HH_AC_ACCEL(t) * 1.0;
-            if (hh_fabs(delta) <= max_delta) m.spd = m.cmd_spd;
-            else m.spd += delta >= 0.0 ? max_delta : -max_delta;
+        {
+            const double delta = m.cmd_spd - m.spd;
+            const double max_delta = HH_AC_ACCEL(t) * 1.0;
+            const double stepped = m.spd + (delta >= 0.0 ? max_delta : -max_delta);
+            const double ns = hh_fabs(delta) <= max_delta ? m.cmd_spd : stepped;
+            m.spd = m.spd != m.cmd_spd ? ns : m.spd;
         }
         if (m.burst > 0) {
             fired = true;
             m.burst = m.burst - 1 > 0 ? m.burst - 1 : 0;
             m.cannon_remain = m.cannon_remain - 1 > 0 ? m.cannon_remain - 1 : 0;
         }
-        if (m.has_missile) { /* ac1.py:117-128, rocket launched in an earlier step */
-            if (!m.rk_alive) m.has_missile = 0;
-            else m.rk_cmd = hh_clip(m.rk_hdg * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
+        { /* ac1.py:117-128, rocket launched in an earlier step */
+            const bool steer = (m.has_missile != 0) & (m.rk_alive != 0);
+            if (steer) m.rk_cmd = hh_clip(m.rk_hdg * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
+            m.has_missile = ((m.has_missile != 0) & (m.rk_alive == 0)) ? 0 : m.has_missile;
         }
     }
     /* aircraft move + speculative move of this slot's rocket (in flight, or the one a pending launch creates) */
@@ -465,10 +480,11 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
             r_hdg = rk_pre ? m.rk_hdg : hdg_old;
             rk_ncmd = rk_pre ? m.rk_cmd
                              : hh_clip(hdg_old * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
-            if (r_hdg != rk_ncmd) {
-                double delta = d_signed_heading_diff(r_hdg, rk_ncmd);
-                if (hh_fabs(delta) <= HH_ROCKET_TURN_RATE) r_hdg = rk_ncmd;
-                else r_hdg += delta >= 0.0 ? HH_ROCKET_TURN_RATE : -HH_ROCKET_TURN_RATE;
+            {
+                const double delta = d_signed_heading_diff(r_hdg, rk_ncmd);
+                const double stepped = r_hdg + (delta >= 0.0 ? HH_ROCKET_TURN_RATE : -HH_ROCKET_TURN_RATE);
+                const double nh = hh_fabs(delta) <= HH_ROCKET_TURN_RATE ? rk_ncmd : stepped;
+                r_hdg = r_hdg != rk_ncmd ? nh : r_hdg;
             }
             rk_nhdg = r_hdg;
         }

@@ -49,14 +49,14 @@ HH_HD int hh_missile_cone_planar(double lat1, double lon1, double lat2, double l
 #define HH_COS_3P8_DEG 0.99780146829205   /* cos((7 / 2 + 0.3) deg) */
 HH_HD int hh_cannon_cone_planar_outside(double lat1, double lon1, double lat2, double lon2, double he, double hn, int ac_type) {
     const double dx = lon2 - lon1, dy = lat2 - lat1;
-    const int dom = hh_fabs(lat1) <= HH_GEO_EST_MAX_LAT && hh_fabs(lat2) <= HH_GEO_EST_MAX_LAT && hh_fabs(lon1) < 170.0 &&
-                    hh_fabs(lon2) < 170.0 && hh_fabs(dx) <= HH_GEO_EST_SHORT_DEG && hh_fabs(dy) <= HH_GEO_EST_SHORT_DEG;
+    const int dom = (hh_fabs(lat1) <= HH_GEO_EST_MAX_LAT) & (hh_fabs(lat2) <= HH_GEO_EST_MAX_LAT) & (hh_fabs(lon1) < 170.0) &
+                    (hh_fabs(lon2) < 170.0) & (hh_fabs(dx) <= HH_GEO_EST_SHORT_DEG) & (hh_fabs(dy) <= HH_GEO_EST_SHORT_DEG);
     const double d2 = dx * dx + dy * dy;
-    if (!dom || d2 < 1e-10) return 0; /* below ~1 m the bearing of the segment is not defined well enough */
+    const int ok = dom & !(d2 < 1e-10); /* below ~1 m the bearing of the segment is not defined well enough */
     const double dot = he * dx + hn * dy;
     const double h2 = he * he + hn * hn;
     const double cw = ac_type == 1 ? HH_COS_5P3_DEG : HH_COS_3P8_DEG;
-    return dot <= 0.0 || dot * dot < (cw * cw) * (d2 * h2);
+    return ok & ((dot <= 0.0) | (dot * dot < (cw * cw) * (d2 * h2))); /* straight-line: no region for the GPU's exec mask to skip */
 }
 
 #endif /* HH_ENVELOPE_H */

@@ -174,16 +174,16 @@ HH_HD double hh_atan_pos(double x) /* x >= 0 */ {
                  aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02,
                  aT8 = 4.97687799461593236017e-02, aT9 = -3.65315727442169155270e-02,
                  aT10 = 1.62858201153657823623e-02;
-    if (x > 1e300) return 1.57079632679489655800e+00 + 6.12323399573676603587e-17;
-    /* argument reduction t = num/den on five intervals; written with selects and a single
-     * division so that a 64-lane wave does not serialise five divergent paths */
-    double num, den, hi, lo;
-    int low = x < 0.4375;
-    if (x < 0.6875) { num = 2.0 * x - 1.0; den = 2.0 + x; hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; }
-    else if (x < 1.1875) { num = x - 1.0; den = x + 1.0; hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; }
-    else if (x < 2.4375) { num = x - 1.5; den = 1.0 + 1.5 * x; hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; }
-    else { num = -1.0; den = x; hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; }
-    if (low) { num = x; den = 1.0; } /* x / 1 is exact: t = x */
+    /* argument reduction t = num/den on five intervals.  Every candidate is computed and chosen by selects on plain values, and the
+     * special cases are selected at the end: on the GPU a region skipped under the exec mask costs ~14 instruction slots, more than
+     * any of these arms; the chosen expressions, and so the bits, are those of the branching form */
+    const double n0 = 2.0 * x - 1.0, d0 = 2.0 + x, n1 = x - 1.0, d1 = x + 1.0, n2 = x - 1.5, d2 = 1.0 + 1.5 * x;
+    const int low = x < 0.4375, i0 = x < 0.6875, i1 = x < 1.1875, i2 = x < 2.4375;
+    double num = -1.0, den = x, hi = 1.57079632679489655800e+00, lo = 6.12323399573676603587e-17;
+    num = i2 ? n2 : num; den = i2 ? d2 : den; hi = i2 ? 9.82793723247329054082e-01 : hi; lo = i2 ? 1.39033110312309984516e-17 : lo;
+    num = i1 ? n1 : num; den = i1 ? d1 : den; hi = i1 ? 7.85398163397448278999e-01 : hi; lo = i1 ? 3.06161699786838301793e-17 : lo;
+    num = i0 ? n0 : num; den = i0 ? d0 : den; hi = i0 ? 4.63647609000806093515e-01 : hi; lo = i0 ? 2.26987774529616870924e-17 : lo;
+    num = low ? x : num; den = low ? 1.0 : den; /* x / 1 is exact: t = x */
     double t = num / den;
     double z = t * t;
     double w = z * z;
@@ -191,21 +191,28 @@ HH_HD double hh_atan_pos(double x) /* x >= 0 */ {
     double s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
     double r_low = t - t * (s1 + s2);
     double r_hi = hi - ((t * (s1 + s2) - lo) - t);
-    return low ? r_low : r_hi;
+    const double r = low ? r_low : r_hi;
+    const double r_huge = 1.57079632679489655800e+00 + 6.12323399573676603587e-17;
+    return x > 1e300 ? r_huge : r;
 }
 
 HH_HD double hh_atan2(double y, double x) {
     const double PI_LO = 1.2246467991473531772e-16;
-    if (x != x || y != y) return x + y;
-    if (y == 0.0) {
-        if (x > 0.0 || (x == 0.0 && hh_copysign(1.0, x) > 0.0)) return y; /* +-0 */
-        return hh_copysign(HH_PI, y);
-    }
-    if (x == 0.0) return hh_copysign(0.5 * HH_PI, y);
-    double z = hh_atan_pos(hh_fabs(y / x));
-    if (x > 0.0) return y > 0.0 ? z : -z;
-    z = HH_PI - (z - PI_LO);
-    return y > 0.0 ? z : -z;
+    /* main path first, special cases selected over it in reverse order of the branching form's tests (same values for every
+     * operand pair: the main path's garbage for zeros / NaNs is never the one chosen) */
+    const double z = hh_atan_pos(hh_fabs(y / x));
+    const double zn = -z, zz = HH_PI - (z - PI_LO), zzn = -zz;
+    const int ypos = y > 0.0;
+    const double r_right = ypos ? z : zn, r_left = ypos ? zz : zzn;
+    double r = x > 0.0 ? r_right : r_left;
+    const double r_x0 = hh_copysign(0.5 * HH_PI, y);
+    r = x == 0.0 ? r_x0 : r;
+    const int x_plus = (x > 0.0) | ((x == 0.0) & (hh_copysign(1.0, x) > 0.0));
+    const double r_y0b = hh_copysign(HH_PI, y);
+    const double r_y0 = x_plus ? y : r_y0b; /* +-0 */
+    r = y == 0.0 ? r_y0 : r;
+    const double r_nan = x + y;
+    return ((x != x) | (y != y)) ? r_nan : r;
 }
 
 /* ---- acos ---- */

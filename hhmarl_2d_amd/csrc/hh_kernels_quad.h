@@ -608,7 +608,8 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     HH_PROF(3);
     /* ---------------- phase L: launch bookkeeping (env_base.py:227-236, ac1.py:76-79) ---------------- */
     int launched = 0;
-    if (try_launch && (myres & 1)) {
+    const bool launch_now = try_launch & ((myres & 1) != 0);
+    if (__ballot(launch_now)) if (launch_now) {
         launched = 1;
         m.rk_alive = 1; m.rk_lat = lat_old; m.rk_lon = lon_old; m.rk_hdg = hdg_old;
         m.rk_target = launch_tgt + 1; m.rk_life = 0;
@@ -617,15 +618,17 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         evm |= 1u << (24 + s);
         m.rk_cmd = rk_ncmd; /* the launcher's own update in this tick already steers it (ac1.py:127) */
     }
-    if (base_gate) {
+    if (__ballot(base_gate)) if (base_gate) {
         double uu = d_rng(ar, id, HH_SITE_MISSILE_WAIT, 0);
         m.missile_wait = hh_rng_randint(uu, 7, 17);
         if (agent && c.agent_mode == HH_MODE_ESCAPE && m.missile_remain < 3) out.reward -= 0.1;
     }
-    if (snap && (agent || c.ext_opp)) { /* env_base.py:235-236, evaluated before do_tick */
-        if (m.missile_wait > 0 && !(launched || has_missile_pre)) m.missile_wait -= 1;
+    { /* env_base.py:235-236, evaluated before do_tick */
+        const bool dec = snap & (agent | (c.ext_opp != 0)) & (m.missile_wait > 0) & !(launched | has_missile_pre);
+        const int w1 = m.missile_wait - 1;
+        m.missile_wait = dec ? w1 : m.missile_wait;
     }
-    if (want_launch && wait_after >= 0) m.missile_wait = wait_after;
+    m.missile_wait = (want_launch & (wait_after >= 0)) ? wait_after : m.missile_wait;
     const int rk_at_start = m.rk_alive;
     /* launch order = unit id order (cmano_simulator.py:104-108) */
     const int aux = launched | ((fired ? (myres >> 1) & 0xff : 0) << 8);
@@ -653,10 +656,11 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     /* ---------------- phases C + D: id-ordered resolution, computed identically by the four lanes ---------------- */
     int alive = amask0, nev = 0, dead = 0;
     int evpack = 0; /* 5 bits per event: killer slot | victim slot << 2 | by rocket << 4 */
-    if (running) {
+    { /* (an arena that is not running has no shot and no rocket word: nothing below changes anything for it) */
         /* aircraft phase: shooter i (alive at tick start, even if killed earlier in this tick) hits the still-alive
-         * targets in id order (ac1.py:106-115).  Most ticks nobody in the arena has a hit to apply. */
-        if ((aux_[0] | aux_[1] | aux_[2] | aux_[3]) >> 8) {
+         * targets in id order (ac1.py:106-115).  Most ticks nobody in the WAVE has a hit to apply. */
+        const bool any_hit = ((aux_[0] | aux_[1] | aux_[2] | aux_[3]) >> 8) != 0;
+        if (__ballot(any_hit)) if (any_hit) {
 #pragma unroll
             for (int i = 0; i < A; i++) {
                 const int ci = aux_[i] >> 8;
@@ -677,6 +681,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         for (int j = 0; j < A; j++) {
             if ((res_[j] & 1) && (res_[j] & 0xe)) { nact++; w1 = res_[j]; b1 = j; }
         }
+        if (__ballot(nact > 0)) {
         if (nact == 1) {
             const int tg = (w1 >> 4) & 7;
             const int fid = b1 == 1 ? 0 : 1;
@@ -719,6 +724,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                 }
             }
         }
+        }
     }
     if (running && rk_at_start) {
         if ((dead >> s) & 1) {
@@ -733,16 +739,17 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     HH_PROF(4);
     /* ---------------- phase E: out of bounds, rewards, done (env_base.py:240-310, env_hetero.py:188-225) ---------------- */
     int oob = 0;
-    if (active) {
-        m.alive = (alive >> s) & 1;
-        if (running && m.alive) {
-            bool inb = HH_MAP_LON0 <= m.lon && m.lon <= c.lon_hi && HH_MAP_LAT0 <= m.lat && m.lat <= c.lat_hi;
-            if (!inb) { m.alive = 0; oob = 1; }
-        }
+    {
+        const int al = (alive >> s) & 1;
+        const bool inb = (HH_MAP_LON0 <= m.lon) & (m.lon <= c.lon_hi) & (HH_MAP_LAT0 <= m.lat) & (m.lat <= c.lat_hi);
+        oob = (active & running & (al != 0) & !inb) ? 1 : 0;
+        m.alive = active ? (oob ? 0 : al) : m.alive;
     }
     const int oobm = (int)(__ballot(oob) >> base) & 0xf; /* out-of-bounds removals of the arena */
     double rews = 0.0;
     int destroyed = 0;
+    /* kills and removals are rare: rewards and event masks behind one wave-uniform test (nothing below does anything without one) */
+    if (__ballot((nev > 0) | (oob != 0))) {
     if (running && agent) {
         const double sc = c.rew_scale;
         if (oob) { rews += -5.0 * sc; destroyed = 1; }
@@ -774,6 +781,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         evm |= ((w >> 4) & 1) ? (1u << (8 + ((w >> 2) & 3))) : (1u << ((w >> 2) & 3));
     }
     if (oob) evm |= 1u << (16 + s);
+    }
     ev_mask_out = evm;
     const double mate_rews = q_mate_d(rews);
     HH_PROF(5);
@@ -783,13 +791,15 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     HH_PROF(6);
     quad_tables<DUAL>(m, pub, s, helper, tb);
     HH_PROF(7);
-    if (running) {
-        out.kill_event = nev > 0 || oobm != 0;
+    {
         const int ag = __popc(tb.amask & 3), op = __popc(tb.amask & 12);
-        ar.done = (ag <= 0 || op <= 0 || ar.steps >= c.horizon) ? 1 : 0;
+        const int dn = ((ag <= 0) | (op <= 0) | (ar.steps >= c.horizon)) ? 1 : 0;
+        const int ke = ((nev > 0) | (oobm != 0)) ? 1 : 0;
+        out.kill_event = running ? ke : out.kill_event;
+        ar.done = running ? dn : ar.done;
     }
-    if (running && agent) {
-        if (c.agent_mode == HH_MODE_ESCAPE && c.esc_dist_rew && m.alive) { /* env_hetero.py:198-214 */
+    if (c.agent_mode == HH_MODE_ESCAPE && c.esc_dist_rew) { /* wave-uniform: configuration */
+        if (running && agent && m.alive) { /* env_hetero.py:198-214 */
             Near2 nb;
             quad_nearby(c, tb, s, nb);
             const double dr[2] = {nb.r0, nb.r1};
@@ -801,10 +811,13 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                 }
             }
         }
-        if (m.alive || destroyed) {
-            if (c.glob_frac > 0.0 && c.agent_mode == HH_MODE_FIGHT) out.reward += rews + c.glob_frac * mate_rews;
-            else out.reward += rews;
-        }
+    }
+    {
+        const double shared = rews + c.glob_frac * mate_rews;
+        const double add = (c.glob_frac > 0.0 && c.agent_mode == HH_MODE_FIGHT) ? shared : rews;
+        const double nr = out.reward + add;
+        const bool give = running & agent & ((m.alive != 0) | (destroyed != 0));
+        out.reward = give ? nr : out.reward;
     }
     HH_PROF(8);
 }

@@ -275,6 +275,14 @@ __device__ __forceinline__ void quad_lowlevel_obs(const DevCfg &c, const QTab &t
     for (; n < D; n++) out[n] = 0.0f;
 }
 
+/* "does any lane of the wave want this?" as a scalar the compiler cannot fold back into the lanes' own test: a rare body then sits
+ * behind a uniform branch (~30 cycles when nobody wants it) instead of an exec-mask region (~55) */
+__device__ __forceinline__ bool q_any(bool x) {
+    unsigned long long b = __ballot(x);
+    asm volatile("" : "+s"(b));
+    return b != 0ULL;
+}
+
 /* ordering point between LDS accesses of ONE wave (the LDS unit executes a wave's instructions in order, so this
  * only has to stop the compiler from moving them and to drain the counter); the two-wave kernel below cannot use
  * __syncthreads() inside the simulation wave — that would be a workgroup barrier the output wave does not take */
@@ -311,8 +319,8 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
      * (tools/ubench/issue.hip) — more than a dozen instructions.  Short bodies are therefore written as selects on values computed
      * unconditionally (named locals first, so that the front end emits a select and not a branch), nested tests are merged into one
      * region, and rare bodies sit behind ONE wave-uniform ballot test.  Same expressions, same bits. */
-    if (snap) {
-        if (agent || c.ext_opp) {
+    {
+        if (snap & (agent | (c.ext_opp != 0))) {
             int t = m.n_tgt ? m.tgt0 : 0;
             if (!agent) { /* env_base.py:349-398 _policy_actions -> lowlevel_state(opp_mode, i): refresh target */
                 Near2 nb;
@@ -343,7 +351,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                 want_launch = gate ? 1 : want_launch;
                 launch_tgt = gate ? t - 1 : launch_tgt;
             }
-        } else if (c.level <= 2) { /* env_hetero.py:118-136 levels 1-2 */
+        } else if (snap && c.level <= 2) { /* env_hetero.py:118-136 levels 1-2 */
             if (c.level == 2) {
                 arm_cannon(m);
                 bool man = ar.steps <= 5;
@@ -368,12 +376,12 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         int esc = ar.escaping, esc_t = ar.escaping_time;
         bool my_escaping = false;
         const bool draw_tick = ar.steps % 60 == 0; /* one tick in sixty per arena: the draws sit behind a wave-uniform test */
+        const bool any_draw = q_any(draw_tick);
 #pragma unroll
         for (int j = 2; j < A; j++) {
             const bool aj = ((amask0 >> j) & 1) != 0;
-            const bool draws = aj & draw_tick & (esc == 0);
-            if (__ballot(draws)) {
-                if (draws) {
+            if (any_draw) { /* wave-uniform */
+                if (aj & draw_tick & (esc == 0)) {
                     esc = hh_rng_randint(d_rng(ar, j + 1, HH_SITE_L3_ESC_COIN, 0), 0, 1);
                     if (esc) esc_t = (int)hh_rng_uniform(d_rng(ar, j + 1, HH_SITE_L3_ESC_TIME, 0), 20.0, 30.0);
                 }
@@ -464,7 +472,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         }
         { /* ac1.py:117-128, rocket launched in an earlier step */
             const bool steer = (m.has_missile != 0) & (m.rk_alive != 0);
-            if (steer) m.rk_cmd = hh_clip(m.rk_hdg * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
+            if (q_any(steer)) if (steer) m.rk_cmd = hh_clip(m.rk_hdg * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
             m.has_missile = ((m.has_missile != 0) & (m.rk_alive == 0)) ? 0 : m.has_missile;
         }
     }
@@ -478,8 +486,9 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         if (any_rk) {
             r_lat = rk_pre ? m.rk_lat : lat_old; r_lon = rk_pre ? m.rk_lon : lon_old;
             r_hdg = rk_pre ? m.rk_hdg : hdg_old;
-            rk_ncmd = rk_pre ? m.rk_cmd
-                             : hh_clip(hdg_old * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
+            rk_ncmd = m.rk_cmd;
+            if (q_any(!rk_pre & rk_spec)) /* a launch in this tick: rare */
+                if (!rk_pre) rk_ncmd = hh_clip(hdg_old * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
             {
                 const double delta = d_signed_heading_diff(r_hdg, rk_ncmd);
                 const double stepped = r_hdg + (delta >= 0.0 ? HH_ROCKET_TURN_RATE : -HH_ROCKET_TURN_RATE);
@@ -609,7 +618,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     /* ---------------- phase L: launch bookkeeping (env_base.py:227-236, ac1.py:76-79) ---------------- */
     int launched = 0;
     const bool launch_now = try_launch & ((myres & 1) != 0);
-    if (__ballot(launch_now)) if (launch_now) {
+    if (q_any(launch_now)) if (launch_now) {
         launched = 1;
         m.rk_alive = 1; m.rk_lat = lat_old; m.rk_lon = lon_old; m.rk_hdg = hdg_old;
         m.rk_target = launch_tgt + 1; m.rk_life = 0;
@@ -618,7 +627,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         evm |= 1u << (24 + s);
         m.rk_cmd = rk_ncmd; /* the launcher's own update in this tick already steers it (ac1.py:127) */
     }
-    if (__ballot(base_gate)) if (base_gate) {
+    if (q_any(base_gate)) if (base_gate) {
         double uu = d_rng(ar, id, HH_SITE_MISSILE_WAIT, 0);
         m.missile_wait = hh_rng_randint(uu, 7, 17);
         if (agent && c.agent_mode == HH_MODE_ESCAPE && m.missile_remain < 3) out.reward -= 0.1;
@@ -660,7 +669,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         /* aircraft phase: shooter i (alive at tick start, even if killed earlier in this tick) hits the still-alive
          * targets in id order (ac1.py:106-115).  Most ticks nobody in the WAVE has a hit to apply. */
         const bool any_hit = ((aux_[0] | aux_[1] | aux_[2] | aux_[3]) >> 8) != 0;
-        if (__ballot(any_hit)) if (any_hit) {
+        if (q_any(any_hit)) if (any_hit) {
 #pragma unroll
             for (int i = 0; i < A; i++) {
                 const int ci = aux_[i] >> 8;
@@ -681,7 +690,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         for (int j = 0; j < A; j++) {
             if ((res_[j] & 1) && (res_[j] & 0xe)) { nact++; w1 = res_[j]; b1 = j; }
         }
-        if (__ballot(nact > 0)) {
+        if (q_any(nact > 0)) {
         if (nact == 1) {
             const int tg = (w1 >> 4) & 7;
             const int fid = b1 == 1 ? 0 : 1;
@@ -726,7 +735,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         }
         }
     }
-    if (running && rk_at_start) {
+    if (q_any(running & (rk_at_start != 0))) if (running && rk_at_start) {
         if ((dead >> s) & 1) {
             m.rk_alive = 0; m.rk_target = 0; m.rk_life = 0; m.rk_seq = 0;
             m.rk_lat = m.rk_lon = m.rk_hdg = m.rk_cmd = 0.0;
@@ -749,7 +758,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     double rews = 0.0;
     int destroyed = 0;
     /* kills and removals are rare: rewards and event masks behind one wave-uniform test (nothing below does anything without one) */
-    if (__ballot((nev > 0) | (oob != 0))) {
+    if (q_any((nev > 0) | (oob != 0))) {
     if (running && agent) {
         const double sc = c.rew_scale;
         if (oob) { rews += -5.0 * sc; destroyed = 1; }

@@ -891,10 +891,11 @@ template <> struct QuadMailbox<false> {};
 
 /* env_hetero.py:99-101: the observation also refreshes opp_to_attack; the simulation wave needs only that part */
 __device__ __forceinline__ void quad_target_refresh(const DevCfg &c, const QTab &t, int s, Unit &m) {
-    m.n_tgt = 0; m.tgt0 = 0; m.tgt_d0 = 0.0;
     Near2 nb;
     quad_nearby(c, t, s, nb);
-    if (m.alive && nb.n) { m.n_tgt = 1; m.tgt0 = nb.j0 + 1; m.tgt_d0 = nb.d0; }
+    const bool has = (m.alive != 0) & (nb.n != 0);
+    const int j1 = nb.j0 + 1;
+    m.n_tgt = has ? 1 : 0; m.tgt0 = has ? j1 : 0; m.tgt_d0 = has ? nb.d0 : 0.0;
 }
 
 /* PRE = preset: the reference's default training configuration (config.py:17-54: scripted opponents, friendly fire on, no friendly
@@ -1033,10 +1034,11 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         {
             const double rv = so.valid ? so.reward : 0.0;
             const double r0 = q_bc_d<0>(rv), r1 = q_bc_d<1>(rv);
-            if (was_running) {
-                ep_ret += r0;
-                ep_ret += r1;
-                if (ar.done && s == 0) {
+            {
+                const double e2 = (ep_ret + r0) + r1;
+                ep_ret = was_running ? e2 : ep_ret;
+                const bool fin = was_running & (ar.done != 0) & (s == 0);
+                if (q_any(fin)) if (fin) { /* an episode ended: rare */
                     const int ag = __popc(tb.amask & 3), op = __popc(tb.amask & 12);
                     P.last_ret[n] = (float)ep_ret;
                     P.last_len[n] = ar.steps;
@@ -1046,7 +1048,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         }
         if (!TWO && active && s == 0 && done_out) done_out[(size_t)t * c.N + n] = (uint8_t)ar.done;
         const bool need_reset = active && ar.done && c.auto_reset;
-        if (__ballot(need_reset)) { /* K3, wave-uniform */
+        if (q_any(need_reset)) { /* K3, wave-uniform */
             if (need_reset) {
                 reset_arena_scalars(ar);
                 reset_unit<A>(c, s, m, ar);
@@ -1061,7 +1063,12 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         HH_PROF(9);
         if constexpr (TWO) {
             /* hand the agents' rows to the output wave and go on */
-            if (active && s < 2) quad_target_refresh(c, tb, s, m);
+            { /* straight-line on every lane, kept by the agents' */
+                Unit mr = m;
+                quad_target_refresh(c, tb, s, mr);
+                const bool keep = active & (s < 2);
+                m.n_tgt = keep ? mr.n_tgt : m.n_tgt; m.tgt0 = keep ? mr.tgt0 : m.tgt0; m.tgt_d0 = keep ? mr.tgt_d0 : m.tgt_d0;
+            }
             __syncthreads(); /* the one workgroup barrier of the tick */
             HH_PROF(10);
             continue;

@@ -44,7 +44,18 @@ HH_HD double hh_rint(double x) { return __builtin_rint(x); } /* ties-to-even, li
 HH_HD double hh_copysign(double x, double y) { return __builtin_copysign(x, y); }
 HH_HD double hh_min(double a, double b) { return a < b ? a : b; }
 HH_HD double hh_max(double a, double b) { return a > b ? a : b; }
-HH_HD double hh_clip(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+/* clip(x, lo, hi), lo <= hi, as max then min: one v_max_f64 + one v_min_f64 on the GPU (a single clamped instruction for [0, 1])
+ * instead of two compares and four selects.  The host form picks the same operand in every case the device instructions do —
+ * NaN -> lo, -0.0 against a +0.0 bound -> the bound — so both sides still produce the same bits; against numpy.clip the only
+ * difference is the sign of a zero result (and NaN, which the step never produces). */
+#if defined(__HIP_DEVICE_COMPILE__)
+HH_HD double hh_clip(double x, double lo, double hi) { return __builtin_fmin(__builtin_fmax(x, lo), hi); }
+#else
+HH_HD double hh_clip(double x, double lo, double hi) {
+    const double y = x > lo ? x : lo;
+    return y < hi ? y : hi;
+}
+#endif
 /* hypot without scaling: operands here are O(1e-4..1e2), no overflow/underflow risk */
 HH_HD double hh_hypot(double x, double y) { return hh_sqrt(x * x + y * y); }
 

@@ -242,6 +242,14 @@ struct OctShared {
 };
 
 __device__ __forceinline__ void o_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+/* any lane of the wave, as a scalar the compiler cannot fold back into the lanes' own test (q_any of hh_kernels_quad.h; control-flow
+ * notes there: a region under the exec mask costs ~45 - 55 cycles at one wave per SIMD, so short bodies are selects and rare bodies
+ * sit behind a uniform branch) */
+__device__ __forceinline__ bool o_any(bool x) {
+    unsigned long long b = __ballot(x);
+    asm volatile("" : "+s"(b));
+    return b != 0ULL;
+}
 
 /* env_base.py:400-422 _nearby_object from the register table: live units of the other side (friendly = false) or the own
  * side, stable-sorted by normalised distance (ties keep id order).  Near3's ids are RELATIONS here. */
@@ -408,17 +416,17 @@ __device__ __forceinline__ void act_oct(const DevCfg &c, OctShared &sh, int tid,
         const double mx = HH_AC_MAX_SPEED(m.ac_type);
         m.cmd_spd = 100.0 + ((mx - 100.0) / 8.0) * (double)act[1];
         if (act[2] && m.cannon_remain > 0) arm_cannon(m);
-        if (m.ac_type == 1 && act[3]) {
-            if (t && m.missile_remain > 0 && !m.has_missile && m.missile_wait == 0) {
-                base_gate = true;
-                want_launch = 1;
-                launch_pos = o_slot_pos(c, t - 1);
-            }
+        {
+            const bool gate = (m.ac_type == 1) & (act[3] != 0) & (t != 0) & (m.missile_remain > 0) & (m.has_missile == 0) & (m.missile_wait == 0);
+            const int lp = o_slot_pos(c, t ? t - 1 : 0);
+            base_gate = gate;
+            want_launch = gate ? 1 : 0;
+            launch_pos = gate ? lp : 0;
         }
     }
     const bool try_launch = want_launch && !m.has_missile && m.missile_remain > 0;
     int launch_pre = -1;
-    if (try_launch) { /* planar stage of the launch predicate (hh_envelope.h) */
+    if (o_any(try_launch)) if (try_launch) { /* planar stage of the launch predicate (hh_envelope.h) */
         const int r = o_pos_rel(L, launch_pos);
         const double t_lat = o_sel5(tb.lat, r), t_lon = o_sel5(tb.lon, r);
         double foc, dist;
@@ -440,7 +448,8 @@ __device__ __forceinline__ void act_oct(const DevCfg &c, OctShared &sh, int tid,
         myres = sh.res[tid];
     }
     int launched = 0;
-    if (try_launch && ((myres & 1) || launch_pre == 1)) { /* ac1.py:76-79 */
+    const bool launch_now = try_launch & (((myres & 1) != 0) | (launch_pre == 1));
+    if (o_any(launch_now)) if (launch_now) { /* ac1.py:76-79 */
         launched = 1;
         m.rk_alive = 1; m.rk_lat = m.lat; m.rk_lon = m.lon; m.rk_hdg = m.hdg; m.rk_cmd = m.hdg;
         m.rk_target = o_pos_slot(c, launch_pos) + 1; m.rk_life = 0;
@@ -448,13 +457,16 @@ __device__ __forceinline__ void act_oct(const DevCfg &c, OctShared &sh, int tid,
         m.missile_remain = m.missile_remain - 1 > 0 ? m.missile_remain - 1 : 0;
         evm |= 1u << (24 + L.s);
     }
-    if (base_gate) m.missile_wait = hh_rng_randint(d_rng(ar, id, HH_SITE_MISSILE_WAIT, 0), 8, 12);
-    if (snap) {
-        if (m.missile_wait > 0 && !m.has_missile) m.missile_wait -= 1;
+    if (o_any(base_gate)) if (base_gate) m.missile_wait = hh_rng_randint(d_rng(ar, id, HH_SITE_MISSILE_WAIT, 0), 8, 12);
+    {
+        const bool dec = snap & (m.missile_wait > 0) & (m.has_missile == 0);
+        const int w1 = m.missile_wait - 1;
+        m.missile_wait = dec ? w1 : m.missile_wait;
     }
     {   /* rocket ids in unit id order (cmano_simulator.py:104-108) */
         const int lb = oct_arena_bits(__ballot(launched != 0), L);
-        if (launched) m.rk_seq = ar.next_seq + __popc(lb & ((1 << L.p) - 1)) + 1;
+        const int sq = ar.next_seq + __popc(lb & ((1 << L.p) - 1)) + 1;
+        m.rk_seq = launched ? sq : m.rk_seq;
         ar.next_seq += __popc(lb);
     }
     oct_publish_flags(m, pub); /* weapon flags other lanes observe (env_base.py:208-211) */
@@ -481,27 +493,32 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
     const int rk_pre = m.rk_alive;
     if (snap) {
         const int t = m.ac_type;
-        if (m.hdg != m.cmd_hdg) {
+        {
             const double delta = d_signed_heading_diff(m.hdg, m.cmd_hdg);
             const double max_deg = HH_AC_TURN_RATE(t) * 1.0;
-            if (hh_fabs(delta) <= max_deg) m.hdg = m.cmd_hdg;
-            else { m.hdg += delta >= 0.0 ? max_deg : -max_deg; m.hdg = hh_pymod360(m.hdg); }
+            const double stepped = hh_pymod360(m.hdg + (delta >= 0.0 ? max_deg : -max_deg));
+            const double nh = hh_fabs(delta) <= max_deg ? m.cmd_hdg : stepped;
+            m.hdg = m.hdg != m.cmd_hdg ? nh : m.hdg;
         }
-        if (m.spd != m.cmd_spd) {
+        {
             const double delta = m.cmd_spd - m.spd;
             const double max_delta = HH_AC_ACCEL(t) * 1.0;
-            if (hh_fabs(delta) <= max_delta) m.spd = m.cmd_spd;
-            else m.spd += delta >= 0.0 ? max_delta : -max_delta;
+            const double stepped = m.spd + (delta >= 0.0 ? max_delta : -max_delta);
+            const double ns = hh_fabs(delta) <= max_delta ? m.cmd_spd : stepped;
+            m.spd = m.spd != m.cmd_spd ? ns : m.spd;
         }
-        if (m.burst > 0) {
-            fired = true;
-            m.burst = m.burst - 1 > 0 ? m.burst - 1 : 0;
-            m.cannon_remain = m.cannon_remain - 1 > 0 ? m.cannon_remain - 1 : 0;
+        {
+            const bool f = m.burst > 0;
+            const int b1 = m.burst - 1 > 0 ? m.burst - 1 : 0, c1 = m.cannon_remain - 1 > 0 ? m.cannon_remain - 1 : 0;
+            fired = f;
+            m.burst = f ? b1 : m.burst;
+            m.cannon_remain = f ? c1 : m.cannon_remain;
         }
-        if (m.has_missile) { /* ac1.py:117-128 */
-            if (!m.rk_alive) m.has_missile = 0;
-            else m.rk_cmd = hh_clip(m.rk_hdg * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
-        }
+    }
+    { /* ac1.py:117-128 */
+        const bool steer = snap & (m.has_missile != 0) & (m.rk_alive != 0);
+        if (o_any(steer)) if (steer) m.rk_cmd = hh_clip(m.rk_hdg * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
+        m.has_missile = (snap & (m.has_missile != 0) & (m.rk_alive == 0)) ? 0 : m.has_missile;
     }
     const bool rk_spec = running && L.exists && rk_pre && m.rk_life <= HH_ROCKET_MAX_LIFE;
     double rk_nlat = 0.0, rk_nlon = 0.0, rk_nhdg = 0.0;
@@ -511,10 +528,11 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
         if (any_rk) {
             double r_hdg = m.rk_hdg;
             const double r_cmd = m.rk_cmd;
-            if (r_hdg != r_cmd) {
+            {
                 const double delta = d_signed_heading_diff(r_hdg, r_cmd);
-                if (hh_fabs(delta) <= HH_ROCKET_TURN_RATE) r_hdg = r_cmd;
-                else r_hdg += delta >= 0.0 ? HH_ROCKET_TURN_RATE : -HH_ROCKET_TURN_RATE;
+                const double stepped = r_hdg + (delta >= 0.0 ? HH_ROCKET_TURN_RATE : -HH_ROCKET_TURN_RATE);
+                const double nh = hh_fabs(delta) <= HH_ROCKET_TURN_RATE ? r_cmd : stepped;
+                r_hdg = r_hdg != r_cmd ? nh : r_hdg;
             }
             rk_nhdg = r_hdg;
             double a_lat, a_lon;
@@ -539,6 +557,7 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
     int q_total = 0;
     {
         const int t = m.ac_type;
+        int push[5], pjs[5], any_push = 0;
 #pragma unroll
         for (int r = 0; r < 5; r++) {
             const int pj = o_rel_pos(L, r);
@@ -547,11 +566,16 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
             const bool lower = pj < L.p; /* target already moved iff its id is lower (cmano_simulator.py:142) */
             const double tl = lower ? lat1[r] : tb.lat[r];
             const double to = lower ? lon1[r] : tb.lon[r];
-            HH_O_PUSH(fired && snap_j && (c.friendly_kill || enemy) && d_maybe_within_km(lat_old, lon_old, tl, to, HH_AC_CANNON_KM(t)) &&
-                          !hh_cannon_cone_planar_outside(lat_old, lon_old, tl, to, pn.uc, pn.us, t),
-                      tid | (1 << 8) | (pj << 10));
+            push[r] = (int)fired & (int)snap_j & ((int)(c.friendly_kill != 0) | (int)enemy) & (int)d_maybe_within_km(lat_old, lon_old, tl, to, HH_AC_CANNON_KM(t)) &
+                      (int)!hh_cannon_cone_planar_outside(lat_old, lon_old, tl, to, pn.uc, pn.us, t);
+            pjs[r] = pj;
+            any_push |= push[r];
         }
-        if (__ballot(rk_maybe)) { /* wave-uniform */
+        if (o_any(any_push != 0)) {
+#pragma unroll
+            for (int r = 0; r < 5; r++) HH_O_PUSH(push[r] != 0, tid | (1 << 8) | (pjs[r] << 10));
+        }
+        if (o_any(rk_maybe)) { /* wave-uniform */
             const int tp = rk_maybe ? o_slot_pos(c, m.rk_target - 1) : ((1 - L.q) << 2);
             const int rt = o_pos_rel(L, tp);
             HH_O_PUSH(rk_maybe && d_maybe_within_km(rk0_lat, rk0_lon, o_sel5(lat1, rt), o_sel5(lon1, rt), HH_ROCKET_FUSE_KM), tid | (2 << 8) | (tp << 10));
@@ -642,7 +666,7 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
             }
         }
     }
-    if (running && L.exists && rk_at_start) {
+    if (o_any(running & L.exists & (rk_at_start != 0))) if (running && L.exists && rk_at_start) {
         if ((dead >> L.p) & 1) {
             m.rk_alive = 0; m.rk_target = 0; m.rk_life = 0; m.rk_seq = 0;
             m.rk_lat = m.rk_lon = m.rk_hdg = m.rk_cmd = 0.0;
@@ -654,16 +678,16 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
 
     /* ---------------- phase E: out of bounds, rewards (env_base.py:240-310) ---------------- */
     int oob = 0;
-    if (L.exists) {
-        m.alive = (alive >> L.p) & 1;
-        if (running && m.alive) {
-            const bool inb = HH_MAP_LON0 <= m.lon && m.lon <= c.lon_hi && HH_MAP_LAT0 <= m.lat && m.lat <= c.lat_hi;
-            if (!inb) { m.alive = 0; oob = 1; }
-        }
+    {
+        const int al = (alive >> L.p) & 1;
+        const bool inb = (HH_MAP_LON0 <= m.lon) & (m.lon <= c.lon_hi) & (HH_MAP_LAT0 <= m.lat) & (m.lat <= c.lat_hi);
+        oob = (L.exists & running & (al != 0) & !inb) ? 1 : 0;
+        m.alive = L.exists ? (oob ? 0 : al) : m.alive;
     }
     const int oobm = oct_arena_bits(__ballot(oob != 0), L);
     double rews = 0.0;
     int destroyed = 0;
+    if (o_any((nev > 0) | (oob != 0))) { /* kills and removals are rare */
     if (running && L.exists && agent) {
         const double sc = c.rew_scale;
         if (oob) { rews += -2.0 * sc; destroyed = 1; }
@@ -683,6 +707,7 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
         evm |= ((w >> 6) & 1) ? (1u << (8 + ds)) : (1u << ds);
     }
     if (oob) evm |= 1u << (16 + s);
+    }
     ev_mask_out = evm;
     /* post-tick state */
     oct_publish_flags(m, pn);
@@ -693,22 +718,25 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
         for (int r = 0; r < 5; r++) { tb.lat[r] = lat1[r]; tb.lon[r] = lon1[r]; }
         tb.amask = oct_arena_bits(__ballot(m.alive != 0), L);
     }
-    if (running) out.kill_event = nev > 0 || oobm != 0;
+    {
+        const int ke = ((nev > 0) | (oobm != 0)) ? 1 : 0;
+        out.kill_event = running ? ke : out.kill_event;
+    }
     double r0 = 0.0, r1 = 0.0, r2 = 0.0;
     if (c.glob_frac > 0.0) { r0 = o_qbc_d<0>(rews); r1 = o_qbc_d<1>(rews); r2 = o_qbc_d<2>(rews); } /* uniform: the agents' quad */
-    if (running && L.exists && agent) {
-        if (m.alive || destroyed) {
-            if (c.glob_frac > 0.0) {
-                /* env_base.py:268-276 shared reward: the other agents' event rewards in id order */
-                double other = 0.0;
-                if (0 < c.nA && L.i != 0) other += r0;
-                if (1 < c.nA && L.i != 1) other += r1;
-                if (2 < c.nA && L.i != 2) other += r2;
-                out.reward += rews + c.glob_frac * other;
-            } else {
-                out.reward += rews;
-            }
+    {
+        double add = rews;
+        if (c.glob_frac > 0.0) { /* wave-uniform: configuration */
+            /* env_base.py:268-276 shared reward: the other agents' event rewards in id order */
+            double other = 0.0;
+            if (0 < c.nA && L.i != 0) other += r0;
+            if (1 < c.nA && L.i != 1) other += r1;
+            if (2 < c.nA && L.i != 2) other += r2;
+            add = rews + c.glob_frac * other;
         }
+        const double nr = out.reward + add;
+        const bool give = running & L.exists & agent & ((m.alive != 0) | (destroyed != 0));
+        out.reward = give ? nr : out.reward;
     }
 }
 

@@ -292,8 +292,10 @@ __device__ __forceinline__ void q_wave_sync() { asm volatile("s_waitcnt lgkmcnt(
  * table on return.  Line-by-line counterpart of tick<4, 64>(tmode 0) in hh_kernels.h. */
 template <bool IX, bool DUAL>
 __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, int tid, int g, int s, int base, bool active, bool helper, Unit &m,
-                                          Arena &ar, const int8_t *act, QTab &tb, QPub &pub, StepOut &out,
+                                          Arena &ar, const int8_t *act, QTab &tb, QPub &pub, Near2 &nbc, StepOut &out,
                                           uint32_t &ev_mask_out HH_PROF_ARGS) {
+    /* nbc: _nearby_object of the lane against `tb` — the pre-tick table on entry (what the scripts and the target refresh of this tick
+     * read), the post-tick table on return: computed once per tick, straight-line on every lane, instead of once per reader */
     constexpr int A = 4;
     const int id = s + 1;
     const bool running = active && !ar.done;
@@ -323,8 +325,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         if (snap & (agent | (c.ext_opp != 0))) {
             int t = m.n_tgt ? m.tgt0 : 0;
             if (!agent) { /* env_base.py:349-398 _policy_actions -> lowlevel_state(opp_mode, i): refresh target */
-                Near2 nb;
-                quad_nearby(c, tb, s, nb);
+                const Near2 nb = nbc;
                 m.n_tgt = nb.n ? 1 : 0; m.tgt0 = nb.n ? nb.j0 + 1 : 0; m.tgt_d0 = nb.n ? nb.d0 : 0.0;
                 t = m.tgt0;
             }
@@ -364,8 +365,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
             }
             if (!m.has_missile && (ar.steps % 40) < 3 && hh_rng_randint(d_rng(ar, id, HH_SITE_L12_COIN, 0), 0, 1) &&
                 m.missile_wait == 0 && m.ac_type == 1) {
-                Near2 nb;
-                quad_nearby(c, tb, s, nb);
+                const Near2 nb = nbc;
                 if (nb.n) { want_launch = 1; launch_tgt = nb.j0; wait_after = 5; }
             }
         }
@@ -406,8 +406,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                 speed = (double)(int)hh_rng_uniform(d_rng(ar, id, HH_SITE_ESC_SPEED, 0), 300.0, 600.0);
                 fire = hh_rng_randint(d_rng(ar, id, HH_SITE_ESC_FIRE, 0), 0, 1);
             } else { /* env_hetero.py:247-271 _hardcoded_opp */
-                Near2 nb;
-                quad_nearby(c, tb, s, nb);
+                const Near2 nb = nbc;
                 heading = m.hdg;
                 speed = (double)(int)hh_rng_uniform(d_rng(ar, id, HH_SITE_HC_SPEED1, 0), 100.0, 400.0);
                 if (nb.n) {
@@ -799,6 +798,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     pub = pn;
     HH_PROF(6);
     quad_tables<DUAL>(m, pub, s, helper, tb);
+    quad_nearby(c, tb, s, nbc);
     HH_PROF(7);
     {
         const int ag = __popc(tb.amask & 3), op = __popc(tb.amask & 12);
@@ -809,8 +809,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     }
     if (c.agent_mode == HH_MODE_ESCAPE && c.esc_dist_rew) { /* wave-uniform: configuration */
         if (running && agent && m.alive) { /* env_hetero.py:198-214 */
-            Near2 nb;
-            quad_nearby(c, tb, s, nb);
+            const Near2 nb = nbc;
             const double dr[2] = {nb.r0, nb.r1};
 #pragma unroll
             for (int j = 1; j <= 2; j++) {
@@ -890,9 +889,7 @@ template <bool TWO> struct QuadMailbox { /* LDS of the two-wave form only */
 template <> struct QuadMailbox<false> {};
 
 /* env_hetero.py:99-101: the observation also refreshes opp_to_attack; the simulation wave needs only that part */
-__device__ __forceinline__ void quad_target_refresh(const DevCfg &c, const QTab &t, int s, Unit &m) {
-    Near2 nb;
-    quad_nearby(c, t, s, nb);
+__device__ __forceinline__ void quad_target_refresh(const Near2 &nb, Unit &m) {
     const bool has = (m.alive != 0) & (nb.n != 0);
     const int j1 = nb.j0 + 1;
     m.n_tgt = has ? 1 : 0; m.tgt0 = has ? j1 : 0; m.tgt_d0 = has ? nb.d0 : 0.0;
@@ -1000,8 +997,10 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
     }
     QPub pub;
     QTab tb;
+    Near2 nbc;
     quad_publish(c, m, pub);
     quad_tables<DUAL>(m, pub, s, helper, tb);
+    quad_nearby(c, tb, s, nbc);
     /* Action words: vmcnt is one in-order counter for loads AND stores, so waiting for a load also waits for the
      * write acknowledgements of every store issued before it.  The word of tick t+1 is therefore taken (waited
      * for) right after tick t's compute and BEFORE tick t's output stores, when the load is a whole tick old and
@@ -1017,7 +1016,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         int8_t act[4];
         act[0] = (int8_t)(act_cur & 0xff); act[1] = (int8_t)((act_cur >> 8) & 0xff); act[2] = (int8_t)((act_cur >> 16) & 0xff); act[3] = (int8_t)((act_cur >> 24) & 0xff);
         const bool was_running = active && !ar.done;
-        tick_quad<(W >= 2), DUAL>(c, sh, tid, g, s, base, active, helper, m, ar, act, tb, pub, so, evm_last HH_PROF_PASS);
+        tick_quad<(W >= 2), DUAL>(c, sh, tid, g, s, base, active, helper, m, ar, act, tb, pub, nbc, so, evm_last HH_PROF_PASS);
         const int done_now = ar.done;
         if constexpr (TWO) { /* post the agents' rows as early as they exist: the LDS stores drain behind the work below */
             if (!helper && s < 2) mail_post(mbx.mail[t & 1], g * 2 + s, tb, pub, m, so, done_now);
@@ -1056,6 +1055,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
             }
             quad_publish(c, m, pub);
             quad_tables<DUAL>(m, pub, s, helper, tb);
+            quad_nearby(c, tb, s, nbc);
             if constexpr (TWO) { /* the first observation of the new episode replaces the posted rows */
                 if (!helper && s < 2) mail_post(mbx.mail[t & 1], g * 2 + s, tb, pub, m, so, done_now);
             }
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
             /* hand the agents' rows to the output wave and go on */
             { /* straight-line on every lane, kept by the agents' */
                 Unit mr = m;
-                quad_target_refresh(c, tb, s, mr);
+                quad_target_refresh(nbc, mr);
                 const bool keep = active & (s < 2);
                 m.n_tgt = keep ? mr.n_tgt : m.n_tgt; m.tgt0 = keep ? mr.tgt0 : m.tgt0; m.tgt_d0 = keep ? mr.tgt_d0 : m.tgt_d0;
             }

@@ -687,6 +687,40 @@ extern "C" int hh_gae_rllib(int32_t T, int32_t N, int32_t n_agents, const float 
     return HH_OK;
 }
 
+/* hh_math_eval: the shared math headers on the device (test probe, include/hh_abi.h) */
+__global__ void hh_k_math_eval(int fn, int n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ o0, double *__restrict__ o1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = a[i], y = b ? b[i] : 0.0;
+    double r0 = 0.0, r1 = 0.0;
+    switch (fn) {
+        case 0: hh_sincos(x, &r0, &r1); break;
+        case 1: r0 = hh_atan2(x, y); break;
+        case 2: r0 = hh_acos(x); break;
+        case 3: hh_sincosd(x, &r0, &r1); break;
+        case 4: r0 = hh_atan2d(x, y); break;
+        case 5: r0 = hh_pymod(x, y); break;
+        case 6: r0 = hh_remainder(x, y); break;
+        case 7: r0 = hh_fmod(x, y); break;
+        case 8: r0 = hh_round3(x); break;
+        case 9: r0 = hh_div_known(x, y, 1.0 / y); break;
+        case 10: r0 = hh_pymod_turn(x, y); break;
+        case 11: r0 = hh_sqrt(x); break;
+        case 12: r0 = hh_clip(x, 0.0, 1.0); break;
+        case 13: r0 = hh_clip(x, -y, y); break;
+        case 14: d_geo_move(x, y, o0[i], o1[i], r0, r1); break;
+        default: break;
+    }
+    o0[i] = r0;
+    if (o1) o1[i] = r1;
+}
+extern "C" int hh_math_eval(int32_t fn, int32_t n, const double *a, const double *b, double *o0, double *o1, void *stream) {
+    if (fn < 0 || fn > 14 || n <= 0 || !a || !o0 || (fn == 14 && (!b || !o1))) { g_err = "hh_math_eval: bad argument"; return HH_E_ARG; }
+    hipLaunchKernelGGL(hh_k_math_eval, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, fn, n, a, b, o0, o1);
+    HIPCHK(hipGetLastError());
+    return HH_OK;
+}
+
 /* commander_actions after _action_assess expanded them (agents: validated action, opponents: drawn fight target /
  * escape; env_hier.py:142-190) — what evaluation.py's eval_info counters read (env_base.py:91-107) */
 extern "C" int hh_hl_commands(hh_world *w, int8_t *out /* [host] [N, A] */) {

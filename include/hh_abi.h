@@ -220,6 +220,14 @@ int hh_gae(int32_t T, int32_t N, int32_t n_agents, const float *reward, const fl
 int hh_gae_rllib(int32_t T, int32_t N, int32_t n_agents, const float *reward, const float *value, const uint8_t *done, double gamma,
                  double lam, float *adv, float *ret, void *stream);
 
+/* Test probe: the shared math of include/hh_math.h / hh_geodesic.h evaluated ON THE DEVICE over arrays of operands, so that a
+ * -m gpu test can compare the kernels' arithmetic with the CPU oracle's bit for bit (tests/test_gpu_math.py), not only through
+ * trajectories.  fn: 0 sincos(a) -> o0, o1 | 1 atan2(a, b) | 2 acos(a) | 3 sincosd(a) -> o0, o1 | 4 atan2d(a, b) | 5 pymod(a, b) |
+ * 6 remainder(a, b) | 7 fmod(a, b) | 8 round3(a) | 9 a / b by hh_div_known | 10 pymod_turn(a, b) | 11 sqrt(a) | 12 clip(a, 0, 1) |
+ * 13 clip(a, -b, b) | 14 geo_move(lat = a, lon = b, azi = o0_in, s = o1_in) -> o0, o1 (the outputs carry the third and fourth
+ * operand in).  a, b, o0, o1: device arrays of n doubles. */
+int hh_math_eval(int32_t fn, int32_t n, const double *a, const double *b, double *o0, double *o1, void *stream);
+
 /* host snapshot in / out (synchronises the stream) */
 int hh_get_state(hh_world *w, hh_state_view *view);
 int hh_set_state(hh_world *w, const hh_state_view *view);

@@ -36,7 +36,27 @@
 
 /* ---- primitives that map to single correctly-rounded instructions on both targets ---- */
 HH_HD double hh_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+/* sqrt: the host's instruction is correctly rounded.  On gfx950 there is no such instruction and the compiler expands the operator
+ * into v_rsq_f64 + a Goldschmidt / Newton sequence that IS correctly rounded, wrapped in a rescaling for operands below 2^-767 (two
+ * compares, two ldexp, two selects) that no operand of the step can need: squares of sines and cosines, squared separations in
+ * degrees (zero, or >= 1e-32) and 1 - e^2 sin^2.  The device form is that same sequence without the rescaling — identical bits for
+ * x = 0, x = +inf and x >= 2^-767, seven instructions fewer per root (tests/test_gpu_math.py compares it with the host on the GPU). */
+#if defined(__HIP_DEVICE_COMPILE__)
+HH_HD double hh_sqrt(double x) /* x = 0 or x >= 2^-767 */ {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d0 = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d0, h, g);
+    const double d1 = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d1, h, g);
+    return ((x == 0.0) | (x == __builtin_inf())) ? x : g;
+}
+#else
 HH_HD double hh_sqrt(double x) { return __builtin_sqrt(x); }
+#endif
 HH_HD double hh_fabs(double x) { return __builtin_fabs(x); }
 HH_HD double hh_floor(double x) { return __builtin_floor(x); }
 HH_HD double hh_trunc(double x) { return __builtin_trunc(x); }
@@ -371,7 +391,8 @@ HH_HD double hh_ang_diff(double x, double y, double *e) {
 HH_HD double hh_round3(double x) {
     double y = x * 1000.0;
     double z = hh_rint(y);
-    return z / 1000.0;
+    return HH_DIVC(z, 1000.0); /* = z / 1000.0 for every integer the callers reach (sines and cosines: |z| <= 1000; tests/test_math.py
+                                * checks |z| <= 10^6): three multiply-adds instead of an IEEE division */
 }
 
 #endif /* HH_MATH_H */

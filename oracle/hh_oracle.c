@@ -1438,6 +1438,9 @@ API void hho_math_eval(int fn, int n, const double *a, const double *b, double *
             case 8: o0[i] = hh_round3(a[i]); break;
             case 9: o0[i] = hh_div_known(a[i], b[i], 1.0 / b[i]); break;
             case 10: o0[i] = hh_pymod_turn(a[i], b[i]); break;
+            case 11: o0[i] = hh_sqrt(a[i]); break;
+            case 12: o0[i] = hh_clip(a[i], 0.0, 1.0); break;
+            case 13: o0[i] = hh_clip(a[i], -b[i], b[i]); break;
             default: break;
         }
     }

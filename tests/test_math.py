@@ -75,6 +75,11 @@ def test_modulo_family_exact(oracle):
     assert np.array_equal(oracle.math_eval(6, t, np.full(5, 360.0))[0], np.array([math.remainder(u, 360.0) for u in t]))
 
 
+def test_round3_quotient_is_the_division(oracle):
+    z = np.arange(-10 ** 6, 10 ** 6 + 1, dtype=np.float64)   # hh_round3 divides the rounded integer by 1000 with hh_div_known
+    assert np.array_equal(oracle.math_eval(9, z, np.full(z.size, 1000.0))[0], z / 1000.0)
+
+
 def test_round3(oracle):
     rng = np.random.default_rng(5)
     x = rng.uniform(-1, 1, 20000)

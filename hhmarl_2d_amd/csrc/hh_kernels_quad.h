@@ -372,9 +372,10 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     }
     HH_PROF(11);
     /* env_hetero.py:138-158 level 3: the arena-level escape flag, consumed once per live opponent in id order */
+    bool my_escaping = false;
+    bool escj[2] = {false, false}; /* the flag as opponent slot 2 / 3 consumes it (every lane of the arena computes both) */
     if (running && !c.ext_opp && c.level >= 3) {
         int esc = ar.escaping, esc_t = ar.escaping_time;
-        bool my_escaping = false;
         const bool draw_tick = ar.steps % 60 == 0; /* one tick in sixty per arena: the draws sit behind a wave-uniform test */
         const bool any_draw = q_any(draw_tick);
 #pragma unroll
@@ -388,27 +389,57 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
             }
             const bool mine = aj & (j == s), upd = aj & (esc != 0);
             my_escaping = mine ? (esc != 0) : my_escaping;
+            escj[j - 2] = aj & (esc != 0);
             const int esc_t1 = esc_t - 1;
             esc_t = upd ? esc_t1 : esc_t;
             esc = (upd & (esc_t <= 0)) ? 0 : esc;
         }
         ar.escaping = esc;
         ar.escaping_time = esc_t;
+    }
+    double u0 = 0.0, u1 = 0.0, u2 = 0.0;
+    if (!c.ext_opp && c.level >= 3) { /* wave-uniform (configuration): every lane, the helpers included, takes part in the exchange */
+        /* The three uniform draws of an opponent's script (escaping: heading, speed, fire; otherwise: speed, turn factor, second speed)
+         * are the same ~45 instructions with different site keys, and while the opponents' lanes run their script the agents' lanes
+         * and the helper lanes idle: so ONE pass over the mixer computes all three side by side — draw 0 on the opponent's own lane,
+         * draw 1 on the agent lane two slots below, draw 2 on the opponent's helper lane (small-world form; otherwise a second
+         * pass) — and three lane moves hand them over.  Keyed draws: the values are those of the sequential form. */
+        {
+            const int du = (s | 2) + 1;                           /* unit id of the opponent this lane draws for */
+            const bool desc = (s & 1) ? escj[1] : escj[0];
+            uint64_t key = ar.tkey;
+            int role = agent ? 1 : 0, de = desc ? 1 : 0;
+            if (DUAL) {
+                const int klo = q_down_i((int)(uint32_t)key), khi = q_down_i((int)(uint32_t)(key >> 32)), deh = q_down_i(de);
+                key = helper ? (((uint64_t)(uint32_t)khi << 32) | (uint64_t)(uint32_t)klo) : key;
+                de = helper ? deh : de;
+                role = helper ? 2 : role;
+            }
+            const int site_e = role == 0 ? HH_SITE_ESC_HDG : (role == 1 ? HH_SITE_ESC_SPEED : HH_SITE_ESC_FIRE);
+            const int site_h = role == 0 ? HH_SITE_HC_SPEED1 : (role == 1 ? HH_SITE_HC_R : HH_SITE_HC_SPEED2);
+            const double u = hh_rng_u01(key, (uint32_t)du, (uint32_t)(de ? site_e : site_h), 0u);
+            u0 = u;
+            u1 = q_perm_d<HH_QP(0, 1, 0, 1)>(u); /* slot 2 <- slot 0, slot 3 <- slot 1 */
+            if (DUAL) u2 = q_up_d(u);
+            else u2 = hh_rng_u01(ar.tkey, (uint32_t)id, (uint32_t)(my_escaping ? HH_SITE_ESC_FIRE : HH_SITE_HC_SPEED2), 0u);
+        }
+    }
+    if (running && !c.ext_opp && c.level >= 3) {
         if (snap && !agent) {
             int opp = -1, fire = 0, fire_m = 0;
             double heading, speed;
             if (my_escaping) { /* env_hetero.py:227-245 _escaping_opp */
                 double y = hh_clip(hh_div_known(m.lat - HH_MAP_LAT0, c.ext_lat, c.inv_ext_lat), 0.0, 1.0);
                 double x = hh_clip(hh_div_known(m.lon - HH_MAP_LON0, c.ext_lon, c.inv_ext_lon), 0.0, 1.0);
-                double uh = d_rng(ar, id, HH_SITE_ESC_HDG, 0);
+                double uh = u0;
                 double lo_h = y < 0.5 ? (x < 0.5 ? 30.0 : 300.0) : (x < 0.5 ? 120.0 : 210.0);
                 heading = (double)(int)hh_rng_uniform(uh, lo_h, lo_h + 30.0);
-                speed = (double)(int)hh_rng_uniform(d_rng(ar, id, HH_SITE_ESC_SPEED, 0), 300.0, 600.0);
-                fire = hh_rng_randint(d_rng(ar, id, HH_SITE_ESC_FIRE, 0), 0, 1);
+                speed = (double)(int)hh_rng_uniform(u1, 300.0, 600.0);
+                fire = hh_rng_randint(u2, 0, 1);
             } else { /* env_hetero.py:247-271 _hardcoded_opp */
                 const Near2 nb = nbc;
                 heading = m.hdg;
-                speed = (double)(int)hh_rng_uniform(d_rng(ar, id, HH_SITE_HC_SPEED1, 0), 100.0, 400.0);
+                speed = (double)(int)hh_rng_uniform(u0, 100.0, 400.0);
                 if (nb.n) {
                     const double ag_lat = q_sel(tb.lat, nb.k0), ag_lon = q_sel(tb.lon, nb.k0);
                     /* env_base.py:464-487 _correct_angle_sign */
@@ -417,11 +448,11 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                     double x1 = m.lon + hh_round3(sn), y1 = m.lat + hh_round3(cs);
                     double val = (x1 - m.lon) * (ag_lat - m.lat) - (ag_lon - m.lon) * (y1 - m.lat);
                     double sign = val < 0.0 ? 1.0 : -1.0;
-                    double r = hh_rng_uniform(d_rng(ar, id, HH_SITE_HC_R, 0), 0.7, 1.3);
+                    double r = hh_rng_uniform(u1, 0.7, 1.3);
                     double focus = q_sel(tb.foc, nb.k0);
                     const double turned = hh_pymod360(heading + r * sign * focus);
                     heading = ((nb.d0 > 0.008) & (focus > 4.0)) ? turned : heading;
-                    const double us = d_rng(ar, id, HH_SITE_HC_SPEED2, 0);
+                    const double us = u2;
                     const double sp_near = (double)(int)hh_rng_uniform(us, 500.0, 800.0), sp_far = (double)(int)hh_rng_uniform(us, 100.0, 500.0);
                     const double sp2 = focus < 30.0 ? sp_near : sp_far;
                     speed = nb.d0 > 0.05 ? sp2 : speed;

@@ -479,7 +479,7 @@ static int hhp_set_net(hh_policy *p, int32_t slot, const hh_net_weights *w) {
         B[o_bs + j] = w->shared_b[j];
     }
     for (int j = 0; j < n_out; j++) {
-        for (int k = 0; k < 500; k++) { B[o_wa + hhp_pidx(k, j, HHP_OUT)] = w->out_w[(size_t)j * 500 + k]; hhp_split_put(Hh, Hl, h_wa, k, j, HHP_OUT, w->out_w[(size_t)j * 500 + k]); }
+        for (int k = 0; k < 500; k++) { B[o_wa + hhp_pidx(k, j, HHP_OUT)] = w->out_w[(size_t)j * 500 + k]; hhp_split_put_t(Hh, Hl, h_wa, k, j, HHP_OUT, w->out_w[(size_t)j * 500 + k]); }
         B[o_ba + j] = w->out_b[j];
     }
     static_assert(HHP_SLOT_BYTES >= (size_t)2 * 1024 * 1024 + 2 * 309248 * 2, "slot too small");

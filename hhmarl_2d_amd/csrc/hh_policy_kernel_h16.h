@@ -31,6 +31,12 @@ struct HhpBankH {
 
 /* index (in halves) of element (k, col) of a [K x J] operand */
 __host__ __device__ inline size_t hhp_hidx(int k, int col, int J) { return ((size_t)((k >> 4) * 2 + ((k >> 3) & 1)) * J + col) * 8 + (k & 7); }
+/* the output layer's weights for L3 FROM REGISTERS: the B operand there is built from the shared layer's transposed C tile, where lane
+ * group g holds columns 16 b + 4 g + (0..3) and 16 b + 8 + 4 g + (0..3) of k-block b — the A fragments follow the same k order */
+__host__ __device__ inline size_t hhp_hidx_t(int k, int col, int J) {
+    const int kb = k >> 4, w = k & 15, g = (w >> 2) & 1, e = ((w >> 3) << 2) | (w & 3);
+    return ((size_t)(kb * 2 + g) * J + col) * 8 + e;
+}
 /* the same for the R-row LDS activation planes (R = 32 or 64 rows per tile), row slot XOR-swizzled by the plane like hhp_aidx (the
  * XOR touches the low three bits only) */
 template <int R>
@@ -64,6 +70,30 @@ __device__ __forceinline__ void hhp_store_tile(_Float16 *__restrict__ hi_plane, 
         const _Float16 hv = (_Float16)v;
         q[(r >> 2) * 64] = hv;                                   /* +8 rows = 64 halves */
         l[(r >> 2) * 64] = (_Float16)(v - (float)hv);
+    }
+}
+
+/* ---- round 3: the contractions run TRANSPOSED (weights as the A operand, activations as B), so a lane of the C tile holds ONE ROW
+ * (lane & 31) and, per register group q = r >> 2, FOUR CONSECUTIVE COLUMNS 8 q + 4 (lane >> 5) + (r & 3): exactly the four halves that
+ * are contiguous in the [plane][row][8] operand layout.  An epilogue therefore writes a tile with four 8-byte stores per plane instead of
+ * sixteen 2-byte ones, the bias of a column comes as one broadcast float4 per group from a copy staged in LDS, and the split pairs up
+ * for v_cvt_pk_f16_f32.  The products and their accumulation order are those of the untransposed form. */
+typedef _Float16 hh_h4 __attribute__((ext_vector_type(4)));
+template <int R, class F>
+__device__ __forceinline__ void hhp_store_tile_t(_Float16 *__restrict__ hi_plane, _Float16 *__restrict__ lo_plane, int j0, int row, int g,
+                                                 const hh_f32x16 &acc, const float *__restrict__ bias, F f) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int plane = (j0 >> 3) + q;
+        const int off = (plane * R + (row ^ (plane & 7))) * 8 + 4 * g; /* halves; 8-byte aligned */
+        float4 b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (bias) b = *reinterpret_cast<const float4 *>(bias + j0 + 8 * q + 4 * g);
+        const float v0 = f(acc[4 * q + 0] + b.x), v1 = f(acc[4 * q + 1] + b.y), v2 = f(acc[4 * q + 2] + b.z), v3 = f(acc[4 * q + 3] + b.w);
+        hh_h4 h, l;
+        h[0] = (_Float16)v0; h[1] = (_Float16)v1; h[2] = (_Float16)v2; h[3] = (_Float16)v3;
+        l[0] = (_Float16)(v0 - (float)h[0]); l[1] = (_Float16)(v1 - (float)h[1]); l[2] = (_Float16)(v2 - (float)h[2]); l[3] = (_Float16)(v3 - (float)h[3]);
+        *reinterpret_cast<hh_h4 *>(hi_plane + off) = h;
+        *reinterpret_cast<hh_h4 *>(lo_plane + off) = l;
     }
 }
 
@@ -110,10 +140,12 @@ __device__ __forceinline__ void hhp_gemm_h(const float4 *__restrict__ a_hi, cons
             const int kb = base + u;
             if (kb < KB) { /* wave-uniform */
                 HhpBSet<NT> &cur = S[u], &far = S[(u + 2) % 3];
+#ifndef HHP_ABL_NO_BLOAD /* tuning builds only: the shared-layer loop without its weight loads / without its MFMAs (what each costs) */
                 if (kb + 2 < KB) {
 #pragma unroll
                     for (int t = 0; t < NT; t++) { far.h[t] = b_hi[boff + t * 32]; far.l[t] = b_lo[boff + t * 32]; }
                 }
+#endif
                 boff += bstep;
                 float4 ahn[RH], aln[RH];
 #pragma unroll
@@ -124,18 +156,22 @@ __device__ __forceinline__ void hhp_gemm_h(const float4 *__restrict__ a_hi, cons
                     for (int f = 0; f < RH; f++) { ahn[f] = a_hi[p * R + f * 32 + (i ^ (p & 7))]; aln[f] = a_lo[p * R + f * 32 + (i ^ (p & 7))]; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef HHP_ABL_NO_MFMA
 #pragma unroll
                 for (int f = 0; f < RH; f++)
 #pragma unroll
-                    for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(ah[f]), hhp_as_h8(cur.h[t]), acc[f][t], 0, 0, 0);
+                    for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(cur.h[t]), hhp_as_h8(ah[f]), acc[f][t], 0, 0, 0);
 #pragma unroll
                 for (int f = 0; f < RH; f++)
 #pragma unroll
-                    for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(ah[f]), hhp_as_h8(cur.l[t]), acc[f][t], 0, 0, 0);
+                    for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(cur.l[t]), hhp_as_h8(ah[f]), acc[f][t], 0, 0, 0);
 #pragma unroll
                 for (int f = 0; f < RH; f++)
 #pragma unroll
-                    for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(al[f]), hhp_as_h8(cur.h[t]), acc[f][t], 0, 0, 0);
+                    for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(cur.h[t]), hhp_as_h8(al[f]), acc[f][t], 0, 0, 0);
+#else
+                for (int f = 0; f < RH; f++) for (int t = 0; t < NT; t++) { acc[f][t][0] += cur.h[t].x + cur.l[t].y + ah[f].x + al[f].y; }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int f = 0; f < RH; f++) { ah[f] = ahn[f]; al[f] = aln[f]; }
@@ -169,15 +205,15 @@ __device__ __forceinline__ void hhp_gemm_h_short(const float4 *__restrict__ a_hi
 #pragma unroll
         for (int f = 0; f < RH; f++)
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(ah[f]), hhp_as_h8(bh[kb][t]), acc[f][t], 0, 0, 0);
+            for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(bh[kb][t]), hhp_as_h8(ah[f]), acc[f][t], 0, 0, 0);
 #pragma unroll
         for (int f = 0; f < RH; f++)
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(ah[f]), hhp_as_h8(bl[kb][t]), acc[f][t], 0, 0, 0);
+            for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(bl[kb][t]), hhp_as_h8(ah[f]), acc[f][t], 0, 0, 0);
 #pragma unroll
         for (int f = 0; f < RH; f++)
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(al[f]), hhp_as_h8(bh[kb][t]), acc[f][t], 0, 0, 0);
+            for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(bh[kb][t]), hhp_as_h8(al[f]), acc[f][t], 0, 0, 0);
     }
 }
 
@@ -209,7 +245,9 @@ __device__ unsigned long long hhp_prof[16];
 #define HHPH_OFF_LG(RH) (69632 * (RH))
 #define HHPH_OFF_ROWS(RH) (73728 * (RH))
 #define HHPH_OFF_NP(RH) (73984 * (RH))
-#define HHPH_LDS_BYTES(RH) ((73984 + 512) * (RH))
+#define HHPH_OFF_BIAS(RH) ((73984 + 512) * (RH)) /* b1[512] | bs[512] | bov[128] of the tile's network (floats) */
+#define HHPH_BIAS_FLOATS 1152
+#define HHPH_LDS_BYTES(RH) ((73984 + 512) * (RH) + 4864)
 
 /* global tile index -> (network, tile of that network, rows of that network); false past the last tile */
 template <int R>
@@ -253,14 +291,23 @@ __device__ __forceinline__ void hhp_forward_tiles(const HhpBank &bank, const Hhp
     float *Lg = reinterpret_cast<float *>(ldsb + HHPH_OFF_LG(RH));          /* [R][32] logits */
     int *rowsb = reinterpret_cast<int *>(ldsb + HHPH_OFF_ROWS(RH));         /* [2][R] row lists of this tile and the next */
     float *npart = reinterpret_cast<float *>(ldsb + HHPH_OFF_NP(RH));       /* [4][R] */
+    float *bl = reinterpret_cast<float *>(ldsb + HHPH_OFF_BIAS(RH));        /* the network's biases by column */
+    constexpr int PZS = 36;                                                 /* row stride of the L3 partials (floats): 16-byte rows, 4-way banks at worst */
 
     const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int wq = wave & 3, wrow0 = (wave >> 2) * 32; /* attention / L3: column or k quarter, row half of this wave */
     int gt = first_tile, net, tile, cnt;
     if (!hhp_locate<R>(cn, gt, net, tile, cnt)) return;
     HHP_T0;
+#define HHP_STAGE_BIAS(NETV)                                                                          \
+    do {                                                                                              \
+        const HhpNet &sn_ = bank.net[NETV];                                                           \
+        for (int e_ = tid; e_ < 512; e_ += NTH) { bl[e_] = sn_.b1[e_]; bl[512 + e_] = sn_.bs[e_]; }   \
+        if (sn_.has_att) for (int e_ = tid; e_ < 128; e_ += NTH) bl[1024 + e_] = sn_.bov[e_];         \
+    } while (0)
     { /* first tile: rows and observation in the open; later tiles find both prefetched */
         const int tid = tid0;
+        HHP_STAGE_BIAS(net);
         if (tid < R) {
             const int q = tile * R + tid;
             rowsb[tid] = q < cnt ? lists[(size_t)net * max_rows + q] : -1;
@@ -285,10 +332,8 @@ __device__ __forceinline__ void hhp_forward_tiles(const HhpBank &bank, const Hhp
         const HhpNet N = bank.net[net];
         const HhpNetH H = bankh.net[net];
         /* every bias this lane will add, requested now: a global round trip in front of each epilogue is ~1.4 k cycles */
-        float b1r[NT], bsr[NT];
-#pragma unroll
-        for (int t = 0; t < NT; t++) { b1r[t] = N.b1[wave * WC + t * 32 + ci]; bsr[t] = N.bs[wave * WC + t * 32 + ci]; }
-        const float bovr = N.bov[wq * 32 + ci], bar = N.ba[ci];
+        const float bar = N.ba[ci];
+        const int g = lane >> 5; /* which four of a register group's eight columns this lane holds */
         /* the next tile of this workgroup: its row list is requested here and parked in LDS behind the L1 barrier */
         int nnet, ntile, ncnt, nrow = -1;
         const bool more = hhp_locate<R>(cn, gt + tile_stride, nnet, ntile, ncnt);
@@ -309,11 +354,8 @@ __device__ __forceinline__ void hhp_forward_tiles(const HhpBank &bank, const Hhp
 #pragma unroll
             for (int f = 0; f < RH; f++)
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    const int j = wave * WC + t * 32 + ci;
-                    const float bj = b1r[t];
-                    hhp_store_tile<R>(Zh, Zl, j, f * 32, lane, acc[f][t], [bj](float a) { return hhp_tanh(a + bj); });
-                }
+                for (int t = 0; t < NT; t++)
+                    hhp_store_tile_t<R>(Zh, Zl, wave * WC + t * 32, f * 32 + ci, g, acc[f][t], bl, [](float a) { return hhp_tanh(a); });
         }
         if (more && tid < R) rows_next[tid] = nrow;
         __syncthreads();
@@ -325,27 +367,55 @@ __device__ __forceinline__ void hhp_forward_tiles(const HhpBank &bank, const Hhp
             acc[0][0] = hhp_zero16();
             hhp_gemm_h_short<1, 7, 1, R>(reinterpret_cast<const float4 *>(Zh), reinterpret_cast<const float4 *>(Zl), 25, wrow0, H.wovh, H.wovl, 0, HHP_ATT_J, wq * 32, lane, acc);
             HHP_T(9);
-            const int j = wq * 32 + ci;
-            const float bj = bovr;
+            const int row = wrow0 + ci;
             float y[16];
+            float ssum = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = wrow0 + hhp_crow(r, lane);
-                const int ix = hhp_haidx<R>(400 + (j < 100 ? j : 0), row);
-                const float x = (float)Zh[ix] + (float)Zl[ix];
-                y[r] = j < 100 ? x + (acc[0][0][r] + bj) : 0.0f;
-                const float s = hhp_sum32(y[r] * y[r]);
-                if (ci == 0) npart[wq * R + row] = s;
+            for (int q = 0; q < 4; q++) {
+                const int jb = wq * 32 + 8 * q + 4 * g; /* first of this group's four columns; 100 % 4 == 0: valid or not as a whole */
+                const bool ok = jb < 100;
+                const int col = 400 + (ok ? jb : 0), plane = col >> 3;
+                const int off = (plane * R + (row ^ (plane & 7))) * 8 + 4 * g;
+                const hh_h4 xh = *reinterpret_cast<const hh_h4 *>(Zh + off), xl = *reinterpret_cast<const hh_h4 *>(Zl + off);
+                const float4 b = *reinterpret_cast<const float4 *>(bl + 1024 + (ok ? jb : 0));
+                const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float x = (float)xh[i] + (float)xl[i];
+                    const float v = ok ? x + (acc[0][0][4 * q + i] + bb[i]) : 0.0f;
+                    y[4 * q + i] = v;
+                    ssum += v * v;
+                }
+            }
+            { /* the row's other sixteen columns of this quarter sit on lane ^ 32: low half + high half, the same order on both */
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(ssum), __float_as_int(ssum), false, false);
+                const float other = __int_as_float(g ? sw[0] : sw[1]);
+                const float tot = g ? other + ssum : ssum + other;
+                if (!g) npart[wq * R + row] = tot;
             }
             HHP_T(10);
             __syncthreads();
             HHP_T(11);
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = wrow0 + hhp_crow(r, lane);
+            {
                 const float nn = ((npart[row] + npart[R + row]) + npart[2 * R + row]) + npart[3 * R + row];
                 const float den = fmaxf(sqrtf(nn), 1e-12f);
-                if (j < 100) hhp_split_store<R>(Zh, Zl, hhp_haidx<R>(400 + j, row), y[r] / den);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int jb = wq * 32 + 8 * q + 4 * g;
+                    if (jb < 100) {
+                        const int col = 400 + jb, plane = col >> 3;
+                        const int off = (plane * R + (row ^ (plane & 7))) * 8 + 4 * g;
+                        hh_h4 h, l;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const float v = y[4 * q + i] / den;
+                            h[i] = (_Float16)v;
+                            l[i] = (_Float16)(v - (float)h[i]);
+                        }
+                        *reinterpret_cast<hh_h4 *>(Zh + off) = h;
+                        *reinterpret_cast<hh_h4 *>(Zl + off) = l;
+                    }
+                }
             }
             __syncthreads();
         }
@@ -370,23 +440,66 @@ __device__ __forceinline__ void hhp_forward_tiles(const HhpBank &bank, const Hhp
                 for (int t = 0; t < NT; t++) acc[f][t] = hhp_zero16();
             hhp_gemm_h<NT, RH>(reinterpret_cast<const float4 *>(Zh), reinterpret_cast<const float4 *>(Zl), 0, HHP_H / 16, H.wsh, H.wsl, 0, HHP_H, wave * WC, lane, acc);
             HHP_T(4);
+            /* ---- L3 straight from the registers: the tanh of this wave's 32 WC columns never goes to LDS.  Every C^T tile is two
+             * 16-k B fragments as it stands (register group pairs), the output weights come in the matching k order (hhp_hidx_t), and
+             * the wave accumulates ITS k range of the logits for its rows; the WV partials meet in LDS afterwards. ---- */
+            float4 wfh[NT][2], wfl[NT][2];
+            {
+                const int hh_ = lane >> 5;
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++) {
+                        const int idx = ((((wave * WC + t * 32) >> 4) + b) * 2 + hh_) * HHP_OUT + ci;
+                        wfh[t][b] = H.wah[idx]; wfl[t][b] = H.wal[idx];
+                    }
+            }
+            constexpr int NP = NT / 2; /* partial sums per wave: one per 64 columns, so that every tile width adds the same eight ranges in the same order */
+            hh_f32x16 lacc[RH][NP];
+#pragma unroll
+            for (int f = 0; f < RH; f++)
+#pragma unroll
+                for (int pp = 0; pp < NP; pp++) lacc[f][pp] = hhp_zero16();
 #pragma unroll
             for (int f = 0; f < RH; f++)
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
-                    const float bj = bsr[t];
+                    float v[16];
 #pragma unroll
-                    for (int r = 0; r < 16; r++) acc[f][t][r] = hhp_tanh(acc[f][t][r] + bj);
+                    for (int q = 0; q < 4; q++) {
+                        const float4 b = *reinterpret_cast<const float4 *>(bl + 512 + wave * WC + t * 32 + 8 * q + 4 * g);
+                        v[4 * q + 0] = hhp_tanh(acc[f][t][4 * q + 0] + b.x);
+                        v[4 * q + 1] = hhp_tanh(acc[f][t][4 * q + 1] + b.y);
+                        v[4 * q + 2] = hhp_tanh(acc[f][t][4 * q + 2] + b.z);
+                        v[4 * q + 3] = hhp_tanh(acc[f][t][4 * q + 3] + b.w);
+                    }
+#pragma unroll
+                    for (int b = 0; b < 2; b++) {
+                        hh_h8 xh, xl;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            xh[e] = (_Float16)v[8 * b + e];
+                            xl[e] = (_Float16)(v[8 * b + e] - (float)xh[e]);
+                        }
+                        lacc[f][t >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(wfh[t][b]), xh, lacc[f][t >> 1], 0, 0, 0);
+                        lacc[f][t >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(wfl[t][b]), xh, lacc[f][t >> 1], 0, 0, 0);
+                        lacc[f][t >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(wfh[t][b]), xl, lacc[f][t >> 1], 0, 0, 0);
+                    }
                 }
             HHP_T(5);
-            __syncthreads(); /* Z is dead */
+            __syncthreads(); /* every wave is done reading Z: the partials go there (8 x R rows x PZS floats from the start of the hi plane) */
             HHP_T(6);
 #pragma unroll
             for (int f = 0; f < RH; f++)
 #pragma unroll
-                for (int t = 0; t < NT; t++) hhp_store_tile<R>(Zh, Zl, wave * WC + t * 32 + ci, f * 32, lane, acc[f][t], [](float a) { return a; });
+                for (int pp = 0; pp < NP; pp++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) /* the lane's row, output columns 8 q + 4 g .. + 3 */
+                        *reinterpret_cast<float4 *>(Pz + (wave * NP + pp) * (R * PZS) + (f * 32 + ci) * PZS + 8 * q + 4 * g) =
+                            make_float4(lacc[f][pp][4 * q], lacc[f][pp][4 * q + 1], lacc[f][pp][4 * q + 2], lacc[f][pp][4 * q + 3]);
         }
         if (more) {
+            if (nnet != net) HHP_STAGE_BIAS(nnet); /* wave-uniform; this tile's L1 / attention / L2 biases are spent */
 #pragma unroll
             for (int u = 0; u < XPT; u++) {
                 const int e = tid + u * NTH;
@@ -394,19 +507,13 @@ __device__ __forceinline__ void hhp_forward_tiles(const HhpBank &bank, const Hhp
             }
         }
         __syncthreads();
-
         HHP_T(7);
-        /* ---- L3: split-K, k quarter wq (blocks 8 wq .. 8 wq + 7) of row half wrow0 ---- */
-        hh_f32x16 lacc[1][1];
-        lacc[0][0] = hhp_zero16();
-        hhp_gemm_h_short<1, 8, 1, R>(reinterpret_cast<const float4 *>(Zh), reinterpret_cast<const float4 *>(Zl), wq * 8, wrow0, H.wah, H.wal, wq * 8, HHP_OUT, 0, lane, lacc);
-        __syncthreads(); /* every wave is done reading S: the hi plane now takes the four partials (16 KB x RH) */
-#pragma unroll
-        for (int r = 0; r < 16; r++) Pz[wq * (R * 32) + (wrow0 + hhp_crow(r, lane)) * 32 + ci] = lacc[0][0][r];
-        __syncthreads();
         for (int e = tid; e < R * HHP_OUT; e += NTH) {
-            const int i = e >> 5, c = e & 31;
-            const float v = (((Pz[e] + Pz[R * 32 + e]) + Pz[2 * R * 32 + e]) + Pz[3 * R * 32 + e]) + bar; /* c == tid & 31 == ci for every e of this thread */
+            const int i = e >> 5, c = e & 31, pe = i * PZS + c;
+            float v = Pz[pe];
+#pragma unroll
+            for (int w_ = 1; w_ < 8; w_++) v += Pz[w_ * (R * PZS) + pe]; /* eight 64-column ranges in column order, whatever the tile width */
+            v += bar; /* c == tid & 31 == ci for every e of this thread */
             Lg[e] = v;
             if (logits_out && rows[i] >= 0) logits_out[(size_t)rows[i] * HH_POLICY_LOGITS + c] = c < N.n_out ? v : 0.0f;
         }
@@ -480,6 +587,12 @@ static inline void hhp_split_put(std::vector<uint16_t> &hi, std::vector<uint16_t
     const uint16_t h = hhp_f2h(v);
     hi[off + hhp_hidx(k, col, J)] = h;
     lo[off + hhp_hidx(k, col, J)] = hhp_f2h(v - hhp_h2f(h));
+}
+/* the same in the k order of hhp_hidx_t (the output layer, contracted with the shared layer's C tile in registers) */
+static inline void hhp_split_put_t(std::vector<uint16_t> &hi, std::vector<uint16_t> &lo, size_t off, int k, int col, int J, float v) {
+    const uint16_t h = hhp_f2h(v);
+    hi[off + hhp_hidx_t(k, col, J)] = h;
+    lo[off + hhp_hidx_t(k, col, J)] = hhp_f2h(v - hhp_h2f(h));
 }
 
 #endif /* HH_POLICY_KERNEL_H16_H */

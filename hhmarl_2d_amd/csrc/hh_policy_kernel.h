@@ -338,7 +338,7 @@ struct hh_policy {
     HhpBankH bankh;
     int binned_rows;          /* n_rows of the call that built the current row lists (0: none) */
     int fp32;                 /* HH_POLICY_FP32=1: the fp32-MFMA kernel (A/B runs; default is the split-fp16 kernel) */
-    int tile_rows;            /* HH_POLICY_TILE=64: the 64-row-tile instance of the split-fp16 kernel (A/B runs; default 32-row tiles) */
+    int tile_rows;            /* HH_POLICY_TILE=32 / 64: that tile instance of the split-fp16 kernel (A/B runs); 0 = unset: chosen per call by the row count */
     int n_cu;
     int persist;              /* HH_POLICY_PERSIST=0: 64-row tiles one workgroup per tile instead of a grid-stride walk (A/B runs) */
     int n_nets;               /* highest loaded slot + 1 */
@@ -381,7 +381,7 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     memset(&p->bank, 0, sizeof(p->bank));
     memset(&p->bankh, 0, sizeof(p->bankh));
     { const char *e = getenv("HH_POLICY_FP32"); p->fp32 = e ? atoi(e) : 0; }
-    { const char *e = getenv("HH_POLICY_TILE"); p->tile_rows = e ? atoi(e) : 0; }
+    { const char *e = getenv("HH_POLICY_TILE"); p->tile_rows = e ? atoi(e) : 0; } /* 32 / 64: that instance; unset: by row count (hhp_rows_suit_wide_tiles) */
     { const char *e = getenv("HH_POLICY_PERSIST"); p->persist = e ? atoi(e) : 1; }
     { hipDeviceProp_t prop; p->n_cu = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256; }
     for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { p->blob[i] = nullptr; p->blobh[i] = nullptr; }
@@ -513,13 +513,21 @@ extern "C" int hh_policy_set_lut(hh_policy *p, const uint8_t *lut) {
     return HH_OK;
 }
 
+/* Which tile width (HH_POLICY_TILE unset): the 64-row instance streams half the weights per row and is 6 - 9 % faster when its tiles come
+ * in whole rounds of one per CU (16384, 32768, 49152 ... rows on 256 CUs: 42.2 against 46.2 us, 79.4 against 84.2), and slower when the last
+ * round is mostly empty (24576 rows: 78 against 67 us; 8192: half the CUs idle) — the 32-row instance packs two workgroups per CU and fills
+ * a partial round better.  The host knows the total row count; how the rows spread over the networks only rounds each network up by a tile. */
+static inline bool hhp_rows_suit_wide_tiles(int n_rows, int n_cu) {
+    const int tiles = (n_rows + 63) / 64, rem = tiles % n_cu;
+    return tiles >= n_cu && (rem == 0 || rem * 4 > n_cu * 3);
+}
 /* the forward kernel over the current row lists; consume: the last workgroup to read the counters clears them */
 static int hhp_launch_forward(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, int8_t *actions, float *logits, int consume, hipStream_t st) {
     const int grid = (n_rows + HHP_ROWS - 1) / HHP_ROWS + p->n_nets; /* upper bound of the tiles over all networks */
     if (p->fp32) {
         hipLaunchKernelGGL(hh_k_policy, dim3(grid), dim3(256), HHP_LDS_BYTES, st, p->bank, p->n_nets, obs, obs_stride, p->counts, p->lists, p->max_rows,
                            actions, logits, consume);
-    } else if (p->tile_rows == 64) { /* persistent: one workgroup per CU walks the tiles grid-stride */
+    } else if (p->tile_rows == 64 || (p->tile_rows == 0 && hhp_rows_suit_wide_tiles(n_rows, p->n_cu))) { /* persistent: one workgroup per CU walks the tiles grid-stride */
         const int tiles = (n_rows + 63) / 64 + p->n_nets;
         hipLaunchKernelGGL(hh_k_policy_h<2>, dim3(p->persist && tiles > p->n_cu ? p->n_cu : tiles), dim3(512), HHPH_LDS_BYTES(2), st, p->bank, p->bankh, p->n_nets,
                            obs, obs_stride, p->counts, p->lists, p->max_rows, actions, logits, consume);

@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_2V2_STEP = 1113       # state r/w 2*448 + actions 8 + obs 200 + reward 8 + done 1
 ALGO_BYTES_3V3_TICK = 2056       # 656 + 656 + pilot obs 720 + pilot actions 24
 ALGO_BYTES_3V3_CMD_FIXED = 424   # commander obs 408 + actions 3 + rewards 12 + done 1
-DEFAULT_STREAMS = {"rollout": 1, "hier_net": 2}   # sub-worlds / streams of the policy-in-the-loop workloads (--streams)
+DEFAULT_STREAMS = {"rollout": 1, "hier_net": 4}   # sub-worlds / streams of the policy-in-the-loop workloads (--streams)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F16_PEAK_TFLOPS = 2500.0    # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md; AMD's headline figure includes 2:1 sparsity)
 MFMA_F32_PEAK_TFLOPS = 157.3     # fp32-in MFMA runs at the vector rate
@@ -619,6 +619,9 @@ def main_hier_split(args, R, own, N, K):
     for w in worlds:
         w.reset()
     pilots_ = [NetPilot(w, seed=args.seed) for w in worlds]
+    if "HH_POLICY_TILE" not in os.environ:
+        for pl in pilots_:   # several banks busy on concurrent streams: wide tiles, the other streams fill what a partial round leaves idle
+            pl.bank.set_tile_rows(64)
     gen = torch.Generator(device=R.dev)
     gen.manual_seed(args.seed + 17 + R.rank)
     cmds = (torch.rand((64, N, 3), device=R.dev, generator=gen) * 3).to(torch.int8).contiguous()

@@ -46,7 +46,7 @@ EXPORTS = ["hh_world_create", "hh_world_destroy", "hh_last_error", "hh_obs_dim",
            "hh_rollout", "hh_episode_stats", "hh_get_state", "hh_set_state", "hh_get_event_masks", "hh_observe",
            "hh_hl_begin", "hh_hl_agents_act", "hh_hl_tick", "hh_hl_end", "hh_step_begin", "hh_step_finish", "hh_gae", "hh_hl_commands",
            "hh_episode_stats_packed", "hh_hl_tick_count", "hh_rollout_kernel_name", "hh_opp_policy", "hh_eval_info", "hh_arena_status", "hh_hl_rollout", "hh_trace_enable", "hh_trace_read",
-           "hh_policy_create", "hh_policy_destroy", "hh_policy_set_net", "hh_policy_set_lut", "hh_policy_act",
+           "hh_policy_create", "hh_policy_destroy", "hh_policy_set_net", "hh_policy_set_lut", "hh_policy_set_tile_rows", "hh_policy_act",
            "hh_bind_policy", "hh_policy_act_binned", "hh_kernel_instance", "hh_gae_rllib", "hh_hl_step_nets", "hh_hl_step_nets_status", "hh_math_eval"]
 
 _lib = None
@@ -98,6 +98,7 @@ def lib():
         L.hh_policy_destroy.argtypes = [vp]
         L.hh_policy_set_net.argtypes = [vp, C.c_int32, C.POINTER(HHNetWeights)]
         L.hh_policy_set_lut.argtypes = [vp, vp]
+        L.hh_policy_set_tile_rows.argtypes = [vp, C.c_int32]
         L.hh_policy_act.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.hh_bind_policy.argtypes = [vp, vp]
         L.hh_policy_act_binned.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp]

@@ -513,6 +513,12 @@ extern "C" int hh_policy_set_lut(hh_policy *p, const uint8_t *lut) {
     return HH_OK;
 }
 
+extern "C" int hh_policy_set_tile_rows(hh_policy *p, int32_t rows) {
+    if (!p || (rows != 0 && rows != 32 && rows != 64)) { g_err = "hh_policy_set_tile_rows: rows must be 0 (by row count), 32 or 64"; return HH_E_ARG; }
+    p->tile_rows = rows;
+    return HH_OK;
+}
+
 /* Which tile width (HH_POLICY_TILE unset): the 64-row instance streams half the weights per row and is 6 - 9 % faster when its tiles come
  * in whole rounds of one per CU (16384, 32768, 49152 ... rows on 256 CUs: 42.2 against 46.2 us, 79.4 against 84.2), and slower when the last
  * round is mostly empty (24576 rows: 78 against 67 us; 8192: half the CUs idle) — the 32-row instance packs two workgroups per CU and fills

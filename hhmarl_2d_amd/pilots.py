@@ -66,6 +66,10 @@ class PolicyBank:
         L.check(L.lib().hh_policy_set_net(self.h, int(slot), C.byref(w)))
         self.kinds[int(slot)] = kind
 
+    def set_tile_rows(self, rows):
+        """rows per workgroup tile of the forward kernel: 0 = by row count (default), 32 or 64 (hh_policy_set_tile_rows)"""
+        L.check(L.lib().hh_policy_set_tile_rows(self.h, int(rows)))
+
     def set_lut(self, mapping):
         """mapping: selector byte -> network slot (everything else: no action)"""
         lut = np.zeros(256, dtype=np.uint8)

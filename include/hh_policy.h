@@ -55,6 +55,11 @@ int hh_policy_set_net(hh_policy *p, int32_t slot, const hh_net_weights *w);
  * network slot s.  The world kernels emit selector bytes as pilot_mode (hh_hl_*: policy type | ac_type << 2); callers of the
  * LowLevelEnv split step build them from the unit's slot and the arena's level-5 draw. */
 int hh_policy_set_lut(hh_policy *p, const uint8_t *lut);
+/* Rows per workgroup tile of the forward kernel: 0 = chosen per call from the row count (the default: 64-row tiles when they come in whole
+ * rounds of one per CU, 32-row tiles otherwise), 32 or 64 = that instance always.  Same results either way (bit-identical logits); a caller
+ * that keeps several banks busy on concurrent streams (bench.py --workload hier --pilot net --streams K) prefers 64: the other streams'
+ * kernels fill the CUs a partial round leaves idle.  The environment variable HH_POLICY_TILE, read at hh_policy_create, sets the same. */
+int hh_policy_set_tile_rows(hh_policy *p, int32_t rows);
 
 /* greedy actions of n_rows units in one launch sequence (row binning by network + the fused forward):
  *   obs     [dev] f32 [n_rows, obs_stride]   zero-padded observation rows (hh_step's obs, hh_step_begin's opp_obs, pilot_obs)

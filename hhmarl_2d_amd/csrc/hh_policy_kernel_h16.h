@@ -13,6 +13,10 @@
  * next layer's output overwrites in place, two workgroups per CU.  Operand layout: [k/16][(k/8)&1][col or row][8 halves] — lane l of
  * a 32x32x16 MFMA holds A[l&31][8 (l>>5) .. +7] / B[8 (l>>5) .. +7][l&31], so one 16-byte access per lane is one fragment.
  * Weight fragments are requested two 16-k blocks (2 x 12 MFMAs = 768 matrix-pipe cycles) ahead of their use.
+ * Round 3: every contraction runs TRANSPOSED — the weight fragment is the MFMA's A operand, the activation fragment its B operand (both
+ * are "32 vectors of 8 halves", so this is only the order of the two arguments) — which leaves a lane of the C tile with one ROW and four
+ * consecutive COLUMNS per register group: 8-byte packed epilogue stores, broadcast float4 biases from an LDS copy, and the output layer
+ * contracted straight from the shared layer's registers (see hhp_store_tile_t and the L2 / L3 section of hhp_forward_tiles).
  */
 #ifndef HH_POLICY_KERNEL_H16_H
 #define HH_POLICY_KERNEL_H16_H

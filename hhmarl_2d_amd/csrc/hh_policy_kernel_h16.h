@@ -54,29 +54,6 @@ __device__ __forceinline__ void hhp_split_store(_Float16 *__restrict__ hi, _Floa
     hi[idx] = h;
     lo[idx] = (_Float16)(v - (float)h);
 }
-/* the 16 values a lane holds of one 32x32 C tile (column j, rows row0 + (r & 3) + 4 (lane >> 5) + 8 (r >> 2)) -> hi / lo planes.  The
- * row slot is row ^ (plane & 7): the four (r & 3) slots are computed once per tile and the (r >> 2) part (+128 bytes) rides in the
- * ds_write offset field: no address arithmetic per element (the lo plane has its own four pointers: 64 KB away with 64-row tiles,
- * one more than the offset field holds). */
-template <int R, class F>
-__device__ __forceinline__ void hhp_store_tile(_Float16 *__restrict__ hi_plane, _Float16 *__restrict__ lo_plane, int j, int row0, int lane,
-                                               const hh_f32x16 &acc, F f) {
-    const int plane = (j >> 4) * 2 + ((j >> 3) & 1), swz = plane & 7, h4 = 4 * (lane >> 5);
-    const int base = plane * (R * 8) + row0 * 8 + (j & 7); /* R rows x 8 halves per plane; row0 is a multiple of 32 */
-    const int o0 = base + (((0 + h4) ^ swz) << 3), o1 = base + (((1 + h4) ^ swz) << 3), o2 = base + (((2 + h4) ^ swz) << 3), o3 = base + (((3 + h4) ^ swz) << 3);
-    _Float16 *q0 = hi_plane + o0, *q1 = hi_plane + o1, *q2 = hi_plane + o2, *q3 = hi_plane + o3;
-    _Float16 *l0 = lo_plane + o0, *l1 = lo_plane + o1, *l2 = lo_plane + o2, *l3 = lo_plane + o3;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        _Float16 *q = (r & 3) == 0 ? q0 : ((r & 3) == 1 ? q1 : ((r & 3) == 2 ? q2 : q3));
-        _Float16 *l = (r & 3) == 0 ? l0 : ((r & 3) == 1 ? l1 : ((r & 3) == 2 ? l2 : l3));
-        const float v = f(acc[r]);
-        const _Float16 hv = (_Float16)v;
-        q[(r >> 2) * 64] = hv;                                   /* +8 rows = 64 halves */
-        l[(r >> 2) * 64] = (_Float16)(v - (float)hv);
-    }
-}
-
 /* ---- round 3: the contractions run TRANSPOSED (weights as the A operand, activations as B), so a lane of the C tile holds ONE ROW
  * (lane & 31) and, per register group q = r >> 2, FOUR CONSECUTIVE COLUMNS 8 q + 4 (lane >> 5) + (r & 3): exactly the four halves that
  * are contiguous in the [plane][row][8] operand layout.  An epilogue therefore writes a tile with four 8-byte stores per plane instead of
@@ -219,17 +196,6 @@ __device__ __forceinline__ void hhp_gemm_h_short(const float4 *__restrict__ a_hi
 #pragma unroll
             for (int t = 0; t < NT; t++) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hhp_as_h8(bh[kb][t]), hhp_as_h8(al[f]), acc[f][t], 0, 0, 0);
     }
-}
-
-/* sum over the 32 lanes of a half wave, result on every lane: four DPP steps (quad xor 1, xor 2, mirror within 8, mirror within 16:
- * VALU modifiers, no LDS) and one ds_swizzle for the two 16-lane rows — __shfl_xor would be five dependent ds_bpermute round trips */
-__device__ __forceinline__ float hhp_sum32(float v) {
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));  /* quad_perm [1,0,3,2] */
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));  /* quad_perm [2,3,0,1] */
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true)); /* row_half_mirror */
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true)); /* row_mirror */
-    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));             /* bit mode: xor 0x10, and 0x1f */
-    return v;
 }
 
 /* tuning builds only (-DHHP_PROFILE): s_memtime deltas per phase of wave 0 of every tile, summed into hhp_prof[] */

@@ -67,6 +67,19 @@ __device__ __forceinline__ float hhp_tanh(float x) {
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f); /* raw v_rcp_f32 (1 ulp): __frcp_rn expands to the ten-instruction IEEE division */
 }
 
+/* two at a time: the multiply, the add and the final multiply-add are packed instructions (v_pk_mul / add / fma_f32: one issue slot
+ * for both values); the exponential and the reciprocal stay one transcendental each */
+typedef float hh_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ hh_f2 hhp_tanh2(hh_f2 x) {
+    const hh_f2 t = x * (hh_f2)(2.885390081777926815f); /* 2 log2(e) */
+    hh_f2 e;
+    e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+    const hh_f2 d = e + (hh_f2)(1.0f);
+    hh_f2 r;
+    r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+    return __builtin_elementwise_fma(r, (hh_f2)(-2.0f), (hh_f2)(1.0f));
+}
+
 /* rows -> per-network lists.  One atomic ROUND TRIP per WORKGROUP: a per-row atomic on two or four hot counters serialises (measured
  * 187 us for 32768 rows; one returning atomic per wave and network 13.6 us, all of a wave's in one instruction 10.9 us — device-scope
  * atomics on one address cost ~13 ns apiece however they are issued).  The four waves' ballots meet in LDS, lane n - 1 of wave 0

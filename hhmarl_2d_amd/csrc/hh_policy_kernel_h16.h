@@ -69,7 +69,8 @@ __device__ __forceinline__ void hhp_store_tile_t(_Float16 *__restrict__ hi_plane
         const int off = (plane * R + (row ^ (plane & 7))) * 8 + 4 * g; /* halves; 8-byte aligned */
         float4 b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (bias) b = *reinterpret_cast<const float4 *>(bias + j0 + 8 * q + 4 * g);
-        const float v0 = f(acc[4 * q + 0] + b.x), v1 = f(acc[4 * q + 1] + b.y), v2 = f(acc[4 * q + 2] + b.z), v3 = f(acc[4 * q + 3] + b.w);
+        const hh_f2 p0 = f(hh_f2{acc[4 * q + 0], acc[4 * q + 1]} + hh_f2{b.x, b.y}), p1 = f(hh_f2{acc[4 * q + 2], acc[4 * q + 3]} + hh_f2{b.z, b.w});
+        const float v0 = p0.x, v1 = p0.y, v2 = p1.x, v3 = p1.y;
         hh_h4 h, l;
         h[0] = (_Float16)v0; h[1] = (_Float16)v1; h[2] = (_Float16)v2; h[3] = (_Float16)v3;
         l[0] = (_Float16)(v0 - (float)h[0]); l[1] = (_Float16)(v1 - (float)h[1]); l[2] = (_Float16)(v2 - (float)h[2]); l[3] = (_Float16)(v3 - (float)h[3]);
@@ -325,7 +326,7 @@ __device__ __forceinline__ void hhp_forward_tiles(const HhpBank &bank, const Hhp
             for (int f = 0; f < RH; f++)
 #pragma unroll
                 for (int t = 0; t < NT; t++)
-                    hhp_store_tile_t<R>(Zh, Zl, wave * WC + t * 32, f * 32 + ci, g, acc[f][t], bl, [](float a) { return hhp_tanh(a); });
+                    hhp_store_tile_t<R>(Zh, Zl, wave * WC + t * 32, f * 32 + ci, g, acc[f][t], bl, [](hh_f2 a) { return hhp_tanh2(a); });
         }
         if (more && tid < R) rows_next[tid] = nrow;
         __syncthreads();
@@ -438,10 +439,9 @@ __device__ __forceinline__ void hhp_forward_tiles(const HhpBank &bank, const Hhp
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         const float4 b = *reinterpret_cast<const float4 *>(bl + 512 + wave * WC + t * 32 + 8 * q + 4 * g);
-                        v[4 * q + 0] = hhp_tanh(acc[f][t][4 * q + 0] + b.x);
-                        v[4 * q + 1] = hhp_tanh(acc[f][t][4 * q + 1] + b.y);
-                        v[4 * q + 2] = hhp_tanh(acc[f][t][4 * q + 2] + b.z);
-                        v[4 * q + 3] = hhp_tanh(acc[f][t][4 * q + 3] + b.w);
+                        const hh_f2 p0 = hhp_tanh2(hh_f2{acc[f][t][4 * q + 0], acc[f][t][4 * q + 1]} + hh_f2{b.x, b.y});
+                        const hh_f2 p1 = hhp_tanh2(hh_f2{acc[f][t][4 * q + 2], acc[f][t][4 * q + 3]} + hh_f2{b.z, b.w});
+                        v[4 * q + 0] = p0.x; v[4 * q + 1] = p0.y; v[4 * q + 2] = p1.x; v[4 * q + 3] = p1.y;
                     }
 #pragma unroll
                     for (int b = 0; b < 2; b++) {

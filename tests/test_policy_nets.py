@@ -248,6 +248,23 @@ def test_tile_instances_of_the_kernel_agree_bit_for_bit(monkeypatch):
             bank.close()
         for lg, act in res[1:]:
             assert torch.equal(lg, res[0][0]) and torch.equal(act, res[0][1])
+    # the width can also be pinned per bank (hh_policy_set_tile_rows) or left to the row count (0): same bits again, bad values refused
+    monkeypatch.delenv("HH_POLICY_TILE", raising=False)
+    R = 16384 + 64   # 0 = by row count
+    obs = torch.from_numpy(rng.random((R, 30)).astype(np.float32)).cuda()
+    sel = torch.from_numpy(sels[rng.integers(1, len(sels), R)]).cuda()
+    bank = _bank(7, max_rows=R)
+    outs = []
+    for rows in (0, 32, 64):
+        bank.set_tile_rows(rows)
+        lg = torch.zeros((R, 32), device="cuda")
+        act = bank.act(obs, sel, logits=lg).clone()
+        torch.cuda.synchronize()
+        outs.append((lg, act))
+    assert all(torch.equal(lg, outs[0][0]) and torch.equal(act, outs[0][1]) for lg, act in outs[1:])
+    with pytest.raises(RuntimeError):
+        bank.set_tile_rows(48)
+    bank.close()
 
 
 @pytest.mark.gpu

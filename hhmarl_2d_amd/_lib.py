@@ -42,12 +42,20 @@ class HHNetWeights(C.Structure):
                 ("shared_w", C.c_void_p), ("shared_b", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p)]
 
 
+class HHCriticWeights(C.Structure):
+    """hh_critic_weights (include/hh_policy.h): host pointers to one network's value branch, nn.Linear layout"""
+    _fields_ = [("kind", C.c_int32), ("v_w", C.c_void_p * 3), ("v_b", C.c_void_p * 3),
+                ("att_in_proj_w", C.c_void_p), ("att_in_proj_b", C.c_void_p), ("att_out_w", C.c_void_p), ("att_out_b", C.c_void_p),
+                ("shared_w", C.c_void_p), ("shared_b", C.c_void_p), ("val_w", C.c_void_p), ("val_b", C.c_void_p)]
+
+
 EXPORTS = ["hh_world_create", "hh_world_destroy", "hh_last_error", "hh_obs_dim", "hh_n_ctrl", "hh_reset", "hh_step",
            "hh_rollout", "hh_episode_stats", "hh_get_state", "hh_set_state", "hh_get_event_masks", "hh_observe",
            "hh_hl_begin", "hh_hl_agents_act", "hh_hl_tick", "hh_hl_end", "hh_step_begin", "hh_step_finish", "hh_gae", "hh_hl_commands",
            "hh_episode_stats_packed", "hh_hl_tick_count", "hh_rollout_kernel_name", "hh_opp_policy", "hh_eval_info", "hh_arena_status", "hh_hl_rollout", "hh_trace_enable", "hh_trace_read",
            "hh_policy_create", "hh_policy_destroy", "hh_policy_set_net", "hh_policy_set_lut", "hh_policy_set_tile_rows", "hh_policy_act",
-           "hh_bind_policy", "hh_policy_act_binned", "hh_kernel_instance", "hh_gae_rllib", "hh_hl_step_nets", "hh_hl_step_nets_status", "hh_math_eval"]
+           "hh_bind_policy", "hh_policy_act_binned", "hh_kernel_instance", "hh_gae_rllib", "hh_hl_step_nets", "hh_hl_step_nets_status", "hh_math_eval",
+           "hh_policy_set_critic", "hh_policy_sample"]
 
 _lib = None
 
@@ -102,6 +110,8 @@ def lib():
         L.hh_policy_act.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.hh_bind_policy.argtypes = [vp, vp]
         L.hh_policy_act_binned.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp]
+        L.hh_policy_set_critic.argtypes = [vp, C.c_int32, C.POINTER(HHCriticWeights)]
+        L.hh_policy_sample.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
         L.hh_hl_step_nets.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         L.hh_hl_step_nets_status.argtypes = [vp, C.POINTER(C.c_int32), vp]
         _lib = L

@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256, 2) void hh_k_policy(HhpBank bank, int n_nets, 
 }
 
 #include "hh_policy_kernel_h16.h"
+#include "hh_policy_kernel_ppo.h"
 
 /* ===================================================================== host side */
 #define HHP_SLOT_BYTES ((size_t)4 << 20) /* fp32 blob 1.19 MB + fp16 planes 1.18 MB per network, padded to 4 MB */
@@ -362,6 +363,8 @@ struct hh_policy {
     uint8_t *lut;             /* [256] dev */
     int *counts, *lists;      /* counters (HHP_COUNTS_INTS), [MAX_NETS][max_rows] dev */
     hh_world *bound;          /* hh_bind_policy: the world whose kernels write the lists (one world per bank), or nullptr */
+    HhpCritBank cbank;        /* hh_policy_set_critic: the value branches of the trainable policies (hh_policy_sample) */
+    char *cblob[HH_POLICY_MAX_NETS]; /* one allocation per loaded value branch */
 };
 static void hhp_forget_world(hh_policy *p) { p->bound = nullptr; }
 static void hhp_unbind(hh_policy *p) {
@@ -399,6 +402,8 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     { hipDeviceProp_t prop; p->n_cu = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256; }
     for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { p->blob[i] = nullptr; p->blobh[i] = nullptr; }
     p->slab = nullptr;
+    memset(&p->cbank, 0, sizeof(p->cbank));
+    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) p->cblob[i] = nullptr;
     p->lut = nullptr; p->counts = nullptr; p->lists = nullptr;
     hipError_t e = hipMalloc(&p->lut, 256);
     if (e == hipSuccess) e = hipMemset(p->lut, 0, 256);
@@ -409,6 +414,7 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy), hipFuncAttributeMaxDynamicSharedMemorySize, HHP_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_h<1>), hipFuncAttributeMaxDynamicSharedMemorySize, HHPH_LDS_BYTES(1));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_h<2>), hipFuncAttributeMaxDynamicSharedMemorySize, HHPH_LDS_BYTES(2));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_ppo), hipFuncAttributeMaxDynamicSharedMemorySize, HHPP_LDS_BYTES);
     if (e != hipSuccess) {
         g_err = std::string("hh_policy_create: ") + hipGetErrorString(e);
         if (p->lut) (void)hipFree(p->lut);
@@ -427,6 +433,7 @@ extern "C" int hh_policy_destroy(hh_policy *p) {
     hhp_unbind(p); /* a world still bound to this bank goes back to emitting selector bytes only */
     DeviceGuard guard_(p->device);
     (void)hipFree(p->slab);
+    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) if (p->cblob[i]) (void)hipFree(p->cblob[i]);
     (void)hipFree(p->lut); (void)hipFree(p->counts); (void)hipFree(p->lists);
     delete p;
     return HH_OK;
@@ -600,11 +607,135 @@ extern "C" int hh_policy_act_binned(hh_policy *p, const float *obs, int32_t n_ro
     return hhp_launch_forward(p, obs, n_rows, obs_stride, actions, logits, HHP_CONSUME, (hipStream_t)stream);
 }
 
+
+/* ---- the value branches of the trainable policies + one sampler step (hh_policy_kernel_ppo.h) ---- */
+static const int HHC_DIMS[4][4] = {
+    /* own obs, own act, other obs, other act: train_hetero.py:183-198 observer spaces */
+    {26, 4, 24, 3}, {24, 3, 26, 4}, {30, 4, 29, 3}, {29, 3, 30, 4},
+};
+static int hhp_set_critic(hh_policy *p, int32_t slot, const hh_critic_weights *w);
+extern "C" int hh_policy_set_critic(hh_policy *p, int32_t slot, const hh_critic_weights *w) {
+    try {
+        return hhp_set_critic(p, slot, w);
+    } catch (const std::exception &e) {
+        g_err = std::string("hh_policy_set_critic: ") + e.what();
+        return HH_E_HIP;
+    }
+}
+static int hhp_set_critic(hh_policy *p, int32_t slot, const hh_critic_weights *w) {
+    if (!p || !w || slot < 0 || slot >= HH_POLICY_MAX_NETS || w->kind < 0 || w->kind > 3) { g_err = "bad argument"; return HH_E_ARG; }
+    if (!p->blob[slot] || p->bank.net[slot].kind != w->kind) { g_err = "hh_policy_set_critic: load the actor of the same kind into this slot first (hh_policy_set_net)"; return HH_E_ARG; }
+    const bool att = w->kind <= HH_NET_FIGHT2;
+    if (!w->v_w[0] || !w->v_b[0] || !w->shared_w || !w->shared_b || !w->val_w || !w->val_b ||
+        (att && (!w->v_w[1] || !w->v_b[1] || !w->v_w[2] || !w->v_b[2] || !w->att_in_proj_w || !w->att_in_proj_b || !w->att_out_w || !w->att_out_b))) {
+        g_err = "hh_policy_set_critic: missing weight pointer"; return HH_E_ARG;
+    }
+    HH_GUARD(p);
+    const int d1 = HHC_DIMS[w->kind][0], a1 = HHC_DIMS[w->kind][1], d2 = HHC_DIMS[w->kind][2], a2 = HHC_DIMS[w->kind][3];
+    const int n_in = d1 + a1 + d2 + a2; /* 57 | 66 */
+    /* fragment planes (halves): w1 [80 x 512] | wov [160 x 256] | ws [512 x 512] | wa [512 x 32]; then the float biases b1 | bs | bov | ba */
+    const size_t h_w1 = 0, h_wov = h_w1 + (size_t)(HHC_XK / 16) * 2 * HHP_H * 8, h_ws = h_wov + (size_t)(HHC_ATT_W / 16) * 2 * HHC_ATT_J * 8,
+                 h_wa = h_ws + (size_t)32 * 2 * HHP_H * 8, h_total = h_wa + (size_t)32 * 2 * HHP_OUT * 8;
+    std::vector<uint16_t> Hh(h_total, 0), Hl(h_total, 0);
+    const size_t o_b1 = 0, o_bs = 512, o_bov = 1024, o_ba = 1024 + HHC_ATT_W, n_bias = o_ba + HHP_OUT;
+    std::vector<float> Bf(n_bias, 0.0f);
+    /* hidden column of the reference's concatenation cat(v1, v2, y3) (ac_models_hetero.py:274-281) in the kernel's order y3 | pad | v1 | v2 */
+    auto hcol = [att](int c) { return att ? (c < 350 ? HHC_V12_OFF + c : HHC_V3_OFF + (c - 350)) : c; };
+    if (att) {
+        const int in0[3] = {0, d1 + a1, 0}, in1[3] = {d1 + a1, n_in, n_in}, wd[3] = {175, 175, 150}, out0[3] = {0, 175, 350};
+        for (int b = 0; b < 3; b++)
+            for (int o = 0; o < wd[b]; o++) {
+                for (int c = in0[b]; c < in1[b]; c++) hhp_split_put(Hh, Hl, h_w1, c, hcol(out0[b] + o), HHP_H, w->v_w[b][(size_t)o * (in1[b] - in0[b]) + (c - in0[b])]);
+                Bf[o_b1 + hcol(out0[b] + o)] = w->v_b[b][o];
+            }
+        /* att_val over one key: out_proj(v_proj(t)), folded in double like the actor's */
+        const float *wv = w->att_in_proj_w + (size_t)300 * 150, *bv = w->att_in_proj_b + 300;
+        for (int j = 0; j < 150; j++) {
+            for (int k = 0; k < 150; k++) {
+                double s = 0.0;
+                for (int m = 0; m < 150; m++) s += (double)w->att_out_w[(size_t)j * 150 + m] * (double)wv[(size_t)m * 150 + k];
+                hhp_split_put(Hh, Hl, h_wov, k, j, HHC_ATT_J, (float)s);
+            }
+            double s = (double)w->att_out_b[j];
+            for (int m = 0; m < 150; m++) s += (double)w->att_out_w[(size_t)j * 150 + m] * (double)bv[m];
+            Bf[o_bov + j] = (float)s;
+        }
+    } else {
+        for (int o = 0; o < 500; o++) {
+            for (int c = 0; c < n_in; c++) hhp_split_put(Hh, Hl, h_w1, c, o, HHP_H, w->v_w[0][(size_t)o * n_in + c]);
+            Bf[o_b1 + o] = w->v_b[0][o];
+        }
+    }
+    for (int j = 0; j < 500; j++) {
+        for (int k = 0; k < 500; k++) hhp_split_put(Hh, Hl, h_ws, hcol(k), j, HHP_H, w->shared_w[(size_t)j * 500 + k]);
+        Bf[o_bs + j] = w->shared_b[j];
+    }
+    for (int k = 0; k < 500; k++) hhp_split_put_t(Hh, Hl, h_wa, k, 0, HHP_OUT, w->val_w[k]);
+    Bf[o_ba] = w->val_b[0];
+    const size_t plane_bytes = h_total * sizeof(uint16_t), bytes = 2 * plane_bytes + n_bias * sizeof(float);
+    if (!p->cblob[slot]) HIPCHK(hipMalloc(&p->cblob[slot], bytes));
+    char *d = p->cblob[slot];
+    HIPCHK(hipMemcpy(d, Hh.data(), plane_bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d + plane_bytes, Hl.data(), plane_bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d + 2 * plane_bytes, Bf.data(), n_bias * sizeof(float), hipMemcpyHostToDevice));
+    HhpCrit &Cn = p->cbank.c[slot];
+    const uint16_t *bh = reinterpret_cast<const uint16_t *>(d), *bl = reinterpret_cast<const uint16_t *>(d + plane_bytes);
+    const float *bf = reinterpret_cast<const float *>(d + 2 * plane_bytes);
+    Cn.w1h = reinterpret_cast<const float4 *>(bh + h_w1); Cn.w1l = reinterpret_cast<const float4 *>(bl + h_w1);
+    Cn.wovh = reinterpret_cast<const float4 *>(bh + h_wov); Cn.wovl = reinterpret_cast<const float4 *>(bl + h_wov);
+    Cn.wsh = reinterpret_cast<const float4 *>(bh + h_ws); Cn.wsl = reinterpret_cast<const float4 *>(bl + h_ws);
+    Cn.wah = reinterpret_cast<const float4 *>(bh + h_wa); Cn.wal = reinterpret_cast<const float4 *>(bl + h_wa);
+    Cn.b1 = bf + o_b1; Cn.bs = bf + o_bs; Cn.bov = bf + o_bov; Cn.ba = bf + o_ba;
+    Cn.d1 = d1; Cn.a1 = a1; Cn.d2 = d2; Cn.a2 = a2; Cn.has_att = att ? 1 : 0; Cn.loaded = 1;
+    return HH_OK;
+}
+
+extern "C" int hh_policy_sample(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, const uint8_t *sel, hh_world *w,
+                                const double *uniforms, const float *crit_act, int32_t greedy, int8_t *actions, float *logp, float *vf, float *logits,
+                                void *stream) {
+    if (!p || !obs || !actions || n_rows <= 0 || obs_stride <= 0) { g_err = "bad argument"; return HH_E_ARG; }
+    if (!sel && p->binned_rows != n_rows) { g_err = "hh_policy_sample: sel == NULL re-uses the row lists of the previous call, which had another n_rows"; return HH_E_ARG; }
+    if (n_rows > p->max_rows) { g_err = "hh_policy_sample: n_rows exceeds max_rows of hh_policy_create"; return HH_E_ARG; }
+    if (p->n_nets == 0) { g_err = "hh_policy_sample: no network loaded"; return HH_E_ARG; }
+    if (!greedy && !uniforms && !w) { g_err = "hh_policy_sample: a draw needs the world (keyed RNG) or explicit uniforms"; return HH_E_ARG; }
+    if (vf) {
+        if (n_rows & 1) { g_err = "hh_policy_sample: the value branch pairs row r with row r ^ 1 (rows = [n_arenas, 2]): n_rows must be even"; return HH_E_ARG; }
+        for (int n = 0; n < p->n_nets; n++)
+            if (p->blob[n] && !p->cbank.c[n].loaded) { g_err = "hh_policy_sample: vf asked for, but a loaded network has no value branch (hh_policy_set_critic)"; return HH_E_ARG; }
+    }
+    HhpSampleArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.uniforms = uniforms; sa.crit_act = crit_act; sa.greedy = greedy ? 1 : 0;
+    sa.actions = actions; sa.logp = logp; sa.vf = vf; sa.logits_out = logits;
+    sa.rows_per_arena = 1;
+    if (w && !uniforms && !greedy) {
+        if (w->device != p->device) { g_err = "hh_policy_sample: world and policy bank live on different devices"; return HH_E_ARG; }
+        if (n_rows % w->dc.N != 0) { g_err = "hh_policy_sample: n_rows is not a multiple of the world's arenas"; return HH_E_ARG; }
+        sa.ar_pack = w->P.ar_pack; sa.seed = w->dc.seed; sa.arena_offset = w->dc.arena_offset; sa.rows_per_arena = n_rows / w->dc.N;
+    }
+    HH_GUARD(p);
+    hipStream_t st = (hipStream_t)stream;
+    if (sel) {
+        hipLaunchKernelGGL(hh_k_policy_bin, dim3((n_rows + 255) / 256), dim3(256), 0, st, n_rows, sel, p->lut, p->max_rows, p->counts, p->lists, actions);
+        p->binned_rows = n_rows;
+    }
+    const int tiles = (n_rows + HHP_ROWS - 1) / HHP_ROWS + p->n_nets;
+    hipLaunchKernelGGL(hh_k_policy_ppo, dim3(vf ? 2 * tiles : tiles), dim3(256), HHPP_LDS_BYTES, st, p->bank, p->bankh, p->cbank, p->n_nets, obs, obs_stride,
+                       p->counts, p->lists, p->max_rows, sa, vf ? 1 : 0, sel ? HHP_CONSUME : HHP_FROM_SAVED);
+    HIPCHK(hipGetLastError());
+    return HH_OK;
+}
+
 #ifdef HHP_PROFILE
 extern "C" int hh_policy_prof_read(unsigned long long *out16, int reset) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(hhp_prof), 16 * 8));
-    if (reset) { unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(hhp_prof), z, 16 * 8)); }
+    if (reset) { unsigned long long z[48] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(hhp_prof), z, 48 * 8)); }
+    return HH_OK;
+}
+extern "C" int hh_policy_prof_read_ppo(unsigned long long *out32) { /* the 2 x 16 phase timers of hh_k_policy_ppo's actor / critic tiles */
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(hhp_prof), 32 * 8, 16 * 8));
     return HH_OK;
 }
 #endif

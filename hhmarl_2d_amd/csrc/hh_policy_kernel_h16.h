@@ -201,7 +201,7 @@ __device__ __forceinline__ void hhp_gemm_h_short(const float4 *__restrict__ a_hi
 
 /* tuning builds only (-DHHP_PROFILE): s_memtime deltas per phase of wave 0 of every tile, summed into hhp_prof[] */
 #ifdef HHP_PROFILE
-__device__ unsigned long long hhp_prof[16];
+__device__ unsigned long long hhp_prof[48]; /* 0..15 hhp_forward_tiles, 16..31 / 32..47 actor / critic tiles of hh_k_policy_ppo */
 #define HHP_T(k) do { if (tid == 0) { unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&hhp_prof[k], t_ - pt_); pt_ = t_; } } while (0)
 #define HHP_T0 unsigned long long pt_ = __builtin_readcyclecounter()
 #else

@@ -66,6 +66,69 @@ class PolicyBank:
         L.check(L.lib().hh_policy_set_net(self.h, int(slot), C.byref(w)))
         self.kinds[int(slot)] = kind
 
+    def set_critic(self, slot, kind, sd, csd):
+        """the value branch of the network in `slot` (hh_policy_set_critic): sd = its actor tensors (for the shared layer), csd = the value
+        branch keyed like the reference's state_dict() (policy_nets.critic_keys)"""
+        a = {k: np.ascontiguousarray(csd[k], dtype=np.float32) for k in PN.critic_keys(kind)}
+        for k, shp in PN.critic_keys(kind).items():
+            assert a[k].shape == shp, (k, a[k].shape, shp)
+        a["sw"] = np.ascontiguousarray(sd["shared_layer._model.0.weight"], dtype=np.float32)
+        a["sb"] = np.ascontiguousarray(sd["shared_layer._model.0.bias"], dtype=np.float32)
+        p = lambda k: a[k].ctypes.data_as(C.c_void_p) if k in a else None
+        w = L.HHCriticWeights()
+        w.kind = kind
+        names = ("v1", "v2", "v3") if PN.HAS_ATT[kind] else ("inp1_val",)
+        for i, n in enumerate(names):
+            w.v_w[i] = p(f"{n}._model.0.weight")
+            w.v_b[i] = p(f"{n}._model.0.bias")
+        w.att_in_proj_w, w.att_in_proj_b = p("att_val.in_proj_weight"), p("att_val.in_proj_bias")
+        w.att_out_w, w.att_out_b = p("att_val.out_proj.weight"), p("att_val.out_proj.bias")
+        w.shared_w, w.shared_b = p("sw"), p("sb")
+        w.val_w, w.val_b = p("val_out._model.0.weight"), p("val_out._model.0.bias")
+        L.check(L.lib().hh_policy_set_critic(self.h, int(slot), C.byref(w)))
+
+    def sample(self, obs, sel, world=None, uniforms=None, crit_act=None, greedy=False, actions=None, logp=None, vf=None, logits=None,
+               want_vf=True):
+        """one sampler step of the trainable policies (hh_policy_sample): obs f32 [N, 2, D] rows of LowLevelEnv agents -> (actions int8
+        [N, 2, 4], logp f32 [N, 2], vf f32 [N, 2] or None).  world: keyed draws from its episode / step counters; uniforms f64 [N, 2, 4]
+        overrides them; crit_act f32 [N, 2, 4] = the critic's scaled action inputs (None = zeros, as while sampling)."""
+        assert obs.dtype == torch.float32 and obs.is_contiguous()
+        stride = obs.shape[-1]
+        n_rows = obs.numel() // stride
+        lead = tuple(obs.shape[:-1])
+        if sel is not None:
+            assert sel.dtype == torch.uint8 and sel.is_contiguous() and sel.numel() == n_rows
+        if actions is None:
+            actions = torch.empty(lead + (4,), dtype=torch.int8, device=obs.device)
+        if logp is None:
+            logp = torch.empty(lead, dtype=torch.float32, device=obs.device)
+        if vf is None and want_vf:
+            vf = torch.empty(lead, dtype=torch.float32, device=obs.device)
+        assert actions.dtype == torch.int8 and actions.is_contiguous() and actions.numel() == n_rows * 4
+        assert logp.dtype == torch.float32 and logp.numel() == n_rows and (vf is None or (vf.dtype == torch.float32 and vf.numel() == n_rows))
+        if uniforms is not None:
+            assert uniforms.dtype == torch.float64 and uniforms.is_contiguous() and uniforms.numel() == n_rows * 4
+        if crit_act is not None:
+            assert crit_act.dtype == torch.float32 and crit_act.is_contiguous() and crit_act.numel() == n_rows * 4
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        st = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
+        L.check(L.lib().hh_policy_sample(self.h, ptr(obs), n_rows, stride, ptr(sel), None if world is None else world.h, ptr(uniforms), ptr(crit_act),
+                                         1 if greedy else 0, ptr(actions), ptr(logp), ptr(vf), ptr(logits), st))
+        return actions, logp, vf
+
+    @classmethod
+    def trainable_init(cls, device, mode="fight", seed=0, max_rows=1 << 20):
+        """the two trainable policies of train_hetero.py (ac1_policy = Fight1 | Esc1 in slot 0, ac2_policy = Fight2 | Esc2 in slot 1) with
+        synthetic actor AND value-branch weights; selector bytes as the agents' aircraft types: SEL_FIGHT1 / SEL_FIGHT2 (| SEL_ESC*)"""
+        b = cls(device, max_rows)
+        kinds = (PN.FIGHT1, PN.FIGHT2) if mode == "fight" else (PN.ESC1, PN.ESC2)
+        for slot, kind in enumerate(kinds):
+            sd = PN.random_weights(kind, seed)
+            b.set_net(slot, kind, sd)
+            b.set_critic(slot, kind, sd, PN.random_critic_weights(kind, seed))
+        b.set_lut({(SEL_FIGHT1 if mode == "fight" else SEL_ESC1): 0, (SEL_FIGHT2 if mode == "fight" else SEL_ESC2): 1})
+        return b
+
     def set_tile_rows(self, rows):
         """rows per workgroup tile of the forward kernel: 0 = by row count (default), 32 or 64 (hh_policy_set_tile_rows)"""
         L.check(L.lib().hh_policy_set_tile_rows(self.h, int(rows)))

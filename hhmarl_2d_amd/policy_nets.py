@@ -102,6 +102,118 @@ def decode(logits, n_out):
     return act
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The value branch and the sampler step of the TRAINABLE policies (train_hetero.py:206-243; hh_policy_sample, include/hh_policy.h)
+#
+#   Fight1 (232-255, 277-289) / Fight2 (344-367, 390-402):
+#       y  = cat(tanh(v1 [obs_own | act_own]), tanh(v2 [obs_2 | act_2]))                       175 + 175
+#       t  = tanh(v3 [obs_own | act_own | obs_2 | act_2]);  y3 = normalize(t + att_val(t))     150   (MultiheadAttention(150, 2), sequence length 1)
+#       value = val_out(shared_layer(cat(y, y3)))
+#   Esc1 (72-83, 97-103) / Esc2 (148-159, 173-179):  value = val_out(shared_layer(tanh(inp1_val [obs_own | act_own | obs_2 | act_2])))
+# own / other observation and action widths per kind (train_hetero.py:183-198)
+CRITIC_DIMS = {FIGHT1: (26, 4, 24, 3), FIGHT2: (24, 3, 26, 4), ESC1: (30, 4, 29, 3), ESC2: (29, 3, 30, 4)}
+
+
+def critic_keys(kind):
+    """state_dict keys of the value branch -> shapes (the shared layer is the actor's tensor)"""
+    d1, a1, d2, a2 = CRITIC_DIMS[kind]
+    if HAS_ATT[kind]:
+        return {"v1._model.0.weight": (175, d1 + a1), "v1._model.0.bias": (175,), "v2._model.0.weight": (175, d2 + a2), "v2._model.0.bias": (175,),
+                "v3._model.0.weight": (150, d1 + a1 + d2 + a2), "v3._model.0.bias": (150,),
+                "att_val.in_proj_weight": (450, 150), "att_val.in_proj_bias": (450,), "att_val.out_proj.weight": (150, 150), "att_val.out_proj.bias": (150,),
+                "val_out._model.0.weight": (1, 500), "val_out._model.0.bias": (1,)}
+    return {"inp1_val._model.0.weight": (500, d1 + a1 + d2 + a2), "inp1_val._model.0.bias": (500,),
+            "val_out._model.0.weight": (1, 500), "val_out._model.0.bias": (1,)}
+
+
+def random_critic_weights(kind, seed):
+    """synthetic value-branch weights, a stream of their own (random_weights' actor tensors stay what the committed fixtures were made with)"""
+    rng = np.random.default_rng([int(seed), int(kind), 7])
+    sd = {}
+    for k, shp in critic_keys(kind).items():
+        if k.endswith("weight"):
+            sd[k] = (rng.standard_normal(shp) / np.sqrt(shp[-1])).astype(np.float32)
+        else:
+            sd[k] = (0.1 * rng.standard_normal(shp)).astype(np.float32)
+    return sd
+
+
+def critic_from_torch_module(module, kind):
+    sd = {k: v.detach().cpu().numpy().astype(np.float32) for k, v in module.state_dict().items()}
+    return {k: sd[k] for k in critic_keys(kind)}
+
+
+def torch_value(kind, sd, csd, obs_own, act_own, obs_2, act_2):
+    """plain PyTorch fp32 value_function() (statement order of the reference): sd = actor tensors (for the shared layer), csd = value branch"""
+    import torch
+    import torch.nn.functional as F
+    dev = obs_own.device
+    t = {k: torch.as_tensor(v, dtype=torch.float32, device=dev) for k, v in {**sd, **csd}.items()}
+    d1, a1, d2, a2 = CRITIC_DIMS[kind]
+    v1 = torch.cat((obs_own[:, :d1], act_own[:, :a1]), dim=1).to(torch.float32)
+    v2 = torch.cat((obs_2[:, :d2], act_2[:, :a2]), dim=1).to(torch.float32)
+    v3 = torch.cat((v1, v2), dim=1)
+    if HAS_ATT[kind]:
+        y = torch.cat((torch.tanh(F.linear(v1, t["v1._model.0.weight"], t["v1._model.0.bias"])),
+                       torch.tanh(F.linear(v2, t["v2._model.0.weight"], t["v2._model.0.bias"]))), dim=1)
+        yf = torch.tanh(F.linear(v3, t["v3._model.0.weight"], t["v3._model.0.bias"]))
+        wv, bv = t["att_val.in_proj_weight"][300:450], t["att_val.in_proj_bias"][300:450]
+        att = F.linear(F.linear(yf, wv, bv), t["att_val.out_proj.weight"], t["att_val.out_proj.bias"])
+        y = torch.cat((y, F.normalize(yf + att)), dim=1)
+    else:
+        y = torch.tanh(F.linear(v3, t["inp1_val._model.0.weight"], t["inp1_val._model.0.bias"]))
+    s = torch.tanh(F.linear(y, t["shared_layer._model.0.weight"], t["shared_layer._model.0.bias"]))
+    return F.linear(s, t["val_out._model.0.weight"], t["val_out._model.0.bias"]).reshape(-1)
+
+
+def scale_actions(act):
+    """on_postprocess_trajectory's scaling of an action into the critic's act inputs (train_hetero.py:138-160): a0 / 12, a1 / 8, a2, a3"""
+    a = np.asarray(act, dtype=np.float32).copy()
+    a[..., 0] /= 12.0
+    a[..., 1] /= 8.0
+    return a
+
+
+def inverse_cdf_actions(logits, u, n_out):
+    """hh_policy_sample's draw restated in float64: per component the first index whose cumulative softmax exceeds u (numpy [R, >= n_out],
+    u [R, 4]) -> (actions int8 [R, 4], logp float64 [R], margin float64 [R] = distance of u from the nearest cumulative boundary)"""
+    lg = np.asarray(logits, dtype=np.float64)
+    u = np.asarray(u, dtype=np.float64)
+    act = np.zeros((lg.shape[0], 4), dtype=np.int8)
+    logp = np.zeros(lg.shape[0])
+    margin = np.full(lg.shape[0], np.inf)
+    lo = 0
+    for k, w in enumerate(ACTION_SPLIT[: 4 if n_out == 26 else 3]):
+        seg = lg[:, lo:lo + w]
+        m = seg.max(axis=1, keepdims=True)
+        e = np.exp(seg - m)
+        S = e.sum(axis=1, keepdims=True)
+        cdf = np.cumsum(e, axis=1) / S
+        a = (cdf > u[:, k:k + 1]).argmax(axis=1)
+        a = np.where((cdf > u[:, k:k + 1]).any(axis=1), a, w - 1)
+        act[:, k] = a
+        logp += (seg[np.arange(len(a)), a] - m[:, 0]) - np.log(S[:, 0])
+        margin = np.minimum(margin, np.abs(cdf[:, :-1] - u[:, k:k + 1]).min(axis=1))
+        lo += w
+    return act, logp, margin
+
+
+def multicategorical_logp(logits, act, n_out):
+    """TorchMultiCategorical.logp (ray/rllib/models/torch/torch_action_dist.py): the sum of the components' Categorical log_prob"""
+    import torch
+    lg = torch.as_tensor(logits, dtype=torch.float32)
+    a = torch.as_tensor(np.asarray(act), dtype=torch.int64)
+    parts = lg[:, :n_out].split(ACTION_SPLIT[: 4 if n_out == 26 else 3], dim=1)
+    return sum(torch.distributions.Categorical(logits=p).log_prob(a[:, i]) for i, p in enumerate(parts))
+
+
+def critic_flops_per_row(kind):
+    d1, a1, d2, a2 = CRITIC_DIMS[kind]
+    n = d1 + a1 + d2 + a2
+    macs = ((d1 + a1) * 175 + (d2 + a2) * 175 + n * 150 + 2 * 150 * 150 if HAS_ATT[kind] else n * 500) + 500 * 500 + 500
+    return 2 * macs
+
+
 def flops_per_row(kind):
     (a0, a1, w1), (b0, b1, w2), (c0, c1, w3) = INPUTS[kind]
     macs = (a1 - a0) * w1 + (b1 - b0) * w2 + (c1 - c0) * w3 + 500 * 500 + 500 * N_OUT[kind] + (100 * 100 * 2 if HAS_ATT[kind] else 0)

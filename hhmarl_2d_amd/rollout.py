@@ -91,3 +91,78 @@ def episode_segments(done):
     seg = torch.cumsum(d, dim=0) - d                     # episodes finished strictly before this row
     n_done = d.sum(dim=0, keepdim=True)                  # episodes that end inside the rollout, per arena
     return seg, seg < n_done
+
+
+class PPORollout:
+    """What RLlib's rollout workers produce for train_hetero.py's PPO (train_hetero.py:206-243), for every arena of a `World` at once and
+    without leaving the device: per tick the two trainable policies are sampled by `hh_policy_sample` (actor forward, Categorical draw
+    per action component from the keyed RNG, its log-probability, and the centralised value branch on central_critic_observer's row —
+    the other agent's observation, action inputs zero while sampling) and the world takes one `hh_step`; after T ticks `hh_gae` turns
+    the rewards and value predictions into advantages and value targets (gamma 0.99, lambda 0.95: train_hetero.py:216), bootstrapping
+    the unfinished tail of every arena from one more value evaluation.  The 2 T + 2 launches of a collect are one HIP graph.
+
+    Buffers (device, overwritten by every `collect`):  obs f32 [T+1, N, 2, D] (row t = what the policy saw at tick t), actions i8
+    [T, N, 2, 4], logp f32 [T, N, 2], vf f32 [T+1, N, 2], reward f32 [T, N, 2], valid u8 [T, N, 2], done u8 [T, N], adv / target f32
+    [T, N, 2].  `critic_rows(agent)` gives the flattened CUR_OBS rows the reference's critic is trained on (actions filled in the way
+    on_postprocess_trajectory does)."""
+
+    def __init__(self, world, bank, T, gamma=0.99, lam=0.95, use_graph=True):
+        from . import pilots
+        assert world.cfg.env_kind == L.ENV_LOWLEVEL and world.n_agents == 2 and world.cfg.auto_reset, "PPORollout drives an auto-resetting LowLevelEnv world"
+        self.w, self.bank, self.T, self.gamma, self.lam = world, bank, int(T), float(gamma), float(lam)
+        N, D, dev = world.N, world.D, world.device
+        esc = world.cfg.agent_mode == L.MODE_ESCAPE
+        self.sel = torch.tensor([pilots.SEL_ESC1 if esc else pilots.SEL_FIGHT1, pilots.SEL_ESC2 if esc else pilots.SEL_FIGHT2],
+                                dtype=torch.uint8, device=dev).repeat(N, 1).contiguous()
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        self.obs = z((self.T + 1, N, 2, D), torch.float32)
+        self.actions = z((self.T, N, 2, 4), torch.int8)
+        self.logp = z((self.T, N, 2), torch.float32)
+        self.vf = z((self.T + 1, N, 2), torch.float32)
+        self.reward = z((self.T, N, 2), torch.float32)
+        self.valid = z((self.T, N, 2), torch.uint8)
+        self.done = z((self.T, N), torch.uint8)
+        self.adv = z((self.T, N, 2), torch.float32)
+        self.target = z((self.T, N, 2), torch.float32)
+        self._tmp_act, self._tmp_logp = z((N, 2, 4), torch.int8), z((N, 2), torch.float32)
+        self.use_graph = use_graph
+        self._graph = None
+        self._started = False
+
+    def start(self):
+        """reset every arena; the first observation becomes row 0 of the next collect.  Also builds the row lists of the fixed agent ->
+        network mapping (a greedy evaluation whose results are discarded), so that every later call re-uses them (sel = NULL)."""
+        self.w.reset(obs=self.obs[self.T])
+        self.bank.sample(self.obs[self.T], self.sel, greedy=True, actions=self._tmp_act, logp=self._tmp_logp, vf=self.vf[self.T])
+        self._started = True
+
+    def _run(self):
+        T = self.T
+        self.obs[0].copy_(self.obs[T])      # where the previous collect (or start) left every arena
+        for t in range(T):                  # every launch reads and writes its tick's rows of the [T, ...] buffers in place
+            self.bank.sample(self.obs[t], None, world=self.w, actions=self.actions[t], logp=self.logp[t], vf=self.vf[t])
+            self.w.step(self.actions[t], out=(self.obs[t + 1], self.reward[t], self.valid[t], self.done[t]))
+        # bootstrap value of the observation after the last tick (an arena that just finished starts a new episode there: hh_gae cuts at done)
+        self.bank.sample(self.obs[T], None, greedy=True, actions=self._tmp_act, logp=self._tmp_logp, vf=self.vf[T])
+        st = C.c_void_p(torch.cuda.current_stream(self.w.device).cuda_stream)
+        L.check(L.lib().hh_gae(T, self.w.N, 2, _p(self.reward), _p(self.vf), _p(self.valid), _p(self.done), self.gamma, self.lam,
+                               _p(self.adv), _p(self.target), st))
+
+    def collect(self):
+        """T ticks of every arena -> self (the buffers above): 2 T + 2 launches, replayed from ONE HIP graph; no host synchronisation."""
+        if not self._started:
+            self.start()
+        if not self.use_graph:
+            self._run()
+        else:
+            if self._graph is None:
+                torch.cuda.synchronize(self.w.device)
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph):
+                    self._run()
+            self._graph.replay()
+        return self
+
+    def critic_rows(self, agent):
+        """the CUR_OBS rows of `agent` (1 | 2) for the T collected ticks with both agents' actions filled in (central_critic_rows)"""
+        return central_critic_rows(self.obs[: self.T], self.actions, agent)

@@ -87,6 +87,52 @@ struct hh_world;
 int hh_bind_policy(struct hh_world *w, hh_policy *p);
 int hh_policy_act_binned(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, int8_t *actions, float *logits, void *stream);
 
+/* ---- The TRAINABLE policies inside a PPO rollout (configs[2]).  What RLlib's sampler does per env step for each of
+ * train_hetero.py's two policies (train_hetero.py:206-243): model.forward on the observer's dict (central_critic_observer, 162-181:
+ * own observation, the other agent's observation, and ZERO action inputs while sampling), TorchMultiCategorical.sample() over the split
+ * logits [13,9,2,2] / [13,9,2], its logp (ACTION_LOGP), and model.value_function() (VF_PREDS).  The value branch
+ * (models/ac_models_hetero.py Fight1 232-255 + 277-289, Fight2 344-367 + 390-402; Esc1 72-83 + 97-103, Esc2 148-159 + 173-179):
+ *     fight:  y = cat(tanh(v1 [own obs | own act]), tanh(v2 [other obs | other act]), y3),  y3 = normalize(t + att_val(t)), t = tanh(v3 [all 57]),
+ *             att_val = MultiheadAttention(150, 2) over a sequence of length 1 = out_proj(v_proj(t));   value = val_out(shared_layer(y))
+ *     escape: value = val_out(shared_layer(tanh(inp1_val [own obs | own act | other obs | other act])))
+ * goes through the SAME shared_layer as the actor; it is evaluated as a second tile kind of the same fused kernel (hh_k_policy_ppo). */
+typedef struct hh_critic_weights {
+    int32_t kind;          /* HH_NET_*: the network whose value branch this is (goes into the same slot as its actor) */
+    /* fight nets: v_w[0] = v1._model.0.weight [175, D_own + A_own], v_w[1] = v2 [175, D_other + A_other], v_w[2] = v3 [150, 57];
+     * escape nets: v_w[0] = inp1_val._model.0.weight [500, 66], v_w[1] = v_w[2] = NULL.  Biases alike. */
+    const float *v_w[3];
+    const float *v_b[3];
+    const float *att_in_proj_w, *att_in_proj_b, *att_out_w, *att_out_b; /* att_val: [450,150], [450], [150,150], [150]; NULL for escape nets */
+    const float *shared_w, *shared_b;                                  /* shared_layer._model.0 [500,500], [500] (the tensor the actor uses) */
+    const float *val_w, *val_b;                                        /* val_out._model.0 [1,500], [1] */
+} hh_critic_weights;
+
+/* load (or replace) the value branch of network `slot` (its actor must be loaded: hh_policy_set_net).  Synchronous. */
+int hh_policy_set_critic(hh_policy *p, int32_t slot, const hh_critic_weights *w);
+
+/* One sampler step for n_rows units = [n_arenas, 2] rows of LowLevelEnv agents (row r's partner — "the other agent" of
+ * central_critic_observer — is row r ^ 1), in one launch sequence (binning as in hh_policy_act + the fused forward over actor AND
+ * critic tiles):
+ *   obs, n_rows, obs_stride, sel   as hh_policy_act (sel == NULL re-uses the row lists of the previous call)
+ *   w         the world whose agents these rows are, or NULL.  With a world, component c of row (arena n, slot s) is drawn by inverse
+ *             CDF from  u = U(seed, arena_offset + n, episode, steps, unit s + 1, HH_SITE_POLICY_SAMPLE, c)  (hh_rng.h) with the
+ *             arena's CURRENT episode / steps counters, i.e. the draw belongs to the step the action is about to be used in.
+ *   uniforms  [dev] f64 [n_rows, 4]  overrides the keyed draw (tests; w may then be NULL).  Exactly one of w / uniforms unless greedy.
+ *   crit_act  [dev] f32 [n_rows, 4]  each row's OWN action as the critic's act_1_own input, already scaled as
+ *             on_postprocess_trajectory does (a0 / 12, a1 / 8, a2, a3: train_hetero.py:138-160; the partner's comes from row r ^ 1);
+ *             NULL = zeros, which is what the sampler sees (train_hetero.py:168-177).
+ *   greedy    != 0: arg-max instead of a draw (evaluation; logp is then the log-probability of the arg-max).
+ *   actions   [dev] i8  [n_rows, 4]   the sampled MultiDiscrete action (4th = 0 for type-2 nets)
+ *   logp      [dev] f32 [n_rows]      sum over the components of log softmax(logits_c)[a_c]   (nullable)
+ *   vf        [dev] f32 [n_rows]      value_function()                                         (nullable: the critic tiles are skipped)
+ *   logits    [dev] f32 [n_rows, 32]  optional, as hh_policy_act
+ * Inverse CDF of a component with logits l[0..n): m = max l, e_i = exp(l_i - m), S = sum e_i in index order, t = (float)u * S, the action
+ * is the first i whose running sum exceeds t (the last index if none does); logp_c = (l_a - m) - log S.  Rows without a network: action
+ * 0, logp / vf untouched.  Everything is ordered on `stream`; no host synchronisation (HIP-graph capturable). */
+int hh_policy_sample(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, const uint8_t *sel, struct hh_world *w,
+                     const double *uniforms, const float *crit_act, int32_t greedy, int8_t *actions, float *logp, float *vf, float *logits,
+                     void *stream);
+
 /* HighLevelEnv.step with the pilot networks INSIDE, one cooperative launch per commander step (envs/env_hier.py:114-140 with
  * env_base.py:349-398 evaluated where the reference evaluates it): the same result as
  *     hh_hl_begin; 16 x { hh_policy_act_binned; hh_hl_agents_act; hh_policy_act_binned; hh_hl_tick }; hh_hl_end

@@ -84,7 +84,9 @@ enum {
     HH_SITE_HL_FIGHT = 22,    /* env_hier.py:176  choices([0,1], weights)                 */
     HH_SITE_HL_OTHER = 23,    /* env_hier.py:179  choices([0,1], [1,3])                   */
     HH_SITE_HL_PICK = 24,     /* env_hier.py:181  randint(2, k)                           */
-    HH_SITE_COUNT = 25
+    HH_SITE_POLICY_SAMPLE = 25, /* hh_policy_sample (hh_policy.h): the Categorical draw RLlib's sampler makes per action component
+                                   (TorchMultiCategorical.sample -> torch.multinomial, unseeded in the reference); sub = component */
+    HH_SITE_COUNT = 26
 };
 
 #endif /* HH_SPEC_H */

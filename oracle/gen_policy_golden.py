@@ -12,6 +12,13 @@ What is stubbed: ray.rllib's TorchModelV2 / RecurrentNetwork (constructor bookke
 activation, ray/rllib/models/torch/misc.py), add_time_dimension ([B*T, F] -> [B, T, F]), override, try_import_torch.
 The forward() code that runs is the reference's own.
 
+Round 4 adds tests/golden/policy_value.npz — the sampler's view of the TRAINABLE policies (train_hetero.py:206-243): the same
+reference classes, loaded with synthetic actor AND value-branch weights, called with central_critic_observer's full dict (the other
+agent's observation; action inputs zero as while sampling on half of the rows, scaled actions as on_postprocess_trajectory writes them
+on the other half), `forward()` then `value_function()`.  Recorded per row: logits, value, the log-probability of a given action (the
+sum of the components' Categorical(logits).log_prob, which is what RLlib's TorchMultiCategorical.logp computes), and for a recorded
+uniform tape the inverse-CDF action of hh_policy_sample's definition evaluated in float64 on the REFERENCE's logits.
+
 Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_policy_golden.py [--check]
 """
 import os
@@ -29,6 +36,8 @@ from hhmarl_2d_amd import policy_nets as PN  # noqa: E402
 
 REF_ROOT = "/root/reference"
 OUT = os.path.join(ROOT, "tests", "golden", "policy_nets.npz")
+OUT_VALUE = os.path.join(ROOT, "tests", "golden", "policy_value.npz")
+VALUE_ROWS = 64
 SEED, ROWS = 20240917, 96
 
 
@@ -152,12 +161,73 @@ def generate():
     return out
 
 
+def random_actions(rng, rows, ncomp):
+    a = np.zeros((rows, 4), dtype=np.int8)
+    for i, hi in enumerate((13, 9, 2, 2)[:ncomp]):
+        a[:, i] = rng.integers(0, hi, rows)
+    return a
+
+
+def generate_value():
+    """forward() + value_function() of the reference classes on the observer's full dict; logp of given actions; inverse-CDF draws"""
+    M = reference_models()
+    classes = {PN.FIGHT1: M.Fight1, PN.FIGHT2: M.Fight2, PN.ESC1: M.Esc1, PN.ESC2: M.Esc2}
+    partner = {PN.FIGHT1: PN.FIGHT2, PN.FIGHT2: PN.FIGHT1, PN.ESC1: PN.ESC2, PN.ESC2: PN.ESC1}
+    out = {"seed": np.array(SEED)}
+    for kind, cls in classes.items():
+        model = cls(None, None, PN.N_OUT[kind], {}, PN.KIND_NAMES[kind])
+        sd, csd = PN.random_weights(kind, SEED), PN.random_critic_weights(kind, SEED)
+        full = model.state_dict()
+        for k, v in {**sd, **csd}.items():
+            assert full[k].shape == v.shape, (k, full[k].shape, v.shape)
+            full[k] = torch.from_numpy(v)
+        assert set(full) == set(sd) | set(csd), sorted(set(full) ^ (set(sd) | set(csd)))   # nothing of the module is left at its random init
+        model.load_state_dict(full)
+        model.eval()
+        d1, a1, d2, a2 = PN.CRITIC_DIMS[kind]
+        rng = np.random.default_rng([SEED, 200 + kind])
+        own = synth_obs(rng, kind, VALUE_ROWS)
+        oth = synth_obs(rng, partner[kind], VALUE_ROWS)
+        act_own, act_oth = random_actions(rng, VALUE_ROWS, a1), random_actions(rng, VALUE_ROWS, a2)
+        zero = np.arange(VALUE_ROWS) % 2 == 0                      # the sampler's rows: action inputs are zeros (train_hetero.py:168-177)
+        ca_own, ca_oth = PN.scale_actions(act_own), PN.scale_actions(act_oth)
+        ca_own[zero] = 0.0
+        ca_oth[zero] = 0.0
+        given = random_actions(rng, VALUE_ROWS, a1)
+        u = rng.random((VALUE_ROWS, 4))
+        logits, value = [], []
+        for r in range(VALUE_ROWS):
+            inp = {"obs_1_own": torch.from_numpy(own[r:r + 1]), "obs_2": torch.from_numpy(oth[r:r + 1]),
+                   "act_1_own": torch.from_numpy(ca_own[r:r + 1, :a1]), "act_2": torch.from_numpy(ca_oth[r:r + 1, :a2])}
+            with torch.no_grad():
+                lg = model(input_dict={"obs": inp}, state=[torch.tensor(0)], seq_lens=torch.tensor([1]))[0]
+                vf = model.value_function()
+            logits.append(lg[0].numpy())
+            value.append(float(vf[0]))
+        logits = np.stack(logits).astype(np.float32)
+        logp = PN.multicategorical_logp(logits, given, PN.N_OUT[kind]).numpy().astype(np.float32)
+        drawn, drawn_logp, margin = PN.inverse_cdf_actions(logits, u, PN.N_OUT[kind])
+        name = PN.KIND_NAMES[kind].lower()
+        out.update({f"obs_own_{name}": own, f"obs_other_{name}": oth, f"crit_act_own_{name}": ca_own, f"crit_act_other_{name}": ca_oth,
+                    f"logits_{name}": logits, f"value_{name}": np.asarray(value, dtype=np.float32), f"given_{name}": given, f"logp_given_{name}": logp,
+                    f"u_{name}": u, f"drawn_{name}": drawn, f"drawn_logp_{name}": drawn_logp.astype(np.float32), f"margin_{name}": margin})
+        print(f"{name}: value in [{min(value):.3f}, {max(value):.3f}], logp(given) in [{logp.min():.2f}, {logp.max():.2f}], "
+              f"smallest draw margin {margin.min():.2e}")
+    return out
+
+
+def _check(path, data):
+    old = np.load(path)
+    return [k for k in data if k not in old.files or not np.array_equal(old[k], data[k])]
+
+
 if __name__ == "__main__":
-    data = generate()
+    data, vdata = generate(), generate_value()
     if "--check" in sys.argv:
-        old = np.load(OUT)
-        bad = [k for k in data if k not in old.files or not np.array_equal(old[k], data[k])]
+        bad = _check(OUT, data) + _check(OUT_VALUE, vdata)
         print("policy fixtures reproduce" if not bad else f"DIFFERENT: {bad}")
         sys.exit(1 if bad else 0)
     np.savez_compressed(OUT, **data)
-    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+    np.savez_compressed(OUT_VALUE, **vdata)
+    for pth in (OUT, OUT_VALUE):
+        print("wrote", pth, os.path.getsize(pth), "bytes")

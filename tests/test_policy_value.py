@@ -1,0 +1,220 @@
+"""The TRAINABLE policies of a PPO rollout (BASELINE configs[2]): value branch, Categorical draw and log-probability.
+CPU part: the plain-PyTorch fp32 restatement of value_function() (hhmarl_2d_amd/policy_nets.py) and the float64 restatement of the
+sampler's inverse-CDF draw against vectors recorded from the REAL reference model classes (`forward()` + `value_function()` on
+central_critic_observer's full dict: oracle/gen_policy_golden.py -> tests/golden/policy_value.npz).  GPU part (-m gpu): the fused HIP
+kernel `hh_k_policy_ppo` through the C ABI (`hh_policy_sample`) against the same vectors (value / logits / logp <= 1e-5, drawn action =
+inverse CDF of the recorded uniforms on the recorded logits), against the restatements at rollout sizes with the keyed RNG of a real
+world, and the device-resident PPO rollout driver (obs, action, logp, vf, reward, done, advantage, target) against a step-by-step replay."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hhmarl_2d_amd import policy_nets as PN
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "policy_value.npz")
+TOL = 1e-5
+KINDS = [PN.FIGHT1, PN.FIGHT2, PN.ESC1, PN.ESC2]
+PARTNER = {PN.FIGHT1: PN.FIGHT2, PN.FIGHT2: PN.FIGHT1, PN.ESC1: PN.ESC2, PN.ESC2: PN.ESC1}
+
+
+def _pad4(a):
+    out = np.zeros((a.shape[0], 4), dtype=np.float32)
+    out[:, : a.shape[1]] = a
+    return out
+
+
+@pytest.mark.parametrize("kind", KINDS, ids=lambda k: PN.KIND_NAMES[k])
+def test_torch_value_restatement_matches_reference_classes(kind):
+    g = np.load(GOLD)
+    n = PN.KIND_NAMES[kind].lower()
+    seed = int(g["seed"])
+    sd, csd = PN.random_weights(kind, seed), PN.random_critic_weights(kind, seed)
+    t = lambda k: torch.from_numpy(g[f"{k}_{n}"])
+    v = PN.torch_value(kind, sd, csd, t("obs_own"), t("crit_act_own"), t("obs_other"), t("crit_act_other"))
+    assert np.abs(v.numpy() - g[f"value_{n}"]).max() <= TOL
+    assert np.abs(PN.torch_forward(kind, sd, t("obs_own")).numpy() - g[f"logits_{n}"]).max() <= TOL
+    # half of the rows are the sampler's (zero action inputs), half carry scaled actions: both kinds must be present
+    z = (g[f"crit_act_own_{n}"] == 0).all(axis=1) & (g[f"crit_act_other_{n}"] == 0).all(axis=1)
+    assert 0.3 < z.mean() < 0.7
+
+
+@pytest.mark.parametrize("kind", KINDS, ids=lambda k: PN.KIND_NAMES[k])
+def test_draw_and_logp_restatements(kind):
+    g = np.load(GOLD)
+    n = PN.KIND_NAMES[kind].lower()
+    act, logp, margin = PN.inverse_cdf_actions(g[f"logits_{n}"], g[f"u_{n}"], PN.N_OUT[kind])
+    assert np.array_equal(act, g[f"drawn_{n}"]) and np.abs(logp - g[f"drawn_logp_{n}"]).max() <= 1e-6
+    lp = PN.multicategorical_logp(g[f"logits_{n}"], g[f"given_{n}"], PN.N_OUT[kind]).numpy()
+    assert np.abs(lp - g[f"logp_given_{n}"]).max() <= 1e-6
+    # the float64 inverse-CDF log-probability is the Categorical log_prob of the drawn action
+    assert np.abs(PN.multicategorical_logp(g[f"logits_{n}"], act, PN.N_OUT[kind]).numpy() - logp).max() <= 2e-6
+    # a draw follows its distribution: u = 0 takes the first index, u -> 1 the last of every component
+    a0, _, _ = PN.inverse_cdf_actions(g[f"logits_{n}"], np.zeros((64, 4)), PN.N_OUT[kind])
+    a1, _, _ = PN.inverse_cdf_actions(g[f"logits_{n}"], np.full((64, 4), 1.0 - 1e-12), PN.N_OUT[kind])
+    last = np.array([12, 8, 1, 1 if PN.N_OUT[kind] == 26 else 0])
+    assert (a0 == 0).all() and (a1 == last).all()
+
+
+def test_critic_tables_are_consistent():
+    for kind in KINDS:
+        d1, a1, d2, a2 = PN.CRITIC_DIMS[kind]
+        assert d1 == PN.OBS_DIM[kind] and d2 == PN.OBS_DIM[PARTNER[kind]] and (a1, a2) == ((4, 3) if PN.N_OUT[kind] == 26 else (3, 4))
+        assert d1 + a1 + d2 + a2 == (57 if PN.HAS_ATT[kind] else 66)
+        csd = PN.random_critic_weights(kind, 3)
+        assert set(csd) == set(PN.critic_keys(kind)) and all(v.dtype == np.float32 for v in csd.values())
+        assert PN.critic_flops_per_row(kind) > 5e5
+    assert np.array_equal(PN.scale_actions(np.array([[12, 8, 1, 1]], dtype=np.int8)), np.ones((1, 4), dtype=np.float32))
+
+
+# ---------------------------------------------------------------------------------------------- GPU: hh_policy_sample
+def _trainable(seed, mode="fight", max_rows=1 << 16):
+    from hhmarl_2d_amd.pilots import PolicyBank
+    return PolicyBank.trainable_init(torch.device("cuda", 0), mode=mode, seed=seed, max_rows=max_rows)
+
+
+def _sel(mode, n_arenas):
+    from hhmarl_2d_amd import pilots
+    b = (pilots.SEL_FIGHT1, pilots.SEL_FIGHT2) if mode == "fight" else (pilots.SEL_ESC1, pilots.SEL_ESC2)
+    return torch.tensor(b, dtype=torch.uint8, device="cuda").repeat(n_arenas, 1).contiguous()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", KINDS, ids=lambda k: PN.KIND_NAMES[k])
+def test_hip_sample_matches_reference_vectors(kind):
+    """the recorded rows of `kind` sit at their agent slot of [N, 2] arenas, the recorded other agent beside them: value, logits and logp
+    within 1e-5 of the reference's own forward() / value_function(); the drawn action is the inverse CDF of the recorded uniforms"""
+    g = np.load(GOLD)
+    n = PN.KIND_NAMES[kind].lower()
+    mode = "fight" if PN.HAS_ATT[kind] else "escape"
+    slot = 0 if PN.N_OUT[kind] == 26 else 1
+    bank = _trainable(int(g["seed"]), mode)
+    R, D = 64, 30
+    obs = np.zeros((R, 2, D), dtype=np.float32)
+    ca = np.zeros((R, 2, 4), dtype=np.float32)
+    u = np.zeros((R, 2, 4))
+    obs[:, slot, : PN.OBS_DIM[kind]] = g[f"obs_own_{n}"]
+    obs[:, 1 - slot, : PN.OBS_DIM[PARTNER[kind]]] = g[f"obs_other_{n}"]
+    ca[:, slot] = _pad4(g[f"crit_act_own_{n}"])
+    ca[:, 1 - slot] = _pad4(g[f"crit_act_other_{n}"])
+    u[:, slot] = g[f"u_{n}"]
+    u[:, 1 - slot] = 0.5
+    logits = torch.zeros((R, 2, 32), dtype=torch.float32, device="cuda")
+    act, logp, vf = bank.sample(torch.from_numpy(obs).cuda(), _sel(mode, R), uniforms=torch.from_numpy(u).cuda(), crit_act=torch.from_numpy(ca).cuda(),
+                                logits=logits)
+    torch.cuda.synchronize()
+    lg = logits.cpu().numpy()[:, slot]
+    assert np.abs(lg[:, : PN.N_OUT[kind]] - g[f"logits_{n}"]).max() <= TOL
+    assert np.abs(vf.cpu().numpy()[:, slot] - g[f"value_{n}"]).max() <= TOL
+    clear = g[f"margin_{n}"] > 1e-5
+    assert clear.mean() > 0.95
+    got = act.cpu().numpy()[:, slot]
+    assert np.array_equal(got[clear], g[f"drawn_{n}"][clear])
+    assert np.abs(logp.cpu().numpy()[:, slot][clear] - g[f"drawn_logp_{n}"][clear]).max() <= TOL
+    # greedy: the arg-max and its log-probability; the value does not depend on how the action is chosen
+    act_g, logp_g, vf_g = bank.sample(torch.from_numpy(obs).cuda(), None, greedy=True, crit_act=torch.from_numpy(ca).cuda())
+    want = PN.decode(torch.from_numpy(g[f"logits_{n}"]), PN.N_OUT[kind]).numpy()
+    assert np.array_equal(act_g.cpu().numpy()[:, slot], want)
+    assert np.abs(logp_g.cpu().numpy()[:, slot] - PN.multicategorical_logp(g[f"logits_{n}"], want, PN.N_OUT[kind]).numpy()).max() <= TOL
+    assert torch.equal(vf_g, vf)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fight", "escape"])
+def test_hip_sample_at_rollout_size_with_the_worlds_keyed_draws(mode, oracle):
+    """16384 arenas x 2 agents, observations of a real world, draws keyed by (seed, global arena, episode, steps, unit, site, component):
+    logits / value against the PyTorch fp32 restatements, actions against the float64 inverse CDF of the oracle's hho_rng_u01 on the
+    kernel's own logits, logp against Categorical.log_prob"""
+    from hhmarl_2d_amd.world import World, make_config
+    from hhmarl_2d_amd import _lib as L
+    N = 16384 if mode == "fight" else 4099
+    kinds = (PN.FIGHT1, PN.FIGHT2) if mode == "fight" else (PN.ESC1, PN.ESC2)
+    w = World(make_config(n_arenas=N, level=3, agent_mode=L.MODE_FIGHT if mode == "fight" else L.MODE_ESCAPE, seed=77, arena_offset=1000, auto_reset=True), device=0)
+    bank = _trainable(5, mode, max_rows=2 * N)
+    obs = w.reset()
+    rng = np.random.default_rng(1)
+    for _ in range(3):   # a few ticks in: steps counters differ from zero (and stay equal across arenas until the first episode ends)
+        a = torch.from_numpy(np.stack([rng.integers(0, 13, (N, 2)), rng.integers(0, 9, (N, 2)), rng.integers(0, 2, (N, 2)), rng.integers(0, 2, (N, 2))],
+                                      axis=-1).astype(np.int8)).cuda()
+        obs = w.step(a)[0]
+    logits = torch.zeros((N, 2, 32), dtype=torch.float32, device="cuda")
+    act, logp, vf = bank.sample(obs, _sel(mode, N), world=w, logits=logits)
+    torch.cuda.synchronize()
+    st = w.get_state()["ar_i"]          # steps, alive_agents, alive_opps, escaping, escaping_time, episode
+    o = obs.cpu()
+    zeros4 = torch.zeros((N, 4))
+    lib = oracle.lib()
+    sub = np.arange(0, N, 37)
+    for slot, kind in enumerate(kinds):
+        sd, csd = PN.random_weights(kind, 5), PN.random_critic_weights(kind, 5)
+        ref_l = PN.torch_forward(kind, sd, o[:, slot])
+        ref_v = PN.torch_value(kind, sd, csd, o[:, slot], zeros4, o[:, 1 - slot], zeros4)
+        got_l = logits[:, slot, : PN.N_OUT[kind]].cpu()
+        assert (got_l - ref_l).abs().max() <= TOL and (logits[:, slot, PN.N_OUT[kind]:] == 0).all()
+        assert (vf[:, slot].cpu() - ref_v).abs().max() <= TOL
+        u = np.array([[lib.hho_rng_u01(77, 1000 + int(n), int(st[n, 5]), int(st[n, 0]), slot + 1, 25, c) for c in range(4)] for n in sub])
+        want, want_lp, margin = PN.inverse_cdf_actions(got_l.numpy()[sub].astype(np.float64), u, PN.N_OUT[kind])
+        clear = margin > 1e-6
+        assert clear.mean() > 0.99
+        assert np.array_equal(act[:, slot].cpu().numpy()[sub][clear], want[clear])
+        lp = PN.multicategorical_logp(got_l, act[:, slot].cpu().numpy(), PN.N_OUT[kind])
+        assert (logp[:, slot].cpu() - lp).abs().max() <= TOL
+        # the draw is a draw: every action value of every component occurs, and the empirical mean log-probability is the (negative) entropy scale
+        for c, hi in enumerate((13, 9, 2, 2)[: 4 if PN.N_OUT[kind] == 26 else 3]):
+            assert len(torch.unique(act[:, slot, c])) == hi
+    # the same call again gives the same draws (keyed, not a stream); one tick later they differ
+    act2, _, _ = bank.sample(obs, None, world=w)
+    assert torch.equal(act2, act)
+    obs2 = w.step(act)[0]
+    act3, _, _ = bank.sample(obs2, None, world=w)
+    assert not torch.equal(act3, act)
+
+
+@pytest.mark.gpu
+def test_sample_argument_errors():
+    bank = _trainable(1)
+    obs = torch.zeros((8, 2, 26), device="cuda")
+    with pytest.raises(RuntimeError, match="world"):
+        bank.sample(obs, _sel("fight", 8))                      # a draw without a key or uniforms
+    from hhmarl_2d_amd.pilots import PolicyBank
+    frozen = PolicyBank.random_init(torch.device("cuda", 0), seed=1, max_rows=64)
+    with pytest.raises(RuntimeError, match="value branch"):
+        frozen.sample(obs, _sel("fight", 8), greedy=True)       # vf asked of a bank without critics
+    a, lp, vf = frozen.sample(obs, _sel("fight", 8), greedy=True, want_vf=False)
+    assert vf is None and a.shape == (8, 2, 4)
+
+
+@pytest.mark.gpu
+def test_ppo_rollout_driver_equals_a_step_by_step_replay():
+    """PPORollout (one HIP graph per collect) against the same ticks driven call by call: identical buffers; the buffers are consistent
+    with each other (obs[t+1] = step(actions[t]), vf / logp of obs[t], GAE of the stored rewards / values / dones)"""
+    from hhmarl_2d_amd.world import World, make_config
+    from hhmarl_2d_amd.rollout import PPORollout, gae
+    N, T = 2048, 24
+    kw = dict(n_arenas=N, level=3, seed=11, auto_reset=True, horizon=20)    # short horizon: episodes end (and restart) inside the rollout
+    wa, wb = World(make_config(**kw), device=0), World(make_config(**kw), device=0)
+    bank = _trainable(9, max_rows=2 * N)
+    ro = PPORollout(wa, bank, T)
+    ro.collect()
+    first = {k: getattr(ro, k).clone() for k in ("obs", "actions", "logp", "vf", "reward", "valid", "done", "adv", "target")}
+    ro.collect()                                                              # second collect = graph replay, continues where the first ended
+    second = {k: getattr(ro, k).clone() for k in first}
+    assert torch.equal(second["obs"][0], first["obs"][T]) and first["done"].sum() > N // 2
+    # replay on a second world, eagerly
+    sel = _sel("fight", N)
+    obs = wb.reset()
+    for rec in (first, second):
+        assert torch.equal(rec["obs"][0], obs)
+        for t in range(T):
+            a, lp, vf = bank.sample(obs, sel, world=wb)
+            assert torch.equal(a, rec["actions"][t]) and torch.equal(lp, rec["logp"][t]) and torch.equal(vf, rec["vf"][t])
+            obs, r, v, d = wb.step(a)
+            assert torch.equal(obs, rec["obs"][t + 1]) and torch.equal(r, rec["reward"][t]) and torch.equal(v, rec["valid"][t]) and torch.equal(d, rec["done"][t])
+        _, _, vfT = bank.sample(obs, sel, greedy=True)
+        assert torch.equal(vfT, rec["vf"][T])
+        adv, ret = gae(rec["reward"], rec["vf"], rec["valid"], rec["done"], 0.99, 0.95)
+        assert torch.equal(adv, rec["adv"]) and torch.equal(ret, rec["target"])
+    # the critic's training rows carry the stored actions (central_critic_rows: pinned against the reference's callbacks elsewhere)
+    rows = ro.critic_rows(1)
+    assert rows.shape == (T, N, 57) and torch.equal(rows[..., 0], second["actions"][:, :, 0, 0].double().div(12.0).float())

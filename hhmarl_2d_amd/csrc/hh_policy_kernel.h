@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256, 2) void hh_k_policy(HhpBank bank, int n_nets, 
 
 #include "hh_policy_kernel_h16.h"
 #include "hh_policy_kernel_ppo.h"
+#include "hh_policy_kernel_w.h"
 
 /* ===================================================================== host side */
 #define HHP_SLOT_BYTES ((size_t)4 << 20) /* fp32 blob 1.19 MB + fp16 planes 1.18 MB per network, padded to 4 MB */
@@ -363,6 +364,9 @@ struct hh_policy {
     uint8_t *lut;             /* [256] dev */
     int *counts, *lists;      /* counters (HHP_COUNTS_INTS), [MAX_NETS][max_rows] dev */
     hh_world *bound;          /* hh_bind_policy: the world whose kernels write the lists (one world per bank), or nullptr */
+    HhpBankW bankw;           /* the weights-through-LDS form (hh_policy_kernel_w.h): one linear fragment stream per network */
+    unsigned char *wblob[HH_POLICY_MAX_NETS];
+    int wform;                /* HH_POLICY_W: 1 = always hh_k_policy_w, 0 = never, unset (-1) = by row count (hhp_rows_suit_w) */
     HhpCritBank cbank;        /* hh_policy_set_critic: the value branches of the trainable policies (hh_policy_sample) */
     char *cblob[HH_POLICY_MAX_NETS]; /* one allocation per loaded value branch */
 };
@@ -403,7 +407,9 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { p->blob[i] = nullptr; p->blobh[i] = nullptr; }
     p->slab = nullptr;
     memset(&p->cbank, 0, sizeof(p->cbank));
-    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) p->cblob[i] = nullptr;
+    memset(&p->bankw, 0, sizeof(p->bankw));
+    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { p->cblob[i] = nullptr; p->wblob[i] = nullptr; }
+    { const char *e = getenv("HH_POLICY_W"); p->wform = e ? atoi(e) : -1; }
     p->lut = nullptr; p->counts = nullptr; p->lists = nullptr;
     hipError_t e = hipMalloc(&p->lut, 256);
     if (e == hipSuccess) e = hipMemset(p->lut, 0, 256);
@@ -415,6 +421,7 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_h<1>), hipFuncAttributeMaxDynamicSharedMemorySize, HHPH_LDS_BYTES(1));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_h<2>), hipFuncAttributeMaxDynamicSharedMemorySize, HHPH_LDS_BYTES(2));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_ppo), hipFuncAttributeMaxDynamicSharedMemorySize, HHPP_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_w<4>), hipFuncAttributeMaxDynamicSharedMemorySize, HHW_LDS_BYTES);
     if (e != hipSuccess) {
         g_err = std::string("hh_policy_create: ") + hipGetErrorString(e);
         if (p->lut) (void)hipFree(p->lut);
@@ -433,7 +440,7 @@ extern "C" int hh_policy_destroy(hh_policy *p) {
     hhp_unbind(p); /* a world still bound to this bank goes back to emitting selector bytes only */
     DeviceGuard guard_(p->device);
     (void)hipFree(p->slab);
-    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) if (p->cblob[i]) (void)hipFree(p->cblob[i]);
+    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { if (p->cblob[i]) (void)hipFree(p->cblob[i]); if (p->wblob[i]) (void)hipFree(p->wblob[i]); }
     (void)hipFree(p->lut); (void)hipFree(p->counts); (void)hipFree(p->lists);
     delete p;
     return HH_OK;
@@ -502,6 +509,40 @@ static int hhp_set_net(hh_policy *p, int32_t slot, const hh_net_weights *w) {
         for (int k = 0; k < 500; k++) { B[o_wa + hhp_pidx(k, j, HHP_OUT)] = w->out_w[(size_t)j * 500 + k]; hhp_split_put_t(Hh, Hl, h_wa, k, j, HHP_OUT, w->out_w[(size_t)j * 500 + k]); }
         B[o_ba + j] = w->out_b[j];
     }
+    { /* the same four matrices as ONE linear stream of 1 KB fragments in consumption order (hh_policy_kernel_w.h) */
+        std::vector<uint16_t> S((size_t)HHW_STREAM_PIECES * (HHW_PIECE / 2), 0);
+        auto w1 = [&](int k, int col) { return k < HHP_XK ? B[o_w1 + hhp_pidx(k, col, HHP_H)] : 0.0f; };
+        auto wov = [&](int k, int col) { return (att && k < 100 && col < 100) ? B[o_wov + hhp_pidx(k, col, HHP_ATT_J)] : 0.0f; };
+        auto wsf = [&](int k, int col) { return (k < 500 && col < 500) ? w->shared_w[(size_t)col * 500 + k] : 0.0f; };
+        auto waf = [&](int k, int col) { return (k < 500 && col < n_out) ? w->out_w[(size_t)col * 500 + k] : 0.0f; };
+        for (int T = 0; T < 16; T++)
+            for (int kb = 0; kb < 2; kb++)
+                for (int wq = 0; wq < 16; wq++)
+                    for (int c = 0; c < 32; c++) hhw_put(S, (size_t)(T * 2 + kb) * 2, 16 * kb + wq, 32 * T + c, true, w1(16 * kb + wq, 32 * T + c));
+        for (int j = 0; j < 4; j++)
+            for (int kb = 0; kb < 7; kb++)
+                for (int wq = 0; wq < 16; wq++)
+                    for (int c = 0; c < 32; c++) hhw_put(S, (size_t)HHW_L1_PIECES + (size_t)(j * 7 + kb) * 2, 16 * kb + wq, 32 * j + c, false, wov(16 * kb + wq, 32 * j + c));
+        const size_t l2_0 = (size_t)HHW_L1_PIECES + HHW_ATT_PIECES;
+        for (int pp = 0; pp < 8; pp++) {
+            for (int hf = 0; hf < 2; hf++)
+                for (int kk = 0; kk < 16; kk++)
+                    for (int t = 0; t < 2; t++)
+                        for (int wq = 0; wq < 16; wq++)
+                            for (int c = 0; c < 32; c++)
+                                hhw_put(S, l2_0 + hhw_chunk_piece(pp, hf) + (size_t)kk * 4 + t * 2, 16 * (16 * hf + kk) + wq, 32 * (2 * pp + t) + c, false,
+                                        wsf(16 * (16 * hf + kk) + wq, 32 * (2 * pp + t) + c));
+            const size_t l3 = l2_0 + (pp < 7 ? hhw_chunk_piece(pp + 1, 0) : hhw_chunk_piece(7, 1)) + HHW_L2_PIECES; /* behind the chunk in whose shadow pair pp's epilogue runs */
+            for (int t = 0; t < 2; t++)
+                for (int b2 = 0; b2 < 2; b2++)
+                    for (int wq = 0; wq < 16; wq++)
+                        for (int c = 0; c < 32; c++)
+                            hhw_put(S, l3 + (size_t)(t * 2 + b2) * 2, 16 * ((2 * pp + t) * 2 + b2) + wq, c, false, waf(16 * ((2 * pp + t) * 2 + b2) + wq, c));
+        }
+        if (!p->wblob[slot]) HIPCHK(hipMalloc(&p->wblob[slot], (size_t)HHW_STREAM_PIECES * HHW_PIECE));
+        HIPCHK(hipMemcpy(p->wblob[slot], S.data(), (size_t)HHW_STREAM_PIECES * HHW_PIECE, hipMemcpyHostToDevice));
+        p->bankw.net[slot].stream = p->wblob[slot];
+    }
     static_assert(HHP_SLOT_BYTES >= (size_t)2 * 1024 * 1024 + 2 * 309248 * 2, "slot too small");
     if (total * sizeof(float) > (size_t)2 * 1024 * 1024 || 2 * h_total * sizeof(uint16_t) > HHP_SLOT_BYTES - (size_t)2 * 1024 * 1024) { g_err = "internal: blob exceeds its slot"; return HH_E_ARG; }
     p->blob[slot] = reinterpret_cast<float *>(p->slab + (size_t)slot * HHP_SLOT_BYTES);                                   /* first 2 MB of the slot */
@@ -547,13 +588,26 @@ static inline bool hhp_rows_suit_wide_tiles(int n_rows, int n_cu) {
     const int tiles = (n_rows + 63) / 64, rem = tiles % n_cu;
     return tiles >= n_cu && (rem == 0 || rem * 4 > n_cu * 3);
 }
+/* The weights-through-LDS form (hh_policy_kernel_w.h) carries 128 rows per CU through the network in one pass over the weights and takes
+ * ~60 us for that however few of the CUs have a tile (one wave per SIMD, nothing hides a phase's latency); the LDS-activation-tile forms
+ * take 27 us for 8192 rows and 67 for 24576.  Measured (tools/policy_bench.py, back to back): 32768 rows 64 against 72 - 78 us, 65536 125
+ * against 145, 24576 60 against 67, 8192 51 against 27; inside the tick graphs configs[2] gains 11 %, the four-stream commander step
+ * (12288 rows per call) loses 9 %.  So: from three quarters of a full round of 128-row tiles upwards. */
+static inline bool hhp_rows_suit_w(int n_rows, int n_cu) { return (long long)n_rows * 4 >= (long long)n_cu * 128 * 3; }
 /* the forward kernel over the current row lists; consume: the last workgroup to read the counters clears them */
-static int hhp_launch_forward(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, int8_t *actions, float *logits, int consume, hipStream_t st) {
+static int hhp_launch_forward(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, int8_t *actions, float *logits, int consume, hipStream_t st,
+                              int32_t live_rows = -1) {
     const int grid = (n_rows + HHP_ROWS - 1) / HHP_ROWS + p->n_nets; /* upper bound of the tiles over all networks */
-    if (p->fp32) {
+    /* the form is chosen by the rows that CARRY a network: a bound HighLevelEnv world lists one side's units per call, half of its
+     * [N, 6] row buffer at most (a full-buffer count picked 64-row tiles for 1.5 rounds of work: 78 against 67 us at 8192 arenas) */
+    const int heur_rows = live_rows >= 0 ? live_rows : n_rows;
+    if (p->wform > 0 || (p->wform < 0 && !p->fp32 && p->tile_rows == 0 && hhp_rows_suit_w(heur_rows, p->n_cu))) { /* weights through LDS, activations in registers */
+        hipLaunchKernelGGL(hh_k_policy_w<4>, dim3((n_rows + 127) / 128 + p->n_nets), dim3(256), HHW_LDS_BYTES, st, p->bank, p->bankw, p->n_nets, obs, obs_stride,
+                           p->counts, p->lists, p->max_rows, actions, logits, consume);
+    } else if (p->fp32) {
         hipLaunchKernelGGL(hh_k_policy, dim3(grid), dim3(256), HHP_LDS_BYTES, st, p->bank, p->n_nets, obs, obs_stride, p->counts, p->lists, p->max_rows,
                            actions, logits, consume);
-    } else if (p->tile_rows == 64 || (p->tile_rows == 0 && hhp_rows_suit_wide_tiles(n_rows, p->n_cu))) { /* persistent: one workgroup per CU walks the tiles grid-stride */
+    } else if (p->tile_rows == 64 || (p->tile_rows == 0 && hhp_rows_suit_wide_tiles(heur_rows, p->n_cu))) { /* persistent: one workgroup per CU walks the tiles grid-stride */
         const int tiles = (n_rows + 63) / 64 + p->n_nets;
         hipLaunchKernelGGL(hh_k_policy_h<2>, dim3(p->persist && tiles > p->n_cu ? p->n_cu : tiles), dim3(512), HHPH_LDS_BYTES(2), st, p->bank, p->bankh, p->n_nets,
                            obs, obs_stride, p->counts, p->lists, p->max_rows, actions, logits, consume);
@@ -604,7 +658,8 @@ extern "C" int hh_policy_act_binned(hh_policy *p, const float *obs, int32_t n_ro
     if (n_rows > p->max_rows) { g_err = "hh_policy_act_binned: n_rows exceeds max_rows of hh_policy_create"; return HH_E_ARG; }
     if (p->n_nets == 0) { g_err = "hh_policy_act_binned: no network loaded"; return HH_E_ARG; }
     HH_GUARD(p);
-    return hhp_launch_forward(p, obs, n_rows, obs_stride, actions, logits, HHP_CONSUME, (hipStream_t)stream);
+    const bool one_side = p->bound && p->bound->cfg.env_kind == HH_ENV_HIGHLEVEL;
+    return hhp_launch_forward(p, obs, n_rows, obs_stride, actions, logits, HHP_CONSUME, (hipStream_t)stream, one_side ? n_rows / 2 : -1);
 }
 
 

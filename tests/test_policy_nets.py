@@ -44,12 +44,13 @@ def _bank(seed, max_rows=1 << 16):
     return PolicyBank.random_init(torch.device("cuda", 0), seed=seed, max_rows=max_rows)
 
 
-FORMS = {"split-fp16": {}, "fp32-mfma": {"HH_POLICY_FP32": "1"}, "split-fp16-64-row-tiles": {"HH_POLICY_TILE": "64"}}
+FORMS = {"split-fp16": {}, "fp32-mfma": {"HH_POLICY_FP32": "1"}, "split-fp16-64-row-tiles": {"HH_POLICY_TILE": "64"},
+         "weights-through-lds": {"HH_POLICY_W": "1"}}
 
 
 def _form(monkeypatch, form):
     """the kernel form a bank created from now on runs (read at hh_policy_create)"""
-    for k in ("HH_POLICY_FP32", "HH_POLICY_TILE"):
+    for k in ("HH_POLICY_FP32", "HH_POLICY_TILE", "HH_POLICY_W"):
         monkeypatch.delenv(k, raising=False)
     for k, v in FORMS[form].items():
         monkeypatch.setenv(k, v)

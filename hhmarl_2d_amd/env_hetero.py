@@ -12,6 +12,7 @@ Extra keys of env_config (all optional, none changes the reference semantics):
   num_envs   number of arenas held on the GPU (default 1).  With num_envs > 1 the dict values
              carry a leading arena axis; RLlib-style single-env callers leave it at 1.
   seed       keyed-RNG seed (the reference is unseeded: env_base.py:62-77 ignores `seed`)
+  arena_offset  global id of arena 0 in the keyed RNG (default 0): workers that should not replay each other's episodes take disjoint ranges
   device     GPU index
 The batched tensor API for native rollout drivers is `self.world` (hhmarl_2d_amd.world.World).
 """
@@ -119,7 +120,7 @@ class LowLevelEnv(_Base):
             raise ValueError("levels 4-5 fly frozen opponent policies (envs/env_base.py:312-398); pass env_config['policy_dir'] = the "
                              "directory of the exported L*_AC*_{fight,escape}.pt files, or env_config['opponent_policy'] = "
                              "callable(opp_obs f32 [N,2,30], env) -> int8 actions [N,2,4] for units 3,4")
-        cfg = config_from_args(self.args, L.ENV_LOWLEVEL, self.num_envs, int(env_config.get("seed", 0)))
+        cfg = config_from_args(self.args, L.ENV_LOWLEVEL, self.num_envs, int(env_config.get("seed", 0)), arena_offset=int(env_config.get("arena_offset", 0)))
         self.world = World(cfg, device=int(env_config.get("device", 0)))
         if self.args.level >= 4 and self.opponent_policy is None:   # _get_policies("LowLevel"), env_base.py:312-332
             from .pilots import OpponentNets, PolicyBank

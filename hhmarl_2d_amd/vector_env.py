@@ -1,0 +1,209 @@
+"""An RLlib-consumable surface for MANY arenas: the `BaseEnv` protocol (ray/rllib/env/base_env.py, RLlib 2.4) over one batched world.
+
+The reference hands RLlib ONE `LowLevelEnv` per rollout worker (train_hetero.py:212-215: `num_rollout_workers`, one env each) and RLlib
+wraps it into a `BaseEnv` itself (`convert_to_base_env` -> `MultiAgentEnvToBaseEnv`), whose sampler loop is
+
+    obs, rewards, terminateds, truncateds, infos, off_policy_actions = base_env.poll()      # {env_id: {agent_id: value}}
+    for env_id with terminateds[env_id]["__all__"] or truncateds[env_id]["__all__"]:
+        obs, infos = base_env.try_reset(env_id)                                             # {env_id: {agent_id: obs}}, {env_id: {}}
+    base_env.send_actions({env_id: {agent_id: action}})
+
+`LowLevelVectorEnv` IS such a BaseEnv, for N arenas resident on the GPU: sub-environment i is arena i of one `World(num_envs = N)`.
+`send_actions` packs every sub-environment's action dict into one [N, 2, 4] int8 tensor and takes ONE `hh_step`; `poll` hands out what
+that step produced, in the reference's own dict semantics per sub-environment (observations for every agent id — zeros when dead —,
+rewards only for ids alive at step start, `terminateds == truncateds == {"__all__": done}`, infos {}); `try_reset(env_id)` returns the
+episode's first observation.  Finished arenas are re-sampled by ONE masked `hh_reset` right after the step that finished them (the draw
+is keyed by arena and episode number, so it does not matter when it is made) and `try_reset` serves the cached rows: no device call per
+sub-environment.  An RLlib user swaps `env=LowLevelEnv` for a registered creator that returns this object
+(`tune.register_env("hh_vector", lambda cfg: LowLevelVectorEnv(cfg))`; a BaseEnv instance is passed through by `convert_to_base_env`)
+with `env_config["num_envs"] = N` — INTEGRATION.md.
+
+Sub-environment i draws from the keyed RNG as arena `arena_offset + i`, exactly like a single-arena `LowLevelEnv` created with
+`env_config["arena_offset"] = arena_offset + i` and the same seed: tests/test_gpu_vector_env.py drives 64 of each side by side.
+"""
+import numpy as np
+
+from . import _lib as L
+from . import spaces
+from .env_hetero import OBS_AC1, OBS_AC2, OBS_ESC_AC1, OBS_ESC_AC2, config_from_args
+
+try:  # subclass RLlib's class when ray is importable (it is not in the build image)
+    from ray.rllib.env.base_env import BaseEnv as _Base  # pragma: no cover
+except Exception:  # noqa: BLE001
+    class _Base:
+        pass
+
+
+class _GpuBackend:
+    """the batched world behind the adapter: numpy in, numpy out, pinned host mirrors, one synchronisation per call"""
+
+    def __init__(self, cfg, device):
+        import torch
+        from .world import World
+        self.torch = torch
+        self.world = World(cfg, device=device)
+        w = self.world
+        self.N, self.n_agents, self.D = w.N, w.n_agents, w.D
+        self._act = torch.zeros((w.N, w.n_ctrl, 4), dtype=torch.int8, device=w.device)
+        self._act_pin = torch.zeros((w.N, w.n_ctrl, 4), dtype=torch.int8).pin_memory()
+        self.act_host = self._act_pin.numpy()
+        self._out = w.alloc_outputs()
+        self._out_pin = [torch.zeros(t.shape, dtype=t.dtype).pin_memory() for t in self._out]
+        self._mask = torch.zeros((w.N,), dtype=torch.uint8, device=w.device)
+        self._mask_pin = torch.zeros((w.N,), dtype=torch.uint8).pin_memory()
+        self.mask_host = self._mask_pin.numpy()
+        self._robs = torch.zeros((w.N, w.n_agents, w.D), dtype=torch.float32, device=w.device)
+        self._robs_pin = torch.zeros((w.N, w.n_agents, w.D), dtype=torch.float32).pin_memory()
+
+    def reset(self, masked):
+        """re-sample the arenas flagged in mask_host (all when masked is False) -> observations [N, n_agents, D] (rows of other arenas stale)"""
+        if masked:
+            self._mask.copy_(self._mask_pin, non_blocking=True)
+        self.world.reset(mask=self._mask if masked else None, obs=self._robs)
+        self._robs_pin.copy_(self._robs, non_blocking=True)
+        self.torch.cuda.current_stream(self.world.device).synchronize()
+        return self._robs_pin.numpy()
+
+    def step(self):
+        """one hh_step with the actions in act_host -> (obs, reward, valid, done) host arrays"""
+        self._act.copy_(self._act_pin, non_blocking=True)
+        self.world.step(self._act, out=self._out)
+        for src, dst in zip(self._out, self._out_pin):
+            dst.copy_(src, non_blocking=True)
+        self.torch.cuda.current_stream(self.world.device).synchronize()
+        return [t.numpy() for t in self._out_pin]
+
+    def close(self):
+        self.world.close()
+
+
+class LowLevelVectorEnv(_Base):
+    """N LowLevelEnv sub-environments (2-vs-2) behind RLlib's BaseEnv protocol, one MI355X world underneath."""
+
+    def __init__(self, env_config):
+        self.args = env_config.get("args", None)
+        if self.args.level >= 4:
+            raise ValueError("LowLevelVectorEnv: levels 4-5 fly frozen opponent policies inside the step; use LowLevelEnv(num_envs = N) with "
+                             "env_config['policy_dir'] for those (the vector adapter covers the scripted curriculum stages 1-3)")
+        self.agent_mode = self.args.agent_mode
+        fight = self.agent_mode == "fight"
+        self.obs_dim_map = {1: OBS_AC1 if fight else OBS_ESC_AC1, 2: OBS_AC2 if fight else OBS_ESC_AC2}
+        self._agent_ids = set(range(1, self.args.num_agents + 1))
+        self.num_envs = int(env_config.get("num_envs", 1))
+        # the spaces of ONE sub-environment, as the reference declares them (env_hetero.py:29-43)
+        self._observation_space = spaces.Dict({i: spaces.Box(low=np.zeros(d), high=np.ones(d), dtype=np.float32) for i, d in self.obs_dim_map.items()})
+        self._action_space = spaces.Dict({1: spaces.MultiDiscrete([13, 9, 2, 2]), 2: spaces.MultiDiscrete([13, 9, 2])})
+        backend = env_config.get("_backend", None)   # tests: a CPU stand-in with the same reset / step surface
+        if backend is None:
+            cfg = config_from_args(self.args, L.ENV_LOWLEVEL, self.num_envs, int(env_config.get("seed", 0)), auto_reset=False,
+                                   arena_offset=int(env_config.get("arena_offset", 0)))
+            backend = _GpuBackend(cfg, int(env_config.get("device", 0)))
+        self.b = backend
+        self._started = False
+        self._pending = {}                    # env_id -> (obs, rewards, terminateds, truncateds, infos) not yet polled
+        self._done = set()                    # sub-environments whose episode ended and that were not reset yet
+        self._reset_obs = {}                  # env_id -> the first observation of its next episode (arena already re-sampled)
+        self._fresh = set()                   # sub-environments that were reset and have not stepped since
+        self._ids = sorted(self._agent_ids)
+
+    # ---- BaseEnv surface (ray/rllib/env/base_env.py)
+    @property
+    def observation_space(self):
+        return self._observation_space
+
+    @property
+    def action_space(self):
+        return self._action_space
+
+    def get_agent_ids(self):
+        return self._agent_ids
+
+    def get_sub_environments(self, as_dict=False):
+        return {} if as_dict else []          # the arenas live in one device-resident world: there are no per-env Python objects
+
+    def _obs_of(self, rows):
+        return {i: rows[i - 1, : self.obs_dim_map[i]].copy() for i in self._ids}
+
+    def _start(self):
+        self._started = True
+        rows = self.b.reset(False)
+        for e in range(self.num_envs):
+            self._pending[e] = (self._obs_of(rows[e]), {}, {"__all__": False}, {"__all__": False}, {})
+            self._fresh.add(e)
+
+    def poll(self):
+        """-> (obs, rewards, terminateds, truncateds, infos, off_policy_actions), each {env_id: {agent_id | "__all__": value}}, for every
+        sub-environment with a result nobody polled yet (the first call resets them all)"""
+        if not self._started:
+            self._start()
+        obs, rew, term, trunc, info = {}, {}, {}, {}, {}
+        for e, (o, r, t, tr, i) in self._pending.items():
+            obs[e], rew[e], term[e], trunc[e], info[e] = o, r, t, tr, i
+        self._pending = {}
+        return obs, rew, term, trunc, info, {}
+
+    def send_actions(self, action_dict):
+        """{env_id: {agent_id: MultiDiscrete action}}: every sub-environment whose episode is running must be there (the arenas step
+        together); one that ended needs try_reset first (RLlib's MultiAgentEnvToBaseEnv raises the same ValueError)"""
+        for e in action_dict:
+            if e in self._done:
+                raise ValueError(f"Env {e} is already done and cannot accept new actions")
+        missing = [e for e in range(self.num_envs) if e not in action_dict and e not in self._done]
+        if missing:
+            raise ValueError(f"send_actions: sub-environments {missing[:8]} have a running episode but no action (the arenas of one world step together)")
+        a = self.b.act_host
+        a[:] = 0
+        for e, ad in action_dict.items():
+            for k, v in ad.items():
+                v = np.asarray(v)
+                a[e, k - 1, : v.shape[-1]] = v
+        obs, rew, val, done = self.b.step()
+        n_ag = self.args.num_agents
+        fin = []
+        self._fresh.clear()
+        for e in action_dict:
+            d = bool(done[e])
+            r = {i: float(rew[e, i - 1]) for i in range(1, n_ag + 1) if val[e, i - 1]}
+            dd = {"__all__": d}
+            self._pending[e] = (self._obs_of(obs[e]), r, dd, dd, {})
+            if d:
+                self._done.add(e)
+                fin.append(e)
+        # a sub-environment that ended earlier and was never try_reset (RLlib's sampler always does that at once) was stepped along with
+        # the rest, on zero actions: its arena is re-sampled again, so that the episode it eventually starts is an untouched one
+        fin += [e for e in self._done if e not in action_dict and e not in fin]
+        if fin:   # ONE masked reset for every arena that just finished; try_reset hands out the cached rows
+            m = self.b.mask_host
+            m[:] = 0
+            m[fin] = 1
+            rows = self.b.reset(True)
+            for e in fin:
+                self._reset_obs[e] = self._obs_of(rows[e])
+
+    def try_reset(self, env_id=None, *, seed=None, options=None):
+        """-> ({env_id: obs dict}, {env_id: {}}) of the sub-environment's next episode"""
+        if env_id is None:
+            env_id = 0
+        if not self._started:
+            self._start()
+        if env_id in self._reset_obs:            # its episode ended: the arena was re-sampled right after that step
+            o = self._reset_obs.pop(env_id)
+        elif env_id in self._fresh and env_id in self._pending:   # reset, not stepped, not polled: that observation is the answer
+            o = self._pending[env_id][0]
+        else:                                    # a reset in the middle of an episode (RLlib does this for episodes it truncates itself)
+            m = self.b.mask_host
+            m[:] = 0
+            m[env_id] = 1
+            o = self._obs_of(self.b.reset(True)[env_id])
+        self._done.discard(env_id)
+        self._pending.pop(env_id, None)
+        self._fresh.add(env_id)
+        return {env_id: o}, {env_id: {}}
+
+    def try_restart(self, env_id=None):
+        return None
+
+    def stop(self):
+        self.b.close()
+
+    close = stop

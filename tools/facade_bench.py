@@ -48,3 +48,23 @@ if len(sys.argv) > 2 and sys.argv[2] == "hier":   # HighLevelEnv.step(dict) with
         hl.step(cmds[k % 8])
     dt = (time.perf_counter() - t0) / S
     print(f"HighLevelEnv(num_envs={N}).step(dict), networks in the loop: {dt * 1e3:.2f} ms per call -> {N / dt:.3g} commander-steps/s")
+
+if len(sys.argv) > 2 and sys.argv[2] == "vector":   # the BaseEnv surface RLlib's sampler speaks: poll / try_reset / send_actions, {env_id: {agent_id: ...}}
+    from hhmarl_2d_amd.vector_env import LowLevelVectorEnv
+    venv = LowLevelVectorEnv({"args": make_args(0, level=3), "num_envs": N, "seed": 1})
+    per_env = [[{1: a[1][e], 2: a[2][e]} for e in range(N)] for a in acts[:4]]
+    def it(k):
+        obs, rew, term, trunc, info, _ = venv.poll()
+        for e in obs:
+            if term[e]["__all__"]:
+                venv.try_reset(e)
+        venv.send_actions(dict(enumerate(per_env[k % 4])))
+    for k in range(5):
+        it(k)
+    S = 200 if N <= 256 else 30
+    t0 = time.perf_counter()
+    for k in range(S):
+        it(k)
+    dt = (time.perf_counter() - t0) / S
+    print(f"LowLevelVectorEnv(num_envs={N}) poll + try_reset + send_actions: {dt * 1e6:.0f} us per iteration -> {N / dt / 1e6:.3f} M env-steps/s "
+          f"(RLlib BaseEnv protocol: {2 * N} observation arrays and {N} reward dicts built per iteration)")

@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_2V2_STEP = 1113       # state r/w 2*448 + actions 8 + obs 200 + reward 8 + done 1
 ALGO_BYTES_3V3_TICK = 2056       # 656 + 656 + pilot obs 720 + pilot actions 24
+ALGO_BYTES_3V3_TICK_TAPE = 1336  # the same tick when the pilots' actions come from a tape: nobody builds or reads the 720 B of pilot observations
+ALGO_BYTES_3V3_STATE = 656       # one arena's state record (read once and written once per commander step by the one-launch macro step)
 ALGO_BYTES_3V3_CMD_FIXED = 424   # commander obs 408 + actions 3 + rewards 12 + done 1
 DEFAULT_STREAMS = {"rollout": 1, "hier_net": 4}   # sub-worlds / streams of the policy-in-the-loop workloads (--streams)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
@@ -61,6 +63,9 @@ def parse_args():
     ap.add_argument("--pilot", choices=["tape", "random", "mlp", "net"], default="tape",
                     help="hier: uniform actions from a pre-resident tape (default), drawn by torch kernels inside the step, random-init "
                          "MLP stand-ins in torch, or the reference's Fight/Esc architectures in the fused HIP kernel (net)")
+    ap.add_argument("--ppo", action="store_true", help="rollout: the TRAINABLE policies as RLlib's sampler evaluates them (train_hetero.py:206-243) instead of a greedy "
+                                                        "actor: per tick hh_policy_sample = actor forward + Categorical draw per action component (keyed RNG) + its "
+                                                        "log-probability + the centralised value branch on central_critic_observer's rows, then hh_step")
     ap.add_argument("--no-graph", action="store_true", help="hier/rollout: launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--phases", action="store_true", help="hier with --pilot tape: the 34-launch phase path instead of the one-launch macro step")
     ap.add_argument("--coop", action="store_true", help="hier with --pilot net: the whole commander step as ONE cooperative launch (hh_hl_step_nets: world phases + policy "
@@ -221,7 +226,8 @@ def counter_evidence(instance, n_arenas, ticks, units_per_s_per_gpu, lanes_per_a
     process).  Stored per arena-tick / per wave-tick, so they apply to any --chunk of the same kernel instance — and ONLY to that
     instance: evidence whose profiled kernel name does not contain `instance` (hh_kernel_instance: the template instance this world
     launches, as a profiler prints it) is stale and is not quoted (traffic / fp64 stay null)."""
-    traffic, fp64 = None, None
+    traffic, fp64, issue = None, None, None
+    quoted = "builder's rocprofv3 --pmc run of this kernel instance at this arena count (tools/prof_pmc.sh), NOT measured by this run"
     tj = load_json("latest_traffic.json")
     if tj and tj.get("arenas") == n_arenas and tj.get("hbm_bytes_per_launch") and instance in str(tj.get("kernel_full", tj.get("kernel", ""))):
         per = tj.get("hbm_bytes_per_arena_tick") or tj["hbm_bytes_per_launch"] / (tj["arenas"] * tj["ticks_per_launch"])
@@ -235,7 +241,7 @@ def counter_evidence(instance, n_arenas, ticks, units_per_s_per_gpu, lanes_per_a
         fp64 = {"bound": "fp64 valu issue", "wave_tick": pj.get("wave_tick"), "insts_valu_per_wave_tick": valu, "insts_salu_per_wave_tick": pj.get("insts_salu_per_wave_tick"),
                 "achieved_lane_ops_s": lane_ops, "peak": FP64_ISSUE_PEAK, "unit": "lane-ops/s", "frac": lane_ops / FP64_ISSUE_PEAK,
                 "frac_note": "every VALU instruction counted as an FP64 issue slot (upper bound on the pipe's use)",
-                "source": pj.get("source", "profiles/latest_pmc.json")}
+                "source": "profiles/latest_pmc.json: " + quoted}
         f64 = pj.get("insts_f64_per_wave_tick")   # SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64: the instructions that are FP64 arithmetic
         if f64:
             n64 = sum(f64.values())
@@ -243,7 +249,25 @@ def counter_evidence(instance, n_arenas, ticks, units_per_s_per_gpu, lanes_per_a
             fp64["f64_share_of_valu"] = n64 / valu if valu else None
             fp64["true_frac"] = n64 * lanes_per_arena * units_per_s_per_gpu / FP64_ISSUE_PEAK
             fp64["true_frac_note"] = "only ADD/MUL/FMA/TRANS_F64 instructions counted (an FMA as ONE issue slot): the FP64 pipe's arithmetic use"
-    return traffic, fp64
+        # The bound this kernel actually sits on at one wave per SIMD: every instruction of a wave (vector, scalar, LDS) takes one 4-cycle
+        # issue slot and nothing overlaps inside a wave (tools/ubench/issue.hip).  slots used = instructions per wave-tick; slots available =
+        # the wave-cycles the occupied SIMDs spent on a wave-tick / 4; the rest is waiting (s_waitcnt / barrier) or issue stalls.
+        ipw = pj.get("insts_per_wave_tick") or {"VALU": valu, "SALU": pj.get("insts_salu_per_wave_tick", 0), "LDS": pj.get("insts_lds_per_wave_tick", 0)}
+        used = float(sum(ipw.values()))
+        avail = pj.get("wave_cycles_per_wave_tick", 0) / 4.0
+        if avail:
+            issue = {"bound": "valu-issue", "slots_used_per_wave_tick": used, "slots_available_per_wave_tick": avail, "frac": used / avail, "unit": "4-cycle issue slots",
+                     "insts_per_wave_tick": ipw, "wave_tick": pj.get("wave_tick"),
+                     "note": "one instruction per slot, no overlap inside a wave; `frac` = share of the occupied SIMDs' issue slots that carry an instruction "
+                             "(simulation + output wave of the two-wave form together)",
+                     "source": "profiles/latest_pmc.json: " + quoted}
+            q = pj.get("sq_quad_cycles") or {}
+            if q.get("SQ_WAVE_CYCLES"):
+                wc = float(q["SQ_WAVE_CYCLES"])
+                issue["wave_cycles_split"] = {"issuing": q.get("SQ_ACTIVE_INST_ANY", 0) / wc if "SQ_ACTIVE_INST_ANY" in q else None,
+                                              "waiting (s_waitcnt, barrier)": q.get("SQ_WAIT_ANY", 0) / wc if "SQ_WAIT_ANY" in q else None,
+                                              "issue stalls": q.get("SQ_WAIT_INST_ANY", 0) / wc if "SQ_WAIT_INST_ANY" in q else None}
+    return traffic, fp64, issue
 
 
 def launch_traffic(fname, instance, n_arenas):
@@ -331,13 +355,16 @@ def main_low(args, R=None):
         bytes_per_launch = ALGO_BYTES_2V2_STEP * N * chunk
         achieved = bytes_per_launch / avg_launch_s / 1e9
         kname = w.kernel_name()
-        traffic, fp64 = counter_evidence(w.kernel_instance(), N, chunk, N * chunk / avg_launch_s, 4)   # 2-vs-2: four aircraft lanes per arena
+        traffic, fp64, issue = counter_evidence(w.kernel_instance(), N, chunk, N * chunk / avg_launch_s, 4)   # 2-vs-2: four aircraft lanes per arena
         line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                             "traffic": traffic, "kernel": kname, "kernel_instance": w.kernel_instance(), "avg_launch_ms": avg_launch_s * 1e3,
-                            "algorithmic_bytes_per_launch": bytes_per_launch, "fp64": fp64,
-                            "note": "FP64-VALU issue bound, not HBM bound (DESIGN.md section 4): `fp64.frac` is the fraction of the "
-                                    "vector-FP64 issue slots the measured rate uses; HBM traffic is far below the algorithmic bytes "
-                                    "because state stays in registers across the ticks of a launch"}
+                            "traffic_source": None if traffic is None else "profiles/latest_traffic.json: builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                                                           "kernel instance at this arena count (tools/prof_pmc.sh), NOT measured by this run",
+                            "algorithmic_bytes_per_launch": bytes_per_launch, "issue": issue, "fp64": fp64,
+                            "note": "instruction-issue bound, not HBM bound (DESIGN.md section 4): `issue.frac` is the share of the occupied SIMDs' issue "
+                                    "slots that carry an instruction, `fp64` the share of the vector-FP64 pipe; HBM traffic is far below the algorithmic "
+                                    "bytes because state stays in registers across the ticks of a launch.  `achieved` / `frac` are measured by this run "
+                                    "(HIP events); `traffic`, `issue` and `fp64` are quoted from the committed counter passes"}
         if R.rank == 0 and R.world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, args.level, args.seed)
     if not own:
@@ -365,9 +392,20 @@ def main_policy_rollout(args, R=None):
     sws = [ShardedWorld(dict(n_arenas=n, level=args.level, seed=args.seed, auto_reset=True, arena_offset=k * n + R.rank * (N - n)), rank=R.rank,
                         world_size=R.world, device=R.local_rank) for k in range(K)]
     sw, w = sws[0], sws[0].world
-    banks = [PolicyBank.random_init(R.dev, seed=args.seed, max_rows=n * 2) for _ in range(K)]
+    ppo = bool(getattr(args, "ppo", False))
+    banks = [(PolicyBank.trainable_init(R.dev, seed=args.seed, max_rows=n * 2) if ppo else PolicyBank.random_init(R.dev, seed=args.seed, max_rows=n * 2)) for _ in range(K)]
     bank = banks[0]
     outs, acts = [], []
+    logps = [torch.zeros((n, 2), dtype=torch.float32, device=R.dev) for _ in range(K)]
+    vfs = [torch.zeros((n, 2), dtype=torch.float32, device=R.dev) for _ in range(K)]
+
+    def policy(k, first=False):
+        """one policy evaluation of sub-world k's agents: greedy actor (frozen-policy form) or the PPO sampler's actor + draw + logp + value"""
+        sel = net_id if first else None
+        if ppo:
+            banks[k].sample(outs[k][0], sel, world=sws[k].world, actions=acts[k], logp=logps[k], vf=vfs[k])
+        else:
+            banks[k].act(outs[k][0], sel, acts[k])
     # agent 1 is a type-1 aircraft (Fight1), agent 2 a type-2 (Fight2): env_base.py:560-561 fixes the first two slots
     net_id = torch.tensor([SEL_FIGHT1, SEL_FIGHT2], dtype=torch.uint8, device=R.dev).repeat(n, 1).contiguous()
     for k in range(K):
@@ -375,20 +413,20 @@ def main_policy_rollout(args, R=None):
         o[0].copy_(sws[k].world.reset())
         outs.append(o)
         acts.append(torch.zeros((n, 2, 4), dtype=torch.int8, device=R.dev))
-        banks[k].act(o[0], net_id, acts[k])     # builds the row lists once: agent 1 -> Fight1, agent 2 -> Fight2 never changes
+        policy(k, first=True)                   # builds the row lists once: agent 1 -> Fight1, agent 2 -> Fight2 never changes
     out, act = outs[0], acts[0]
     streams = [torch.cuda.Stream() for _ in range(K)] if K > 1 else []
 
     def tick():
         if K == 1:
-            bank.act(out[0], None, act)   # same selectors as before: no binning pass
+            policy(0)                     # same selectors as before: no binning pass
             w.step(act, out=out)
             return
         cur = torch.cuda.current_stream()
         for k in range(K):
             streams[k].wait_stream(cur)
             with torch.cuda.stream(streams[k]):
-                banks[k].act(outs[k][0], None, acts[k])
+                policy(k)
                 sws[k].world.step(acts[k], out=outs[k])
         for k in range(K):
             cur.wait_stream(streams[k])
@@ -428,12 +466,16 @@ def main_policy_rollout(args, R=None):
     value = N * R.world * args.steps / dt
     achieved = ALGO_BYTES_2V2_STEP * N * args.steps / gpu_s / 1e9
     line = {
-        "metric": "env-steps/sec (2v2, policy in the loop)", "value": value, "unit": "env-steps/s", "n_gpus": R.world, "steps": args.steps,
+        "metric": "env-steps/sec (2v2, PPO sampler in the loop)" if ppo else "env-steps/sec (2v2, policy in the loop)", "value": value, "unit": "env-steps/s", "n_gpus": R.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64 world + f32 policy", "data": "synthetic", "agent_steps_per_s": value * 2, "streams": K,
-        "config": {"workload": f"{N} arenas/GPU x 2-vs-2 fight L{args.level}, actions from random-init Fight1/Fight2 actors (reference "
-                               f"architecture, fp32, fused HIP kernel, greedy decode) evaluated every tick on the same GPU, auto-reset "
-                               f"(BASELINE configs[2])",
+        "config": {"workload": (f"{N} arenas/GPU x 2-vs-2 fight L{args.level} driving a PPO fight-policy rollout: every tick random-init Fight1/Fight2 "
+                                f"(reference architecture) are evaluated the way RLlib's sampler does (train_hetero.py:206-243) — actor logits, a Categorical "
+                                f"draw per action component from the keyed RNG, its log-probability, and the centralised value branch on the other agent's "
+                                f"observation — in the fused HIP kernel on the same GPU, then hh_step; auto-reset (BASELINE configs[2])") if ppo else
+                               (f"{N} arenas/GPU x 2-vs-2 fight L{args.level}, actions from random-init Fight1/Fight2 actors (reference "
+                                f"architecture, fp32, fused HIP kernel, greedy decode) evaluated every tick on the same GPU, auto-reset "
+                                f"(BASELINE configs[2] with a frozen / evaluation policy: no draw, no logp, no value)"),
                    "arenas_per_gpu": N, "ticks_per_step": 1, "parallelism": f"arena-sharded x{R.world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": f"{w.kernel_name()} (T = 1 per launch) + hh_k_policy, " + ("one HIP graph per tick" if graph is not None else "eager"),
@@ -447,17 +489,27 @@ def main_policy_rollout(args, R=None):
             fn()
         b.record(); b.synchronize()
         return a.elapsed_time(b) / n
-    pol_ms = timed(lambda: bank.act(out[0], None, act))
+    from hhmarl_2d_amd import policy_nets as PN
+    pol_ms = timed(lambda: policy(0))
     world_ms = timed(lambda: w.step(act, out=out))
-    flops3 = 3.0 * (bank.flops_per_row(PolicyBank.FIGHT1) + bank.flops_per_row(PolicyBank.FIGHT2)) * n   # split-fp16: three MFMA passes per product; one sub-world's rows
+    useful = (bank.flops_per_row(PolicyBank.FIGHT1) + bank.flops_per_row(PolicyBank.FIGHT2)) * n     # one sub-world's rows, fp32-equivalent
+    if ppo:
+        useful += (PN.critic_flops_per_row(PN.FIGHT1) + PN.critic_flops_per_row(PN.FIGHT2)) * n      # the value branch of every row
     fp32_form = os.environ.get("HH_POLICY_FP32", "0") == "1"
-    line["kernels_ms"] = {"hh_k_policy_h" if not fp32_form else "hh_k_policy": pol_ms, w.kernel_instance(): world_ms, "arenas_per_launch": n}
-    line["roofline"]["dominant"] = {"kernel": "hh_k_policy_h (split-fp16: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16)" if not fp32_form else "hh_k_policy (fp32 MFMA)",
-                                    "bound": "mfma", "avg_launch_ms": pol_ms,
-                                    "achieved": (flops3 if not fp32_form else flops3 / 3.0) / (pol_ms * 1e-3) / 1e12,
-                                    "peak": MFMA_F16_PEAK_TFLOPS if not fp32_form else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s"}
-    line["roofline"]["dominant"]["frac"] = line["roofline"]["dominant"]["achieved"] / line["roofline"]["dominant"]["peak"]
-    line["roofline"]["dominant"]["traffic"] = launch_traffic("r03_policy16384_traffic.json", "hh_k_policy_h<1>", n) if not fp32_form else None
+    pname = bank.kernel_name(2 * n, sampler=ppo)
+    line["kernels_ms"] = {pname: pol_ms, w.kernel_instance(): world_ms, "arenas_per_launch": n}
+    issued = useful if fp32_form else 3.0 * useful   # split-fp16: hi*hi + hi*lo + lo*hi = three MFMA passes per product
+    peak = MFMA_F32_PEAK_TFLOPS if fp32_form else MFMA_F16_PEAK_TFLOPS
+    line["roofline"]["dominant"] = {
+        "kernel": pname + (" (fp32 MFMA)" if fp32_form else " (split-fp16: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16)"), "bound": "mfma", "avg_launch_ms": pol_ms,
+        "achieved": useful / (pol_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": useful / (pol_ms * 1e-3) / 1e12 / peak,
+        "frac_note": "USEFUL flops (one fp32-equivalent multiply-add per weight and row) over the dense fp16 MFMA peak; the three emulation passes "
+                     "that buy fp32 accuracy are matrix-pipe work, not useful work: `issued_frac` counts them",
+        "issued_tflops": issued / (pol_ms * 1e-3) / 1e12, "issued_frac": issued / (pol_ms * 1e-3) / 1e12 / peak}
+    tr = load_json("latest_policy_traffic.json")
+    line["roofline"]["dominant"]["traffic"] = (int(tr["hbm_bytes_per_launch"]) if tr and tr.get("rows") == 2 * n and pname in str(tr.get("kernel_full", "")) else None)
+    if line["roofline"]["dominant"]["traffic"] is not None:
+        line["roofline"]["dominant"]["traffic_source"] = "profiles/latest_policy_traffic.json (builder's rocprofv3 --pmc run of this kernel instance, not this run)"
     if not own:
         return line
     if R.rank == 0:
@@ -569,26 +621,38 @@ def main_hier(args, R=None):
     gpu_s = e0.elapsed_time(e1) * 1e-3
     steps = args.steps
     value = N * R.world * steps / dt
-    algo_bytes = ALGO_BYTES_3V3_TICK * ticks + ALGO_BYTES_3V3_CMD_FIXED * N * steps
+    tape_launch = one_launch and not coop
+    tick_bytes = ALGO_BYTES_3V3_TICK_TAPE if tape_launch else ALGO_BYTES_3V3_TICK
+    algo_bytes = tick_bytes * ticks + ALGO_BYTES_3V3_CMD_FIXED * N * steps
     achieved = algo_bytes / gpu_s / 1e9
+    per_rank = R.gather_floats(N * steps / dt)
     line = {
         "metric": "commander-steps/sec (3v3 HighLevelEnv)", "value": value, "unit": "env-steps/s", "n_gpus": R.world, "steps": steps,
         "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic", "agent_steps_per_s": value * 3,
+        "dtype": "f64", "data": "synthetic", "agent_steps_per_s": value * 3, "per_rank_commander_steps_per_s": per_rank,
         "sim_ticks_per_s": ticks * R.world / dt, "ticks_per_commander_step": ticks / float(N * steps),
         "config": {"workload": f"{N} arenas/GPU x 3-vs-3 HighLevelEnv commander steps (<= 16 sub-steps each), uniform commander actions, "
-                               f"pilots = {PILOT_DESC[args.pilot]}, auto-reset (BASELINE configs[3])", "arenas_per_gpu": N,
-                   "parallelism": f"arena-sharded x{R.world}, no data-path collective"},
+                               f"pilots = {PILOT_DESC[args.pilot]}, auto-reset (BASELINE configs[{3 if R.world == 1 else 4}])", "arenas_per_gpu": N,
+                   "parallelism": f"arena-sharded x{R.world}, no data-path collective; logging all-gather of [N, 3] episode statistics every 16 commander steps on a side stream"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel": ("hh_k_hier_nets (one cooperative launch per commander step: world phases + policy tiles behind grid barriers)" if coop else
                                                  f"{w.kernel_instance(1)} (one persistent launch per commander step)" if one_launch else
                                                  f"{w.kernel_name()} (every phase launch of the macro step, plus the pilots' kernels if any)"),
                      "algorithmic_bytes": algo_bytes,
-                     "note": "2056 B per arena-tick actually run + 424 B per commander step (SURVEY.md 8d)"},
+                     "note": (f"{tick_bytes} B per arena-tick actually run + 424 B per commander step (SURVEY.md 8d" +
+                              ("; the 720 B of pilot observations per tick are not charged: with the actions on a tape nobody builds them)" if tape_launch else ")"))},
     }
+    if tape_launch:   # what the fused schedule has to move: the state once per commander step, the pilots' action words per tick, the commander's rows
+        sched = (2 * ALGO_BYTES_3V3_STATE + ALGO_BYTES_3V3_CMD_FIXED) * N * steps + 24 * ticks
+        line["roofline"]["schedule"] = {"bytes": sched, "achieved": sched / gpu_s / 1e9, "frac": sched / gpu_s / 1e9 / HBM_PEAK_GBS,
+                                        "note": "bytes the one-launch schedule needs (state stays in registers across the sub-steps): the figure the counter traffic should be compared with"}
     line["gpu_ms_per_step"] = gpu_s / steps * 1e3
-    if one_launch and not coop:   # HBM bytes per commander step of the one-launch kernel, from the committed PMC passes
-        line["roofline"]["traffic"] = launch_traffic("r03_hier8192_traffic.json", w.kernel_instance(1), N)
+    if tape_launch:   # HBM bytes per commander step of the one-launch kernel, from the committed PMC passes
+        tr = launch_traffic("r03_hier8192_traffic.json", w.kernel_instance(1), N)
+        line["roofline"]["traffic"] = tr
+        if tr is not None:
+            line["roofline"]["traffic_frac"] = tr / (gpu_s / steps) / 1e9 / HBM_PEAK_GBS
+            line["roofline"]["traffic_source"] = "profiles/r03_hier8192_traffic.json: builder's rocprofv3 --pmc passes of this kernel instance (bytes per commander step), NOT measured by this run"
     if not one_launch:
         line["launches_per_step"] = 2 + 16 * (4 if args.pilot in ("net", "mlp", "random") else 2)
     if coop:
@@ -712,7 +776,18 @@ def main():
     if args.workload == "rollout":
         return main_policy_rollout(args)
     single = args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1
-    if args.dry_run or args.no_extra or not single:
+    if not single and not args.no_extra:
+        # N ranks: configs[1] per rank stays the headline `value`; BASELINE configs[4] (8192 arenas x 3-vs-3 HighLevelEnv per rank, the episode
+        # statistics all-gathered over RCCL on a side stream) rides along, measured by the same ranks right after it
+        R = Ranks(args)
+        line = main_low(args, R)
+        extra = configs4(args, R)
+        if R.rank == 0:
+            line["extra"] = {"configs4": extra}
+            print(json.dumps(line), flush=True)
+        R.close()
+        return
+    if args.dry_run or args.no_extra:
         return main_low(args)
     # the driver's line: configs[1] is the headline; the other single-GPU configurations of BASELINE.json ride along as short runs
     R = Ranks(args)
@@ -720,6 +795,34 @@ def main():
     line["extra"] = extra_configs(args, R)
     print(json.dumps(line), flush=True)
     R.close()
+
+
+def configs4(args, R):
+    """BASELINE configs[4] on the ranks of this job: 8192 arenas/rank x 3-vs-3 HighLevelEnv, pilot actions from a resident tape (one persistent
+    launch per commander step), logging all-gather on a side stream.  --dry-run: the rank plumbing and the gather only (gloo, no kernel)."""
+    import copy
+    N4 = 8192
+    if R.dry:
+        from hhmarl_2d_amd.sharding import ShardedWorld
+        sw = ShardedWorld(dict(n_arenas=N4, env_kind=1, seed=args.seed, auto_reset=True), rank=R.rank, world_size=R.world, device=R.local_rank, world_factory=DryWorld)
+        R.barrier()
+        sw.log_episode_stats(None)
+        R.barrier()
+        rows = None if sw.last_stats is None else int(sw.last_stats.shape[0])
+        first = None if sw.last_stats is None else [float(sw.last_stats[i * N4, 0]) for i in range(R.world)]   # DryWorld reports the global arena id: ranks in order
+        return {"dry_run": True, "arenas_per_gpu": N4, "n_gpus": R.world, "gathered_rows": rows, "first_global_arena_of_each_block": first}
+    a = copy.copy(args)
+    a.workload, a.pilot, a.arenas, a.steps, a.warmup, a.spinup, a.phases, a.coop, a.streams = "hier", "tape", N4, 30, 6, 0.3, False, False, 0
+    try:
+        line = main_hier(a, R)
+    except Exception as e:   # noqa: BLE001 — reported, never silently dropped
+        return {"error": f"{type(e).__name__}: {e}"}
+    keys = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "gpu_ms_per_step", "per_rank_commander_steps_per_s", "sim_ticks_per_s", "ticks_per_commander_step")
+    out = {k: line[k] for k in keys if k in line}
+    out["workload"] = line["config"]["workload"]
+    out["parallelism"] = line["config"]["parallelism"]
+    out["roofline"] = line["roofline"]
+    return out
 
 
 def extra_configs(args, R):
@@ -737,7 +840,8 @@ def extra_configs(args, R):
 
     extra = {}
     R.torch.cuda.synchronize()
-    for name, flags in (("configs2", ["--workload", "rollout", "--steps", "300", "--warmup", "30"]),
+    for name, flags in (("configs2", ["--workload", "rollout", "--ppo", "--steps", "300", "--warmup", "30"]),
+                        ("configs2_greedy_inference", ["--workload", "rollout", "--steps", "300", "--warmup", "30"]),
                         ("configs3", ["--workload", "hier", "--pilot", "tape", "--steps", "40", "--warmup", "8"]),
                         ("configs3_networks_in_loop", ["--workload", "hier", "--pilot", "net", "--steps", "12", "--warmup", "3"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--spinup", "0.3", "--seed", str(args.seed), "--no-cpu-baseline"] + flags

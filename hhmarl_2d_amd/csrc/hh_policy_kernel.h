@@ -619,6 +619,21 @@ static int hhp_launch_forward(hh_policy *p, const float *obs, int32_t n_rows, in
     return HH_OK;
 }
 
+/* which kernel instance a forward over n_rows rows (live_rows of them carrying a network; < 0: all) launches, as a profiler prints it */
+static const char *hhp_form_name(const hh_policy *p, int n_rows, int live_rows) {
+    const int heur_rows = live_rows >= 0 ? live_rows : n_rows;
+    if (p->wform > 0 || (p->wform < 0 && !p->fp32 && p->tile_rows == 0 && hhp_rows_suit_w(heur_rows, p->n_cu))) return "hh_k_policy_w<4>";
+    if (p->fp32) return "hh_k_policy";
+    if (p->tile_rows == 64 || (p->tile_rows == 0 && hhp_rows_suit_wide_tiles(heur_rows, p->n_cu))) return "hh_k_policy_h<2>";
+    return "hh_k_policy_h<1>";
+}
+extern "C" int hh_policy_kernel_name(hh_policy *p, int32_t n_rows, int32_t sampler, char *buf, int32_t len) {
+    if (!p || !buf || len <= 0 || n_rows <= 0) { g_err = "bad argument"; return HH_E_ARG; }
+    const bool one_side = p->bound && p->bound->cfg.env_kind == HH_ENV_HIGHLEVEL;
+    snprintf(buf, (size_t)len, "%s", sampler ? "hh_k_policy_ppo" : hhp_form_name(p, n_rows, one_side ? n_rows / 2 : -1));
+    return HH_OK;
+}
+
 extern "C" int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, const uint8_t *sel, int8_t *actions,
                              float *logits, void *stream) {
     if (!p || !obs || !actions || n_rows <= 0 || obs_stride <= 0) { g_err = "bad argument"; return HH_E_ARG; }

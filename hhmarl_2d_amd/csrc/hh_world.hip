@@ -67,6 +67,7 @@ struct hh_world {
     struct hh_policy *bound_policy; /* hh_bind_policy: the bank whose row lists P.pol_* point into (it points back at this world) */
     void *coop_mem;  /* hh_hl_step_nets: pilot rows [N,6,30] f32 | pilot actions [N,6,4] i8 | barrier, error flag, running counts, two counter sets */
     int coop_grid;   /* workgroups of the cooperative launch (co-resident by construction) */
+    int coop_timed_out; /* hh_hl_step_nets_status saw the error flag: the next hh_hl_step_nets clears it */
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -75,6 +76,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     if (!cfg || !out) { g_err = "null argument"; return HH_E_ARG; }
     int A = cfg->n_agents + cfg->n_opps;
     if (cfg->n_arenas <= 0 || cfg->n_agents < 1 || cfg->n_opps < 1) { g_err = "unsupported configuration: need n_arenas, n_agents, n_opps > 0"; return HH_E_ARG; }
+    if (cfg->reserved0 != 0) { g_err = "hh_config.reserved0 must be 0 (a caller built against an older hh_abi.h, whose struct had no opp_side_selector / reserved0 pair?)"; return HH_E_ARG; }
     if (cfg->env_kind == HH_ENV_HIGHLEVEL) {
         /* evaluation.py's n-vs-m scenarios (README.md:43): any 1..3 agents against 1..3 opponents live in the six unit slots of the
          * 3-vs-3 kernel — agents in slots 0..n_agents-1, opponents behind them, the remaining slots are never alive */
@@ -123,7 +125,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     w->block = HH_BLOCK;
     w->trace_mem = nullptr;
     w->bound_policy = nullptr;
-    w->coop_mem = nullptr; w->coop_grid = 0;
+    w->coop_mem = nullptr; w->coop_grid = 0; w->coop_timed_out = 0;
     { const char *fw = getenv("HH_FORCE_W"); w->force_w = fw ? atoi(fw) : 0; }
     { const char *e = getenv("HH_APW"); w->apw = e ? atoi(e) : 0; }
     { const char *nq = getenv("HH_NO_QUAD"); w->no_quad = nq ? atoi(nq) : 0; }
@@ -510,9 +512,11 @@ extern "C" int hh_set_state(hh_world *w, const hh_state_view *v) {
     std::vector<int2> rkp(U);
     for (int k = 0; k < 6; k++) f[k].resize(U);
     for (int k = 0; k < 4; k++) rk[k].resize(U);
-    for (size_t u = 0; u < U; u++) { /* the step keeps headings in [0, 360) (ac1.py:94, env_base.py:219-221) and its modulo relies on it */
+    for (size_t u = 0; u < U; u++) { /* the step keeps headings in [0, 360] and its one-turn modulo (hh_pymod_turn: -m <= x < 2 m) relies on it.  360.0
+                                        itself is a value the step produces — Python's (tiny negative) % 360 rounds to 360.0 (ac1.py:94) — so a state read
+                                        with hh_get_state must be accepted here */
         const double h = v->ac_f[u * HH_ACF_K + 2], ch = v->ac_f[u * HH_ACF_K + 4];
-        if (!(h >= 0.0 && h < 360.0 && ch >= 0.0 && ch < 360.0)) { g_err = "hh_set_state: heading / commanded heading outside [0, 360)"; return HH_E_ARG; }
+        if (!(h >= 0.0 && h <= 360.0 && ch >= 0.0 && ch <= 360.0)) { g_err = "hh_set_state: heading / commanded heading outside [0, 360]"; return HH_E_ARG; }
     }
     for (size_t u = 0; u < U; u++) {
         for (int k = 0; k < 6; k++) f[k][u] = v->ac_f[u * HH_ACF_K + k];
@@ -758,7 +762,7 @@ extern "C" int hh_hl_step_nets(hh_world *w, hh_policy *p, const int8_t *commande
     if (p->device != w->device) { g_err = "hh_hl_step_nets: world and policy bank live on different devices"; return HH_E_ARG; }
     if (p->n_nets == 0) { g_err = "hh_hl_step_nets: no network loaded"; return HH_E_ARG; }
     if ((long long)p->max_rows < (long long)c.N * 6) { g_err = "hh_hl_step_nets: the bank's max_rows is smaller than n_arenas x 6"; return HH_E_ARG; }
-    if (p->fp32 || p->tile_rows == 64) { g_err = "hh_hl_step_nets runs the split-fp16 32-row policy tiles (unset HH_POLICY_FP32 / HH_POLICY_TILE)"; return HH_E_ARG; }
+    if (p->fp32) { g_err = "hh_hl_step_nets runs the split-fp16 policy tiles (unset HH_POLICY_FP32)"; return HH_E_ARG; } /* the bank's tile width does not matter: the step always walks 32-row tiles */
     HH_GUARD(w);
     const CoopLayout Lt = hh_coop_layout(c.N);
     if (!w->coop_mem) {
@@ -794,6 +798,14 @@ extern "C" int hh_hl_step_nets(hh_world *w, hh_policy *p, const int8_t *commande
     const int want = tiles > (groups + 3) / 4 ? tiles : (groups + 3) / 4;
     if (grid > want) grid = want;
     if (grid < 1) grid = 1;
+    /* a barrier that timed out in an earlier step leaves the error flag set and the arrival count / generation out of step: every step starts
+     * after a reported timeout (hh_hl_step_nets_status) starts from a clean control block (three words on the stream, ahead of the launch) */
+    if (w->coop_timed_out) {
+        HIPCHK(hipMemsetAsync(ctl.bar_cnt, 0, sizeof(unsigned), (hipStream_t)stream));
+        HIPCHK(hipMemsetAsync(ctl.bar_gen, 0, sizeof(unsigned), (hipStream_t)stream));
+        HIPCHK(hipMemsetAsync(ctl.err, 0, sizeof(int), (hipStream_t)stream));
+        w->coop_timed_out = 0;
+    }
     void *args[] = {&prm};
     HIPCHK(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(hh_k_hier_nets), dim3(grid), dim3(256), args, HHPH_LDS_BYTES(1), (hipStream_t)stream));
     return HH_OK;
@@ -819,6 +831,7 @@ extern "C" int hh_hl_step_nets_status(hh_world *w, int32_t *err_out, void *strea
     const CoopLayout Lt = hh_coop_layout(w->dc.N);
     HIPCHK(hipMemcpyAsync(err_out, (char *)w->coop_mem + Lt.o_ctl + 16 * sizeof(int), sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (*err_out) w->coop_timed_out = 1; /* the next step resets the barrier words and the flag */
     return HH_OK;
 }
 

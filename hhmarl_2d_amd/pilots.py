@@ -129,6 +129,12 @@ class PolicyBank:
         b.set_lut({(SEL_FIGHT1 if mode == "fight" else SEL_ESC1): 0, (SEL_FIGHT2 if mode == "fight" else SEL_ESC2): 1})
         return b
 
+    def kernel_name(self, n_rows, sampler=False):
+        """the forward kernel instance a call of n_rows rows launches (hh_policy_kernel_name)"""
+        buf = C.create_string_buffer(64)
+        L.check(L.lib().hh_policy_kernel_name(self.h, int(n_rows), 1 if sampler else 0, buf, 64))
+        return buf.value.decode()
+
     def set_tile_rows(self, rows):
         """rows per workgroup tile of the forward kernel: 0 = by row count (default), 32 or 64 (hh_policy_set_tile_rows)"""
         L.check(L.lib().hh_policy_set_tile_rows(self.h, int(rows)))

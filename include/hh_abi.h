@@ -50,7 +50,8 @@ typedef struct hh_config {
     int32_t opp_side_selector; /* HighLevelEnv, evaluation.py with eval_hl = False: the opponents fly their OWN fight policies
                                   ("fight_{1,2}_opp" = L{eval_level_opp}, env_base.py:343-346,387-390): pilot_mode of an opponent's
                                   fight row carries HH_SEL_OPP_SIDE on top of policy type | aircraft type << 2 */
-    int32_t reserved0;        /* keeps the doubles 8-byte aligned; must be 0 */
+    int32_t reserved0;        /* keeps the doubles 8-byte aligned; must be 0 (hh_world_create refuses anything else: a caller built against the
+                                 layout before opp_side_selector was added would otherwise be misread silently) */
     double map_size;          /* args.map_size */
     double glob_frac;         /* args.glob_frac */
     double rew_scale;         /* args.rew_scale */
@@ -99,7 +100,9 @@ int hh_reset(hh_world *w, const uint8_t *mask, float *obs, void *stream);
 
 /* step() (env_base.py:79-109 -> env_hetero.py:105-186 _take_action -> cmano_simulator.py:138-157
  * do_tick -> env_hetero.py:188-225 rewards -> env_hetero.py:65-103 state).
- *   actions      [dev] i8 [N, n_ctrl, 4]   MultiDiscrete([13,9,2,2]); 4th ignored for type 2
+ *   actions      [dev] i8 [N, n_ctrl, 4]   MultiDiscrete([13,9,2,2]); 4th ignored for type 2.  Components outside their ranges (the
+ *                                          reference's spaces never emit them: env_hetero.py:37-43) are UNDEFINED — the heading's one-turn
+ *                                          modulo assumes |(a0 - 6) * 15| <= 90 deg; validate untrusted actions before the call
  *   obs          [dev] f32[N, n_agents, D] observation after the tick (all agents, zeros if dead)
  *   reward       [dev] f32[N, n_agents]
  *   reward_valid [dev] u8 [N, n_agents]    1 iff the reference's rewards dict has the key

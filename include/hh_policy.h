@@ -64,6 +64,11 @@ int hh_policy_set_lut(hh_policy *p, const uint8_t *lut);
  * Its logits differ from the tile forms' in the last bits (the output layer is summed in one k-ordered accumulator): same 1e-5 bound. */
 int hh_policy_set_tile_rows(hh_policy *p, int32_t rows);
 
+/* name of the forward kernel instance a call of n_rows rows launches on this bank, as a profiler prints it ("hh_k_policy_h<1>",
+ * "hh_k_policy_h<2>", "hh_k_policy_w<4>", "hh_k_policy"; sampler != 0: hh_policy_sample's "hh_k_policy_ppo"): bench.py quotes counter
+ * evidence only for the instance it actually ran */
+int hh_policy_kernel_name(hh_policy *p, int32_t n_rows, int32_t sampler, char *buf, int32_t len);
+
 /* greedy actions of n_rows units in one launch sequence (row binning by network + the fused forward):
  *   obs     [dev] f32 [n_rows, obs_stride]   zero-padded observation rows (hh_step's obs, hh_step_begin's opp_obs, pilot_obs)
  *   sel     [dev] u8  [n_rows]               selector bytes (through the LUT); NULL = the same selectors as the previous call (a fixed
@@ -142,10 +147,12 @@ int hh_policy_sample(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs
  * on a bound bank, bit for bit (no early exit while any arena of the world is still inside its macro step), but the world phases and
  * the policy tiles run inside ONE persistent kernel separated by grid barriers: nothing is dispatched, drained or re-fetched
  * between them.  commander_actions [dev] i8 [N, n_agents]; obs / reward / reward_valid / done like hh_hl_end.  The bank needs its
- * networks and LUT loaded, max_rows >= n_arenas x 6 and the default split-fp16 32-row tiles; it does NOT have to be bound (the
- * step uses the bank's row lists with counters of its own).  The world keeps the pilots' observation / action scratch.
- * hh_hl_step_nets_status: 0 unless a grid barrier ever timed out (a workgroup gives up after ~0.5 s of polling instead of hanging
- * the device; the results of that step are then invalid).  Synchronises `stream`. */
+ * networks and LUT loaded, max_rows >= n_arenas x 6 and the split-fp16 form (the step walks 32-row tiles whatever width the bank is set
+ * to); it does NOT have to be bound (the step uses the bank's row lists with counters of its own).  The world keeps the pilots'
+ * observation / action scratch.  hh_hl_step_nets only ENQUEUES the launch on `stream` (no host synchronisation).
+ * hh_hl_step_nets_status synchronises `stream` and reports 0 unless a grid barrier timed out since the last report (a workgroup gives up
+ * after ~0.5 s of polling instead of hanging the device; the results of that step are then invalid); after a reported timeout the next
+ * hh_hl_step_nets resets the barrier words and the flag, so later steps are valid again. */
 int hh_hl_step_nets(struct hh_world *w, hh_policy *p, const int8_t *commander_actions, float *obs, float *reward, uint8_t *reward_valid,
                     uint8_t *done, void *stream);
 int hh_hl_step_nets_status(struct hh_world *w, int32_t *err_out, void *stream);

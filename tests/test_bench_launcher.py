@@ -30,6 +30,17 @@ def test_gpus_2_self_spawns_two_ranks():
     assert line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
 
 
+def test_two_rank_line_carries_configs4():
+    """with more than one rank the line keeps configs[1] as its value and adds extra.configs4 (8192 arenas x 3-vs-3 per rank): here the dry
+    run of that branch — both ranks' [8192, 3] blocks arrive in the all-gather, in global arena order"""
+    line = _run(["--gpus", "2"])
+    c4 = line["extra"]["configs4"]
+    assert c4["dry_run"] is True and c4["n_gpus"] == 2 and c4["arenas_per_gpu"] == 8192
+    assert c4["gathered_rows"] == 2 * 8192
+    assert c4["first_global_arena_of_each_block"] == [0.0, 8192.0]
+    assert line["metric"].startswith("env-steps/sec") and line["n_gpus"] == 2   # the headline is still configs[1]
+
+
 def test_single_rank_line_contract():
     line = _run([])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",

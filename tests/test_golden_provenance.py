@@ -18,7 +18,7 @@ def test_golden_fixtures_regenerate_from_the_committed_generator():
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists only in the build container")
-@pytest.mark.parametrize("script", ["gen_policy_golden.py", "gen_critic_golden.py"])
+@pytest.mark.parametrize("script", ["gen_policy_golden.py", "gen_critic_golden.py", "gen_fullsize_golden.py"])
 def test_network_and_critic_fixtures_regenerate(script):
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", script), "--check"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)

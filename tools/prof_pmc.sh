@@ -17,7 +17,7 @@ rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc4 -- python $R/bench.py $ARGS > $O
 MINUS=${MIN_US:-500}
 python $R/tools/rocpd_summary.py --kernel $K --min-us $MINUS $OUT/stats/stats_results.db $OUT/pmc1/pmc1_results.db $OUT/pmc2/pmc2_results.db $OUT/pmc5/pmc5_results.db $OUT/pmc3/pmc3_results.db $OUT/pmc4/pmc4_results.db > $OUT/summary.txt 2>&1
 python $R/tools/rocpd_summary.py --traffic $OUT/pmc3/pmc3_results.db $OUT/pmc4/pmc4_results.db $K $A $C > $OUT/traffic.json
-python $R/tools/rocpd_summary.py --pmcjson $OUT/pmc1/pmc1_results.db $K $A $C ${ARENAS_PER_WAVE:-16} $OUT/pmc5/pmc5_results.db > $OUT/pmc.json
+python $R/tools/rocpd_summary.py --pmcjson $OUT/pmc1/pmc1_results.db $K $A $C ${ARENAS_PER_WAVE:-16} $OUT/pmc5/pmc5_results.db $OUT/pmc2/pmc2_results.db > $OUT/pmc.json
 tail -1 $OUT/stats.log > $OUT/bench_line.json
 cat $OUT/summary.txt $OUT/traffic.json $OUT/pmc.json
 # the rocpd databases are tens of MB each and gpurun_out/ is capped at 64 MiB: keep the text summaries only

@@ -63,14 +63,14 @@ def traffic_json(fetch_db, write_db, kernel, min_us, arenas, ticks):
                       "note": "2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate passes"}))
 
 
-def pmc_json(db_path, kernel, arenas, ticks, arenas_per_wave, f64_db=None):
+def pmc_json(db_path, kernel, arenas, ticks, arenas_per_wave, f64_db=None, more_dbs=()):
     """instruction counters per wave-tick (one wave-tick = `arenas_per_wave` arenas x 1 tick) for bench.py's fp64 roofline block;
     f64_db: the pass with SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 (the instructions that are FP64 arithmetic)"""
     import json
     db = sqlite3.connect(db_path)
     rows = list(db.execute("select kernel_name, counter_name, max(value) from counters_collection group by kernel_name, counter_name"))
-    if f64_db:
-        rows += list(sqlite3.connect(f64_db).execute("select kernel_name, counter_name, max(value) from counters_collection group by kernel_name, counter_name"))
+    for extra in ([f64_db] if f64_db else []) + list(more_dbs):
+        rows += list(sqlite3.connect(extra).execute("select kernel_name, counter_name, max(value) from counters_collection group by kernel_name, counter_name"))
     rows = [r for r in rows if kernel in str(r[0])]
     if not rows:
         print(json.dumps({"error": "kernel not found"}))
@@ -83,6 +83,12 @@ def pmc_json(db_path, kernel, arenas, ticks, arenas_per_wave, f64_db=None):
                       "insts_valu_per_wave_tick": v.get("SQ_INSTS_VALU", 0) / wt, "insts_salu_per_wave_tick": v.get("SQ_INSTS_SALU", 0) / wt,
                       "insts_lds_per_wave_tick": v.get("SQ_INSTS_LDS", 0) / wt, "sq_waves": v.get("SQ_WAVES"),
                       "wave_cycles_per_wave_tick": v.get("SQ_WAVE_CYCLES", 0) * 4 / wt,
+                      # where the waves' cycles go (quad-cycles of ALL waves of the kernel, incl. the output wave of the two-wave form):
+                      # issuing an instruction / parked at s_waitcnt or a barrier / stalled at issue (dependency, pipe busy)
+                      "sq_quad_cycles": {k: v[k] for k in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+                                                            "SQ_WAIT_INST_LDS") if k in v},
+                      "insts_per_wave_tick": {k[len("SQ_INSTS_"):]: v[k] / wt for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
+                                                                                       "SQ_INSTS_SMEM") if k in v},
                       "wave_tick": f"{arenas_per_wave} arenas x 1 tick", "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU ... (tools/prof_pmc.sh)"}))
 
 
@@ -90,6 +96,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--traffic":
         traffic_json(sys.argv[2], sys.argv[3], sys.argv[4], 0, int(sys.argv[5]), int(sys.argv[6]))
     elif len(sys.argv) > 1 and sys.argv[1] == "--pmcjson":
-        pmc_json(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7] if len(sys.argv) > 7 else None)
+        pmc_json(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7] if len(sys.argv) > 7 else None, sys.argv[8:])
     else:
         main()

@@ -683,8 +683,8 @@ def main_hier_split(args, R, own, N, K):
     for w in worlds:
         w.reset()
     pilots_ = [NetPilot(w, seed=args.seed) for w in worlds]
-    if "HH_POLICY_TILE" not in os.environ:
-        for pl in pilots_:   # several banks busy on concurrent streams: wide tiles, the other streams fill what a partial round leaves idle
+    if "HH_POLICY_TILE" not in os.environ and n * 3 <= 10240:
+        for pl in pilots_:   # small calls on concurrent streams stay on the tile forms: wide tiles, the other streams fill what a partial round leaves idle
             pl.bank.set_tile_rows(64)
     gen = torch.Generator(device=R.dev)
     gen.manual_seed(args.seed + 17 + R.rank)

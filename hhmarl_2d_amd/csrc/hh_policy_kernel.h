@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256, 2) void hh_k_policy(HhpBank bank, int n_nets, 
 #include "hh_policy_kernel_h16.h"
 #include "hh_policy_kernel_ppo.h"
 #include "hh_policy_kernel_w.h"
+#include "hh_policy_kernel_w16.h"
 
 /* ===================================================================== host side */
 #define HHP_SLOT_BYTES ((size_t)4 << 20) /* fp32 blob 1.19 MB + fp16 planes 1.18 MB per network, padded to 4 MB */
@@ -366,7 +367,9 @@ struct hh_policy {
     hh_world *bound;          /* hh_bind_policy: the world whose kernels write the lists (one world per bank), or nullptr */
     HhpBankW bankw;           /* the weights-through-LDS form (hh_policy_kernel_w.h): one linear fragment stream per network */
     unsigned char *wblob[HH_POLICY_MAX_NETS];
-    int wform;                /* HH_POLICY_W: 1 = always hh_k_policy_w, 0 = never, unset (-1) = by row count (hhp_rows_suit_w) */
+    HhpBankX bankx;           /* the same for hh_k_policy_w16 (16 rows per wave: other fragment shape) */
+    unsigned char *xblob[HH_POLICY_MAX_NETS];
+    int wform;                /* HH_POLICY_W: 2 = always hh_k_policy_w16, 1 = always hh_k_policy_w, 0 = the tile forms only, unset (-1) = by row count (hhp_rows_suit_w) */
     HhpCritBank cbank;        /* hh_policy_set_critic: the value branches of the trainable policies (hh_policy_sample) */
     char *cblob[HH_POLICY_MAX_NETS]; /* one allocation per loaded value branch */
 };
@@ -408,7 +411,8 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     p->slab = nullptr;
     memset(&p->cbank, 0, sizeof(p->cbank));
     memset(&p->bankw, 0, sizeof(p->bankw));
-    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { p->cblob[i] = nullptr; p->wblob[i] = nullptr; }
+    memset(&p->bankx, 0, sizeof(p->bankx));
+    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { p->cblob[i] = nullptr; p->wblob[i] = nullptr; p->xblob[i] = nullptr; }
     { const char *e = getenv("HH_POLICY_W"); p->wform = e ? atoi(e) : -1; }
     p->lut = nullptr; p->counts = nullptr; p->lists = nullptr;
     hipError_t e = hipMalloc(&p->lut, 256);
@@ -422,6 +426,7 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_h<2>), hipFuncAttributeMaxDynamicSharedMemorySize, HHPH_LDS_BYTES(2));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_ppo), hipFuncAttributeMaxDynamicSharedMemorySize, HHPP_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_w<4>), hipFuncAttributeMaxDynamicSharedMemorySize, HHW_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_w16), hipFuncAttributeMaxDynamicSharedMemorySize, HHX_LDS_BYTES);
     if (e != hipSuccess) {
         g_err = std::string("hh_policy_create: ") + hipGetErrorString(e);
         if (p->lut) (void)hipFree(p->lut);
@@ -440,7 +445,7 @@ extern "C" int hh_policy_destroy(hh_policy *p) {
     hhp_unbind(p); /* a world still bound to this bank goes back to emitting selector bytes only */
     DeviceGuard guard_(p->device);
     (void)hipFree(p->slab);
-    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { if (p->cblob[i]) (void)hipFree(p->cblob[i]); if (p->wblob[i]) (void)hipFree(p->wblob[i]); }
+    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { if (p->cblob[i]) (void)hipFree(p->cblob[i]); if (p->wblob[i]) (void)hipFree(p->wblob[i]); if (p->xblob[i]) (void)hipFree(p->xblob[i]); }
     (void)hipFree(p->lut); (void)hipFree(p->counts); (void)hipFree(p->lists);
     delete p;
     return HH_OK;
@@ -542,6 +547,34 @@ static int hhp_set_net(hh_policy *p, int32_t slot, const hh_net_weights *w) {
         if (!p->wblob[slot]) HIPCHK(hipMalloc(&p->wblob[slot], (size_t)HHW_STREAM_PIECES * HHW_PIECE));
         HIPCHK(hipMemcpy(p->wblob[slot], S.data(), (size_t)HHW_STREAM_PIECES * HHW_PIECE, hipMemcpyHostToDevice));
         p->bankw.net[slot].stream = p->wblob[slot];
+        /* ... and in the fragment shape of hh_k_policy_w16 (16 columns x 32 k per piece; chunk order of hh_policy_kernel_w16.h) */
+        std::vector<uint16_t> X((size_t)HHX_STREAM_PIECES * (HHW_PIECE / 2), 0);
+        for (int T = 0; T < 32; T++)
+            for (int k = 0; k < 32; k++)
+                for (int c = 0; c < 16; c++) hhx_put(X, (size_t)T * 2, k, 16 * T + c, true, w1(k, 16 * T + c));
+        for (int j = 0; j < 7; j++)
+            for (int kb = 0; kb < 4; kb++)
+                for (int wq = 0; wq < 32; wq++)
+                    for (int c = 0; c < 16; c++) { /* K = hidden columns 384 + 32 kb + wq; the block's own index is that - 400 */
+                        const int kh = 384 + 32 * kb + wq - 400;
+                        hhx_put(X, (size_t)HHX_L1_PIECES + (size_t)(j * 4 + kb) * 2, wq, 16 * j + c, false, kh >= 0 ? wov(kh, 16 * j + c) : 0.0f);
+                    }
+        for (int pp = 0; pp < 8; pp++)
+            for (int q = 0; q < 4; q++)
+                for (int kk = 0; kk < 4; kk++)
+                    for (int t = 0; t < 4; t++)
+                        for (int wq = 0; wq < 32; wq++)
+                            for (int c = 0; c < 16; c++)
+                                hhx_put(X, (size_t)HHX_L1_PIECES + HHX_ATT_PIECES + (size_t)((pp * 4 + q) * 16 + kk * 4 + t) * 2, wq, c, false,
+                                        wsf(32 * (4 * q + kk) + wq, 16 * (4 * pp + t) + c));
+        for (int kb = 0; kb < 16; kb++)
+            for (int t = 0; t < 2; t++)
+                for (int wq = 0; wq < 32; wq++)
+                    for (int c = 0; c < 16; c++)
+                        hhx_put(X, (size_t)HHX_L1_PIECES + HHX_ATT_PIECES + HHX_L2_PIECES + (size_t)(kb * 2 + t) * 2, wq, c, false, waf(32 * kb + wq, 16 * t + c));
+        if (!p->xblob[slot]) HIPCHK(hipMalloc(&p->xblob[slot], (size_t)HHX_STREAM_PIECES * HHW_PIECE));
+        HIPCHK(hipMemcpy(p->xblob[slot], X.data(), (size_t)HHX_STREAM_PIECES * HHW_PIECE, hipMemcpyHostToDevice));
+        p->bankx.stream[slot] = p->xblob[slot];
     }
     static_assert(HHP_SLOT_BYTES >= (size_t)2 * 1024 * 1024 + 2 * 309248 * 2, "slot too small");
     if (total * sizeof(float) > (size_t)2 * 1024 * 1024 || 2 * h_total * sizeof(uint16_t) > HHP_SLOT_BYTES - (size_t)2 * 1024 * 1024) { g_err = "internal: blob exceeds its slot"; return HH_E_ARG; }
@@ -588,12 +621,14 @@ static inline bool hhp_rows_suit_wide_tiles(int n_rows, int n_cu) {
     const int tiles = (n_rows + 63) / 64, rem = tiles % n_cu;
     return tiles >= n_cu && (rem == 0 || rem * 4 > n_cu * 3);
 }
-/* The weights-through-LDS form (hh_policy_kernel_w.h) carries 128 rows per CU through the network in one pass over the weights and takes
- * ~60 us for that however few of the CUs have a tile (one wave per SIMD, nothing hides a phase's latency); the LDS-activation-tile forms
- * take 27 us for 8192 rows and 67 for 24576.  Measured (tools/policy_bench.py, back to back): 32768 rows 64 against 72 - 78 us, 65536 125
- * against 145, 24576 60 against 67, 8192 51 against 27; inside the tick graphs configs[2] gains 11 %, the four-stream commander step
- * (12288 rows per call) loses 9 %.  So: from three quarters of a full round of 128-row tiles upwards. */
-static inline bool hhp_rows_suit_w(int n_rows, int n_cu) { return (long long)n_rows * 4 >= (long long)n_cu * 128 * 3; }
+/* Which form for how many rows (tools/policy_bench.py, Fight1 + Fight2 rows, us per call back to back on one MI355X):
+ *      rows            4096   8192  12288  16384  20480  24576  32768  49152  65536
+ *      hh_k_policy_h   23.7   28.0   43.5   41.9   62.8   67.4   78.9  114.0  144.9     (LDS activation tile: 32 / 64 rows per workgroup)
+ *      hh_k_policy_w   46.7   47.5   48.4   50.7   53.6   57.2   63.4  108.8  120.6     (weights through LDS, 128 rows per workgroup, one wave per SIMD)
+ *      hh_k_policy_w16 30.8   32.6   34.4   38.7   51.9   55.8   64.1   93.0  117.4     (weights through LDS, 64 rows per workgroup, two workgroups per CU)
+ * A weights-through-LDS tile takes ~31 us however few CUs have one; the tile forms are faster while the rows fit one round of 32-row tiles
+ * (two per CU) with room to spare.  So: from 10 k rows that carry a network upwards hh_k_policy_w16, below the tile forms. */
+static inline bool hhp_rows_suit_w(int n_rows, int n_cu) { return (long long)n_rows > (long long)n_cu * 40; }
 /* the forward kernel over the current row lists; consume: the last workgroup to read the counters clears them */
 static int hhp_launch_forward(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, int8_t *actions, float *logits, int consume, hipStream_t st,
                               int32_t live_rows = -1) {
@@ -601,7 +636,11 @@ static int hhp_launch_forward(hh_policy *p, const float *obs, int32_t n_rows, in
     /* the form is chosen by the rows that CARRY a network: a bound HighLevelEnv world lists one side's units per call, half of its
      * [N, 6] row buffer at most (a full-buffer count picked 64-row tiles for 1.5 rounds of work: 78 against 67 us at 8192 arenas) */
     const int heur_rows = live_rows >= 0 ? live_rows : n_rows;
-    if (p->wform > 0 || (p->wform < 0 && !p->fp32 && p->tile_rows == 0 && hhp_rows_suit_w(heur_rows, p->n_cu))) { /* weights through LDS, activations in registers */
+    const bool auto_w = p->wform < 0 && !p->fp32 && p->tile_rows == 0 && hhp_rows_suit_w(heur_rows, p->n_cu);
+    if (p->wform == 2 || auto_w) { /* weights through LDS, activations in registers, 16 rows per wave: 64-row tiles, two workgroups per CU */
+        hipLaunchKernelGGL(hh_k_policy_w16, dim3((n_rows + 63) / 64 + p->n_nets), dim3(256), HHX_LDS_BYTES, st, p->bank, p->bankx, p->n_nets, obs, obs_stride, p->counts,
+                           p->lists, p->max_rows, actions, logits, consume);
+    } else if (p->wform == 1) { /* weights through LDS, activations in registers, 32 rows per wave: 128-row tiles, one workgroup per CU (A/B form) */
         hipLaunchKernelGGL(hh_k_policy_w<4>, dim3((n_rows + 127) / 128 + p->n_nets), dim3(256), HHW_LDS_BYTES, st, p->bank, p->bankw, p->n_nets, obs, obs_stride,
                            p->counts, p->lists, p->max_rows, actions, logits, consume);
     } else if (p->fp32) {
@@ -622,7 +661,8 @@ static int hhp_launch_forward(hh_policy *p, const float *obs, int32_t n_rows, in
 /* which kernel instance a forward over n_rows rows (live_rows of them carrying a network; < 0: all) launches, as a profiler prints it */
 static const char *hhp_form_name(const hh_policy *p, int n_rows, int live_rows) {
     const int heur_rows = live_rows >= 0 ? live_rows : n_rows;
-    if (p->wform > 0 || (p->wform < 0 && !p->fp32 && p->tile_rows == 0 && hhp_rows_suit_w(heur_rows, p->n_cu))) return "hh_k_policy_w<4>";
+    if (p->wform == 2 || (p->wform < 0 && !p->fp32 && p->tile_rows == 0 && hhp_rows_suit_w(heur_rows, p->n_cu))) return "hh_k_policy_w16";
+    if (p->wform == 1) return "hh_k_policy_w<4>";
     if (p->fp32) return "hh_k_policy";
     if (p->tile_rows == 64 || (p->tile_rows == 0 && hhp_rows_suit_wide_tiles(heur_rows, p->n_cu))) return "hh_k_policy_h<2>";
     return "hh_k_policy_h<1>";
@@ -793,6 +833,22 @@ extern "C" int hh_policy_sample(hh_policy *p, const float *obs, int32_t n_rows, 
     hipLaunchKernelGGL(hh_k_policy_ppo, dim3(vf ? 2 * tiles : tiles), dim3(256), HHPP_LDS_BYTES, st, p->bank, p->bankh, p->cbank, p->n_nets, obs, obs_stride,
                        p->counts, p->lists, p->max_rows, sa, vf ? 1 : 0, sel ? HHP_CONSUME : HHP_FROM_SAVED);
     HIPCHK(hipGetLastError());
+    return HH_OK;
+}
+
+/* tuning probe: workgroups of a forward kernel form that the runtime reports co-resident per CU (which: 0 hh_k_policy_h<1>, 1 hh_k_policy_h<2>,
+ * 2 hh_k_policy_w<4>, 3 hh_k_policy_w16, 4 hh_k_policy_ppo) */
+extern "C" int hh_policy_occupancy(int32_t which, int32_t *blocks_per_cu) {
+    if (!blocks_per_cu) return HH_E_ARG;
+    int n = 0;
+    hipError_t e = hipErrorInvalidValue;
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(hh_k_policy_h<1>), 256, HHPH_LDS_BYTES(1));
+    else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(hh_k_policy_h<2>), 512, HHPH_LDS_BYTES(2));
+    else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(hh_k_policy_w<4>), 256, HHW_LDS_BYTES);
+    else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(hh_k_policy_w16), 256, HHX_LDS_BYTES);
+    else if (which == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(hh_k_policy_ppo), 256, HHPP_LDS_BYTES);
+    if (e != hipSuccess) { g_err = std::string("hh_policy_occupancy: ") + hipGetErrorString(e); return HH_E_HIP; }
+    *blocks_per_cu = n;
     return HH_OK;
 }
 

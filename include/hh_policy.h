@@ -59,9 +59,10 @@ int hh_policy_set_lut(hh_policy *p, const uint8_t *lut);
  * rounds of one per CU, 32-row tiles otherwise), 32 or 64 = that instance always.  Same results either way (bit-identical logits); a caller
  * that keeps several banks busy on concurrent streams (bench.py --workload hier --pilot net --streams K) prefers 64: the other streams'
  * kernels fill the CUs a partial round leaves idle.  The environment variable HH_POLICY_TILE, read at hh_policy_create, sets the same.
- * Calls of at least 3/4 x 128 x (number of CUs) rows (24576 on an MI355X) run a third form when the width is 0: the weights streamed
- * through LDS once per 128 rows, the activations resident in registers (hh_policy_kernel_w.h; HH_POLICY_W=0 / 1 forces never / always).
- * Its logits differ from the tile forms' in the last bits (the output layer is summed in one k-ordered accumulator): same 1e-5 bound. */
+ * Calls with more than 40 x (number of CUs) rows that carry a network (10240 on an MI355X) run another form when the width is 0: the weights
+ * streamed through LDS once per 64 rows, the activations resident in registers (hh_policy_kernel_w16.h; HH_POLICY_W=0 keeps the tile forms,
+ * 2 forces this one, 1 its 128-row predecessor hh_policy_kernel_w.h).  Its logits differ from the tile forms' in the last bits (the output
+ * layer is summed in one k-ordered accumulator): same 1e-5 bound. */
 int hh_policy_set_tile_rows(hh_policy *p, int32_t rows);
 
 /* name of the forward kernel instance a call of n_rows rows launches on this bank, as a profiler prints it ("hh_k_policy_h<1>",

@@ -372,6 +372,8 @@ struct hh_policy {
     int wform;                /* HH_POLICY_W: 2 = always hh_k_policy_w16, 1 = always hh_k_policy_w, 0 = the tile forms only, unset (-1) = by row count (hhp_rows_suit_w) */
     HhpCritBank cbank;        /* hh_policy_set_critic: the value branches of the trainable policies (hh_policy_sample) */
     char *cblob[HH_POLICY_MAX_NETS]; /* one allocation per loaded value branch */
+    HhpCritBankX cbankx;      /* the same as fragment streams for hh_k_policy_w16_ppo */
+    char *cxblob[HH_POLICY_MAX_NETS];
 };
 static void hhp_forget_world(hh_policy *p) { p->bound = nullptr; }
 static void hhp_unbind(hh_policy *p) {
@@ -412,6 +414,8 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     memset(&p->cbank, 0, sizeof(p->cbank));
     memset(&p->bankw, 0, sizeof(p->bankw));
     memset(&p->bankx, 0, sizeof(p->bankx));
+    memset(&p->cbankx, 0, sizeof(p->cbankx));
+    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) p->cxblob[i] = nullptr;
     for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { p->cblob[i] = nullptr; p->wblob[i] = nullptr; p->xblob[i] = nullptr; }
     { const char *e = getenv("HH_POLICY_W"); p->wform = e ? atoi(e) : -1; }
     p->lut = nullptr; p->counts = nullptr; p->lists = nullptr;
@@ -427,6 +431,7 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_ppo), hipFuncAttributeMaxDynamicSharedMemorySize, HHPP_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_w<4>), hipFuncAttributeMaxDynamicSharedMemorySize, HHW_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_w16), hipFuncAttributeMaxDynamicSharedMemorySize, HHX_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_w16_ppo), hipFuncAttributeMaxDynamicSharedMemorySize, HHXC_LDS_BYTES);
     if (e != hipSuccess) {
         g_err = std::string("hh_policy_create: ") + hipGetErrorString(e);
         if (p->lut) (void)hipFree(p->lut);
@@ -445,7 +450,7 @@ extern "C" int hh_policy_destroy(hh_policy *p) {
     hhp_unbind(p); /* a world still bound to this bank goes back to emitting selector bytes only */
     DeviceGuard guard_(p->device);
     (void)hipFree(p->slab);
-    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { if (p->cblob[i]) (void)hipFree(p->cblob[i]); if (p->wblob[i]) (void)hipFree(p->wblob[i]); if (p->xblob[i]) (void)hipFree(p->xblob[i]); }
+    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { if (p->cblob[i]) (void)hipFree(p->cblob[i]); if (p->wblob[i]) (void)hipFree(p->wblob[i]); if (p->xblob[i]) (void)hipFree(p->xblob[i]); if (p->cxblob[i]) (void)hipFree(p->cxblob[i]); }
     (void)hipFree(p->lut); (void)hipFree(p->counts); (void)hipFree(p->lists);
     delete p;
     return HH_OK;
@@ -667,10 +672,14 @@ static const char *hhp_form_name(const hh_policy *p, int n_rows, int live_rows) 
     if (p->tile_rows == 64 || (p->tile_rows == 0 && hhp_rows_suit_wide_tiles(heur_rows, p->n_cu))) return "hh_k_policy_h<2>";
     return "hh_k_policy_h<1>";
 }
+/* hh_policy_sample: the weights-through-LDS form for large calls (HH_POLICY_W = 2 always, 0 / 1 never), the tile form otherwise */
+static bool hhp_sampler_is_w16(const hh_policy *p, int n_rows) {
+    return p->wform == 2 || (p->wform < 0 && !p->fp32 && p->tile_rows == 0 && hhp_rows_suit_w(n_rows, p->n_cu));
+}
 extern "C" int hh_policy_kernel_name(hh_policy *p, int32_t n_rows, int32_t sampler, char *buf, int32_t len) {
     if (!p || !buf || len <= 0 || n_rows <= 0) { g_err = "bad argument"; return HH_E_ARG; }
     const bool one_side = p->bound && p->bound->cfg.env_kind == HH_ENV_HIGHLEVEL;
-    snprintf(buf, (size_t)len, "%s", sampler ? "hh_k_policy_ppo" : hhp_form_name(p, n_rows, one_side ? n_rows / 2 : -1));
+    snprintf(buf, (size_t)len, "%s", sampler ? (hhp_sampler_is_w16(p, n_rows) ? "hh_k_policy_w16_ppo" : "hh_k_policy_ppo") : hhp_form_name(p, n_rows, one_side ? n_rows / 2 : -1));
     return HH_OK;
 }
 
@@ -782,6 +791,59 @@ static int hhp_set_critic(hh_policy *p, int32_t slot, const hh_critic_weights *w
     }
     for (int k = 0; k < 500; k++) hhp_split_put_t(Hh, Hl, h_wa, k, 0, HHP_OUT, w->val_w[k]);
     Bf[o_ba] = w->val_b[0];
+    { /* the same value branch as ONE linear stream of 1 KB fragments for hh_k_policy_w16_ppo (chunk order of hhx_critic_tile) + its biases */
+        std::vector<float> W1d((size_t)96 * 512, 0.0f), Wovd((size_t)160 * 160, 0.0f), Wsd((size_t)512 * 512, 0.0f);
+        if (att) {
+            const int in0[3] = {0, d1 + a1, 0}, in1[3] = {d1 + a1, n_in, n_in}, wd[3] = {175, 175, 150}, out0[3] = {0, 175, 350};
+            for (int b = 0; b < 3; b++)
+                for (int o = 0; o < wd[b]; o++)
+                    for (int c = in0[b]; c < in1[b]; c++) W1d[(size_t)c * 512 + hcol(out0[b] + o)] = w->v_w[b][(size_t)o * (in1[b] - in0[b]) + (c - in0[b])];
+            const float *wv = w->att_in_proj_w + (size_t)300 * 150;
+            for (int j = 0; j < 150; j++)
+                for (int k = 0; k < 150; k++) {
+                    double sacc = 0.0;
+                    for (int m = 0; m < 150; m++) sacc += (double)w->att_out_w[(size_t)j * 150 + m] * (double)wv[(size_t)m * 150 + k];
+                    Wovd[(size_t)k * 160 + j] = (float)sacc;
+                }
+        } else {
+            for (int o = 0; o < 500; o++)
+                for (int c = 0; c < n_in; c++) W1d[(size_t)c * 512 + o] = w->v_w[0][(size_t)o * n_in + c];
+        }
+        for (int j = 0; j < 500; j++)
+            for (int k = 0; k < 500; k++) Wsd[(size_t)hcol(k) * 512 + j] = w->shared_w[(size_t)j * 500 + k];
+        std::vector<uint16_t> X((size_t)HHXC_STREAM_PIECES * (HHW_PIECE / 2), 0);
+        for (int T = 0; T < 32; T++) /* chunk c = T / 4: tile (T & 3), k-block kb: hi, lo */
+            for (int kb = 0; kb < 3; kb++)
+                for (int wq = 0; wq < 32; wq++)
+                    for (int c = 0; c < 16; c++) hhx_put(X, (size_t)(T * 3 + kb) * 2, wq, c, true, W1d[(size_t)(32 * kb + wq) * 512 + 16 * T + c]);
+        for (int j = 0; j < 10; j++)
+            for (int kb = 0; kb < 5; kb++)
+                for (int wq = 0; wq < 32; wq++)
+                    for (int c = 0; c < 16; c++) hhx_put(X, (size_t)HHXC_L1_PIECES + (size_t)(j * 5 + kb) * 2, wq, c, false, Wovd[(size_t)(32 * kb + wq) * 160 + 16 * j + c]);
+        for (int pp = 0; pp < 8; pp++)
+            for (int q = 0; q < 4; q++)
+                for (int kk = 0; kk < 4; kk++)
+                    for (int t = 0; t < 4; t++)
+                        for (int wq = 0; wq < 32; wq++)
+                            for (int c = 0; c < 16; c++)
+                                hhx_put(X, (size_t)HHXC_L1_PIECES + HHXC_ATT_PIECES + (size_t)((pp * 4 + q) * 16 + kk * 4 + t) * 2, wq, c, false,
+                                        Wsd[(size_t)(32 * (4 * q + kk) + wq) * 512 + 16 * (4 * pp + t) + c]);
+        for (int kb = 0; kb < 16; kb++)
+            for (int wq = 0; wq < 32; wq++) { const int k = 32 * kb + wq; hhx_put(X, (size_t)HHXC_L1_PIECES + HHXC_ATT_PIECES + HHX_L2_PIECES + (size_t)kb * 2, wq, 0, false, k < 500 ? w->val_w[k] : 0.0f); }
+        const size_t xbytes = (size_t)HHXC_STREAM_PIECES * HHW_PIECE, xbias = (size_t)(512 + 512 + 160 + 32) * sizeof(float);
+        if (!p->cxblob[slot]) HIPCHK(hipMalloc(&p->cxblob[slot], xbytes + xbias));
+        HIPCHK(hipMemcpy(p->cxblob[slot], X.data(), xbytes, hipMemcpyHostToDevice));
+        std::vector<float> Xb(512 + 512 + 160 + 32, 0.0f);
+        for (int i = 0; i < 512; i++) { Xb[i] = Bf[o_b1 + i]; Xb[512 + i] = Bf[o_bs + i]; }
+        for (int i = 0; i < 160; i++) Xb[1024 + i] = Bf[o_bov + i];
+        Xb[1184] = Bf[o_ba];
+        HIPCHK(hipMemcpy(p->cxblob[slot] + xbytes, Xb.data(), xbias, hipMemcpyHostToDevice));
+        HhpCritX &Cx = p->cbankx.c[slot];
+        const float *xb = reinterpret_cast<const float *>(p->cxblob[slot] + xbytes);
+        Cx.stream = reinterpret_cast<const unsigned char *>(p->cxblob[slot]);
+        Cx.b1 = xb; Cx.bs = xb + 512; Cx.bov = xb + 1024; Cx.ba = xb + 1184;
+        Cx.d1 = d1; Cx.a1 = a1; Cx.d2 = d2; Cx.a2 = a2; Cx.has_att = att ? 1 : 0; Cx.loaded = 1;
+    }
     const size_t plane_bytes = h_total * sizeof(uint16_t), bytes = 2 * plane_bytes + n_bias * sizeof(float);
     if (!p->cblob[slot]) HIPCHK(hipMalloc(&p->cblob[slot], bytes));
     char *d = p->cblob[slot];
@@ -829,9 +891,15 @@ extern "C" int hh_policy_sample(hh_policy *p, const float *obs, int32_t n_rows, 
         hipLaunchKernelGGL(hh_k_policy_bin, dim3((n_rows + 255) / 256), dim3(256), 0, st, n_rows, sel, p->lut, p->max_rows, p->counts, p->lists, actions);
         p->binned_rows = n_rows;
     }
-    const int tiles = (n_rows + HHP_ROWS - 1) / HHP_ROWS + p->n_nets;
-    hipLaunchKernelGGL(hh_k_policy_ppo, dim3(vf ? 2 * tiles : tiles), dim3(256), HHPP_LDS_BYTES, st, p->bank, p->bankh, p->cbank, p->n_nets, obs, obs_stride,
-                       p->counts, p->lists, p->max_rows, sa, vf ? 1 : 0, sel ? HHP_CONSUME : HHP_FROM_SAVED);
+    if (hhp_sampler_is_w16(p, n_rows)) { /* weights through LDS, 64-row tiles: the form of large calls (hh_policy_kernel_w16.h) */
+        const int tiles = (n_rows + 63) / 64 + p->n_nets;
+        hipLaunchKernelGGL(hh_k_policy_w16_ppo, dim3(vf ? 2 * tiles : tiles), dim3(256), HHXC_LDS_BYTES, st, p->bank, p->bankx, p->cbankx, p->n_nets, obs, obs_stride,
+                           p->counts, p->lists, p->max_rows, sa, vf ? 1 : 0, sel ? HHP_CONSUME : HHP_FROM_SAVED);
+    } else {
+        const int tiles = (n_rows + HHP_ROWS - 1) / HHP_ROWS + p->n_nets;
+        hipLaunchKernelGGL(hh_k_policy_ppo, dim3(vf ? 2 * tiles : tiles), dim3(256), HHPP_LDS_BYTES, st, p->bank, p->bankh, p->cbank, p->n_nets, obs, obs_stride,
+                           p->counts, p->lists, p->max_rows, sa, vf ? 1 : 0, sel ? HHP_CONSUME : HHP_FROM_SAVED);
+    }
     HIPCHK(hipGetLastError());
     return HH_OK;
 }

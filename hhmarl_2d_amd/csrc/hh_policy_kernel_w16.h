@@ -69,12 +69,86 @@ __device__ __forceinline__ void hhx_pair_to_frag(const hh_f32x4 &a0, const hh_f3
     }
 }
 
-/* one 64-row tile of one network: four waves of 16 rows */
+/* The shared layer and the head contracted from its registers: 8 groups of four column tiles x 4 K quarters (chunks of 32 pieces, chunk
+ * (p, q) in buf[(q + par) & 1], the first one already requested; sp = the next chunk to request), the head's NOUT 16-column output tiles
+ * (pieces straight from global memory at l3, NOUT x (hi, lo) per k-block) accumulated in lacc.  bs = the shared layer's biases in LDS. */
+template <int NOUT>
+__device__ __forceinline__ void hhx_l2_l3(const hh_h8 (&zh)[16], const hh_h8 (&zl)[16], unsigned char *const (&buf)[2], int par, const unsigned char *sp,
+                                          const unsigned char *l3, const float *__restrict__ bl, int wave, int lane, int g, hh_f32x4 (&lacc)[NOUT]) {
+    /* ---- L2 (shared layer): 8 groups of four column tiles x 4 K quarters; the output layer from the group's registers ---- */
+#pragma unroll
+    for (int t = 0; t < NOUT; t++) lacc[t] = hh_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma nounroll
+    for (int p = 0; p < 8; p++) {
+        hh_f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = hhx_bias_acc(bl + 512 + 64 * p + 16 * t, g);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            __syncthreads(); /* chunk (p, q) landed in buf[(q + par) & 1]; the other buffer is free */
+            const bool more = p < 7 || q < 3;
+            const unsigned char *gsrc = sp + (size_t)wave * 8 * HHW_PIECE + lane * 16; /* this wave's eight pieces of the next chunk: two per step, behind the */
+            unsigned char *gdst = buf[(q + 1 + par) & 1] + wave * 8 * HHW_PIECE;              /* MFMAs of the first four steps (an LDS-DMA request costs ~60 cycles to issue) */
+            sp += (size_t)HHX_CHUNK * HHW_PIECE;
+            { /* eight steps of (k-block kk, tile pair tp) = 4 fragments, 6 MFMAs; the fragments of step s + 1 are requested before the MFMAs of step s */
+                const unsigned char *cb = buf[(q + par) & 1];
+                hh_h8 an[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) an[u] = hhw_frag(cb, u, lane);
+#pragma unroll
+                for (int s_ = 0; s_ < 8; s_++) {
+                    const int kk = s_ >> 1, tp = s_ & 1;
+                    hh_h8 a[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) a[u] = an[u];
+                    hhw_need4(a);
+                    if (s_ + 1 < 8) {
+#ifdef HHX_ABL_HALF_LDS /* tuning builds: half of the fragment reads (wrong results): is the LDS read path what two co-resident tiles fight over? */
+                        an[0] = hhw_frag(cb, (s_ + 1) * 4, lane); an[1] = hhw_frag(cb, (s_ + 1) * 4 + 1, lane); an[2] = an[0]; an[3] = an[1];
+#else
+#pragma unroll
+                        for (int u = 0; u < 4; u++) an[u] = hhw_frag(cb, (s_ + 1) * 4 + u, lane);
+#endif
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    HHX_MFMA(a[0], zh[4 * q + kk], acc[2 * tp]); HHX_MFMA(a[2], zh[4 * q + kk], acc[2 * tp + 1]);
+#ifndef HHX_ABL_THIRD_MFMA /* tuning builds: the hi x hi products only (wrong results): is the matrix pipe what two co-resident tiles fight over? */
+                    HHX_MFMA(a[1], zh[4 * q + kk], acc[2 * tp]); HHX_MFMA(a[3], zh[4 * q + kk], acc[2 * tp + 1]);
+                    HHX_MFMA(a[0], zl[4 * q + kk], acc[2 * tp]); HHX_MFMA(a[2], zl[4 * q + kk], acc[2 * tp + 1]);
+#endif
+#ifndef HHX_ABL_NO_GLDS /* tuning builds: the shared layer's chunks are never copied (wrong results): what does the LDS-DMA stream cost? */
+                    if (s_ < 4 && more) hhw_issue_some(gsrc, gdst, 2 * s_, 2);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        /* tanh of the four tiles = two B fragments of the output layer (S columns 64 p .. 64 p + 63 = k-blocks 2 p, 2 p + 1) */
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            hh_h8 sh, sl;
+            hhx_pair_to_frag(acc[2 * u], acc[2 * u + 1], sh, sl);
+#pragma unroll
+            for (int t = 0; t < NOUT; t++) {
+                const float4 *w = reinterpret_cast<const float4 *>(l3 + (size_t)(((2 * p + u) * NOUT + t) * 2) * HHW_PIECE);
+                const hh_h8 wh = hhp_as_h8(w[0]), wl = hhp_as_h8(w[HHW_PIECE / 16]);
+                HHX_MFMA(wh, sh, lacc[t]);
+                HHX_MFMA(wl, sh, lacc[t]);
+                HHX_MFMA(wh, sl, lacc[t]);
+            }
+        }
+    }
+
+}
+
+/* one 64-row tile of one network: four waves of 16 rows.  SAMPLE: the PPO sampler's tail (hh_policy_sample: a Categorical draw per action
+ * component, its log-probability) instead of the greedy decode */
+template <bool SAMPLE>
 __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned char *__restrict__ st, const float *__restrict__ obs, int obs_stride,
                                                  const int *__restrict__ list, int tile, int cnt, int8_t *__restrict__ actions, float *__restrict__ logits_out,
-                                                 unsigned char *ldsb) {
+                                                 unsigned char *ldsb, const HhpSampleArgs *sa = nullptr) {
     constexpr int NTH = 256, R = 64;
-    unsigned char *buf[2] = {ldsb, ldsb + HHX_BUF_BYTES};
+    unsigned char *const buf[2] = {ldsb, ldsb + HHX_BUF_BYTES};
     float *bl = reinterpret_cast<float *>(ldsb + HHX_OFF_BIAS);
     int *rows = reinterpret_cast<int *>(ldsb + HHX_OFF_ROWS);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -166,13 +240,15 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
         }
         ssum += __shfl_xor(ssum, 16);
         ssum += __shfl_xor(ssum, 32); /* the four k groups of a row: (s0 + s1) + (s2 + s3) on every lane */
-        const float inv = 1.0f / fmaxf(sqrtf(ssum), 1e-12f);
+        /* F.normalize divides; `y * (1.0f / den)` is NOT a substitute here: hipcc folds 1 / max(sqrt(s), eps) into an approximate reciprocal square
+         * root and 0.2 % of real observation rows then leave the fp32 forward by 2e-5 (found by the world-observation test of tests/test_policy_nets.py) */
+        const float den = fmaxf(sqrtf(ssum), 1e-12f);
 #pragma unroll
         for (int j = 0; j < 7; j++) {
             const int f = (25 + j) >> 1, e0 = 4 * ((25 + j) & 1);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float v = y[j][r] * inv; /* columns >= 500 were zeroed above */
+                const float v = y[j][r] / den; /* columns >= 500 were zeroed above */
                 const _Float16 h = (_Float16)v;
                 zh[f][e0 + r] = h;
                 zl[f][e0 + r] = (_Float16)(v - (float)h);
@@ -180,69 +256,9 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
         }
     }
 
-    /* ---- L2 (shared layer): 8 groups of four column tiles x 4 K quarters; the output layer from the group's registers ---- */
-    const unsigned char *l3 = st + (size_t)(HHX_L1_PIECES + HHX_ATT_PIECES + HHX_L2_PIECES) * HHW_PIECE + lane * 16;
-    hh_f32x4 lacc[2] = {hh_f32x4{0.0f, 0.0f, 0.0f, 0.0f}, hh_f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
-#pragma nounroll
-    for (int p = 0; p < 8; p++) {
-        hh_f32x4 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = hhx_bias_acc(bl + 512 + 64 * p + 16 * t, g);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            __syncthreads(); /* chunk (p, q) landed in buf[q & 1]; the other buffer is free */
-            const bool more = p < 7 || q < 3;
-            const unsigned char *gsrc = sp + (size_t)wave * 8 * HHW_PIECE + lane * 16; /* this wave's eight pieces of the next chunk: two per step, behind the */
-            unsigned char *gdst = buf[(q + 1) & 1] + wave * 8 * HHW_PIECE;              /* MFMAs of the first four steps (an LDS-DMA request costs ~60 cycles to issue) */
-            sp += (size_t)HHX_CHUNK * HHW_PIECE;
-            { /* eight steps of (k-block kk, tile pair tp) = 4 fragments, 6 MFMAs; the fragments of step s + 1 are requested before the MFMAs of step s */
-                const unsigned char *cb = buf[q & 1];
-                hh_h8 an[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) an[u] = hhw_frag(cb, u, lane);
-#pragma unroll
-                for (int s_ = 0; s_ < 8; s_++) {
-                    const int kk = s_ >> 1, tp = s_ & 1;
-                    hh_h8 a[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) a[u] = an[u];
-                    hhw_need4(a);
-                    if (s_ + 1 < 8) {
-#ifdef HHX_ABL_HALF_LDS /* tuning builds: half of the fragment reads (wrong results): is the LDS read path what two co-resident tiles fight over? */
-                        an[0] = hhw_frag(cb, (s_ + 1) * 4, lane); an[1] = hhw_frag(cb, (s_ + 1) * 4 + 1, lane); an[2] = an[0]; an[3] = an[1];
-#else
-#pragma unroll
-                        for (int u = 0; u < 4; u++) an[u] = hhw_frag(cb, (s_ + 1) * 4 + u, lane);
-#endif
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    HHX_MFMA(a[0], zh[4 * q + kk], acc[2 * tp]); HHX_MFMA(a[2], zh[4 * q + kk], acc[2 * tp + 1]);
-#ifndef HHX_ABL_THIRD_MFMA /* tuning builds: the hi x hi products only (wrong results): is the matrix pipe what two co-resident tiles fight over? */
-                    HHX_MFMA(a[1], zh[4 * q + kk], acc[2 * tp]); HHX_MFMA(a[3], zh[4 * q + kk], acc[2 * tp + 1]);
-                    HHX_MFMA(a[0], zl[4 * q + kk], acc[2 * tp]); HHX_MFMA(a[2], zl[4 * q + kk], acc[2 * tp + 1]);
-#endif
-#ifndef HHX_ABL_NO_GLDS /* tuning builds: the shared layer's chunks are never copied (wrong results): what does the LDS-DMA stream cost? */
-                    if (s_ < 4 && more) hhw_issue_some(gsrc, gdst, 2 * s_, 2);
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        /* tanh of the four tiles = two B fragments of the output layer (S columns 64 p .. 64 p + 63 = k-blocks 2 p, 2 p + 1) */
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            hh_h8 sh, sl;
-            hhx_pair_to_frag(acc[2 * u], acc[2 * u + 1], sh, sl);
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const float4 *w = reinterpret_cast<const float4 *>(l3 + (size_t)(((2 * p + u) * 2 + t) * 2) * HHW_PIECE);
-                const hh_h8 wh = hhp_as_h8(w[0]), wl = hhp_as_h8(w[HHW_PIECE / 16]);
-                HHX_MFMA(wh, sh, lacc[t]);
-                HHX_MFMA(wl, sh, lacc[t]);
-                HHX_MFMA(wh, sl, lacc[t]);
-            }
-        }
-    }
+    /* ---- L2 (shared layer) + the output layer from its registers ---- */
+    hh_f32x4 lacc[2];
+    hhx_l2_l3<2>(zh, zl, buf, 0, sp, st + (size_t)(HHX_L1_PIECES + HHX_ATT_PIECES + HHX_L2_PIECES) * HHW_PIECE + lane * 16, bl, wave, lane, g, lacc);
 
     /* ---- logits: lane (row, g) holds output columns 16 t + 4 g + (0..3); they meet in LDS for the decode ---- */
     __syncthreads(); /* every wave is done with the chunk buffers */
@@ -258,7 +274,7 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
             const int i = e >> 5, c = e & 31;
             if (rows[i] >= 0) logits_out[(size_t)rows[i] * HH_POLICY_LOGITS + c] = c < N.n_out ? Lg[e] : 0.0f;
         }
-    { /* greedy decode (env_base.py:373-382), one thread per (row, MultiDiscrete component): first maximum of its segment */
+    if constexpr (!SAMPLE) { /* greedy decode (env_base.py:373-382), one thread per (row, MultiDiscrete component): first maximum of its segment */
         const int i = tid >> 2, k = tid & 3;
         const int lo = k == 0 ? 0 : (k == 1 ? 13 : (k == 2 ? 22 : 24)), hi = k == 0 ? 13 : (k == 1 ? 22 : (k == 2 ? 24 : 26));
         const float *lg = Lg + i * 32;
@@ -269,7 +285,198 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
         a |= __builtin_amdgcn_mov_dpp(a, 0xB1, 0xf, 0xf, true);
         a |= __builtin_amdgcn_mov_dpp(a, 0x4E, 0xf, 0xf, true);
         if (k == 0 && rows[i] >= 0) reinterpret_cast<int *>(actions)[rows[i]] = a;
+    } else { /* TorchMultiCategorical over [13, 9, 2, 2] (| [13, 9, 2]): the tail of hh_k_policy_ppo's actor tiles (hh_policy_kernel_ppo.h), same arithmetic */
+        const int i = tid >> 2, k = tid & 3, r = rows[i];
+        const int lo = k == 0 ? 0 : (k == 1 ? 13 : (k == 2 ? 22 : 24)), hi = k == 0 ? 13 : (k == 1 ? 22 : (k == 2 ? 24 : 26));
+        const float *lg = Lg + i * 32;
+        int a = 0;
+        float lp = 0.0f;
+        if (k < (N.n_out == 26 ? 4 : 3)) {
+            float m = lg[lo];
+            int best = lo;
+            for (int c = lo + 1; c < hi; c++) if (lg[c] > m) { m = lg[c]; best = c; }
+            float S = 0.0f;
+            for (int c = lo; c < hi; c++) S += __expf(lg[c] - m);
+            a = best - lo;
+            if (!sa->greedy && r >= 0) {
+                double u;
+                if (sa->uniforms) u = sa->uniforms[(size_t)r * 4 + k];
+                else {
+                    const int n = r / sa->rows_per_arena, sl_ = r - n * sa->rows_per_arena;
+                    const int4 ap = sa->ar_pack[n];
+                    u = hh_rng_u01(hh_rng_tick_key(hh_rng_arena_key(sa->seed, sa->arena_offset + (unsigned long long)n), (uint32_t)ap.y, (uint32_t)ap.x),
+                                   (uint32_t)(sl_ + 1), HH_SITE_POLICY_SAMPLE, (uint32_t)k);
+                }
+                const float t = (float)u * S;
+                float cum = 0.0f;
+                a = hi - lo - 1;
+                bool found = false;
+                for (int c = lo; c < hi; c++) {
+                    cum += __expf(lg[c] - m);
+                    if (!found && cum > t) { a = c - lo; found = true; }
+                }
+            }
+            lp = (lg[lo + a] - m) - logf(S);
+        }
+        lp += __shfl_xor(lp, 1);
+        lp += __shfl_xor(lp, 2);
+        int aw = a << (8 * k);
+        aw |= __builtin_amdgcn_mov_dpp(aw, 0xB1, 0xf, 0xf, true);
+        aw |= __builtin_amdgcn_mov_dpp(aw, 0x4E, 0xf, 0xf, true);
+        if (k == 0 && r >= 0) {
+            reinterpret_cast<int *>(actions)[r] = aw;
+            if (sa->logp) sa->logp[r] = lp;
+        }
     }
+}
+
+/* ---- the value branch as a 64-row tile (hh_policy_sample; see hh_policy_kernel_ppo.h for the reference lines): input row = own observation |
+ * own action | the other agent's observation (row r ^ 1) | its action in THREE 32-column k-blocks; hidden columns in the critic's order
+ * (attention block first: fragments 0..4 = columns 0..159); chunks: first layer 8 x (4 tiles x 3 k-blocks x (hi, lo) = 24 pieces), attention 5 x
+ * (2 tiles x 5 k-blocks x 2 = 20 pieces, fight nets), then the shared layer's 32 chunks; the head is one 16-column tile whose column 0 is the value. */
+#define HHXC_L1_PIECES 192
+#define HHXC_ATT_PIECES 100
+#define HHXC_L3_PIECES 32
+#define HHXC_STREAM_PIECES (HHXC_L1_PIECES + HHXC_ATT_PIECES + HHX_L2_PIECES + HHXC_L3_PIECES)
+struct HhpCritX {
+    const unsigned char *stream;
+    const float *b1, *bs, *bov, *ba; /* [512], [512], [160], [32] */
+    int d1, a1, d2, a2, has_att, loaded;
+};
+struct HhpCritBankX {
+    HhpCritX c[HH_POLICY_MAX_NETS];
+};
+#define HHXC_OFF_ROWS (HHX_OFF_BIAS + (512 + 512 + 160 + 32) * 4)
+#define HHXC_LDS_BYTES (HHXC_OFF_ROWS + 64 * 4)
+
+template <bool ATT> /* fight nets (attention block, 13 chunks ahead of the shared layer) | escape nets (8): compile-time, so that the buffer parity is too */
+__device__ __forceinline__ void hhx_critic_tile(const HhpCritX &Cw, const float *__restrict__ obs, int obs_stride, const int *__restrict__ list, int tile, int cnt,
+                                                const HhpSampleArgs &sa, unsigned char *ldsb) {
+    constexpr int NTH = 256, R = 64;
+    unsigned char *const buf[2] = {ldsb, ldsb + HHX_BUF_BYTES};
+    float *bl = reinterpret_cast<float *>(ldsb + HHX_OFF_BIAS); /* b1 512 | bs 512 | bov 160 | ba 32 */
+    int *rows = reinterpret_cast<int *>(ldsb + HHXC_OFF_ROWS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci = lane & 15, g = lane >> 4;
+    const unsigned char *st = Cw.stream;
+
+    hhx_issue<6>(st, buf[0], wave, lane); /* chunk 0: first-layer tiles 0..3 (24 pieces) */
+    for (int e = tid; e < 512; e += NTH) { bl[e] = Cw.b1[e]; bl[512 + e] = Cw.bs[e]; }
+    if (tid < 160) bl[1024 + tid] = ATT ? Cw.bov[tid] : 0.0f;
+    if (tid < 32) bl[1184 + tid] = Cw.ba[tid];
+    const int q_ = tile * R + wave * 16 + ci;
+    const int row = q_ < cnt ? list[q_] : -1;
+    if (g == 0) rows[wave * 16 + ci] = row;
+    hh_h8 xh[3], xl[3]; /* central_critic_observer's row (train_hetero.py:162-181): lane (row, g) holds columns 32 b + 8 g .. + 7 of k-block b */
+    {
+        const int e1 = Cw.d1, e2 = e1 + Cw.a1, e3 = e2 + Cw.d2, e4 = e3 + Cw.a2;
+        const float *ca = sa.crit_act;
+        float xv[24];
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int c = 32 * b + 8 * g + e;
+                const bool own = c < e2, is_obs = c < e1 || (c >= e2 && c < e3);
+                const int cc = c < e1 ? c : (c < e2 ? c - e1 : (c < e3 ? c - e2 : c - e3));
+                const bool ok = row >= 0 && c < e4 && (is_obs || ca != nullptr);
+                const size_t rr = (size_t)(own ? row : row ^ 1);
+                const float *src = is_obs ? obs + rr * obs_stride + cc : ca + rr * 4 + cc;
+                const float x = *(ok ? src : obs);
+                xv[8 * b + e] = ok ? x : 0.0f;
+            }
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const _Float16 h = (_Float16)xv[8 * b + e];
+                xh[b][e] = h;
+                xl[b][e] = (_Float16)(xv[8 * b + e] - (float)h);
+            }
+    }
+    const unsigned char *sp = st + (size_t)24 * HHW_PIECE; /* the next chunk to request */
+    hh_h8 zh[16], zl[16];
+    int ck = 0; /* chunk counter: chunk ck sits in buf[ck & 1] */
+
+    /* ---- first layer: 8 chunks of 4 tiles (two fragments of the hidden row each) ---- */
+#pragma unroll
+    for (int c = 0; c < 8; c++, ck++) {
+        __syncthreads(); /* chunk ck landed; the other buffer is free */
+        if (c < 7) { hhx_issue<6>(sp, buf[(ck + 1) & 1], wave, lane); sp += (size_t)24 * HHW_PIECE; }
+        else if (ATT) { hhx_issue<5>(sp, buf[(ck + 1) & 1], wave, lane); sp += (size_t)20 * HHW_PIECE; }                            /* attention tiles 0, 1 */
+        else { sp += (size_t)HHXC_ATT_PIECES * HHW_PIECE; hhx_issue<8>(sp, buf[(ck + 1) & 1], wave, lane); sp += (size_t)HHX_CHUNK * HHW_PIECE; } /* escape nets: shared layer (0, 0) */
+#pragma unroll
+        for (int tp = 0; tp < 2; tp++) {
+            hh_f32x4 a[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int tt = tp * 2 + u, T = c * 4 + tt;
+                a[u] = hhx_bias_acc(bl + 16 * T, g);
+#pragma unroll
+                for (int kb = 0; kb < 3; kb++) {
+                    const hh_h8 wh = hhw_frag(buf[ck & 1], (tt * 3 + kb) * 2, lane), wl = hhw_frag(buf[ck & 1], (tt * 3 + kb) * 2 + 1, lane);
+                    HHX_MFMA(wh, xh[kb], a[u]);
+                    HHX_MFMA(wl, xh[kb], a[u]);
+                    HHX_MFMA(wh, xl[kb], a[u]);
+                }
+                __builtin_amdgcn_sched_barrier(0); /* one tile's six fragments at a time: hipcc otherwise hoists the whole chunk's reads (96 registers) */
+            }
+            hhx_pair_to_frag(a[0], a[1], zh[c * 2 + tp], zl[c * 2 + tp]);
+        }
+    }
+
+    /* ---- fight nets: y3 <- normalize(y3 + att_val(y3)) on hidden columns 0..149 = fragments 0..4; output tile j = half j & 1 of fragment j >> 1 ---- */
+    if constexpr (ATT) {
+        hh_f32x4 y[10];
+        float ssum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 5; c++, ck++) {
+            __syncthreads();
+            if (c < 4) { hhx_issue<5>(sp, buf[(ck + 1) & 1], wave, lane); sp += (size_t)20 * HHW_PIECE; }
+            else { hhx_issue<8>(sp, buf[(ck + 1) & 1], wave, lane); sp += (size_t)HHX_CHUNK * HHW_PIECE; }                           /* shared layer (0, 0) */
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const int j = c * 2 + jj;
+                hh_f32x4 acc = hhx_bias_acc(bl + 1024 + 16 * j, g);
+#pragma unroll
+                for (int kb = 0; kb < 5; kb++) {
+                    const hh_h8 wh = hhw_frag(buf[ck & 1], (jj * 5 + kb) * 2, lane), wl = hhw_frag(buf[ck & 1], (jj * 5 + kb) * 2 + 1, lane);
+                    HHX_MFMA(wh, zh[kb], acc);
+                    HHX_MFMA(wl, zh[kb], acc);
+                    HHX_MFMA(wh, zl[kb], acc);
+                    if (kb == 2) __builtin_amdgcn_sched_barrier(0); /* at most six fragments in flight beside the 168 registers of hidden row and tile outputs */
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int f = j >> 1, e0 = 4 * (j & 1);
+#pragma unroll
+                for (int r = 0; r < 4; r++) { /* columns 150..159 are padding: zero first-layer outputs, zero weights, zero biases -> v = 0 */
+                    const float x = (float)zh[f][e0 + r] + (float)zl[f][e0 + r];
+                    const float v = x + acc[r];
+                    y[j][r] = v;
+                    ssum += v * v;
+                }
+            }
+        }
+        ssum += __shfl_xor(ssum, 16);
+        ssum += __shfl_xor(ssum, 32);
+        const float den = fmaxf(sqrtf(ssum), 1e-12f); /* a true division, as above */
+#pragma unroll
+        for (int j = 0; j < 10; j++) {
+            const int f = j >> 1, e0 = 4 * (j & 1);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float v = y[j][r] / den;
+                const _Float16 h = (_Float16)v;
+                zh[f][e0 + r] = h;
+                zl[f][e0 + r] = (_Float16)(v - (float)h);
+            }
+        }
+    }
+
+    /* ---- the shared layer and val_out ---- */
+    hh_f32x4 lacc[1];
+    hhx_l2_l3<1>(zh, zl, buf, ck & 1, sp, st + (size_t)(HHXC_L1_PIECES + HHXC_ATT_PIECES + HHX_L2_PIECES) * HHW_PIECE + lane * 16, bl, wave, lane, g, lacc);
+    if (g == 0 && row >= 0) sa.vf[row] = lacc[0][0] + bl[1184]; /* output column 0 of the head's tile */
 }
 
 __global__ __launch_bounds__(256, 2) void hh_k_policy_w16(HhpBank bank, HhpBankX bankx, int n_nets, const float *__restrict__ obs, int obs_stride, int *counts,
@@ -285,7 +492,28 @@ __global__ __launch_bounds__(256, 2) void hh_k_policy_w16(HhpBank bank, HhpBankX
         for (int i = 0; i < HHX_STAGGER_SLEEPS; i++) __builtin_amdgcn_s_sleep(127);
 #endif
     if (hhp_locate<64>(cn, (int)blockIdx.x, net, tile, cnt))
-        hhx_forward_tile(bank.net[net], bankx.stream[net], obs, obs_stride, lists + (size_t)net * max_rows, tile, cnt, actions, logits_out, ldsb);
+        hhx_forward_tile<false>(bank.net[net], bankx.stream[net], obs, obs_stride, lists + (size_t)net * max_rows, tile, cnt, actions, logits_out, ldsb);
+    hhp_consume_counts(counts, consume);
+}
+
+/* hh_policy_sample in this form: workgroup 2 t = actor tile t with the sampler's tail, workgroup 2 t + 1 = the value branch of the same 64 rows */
+__global__ __launch_bounds__(256, 2) void hh_k_policy_w16_ppo(HhpBank bank, HhpBankX bankx, HhpCritBankX cbank, int n_nets, const float *__restrict__ obs,
+                                                              int obs_stride, int *counts, const int *__restrict__ lists, int max_rows, HhpSampleArgs sa,
+                                                              int with_critic, int consume) {
+    extern __shared__ __align__(16) unsigned char ldsb[];
+    int cn[HH_POLICY_MAX_NETS];
+#pragma unroll
+    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? min(hhp_row_count(counts, n, consume), max_rows) : 0;
+    const int gt = with_critic ? (int)blockIdx.x >> 1 : (int)blockIdx.x, crit = with_critic ? (int)blockIdx.x & 1 : 0;
+    int net, tile, cnt;
+    if (hhp_locate<64>(cn, gt, net, tile, cnt)) {
+        const int *list = lists + (size_t)net * max_rows;
+        if (crit) {
+            if (cbank.c[net].has_att) hhx_critic_tile<true>(cbank.c[net], obs, obs_stride, list, tile, cnt, sa, ldsb);
+            else hhx_critic_tile<false>(cbank.c[net], obs, obs_stride, list, tile, cnt, sa, ldsb);
+        }
+        else hhx_forward_tile<true>(bank.net[net], bankx.stream[net], obs, obs_stride, list, tile, cnt, sa.actions, sa.logits_out, ldsb, &sa);
+    }
     hhp_consume_counts(counts, consume);
 }
 
@@ -300,5 +528,16 @@ static inline void hhx_put(std::vector<uint16_t> &S, size_t piece_hi, int k, int
     S[piece_hi * (HHW_PIECE / 2) + at] = h;
     S[(piece_hi + 1) * (HHW_PIECE / 2) + at] = hhp_f2h(v - hhp_h2f(h));
 }
+
+#ifdef HHX_SPLIT_PROBE /* tuning builds: the two tile kinds as kernels of their own (register budgets) */
+__global__ __launch_bounds__(256, 2) void hhx_probe_crit(HhpCritBankX cbank, const float *obs, int obs_stride, const int *lists, int cnt, HhpSampleArgs sa) {
+    extern __shared__ __align__(16) unsigned char ldsb[];
+    hhx_critic_tile<true>(cbank.c[0], obs, obs_stride, lists, (int)blockIdx.x, cnt, sa, ldsb);
+}
+__global__ __launch_bounds__(256, 2) void hhx_probe_actor(HhpBank bank, HhpBankX bankx, const float *obs, int obs_stride, const int *lists, int cnt, HhpSampleArgs sa) {
+    extern __shared__ __align__(16) unsigned char ldsb[];
+    hhx_forward_tile<true>(bank.net[0], bankx.stream[0], obs, obs_stride, lists, (int)blockIdx.x, cnt, sa.actions, sa.logits_out, ldsb, &sa);
+}
+#endif
 
 #endif /* HH_POLICY_KERNEL_W16_H */

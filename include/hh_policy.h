@@ -145,7 +145,9 @@ int hh_policy_sample(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs
 /* HighLevelEnv.step with the pilot networks INSIDE, one cooperative launch per commander step (envs/env_hier.py:114-140 with
  * env_base.py:349-398 evaluated where the reference evaluates it): the same result as
  *     hh_hl_begin; 16 x { hh_policy_act_binned; hh_hl_agents_act; hh_policy_act_binned; hh_hl_tick }; hh_hl_end
- * on a bound bank, bit for bit (no early exit while any arena of the world is still inside its macro step), but the world phases and
+ * on a bound bank whose calls run a tile form (HH_POLICY_W=0, or a world small enough that the row count picks one), bit for bit (no
+ * early exit while any arena of the world is still inside its macro step; against the weights-through-LDS forms the logits agree to
+ * the last bits only, so an argmax on a near-tie can differ), but the world phases and
  * the policy tiles run inside ONE persistent kernel separated by grid barriers: nothing is dispatched, drained or re-fetched
  * between them.  commander_actions [dev] i8 [N, n_agents]; obs / reward / reward_valid / done like hh_hl_end.  The bank needs its
  * networks and LUT loaded, max_rows >= n_arenas x 6 and the split-fp16 form (the step walks 32-row tiles whatever width the bank is set

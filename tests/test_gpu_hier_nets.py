@@ -10,8 +10,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("N,nA,nO,steps", [(8192, 3, 3, 5), (203, 3, 3, 7), (1, 3, 3, 8), (640, 2, 3, 6), (3000, 3, 1, 6)],
                          ids=["8192-3v3", "203-3v3", "1-3v3", "640-2v3", "3000-3v1"])
-def test_cooperative_step_equals_the_launch_by_launch_path(N, nA, nO, steps):
+def test_cooperative_step_equals_the_launch_by_launch_path(N, nA, nO, steps, monkeypatch):
     import torch
+    monkeypatch.setenv("HH_POLICY_W", "0")   # the cooperative step walks tile-form tiles: bit equality is against that form of the separate launches
     from hhmarl_2d_amd import pilots
     from hhmarl_2d_amd.env_hier import macro_step
     from hhmarl_2d_amd.world import World, make_config

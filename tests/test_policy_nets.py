@@ -123,6 +123,41 @@ def test_hip_kernel_mixed_networks_against_torch_fp32():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", list(FORMS))
+@pytest.mark.parametrize("mode", ["fight", "escape"])
+def test_every_form_on_real_observations_of_a_full_world(monkeypatch, form, mode):
+    """16384 arenas x 2 agents a few ticks into their episodes — real observation rows (exact 0 / 1 flags, clipped values, zero friend
+    blocks), not uniform noise: every form of the forward kernel against the plain PyTorch fp32 forward, logits 1e-5 on EVERY row.  (Uniform
+    random rows let a folded reciprocal square root in the attention block's normalisation pass: 0.2 % of real rows were 2e-5 off.)"""
+    from hhmarl_2d_amd import _lib as L, pilots
+    from hhmarl_2d_amd.world import World, make_config
+    _form(monkeypatch, form)
+    N = 16384
+    w = World(make_config(n_arenas=N, level=3, agent_mode=L.MODE_FIGHT if mode == "fight" else L.MODE_ESCAPE, seed=77, arena_offset=1000, auto_reset=True), device=0)
+    obs = w.reset()
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        a = torch.from_numpy(np.stack([rng.integers(0, 13, (N, 2)), rng.integers(0, 9, (N, 2)), rng.integers(0, 2, (N, 2)), rng.integers(0, 2, (N, 2))],
+                                      axis=-1).astype(np.int8)).cuda()
+        obs = w.step(a)[0]
+    bank = _bank(5, max_rows=2 * N)
+    kinds = (PN.FIGHT1, PN.FIGHT2) if mode == "fight" else (PN.ESC1, PN.ESC2)
+    bytes_ = (pilots.SEL_FIGHT1, pilots.SEL_FIGHT2) if mode == "fight" else (pilots.SEL_ESC1, pilots.SEL_ESC2)
+    sel = torch.tensor(bytes_, dtype=torch.uint8, device="cuda").repeat(N, 1).contiguous()
+    logits = torch.zeros((N, 2, 32), dtype=torch.float32, device="cuda")
+    act = bank.act(obs, sel, logits=logits)
+    torch.cuda.synchronize()
+    o = obs.cpu()
+    for slot, kind in enumerate(kinds):
+        ref = PN.torch_forward(kind, PN.random_weights(kind, 5), o[:, slot])
+        err = (logits[:, slot, : PN.N_OUT[kind]].cpu() - ref).abs()
+        assert err.max() <= LOGIT_TOL, f"{PN.KIND_NAMES[kind]}: {float(err.max()):.2e} on {int((err.max(dim=1).values > LOGIT_TOL).sum())} rows"
+        parts = ref.split(PN.ACTION_SPLIT[: 4 if PN.N_OUT[kind] == 26 else 3], dim=1)
+        clear = torch.stack([(p.topk(2, dim=1).values[:, 0] - p.topk(2, dim=1).values[:, 1]) > 1e-4 for p in parts], dim=1).all(dim=1)
+        assert torch.equal(act[:, slot].cpu()[clear], PN.decode(ref, PN.N_OUT[kind])[clear])
+
+
+@pytest.mark.gpu
 def test_net_pilot_drives_highlevel_env_and_matches_torch():
     """NetPilot inside the HighLevelEnv macro step: the selector bytes the world emits (policy type | aircraft type << 2) pick the
     network; actions equal the PyTorch forward of the same rows"""
@@ -251,6 +286,7 @@ def test_tile_instances_of_the_kernel_agree_bit_for_bit(monkeypatch):
             assert torch.equal(lg, res[0][0]) and torch.equal(act, res[0][1])
     # the width can also be pinned per bank (hh_policy_set_tile_rows) or left to the row count (0): same bits again, bad values refused
     monkeypatch.delenv("HH_POLICY_TILE", raising=False)
+    monkeypatch.setenv("HH_POLICY_W", "0")   # the tile forms only: left alone, 0 hands a batch this large to hh_k_policy_w16 (last bits differ)
     R = 16384 + 64   # 0 = by row count
     obs = torch.from_numpy(rng.random((R, 30)).astype(np.float32)).cuda()
     sel = torch.from_numpy(sels[rng.integers(1, len(sels), R)]).cuda()

@@ -80,16 +80,22 @@ def _sel(mode, n_arenas):
     return torch.tensor(b, dtype=torch.uint8, device="cuda").repeat(n_arenas, 1).contiguous()
 
 
+SAMPLER_FORMS = {"tile-form": "0", "weights-through-lds-16-rows": "2"}   # HH_POLICY_W, read at hh_policy_create: hh_k_policy_ppo | hh_k_policy_w16_ppo
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", list(SAMPLER_FORMS))
 @pytest.mark.parametrize("kind", KINDS, ids=lambda k: PN.KIND_NAMES[k])
-def test_hip_sample_matches_reference_vectors(kind):
+def test_hip_sample_matches_reference_vectors(monkeypatch, kind, form):
     """the recorded rows of `kind` sit at their agent slot of [N, 2] arenas, the recorded other agent beside them: value, logits and logp
     within 1e-5 of the reference's own forward() / value_function(); the drawn action is the inverse CDF of the recorded uniforms"""
+    monkeypatch.setenv("HH_POLICY_W", SAMPLER_FORMS[form])
     g = np.load(GOLD)
     n = PN.KIND_NAMES[kind].lower()
     mode = "fight" if PN.HAS_ATT[kind] else "escape"
     slot = 0 if PN.N_OUT[kind] == 26 else 1
     bank = _trainable(int(g["seed"]), mode)
+    assert bank.kernel_name(128, sampler=True) == ("hh_k_policy_ppo" if form == "tile-form" else "hh_k_policy_w16_ppo")
     R, D = 64, 30
     obs = np.zeros((R, 2, D), dtype=np.float32)
     ca = np.zeros((R, 2, 4), dtype=np.float32)
@@ -121,13 +127,15 @@ def test_hip_sample_matches_reference_vectors(kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", list(SAMPLER_FORMS))
 @pytest.mark.parametrize("mode", ["fight", "escape"])
-def test_hip_sample_at_rollout_size_with_the_worlds_keyed_draws(mode, oracle):
+def test_hip_sample_at_rollout_size_with_the_worlds_keyed_draws(monkeypatch, mode, form, oracle):
     """16384 arenas x 2 agents, observations of a real world, draws keyed by (seed, global arena, episode, steps, unit, site, component):
     logits / value against the PyTorch fp32 restatements, actions against the float64 inverse CDF of the oracle's hho_rng_u01 on the
     kernel's own logits, logp against Categorical.log_prob"""
     from hhmarl_2d_amd.world import World, make_config
     from hhmarl_2d_amd import _lib as L
+    monkeypatch.setenv("HH_POLICY_W", SAMPLER_FORMS[form])
     N = 16384 if mode == "fight" else 4099
     kinds = (PN.FIGHT1, PN.FIGHT2) if mode == "fight" else (PN.ESC1, PN.ESC2)
     w = World(make_config(n_arenas=N, level=3, agent_mode=L.MODE_FIGHT if mode == "fight" else L.MODE_ESCAPE, seed=77, arena_offset=1000, auto_reset=True), device=0)

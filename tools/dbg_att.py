@@ -1,0 +1,62 @@
+"""where do hh_k_policy_w16's logits leave the fp32 forward on world observations?  variants of the Fight1 weights: att off (zero out_proj), tiny norm, ..."""
+import os, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+os.environ["HH_POLICY_W"] = sys.argv[1] if len(sys.argv) > 1 else "2"
+from hhmarl_2d_amd.world import World, make_config
+from hhmarl_2d_amd import pilots, policy_nets as PN
+N = 16384
+w = World(make_config(n_arenas=N, level=3, seed=77, arena_offset=1000, auto_reset=True), device=0)
+obs = w.reset()
+rng = np.random.default_rng(1)
+for _ in range(3):
+    a = torch.from_numpy(np.stack([rng.integers(0, 13, (N, 2)), rng.integers(0, 9, (N, 2)), rng.integers(0, 2, (N, 2)), rng.integers(0, 2, (N, 2))], axis=-1).astype(np.int8)).cuda()
+    obs = w.step(a)[0]
+o = obs[:, 0].contiguous()       # agent 1 rows (Fight1)
+sel = torch.full((N,), pilots.SEL_FIGHT1, dtype=torch.uint8, device="cuda")
+for variant in ("plain", "att_out_zero", "att_all_zero", "inp3_small"):
+    sd = PN.random_weights(PN.FIGHT1, 5)
+    if variant == "att_out_zero":
+        sd["att_act.out_proj.weight"][:] = 0
+    if variant == "att_all_zero":
+        sd["att_act.out_proj.weight"][:] = 0; sd["att_act.out_proj.bias"][:] = 0
+    if variant == "inp3_small":
+        sd["inp3._model.0.weight"] *= 0.01; sd["inp3._model.0.bias"] *= 0.01
+    bank = pilots.PolicyBank(torch.device("cuda", 0), N)
+    bank.set_net(0, PN.FIGHT1, sd)
+    bank.set_lut({pilots.SEL_FIGHT1: 0})
+    logits = torch.zeros((N, 32), dtype=torch.float32, device="cuda")
+    bank.act(o, sel, logits=logits)
+    torch.cuda.synchronize()
+    ref = PN.torch_forward(PN.FIGHT1, sd, o.cpu())
+    ref64 = PN.torch_forward(PN.FIGHT1, sd, o.cpu()).double()
+    err = (logits[:, :26].cpu() - ref).abs()
+    r = int(err.max(dim=1).values.argmax())
+    print(f"{variant:14s} max err {float(err.max()):.2e}  rows > 5e-6: {int((err.max(dim=1).values > 5e-6).sum())}  worst row {r}: per-column err {err[r].numpy().round(7)[:8]}")
+
+# what do the rows that deviate have in common?
+sd = PN.random_weights(PN.FIGHT1, 5)
+bank = pilots.PolicyBank(torch.device("cuda", 0), N); bank.set_net(0, PN.FIGHT1, sd); bank.set_lut({pilots.SEL_FIGHT1: 0})
+logits = torch.zeros((N, 32), dtype=torch.float32, device="cuda")
+bank.act(o, sel, logits=logits); torch.cuda.synchronize()
+ref = PN.torch_forward(PN.FIGHT1, sd, o.cpu())
+err = (logits[:, :26].cpu() - ref).abs().max(dim=1).values
+bad = err > 5e-6
+oc = o.cpu()
+print("bad rows", int(bad.sum()), "indices mod 64:", sorted(set((bad.nonzero().flatten() % 64).tolist()))[:40])
+print("indices mod 16:", sorted(set((bad.nonzero().flatten() % 16).tolist())))
+print("first bad indices:", bad.nonzero().flatten()[:30].tolist())
+print("col means  bad:", oc[bad].mean(0).numpy().round(3))
+print("col means  all:", oc.mean(0).numpy().round(3))
+# the same rows alone, in another order: does the error follow the row or the position?
+idx = bad.nonzero().flatten()
+sub = oc[idx].contiguous().cuda()
+lg2 = torch.zeros((len(idx), 32), dtype=torch.float32, device="cuda")
+bank2 = pilots.PolicyBank(torch.device("cuda", 0), N); bank2.set_net(0, PN.FIGHT1, sd); bank2.set_lut({pilots.SEL_FIGHT1: 0})
+bank2.act(sub, torch.full((len(idx),), pilots.SEL_FIGHT1, dtype=torch.uint8, device="cuda"), logits=lg2); torch.cuda.synchronize()
+e2 = (lg2[:, :26].cpu() - ref[idx]).abs().max(dim=1).values
+print("the bad rows re-run alone: max err", float(e2.max()), "still bad:", int((e2 > 5e-6).sum()))
+np.save(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out", "bad_rows_obs.npy"), oc[idx].numpy())
+np.save(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out", "bad_rows_logits.npy"), lg2.cpu().numpy())
+good = (~bad).nonzero().flatten()[:64]
+np.save(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out", "good_rows_obs.npy"), oc[good].numpy())

@@ -14,7 +14,7 @@
  *     into a double buffer one chunk ahead; the output layer's 64 pieces are read straight from global memory (L2 hits; they would make the
  *     last chunk of a column group 40 pieces).
  * Chunks (pieces): L1 tiles 0..15 (32) | L1 tiles 16..31 (32) | ATT tiles 0..3 (32) | ATT tiles 4..6 (24) | 8 column groups x 4 K quarters
- * (32 each: 4 k-blocks x 4 tiles x (hi, lo)) | output layer 64 (not chunked).
+ * (32 each: 4 k-blocks x 4 tiles x (hi, lo)) | output layer 64 (8 per column group, side buffer).
  */
 #ifndef HH_POLICY_KERNEL_W16_H
 #define HH_POLICY_KERNEL_W16_H
@@ -30,7 +30,8 @@ typedef float hh_f32x4 __attribute__((ext_vector_type(4)));
 #define HHX_STREAM_PIECES (HHX_L1_PIECES + HHX_ATT_PIECES + HHX_L2_PIECES + HHX_L3_PIECES)
 #define HHX_OFF_BIAS (2 * HHX_BUF_BYTES)
 #define HHX_OFF_ROWS (HHX_OFF_BIAS + (512 + 512 + 128 + 32) * 4)
-#define HHX_LDS_BYTES (HHX_OFF_ROWS + 64 * 4)
+#define HHX_OFF_L3 (HHX_OFF_ROWS + 64 * 4) /* the head's eight pieces of one column group */
+#define HHX_LDS_BYTES (HHX_OFF_L3 + 8 * HHW_PIECE)
 
 struct HhpBankX {
     const unsigned char *stream[HH_POLICY_MAX_NETS];
@@ -45,6 +46,23 @@ __host__ __device__ inline void hhw16_korder(int w, int &kg, int &e) {
 
 #define HHX_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, C, 0, 0, 0)
 
+/* tuning builds (-DHHP_PROFILE): per-phase cycles of wave 0 of every tile, summed in registers, flushed once (tools/policy_w16_phase_profile.py) */
+#ifdef HHP_PROFILE
+struct HhxProf { unsigned long long acc[16], pt, rt; }; /* slot 15: the tile in s_memrealtime ticks (100 MHz): slots 0..9 against it = the shader clock the tile ran at */
+#define HHX_T0(P) do { for (int k_ = 0; k_ < 16; k_++) (P).acc[k_] = 0; (P).rt = __builtin_amdgcn_s_memrealtime(); (P).pt = __builtin_readcyclecounter(); } while (0)
+#ifdef HHP_PROFILE_LITE /* the two ends of the tile only: the phase stamps (an s_waitcnt lgkmcnt(0) each) perturb what they measure */
+#define HHX_T(P, k) do { if ((k) == 9) { const unsigned long long t_ = __builtin_readcyclecounter(); (P).acc[k] += t_ - (P).pt; (P).pt = t_; } } while (0)
+#else
+#define HHX_T(P, k) do { const unsigned long long t_ = __builtin_readcyclecounter(); (P).acc[k] += t_ - (P).pt; (P).pt = t_; } while (0)
+#endif
+#define HHX_TFLUSH(P) do { (P).acc[15] = __builtin_amdgcn_s_memrealtime() - (P).rt; if (threadIdx.x == 0) for (int k_ = 0; k_ < 16; k_++) atomicAdd(&hhp_prof[k_], (P).acc[k_]); } while (0)
+#else
+struct HhxProf {};
+#define HHX_T0(P)
+#define HHX_T(P, k)
+#define HHX_TFLUSH(P)
+#endif
+
 __device__ __forceinline__ hh_f32x4 hhx_bias_acc(const float *__restrict__ bias /* LDS: the tile's 16 columns */, int g) {
     const float4 b = *reinterpret_cast<const float4 *>(bias + 4 * g);
     return hh_f32x4{b.x, b.y, b.z, b.w};
@@ -57,24 +75,61 @@ __device__ __forceinline__ void hhx_issue(const unsigned char *__restrict__ src,
 #pragma unroll
     for (int u = 0; u < NPW; u++) hhw_glds(s + (size_t)(u >> 2) * 4 * HHW_PIECE, d + (u >> 2) * 4 * HHW_PIECE, u & 3);
 }
+/* the fp16 split of two values in four instructions: hi pair = v_cvt_pk_f16_f32 (round to nearest even, like a scalar cast), the two exact remainders
+ * v - (float)hi by v_fma_mix_f32 straight from the packed halves (no unpacking conversion, no subtraction of its own), lo pair = v_cvt_pk_f16_f32.
+ * The same bits as `h = (_Float16)v; l = (_Float16)(v - (float)h)`, which hipcc spells with eight. */
+typedef _Float16 hh_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void hhx_split2(hh_f2 v, unsigned &hi, unsigned &lo) {
+    union { hh_h2 h; unsigned u; } a, b;
+    a.h = __builtin_convertvector(v, hh_h2);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(a.u), "v"(v.x));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(a.u), "v"(v.y));
+    b.h = __builtin_convertvector(hh_f2{r0, r1}, hh_h2);
+    hi = a.u;
+    lo = b.u;
+}
+__device__ __forceinline__ void hhx_split8(const hh_f2 (&p)[4], hh_h8 &fh, hh_h8 &fl) {
+    union { unsigned u[4]; hh_h8 h; } H, L;
+#pragma unroll
+    for (int i = 0; i < 4; i++) hhx_split2(p[i], H.u[i], L.u[i]);
+    fh = H.h;
+    fl = L.h;
+}
+/* 1 / max(sqrt(s), 1e-12), correctly rounded from the correctly rounded norm: F.normalize divides every element by the norm, and a product with this
+ * reciprocal is within 1.5 ulp of that quotient.  The empty asm hides the norm from hipcc, which otherwise folds 1 / max(sqrt(s), eps) into ONE approximate
+ * v_rsq_f32: 0.2 % of real observation rows then leave the fp32 forward by 2e-5 (found by the world-observation test of tests/test_policy_nets.py). */
+__device__ __forceinline__ float hhx_recip_norm(float ssum) {
+    float den = fmaxf(sqrtf(ssum), 1e-12f);
+    asm volatile("" : "+v"(den));
+    return 1.0f / den;
+}
+/* four values into elements 2 w .. 2 w + 3 of a fragment's (hi, lo) halves (w = 0 | 2: a compile-time constant where it is used) */
+__device__ __forceinline__ void hhx_put4(hh_h8 &fh, hh_h8 &fl, int w, hh_f2 v01, hh_f2 v23) {
+    union { unsigned u[4]; hh_h8 h; } H, L;
+    H.h = fh;
+    L.h = fl;
+    hhx_split2(v01, H.u[w], L.u[w]);
+    hhx_split2(v23, H.u[w + 1], L.u[w + 1]);
+    fh = H.h;
+    fl = L.h;
+}
 /* tanh of two adjacent C^T tiles (bias already in the accumulators) -> the (hi, lo) halves of one B fragment */
 __device__ __forceinline__ void hhx_pair_to_frag(const hh_f32x4 &a0, const hh_f32x4 &a1, hh_h8 &fh, hh_h8 &fl) {
-    const hh_f2 p0 = hhp_tanh2(hh_f2{a0[0], a0[1]}), p1 = hhp_tanh2(hh_f2{a0[2], a0[3]}), p2 = hhp_tanh2(hh_f2{a1[0], a1[1]}), p3 = hhp_tanh2(hh_f2{a1[2], a1[3]});
-    const float v[8] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const _Float16 h = (_Float16)v[i];
-        fh[i] = h;
-        fl[i] = (_Float16)(v[i] - (float)h);
-    }
+    const hh_f2 p[4] = {hhp_tanh2(hh_f2{a0[0], a0[1]}), hhp_tanh2(hh_f2{a0[2], a0[3]}), hhp_tanh2(hh_f2{a1[0], a1[1]}), hhp_tanh2(hh_f2{a1[2], a1[3]})};
+    hhx_split8(p, fh, fl);
 }
 
 /* The shared layer and the head contracted from its registers: 8 groups of four column tiles x 4 K quarters (chunks of 32 pieces, chunk
  * (p, q) in buf[(q + par) & 1], the first one already requested; sp = the next chunk to request), the head's NOUT 16-column output tiles
- * (pieces straight from global memory at l3, NOUT x (hi, lo) per k-block) accumulated in lacc.  bs = the shared layer's biases in LDS. */
+ * accumulated in lacc.  The head's pieces of group p (2 k-blocks x NOUT x (hi, lo), contiguous at l3 + p x 4 NOUT pieces) travel beside chunk
+ * (p, 2) into a side buffer l3buf of their own: read from global memory where they are used, their L2 latency stood in the open eight times a tile
+ * (tools/policy_w16_phase_profile.py: 8 k of a tile's 69 k cycles).  bl = the biases in LDS. */
 template <int NOUT>
 __device__ __forceinline__ void hhx_l2_l3(const hh_h8 (&zh)[16], const hh_h8 (&zl)[16], unsigned char *const (&buf)[2], int par, const unsigned char *sp,
-                                          const unsigned char *l3, const float *__restrict__ bl, int wave, int lane, int g, hh_f32x4 (&lacc)[NOUT]) {
+                                          const unsigned char *l3, unsigned char *l3buf, const float *__restrict__ bl, int wave, int lane, int g,
+                                          hh_f32x4 (&lacc)[NOUT], HhxProf &pf) {
+    static_assert(NOUT == 1 || NOUT == 2, "one piece (value head) or two (policy head) per wave and group");
     /* ---- L2 (shared layer): 8 groups of four column tiles x 4 K quarters; the output layer from the group's registers ---- */
 #pragma unroll
     for (int t = 0; t < NOUT; t++) lacc[t] = hh_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -85,7 +140,10 @@ __device__ __forceinline__ void hhx_l2_l3(const hh_h8 (&zh)[16], const hh_h8 (&z
         for (int t = 0; t < 4; t++) acc[t] = hhx_bias_acc(bl + 512 + 64 * p + 16 * t, g);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
+#ifndef HHX_ABL_NO_BARRIER /* tuning builds: the shared layer's chunks are not waited for (wrong results): what do the 32 barriers + vmcnt(0) cost? */
             __syncthreads(); /* chunk (p, q) landed in buf[(q + par) & 1]; the other buffer is free */
+#endif
+            HHX_T(pf, 5);
             const bool more = p < 7 || q < 3;
             const unsigned char *gsrc = sp + (size_t)wave * 8 * HHW_PIECE + lane * 16; /* this wave's eight pieces of the next chunk: two per step, behind the */
             unsigned char *gdst = buf[(q + 1 + par) & 1] + wave * 8 * HHW_PIECE;              /* MFMAs of the first four steps (an LDS-DMA request costs ~60 cycles to issue) */
@@ -118,27 +176,32 @@ __device__ __forceinline__ void hhx_l2_l3(const hh_h8 (&zh)[16], const hh_h8 (&z
 #endif
 #ifndef HHX_ABL_NO_GLDS /* tuning builds: the shared layer's chunks are never copied (wrong results): what does the LDS-DMA stream cost? */
                     if (s_ < 4 && more) hhw_issue_some(gsrc, gdst, 2 * s_, 2);
+                    if (q == 1 && s_ == 4) { /* every wave is past barrier (p, 1), so past its reads of group p - 1's head pieces; these land before barrier (p, 2) */
+                        const unsigned char *hs = l3 + (size_t)(p * 4 * NOUT + wave * NOUT) * HHW_PIECE + lane * 16;
+                        hhw_issue_some(hs, l3buf + wave * NOUT * HHW_PIECE, 0, NOUT);
+                    }
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            HHX_T(pf, 6);
         }
         /* tanh of the four tiles = two B fragments of the output layer (S columns 64 p .. 64 p + 63 = k-blocks 2 p, 2 p + 1) */
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             hh_h8 sh, sl;
             hhx_pair_to_frag(acc[2 * u], acc[2 * u + 1], sh, sl);
+            HHX_T(pf, 7);
 #pragma unroll
             for (int t = 0; t < NOUT; t++) {
-                const float4 *w = reinterpret_cast<const float4 *>(l3 + (size_t)(((2 * p + u) * NOUT + t) * 2) * HHW_PIECE);
-                const hh_h8 wh = hhp_as_h8(w[0]), wl = hhp_as_h8(w[HHW_PIECE / 16]);
+                const hh_h8 wh = hhw_frag(l3buf, (u * NOUT + t) * 2, lane), wl = hhw_frag(l3buf, (u * NOUT + t) * 2 + 1, lane);
                 HHX_MFMA(wh, sh, lacc[t]);
                 HHX_MFMA(wl, sh, lacc[t]);
                 HHX_MFMA(wh, sl, lacc[t]);
             }
+            HHX_T(pf, 8);
         }
     }
-
 }
 
 /* one 64-row tile of one network: four waves of 16 rows.  SAMPLE: the PPO sampler's tail (hh_policy_sample: a Categorical draw per action
@@ -154,6 +217,8 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ci = lane & 15, g = lane >> 4;
 
+    HhxProf pf;
+    HHX_T0(pf);
     hhx_issue<8>(st, buf[0], wave, lane); /* chunk 0: L1 tiles 0..15 */
     for (int e = tid; e < 512; e += NTH) { bl[e] = N.b1[e]; bl[512 + e] = N.bs[e]; }
     if (tid < 128) bl[1024 + tid] = N.has_att ? N.bov[tid] : 0.0f;
@@ -182,83 +247,124 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
     const unsigned char *sp = st + (size_t)HHX_CHUNK * HHW_PIECE; /* the next chunk to request */
     hh_h8 zh[16], zl[16]; /* the hidden row: fragment kb = columns 32 kb .. 32 kb + 31 in hhw16_korder */
 
-    /* ---- L1: 32 column tiles of 16, K = one block of 32 observation columns; two chunks of 16 tiles ---- */
+    /* ---- L1: 32 column tiles of 16, K = one block of 32 observation columns; two chunks of 16 tiles.  Steps of one tile pair = one fragment of
+     *      the hidden row: the pair's four weight fragments are requested a step ahead (an LDS round trip in the open per pair was a third of this
+     *      phase), the next chunk's eight LDS-DMA requests of this wave go out one per step ---- */
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         __syncthreads(); /* chunk c landed; the other buffer is free */
-        if (c == 0) hhx_issue<8>(sp, buf[1], wave, lane);
-        else if (N.has_att) hhx_issue<8>(sp, buf[0], wave, lane);                                    /* ATT tiles 0..3 */
-        else { sp += (size_t)HHX_ATT_PIECES * HHW_PIECE; hhx_issue<8>(sp, buf[0], wave, lane); }   /* escape nets: straight to shared layer (0, 0) */
+        HHX_T(pf, c == 0 ? 0 : 2);
+        if (c == 1 && !N.has_att) sp += (size_t)HHX_ATT_PIECES * HHW_PIECE; /* escape nets: straight to shared layer (0, 0) */
+        const unsigned char *gsrc = sp + (size_t)wave * 8 * HHW_PIECE + lane * 16; /* chunk 1 | ATT tiles 0..3 | shared layer (0, 0) */
+        unsigned char *gdst = buf[c ^ 1] + wave * 8 * HHW_PIECE;
         sp += (size_t)HHX_CHUNK * HHW_PIECE;
+        const unsigned char *cb = buf[c];
+        hh_h8 an[4];
 #pragma unroll
-        for (int tp = 0; tp < 8; tp++) { /* pairs of tiles = one fragment of the hidden row */
-            hh_f32x4 a[2];
+        for (int u = 0; u < 4; u++) an[u] = hhw_frag(cb, u, lane);
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int T = c * 16 + tp * 2 + u;
-                a[u] = hhx_bias_acc(bl + 16 * T, g);
-                const hh_h8 wh = hhw_frag(buf[c], (tp * 2 + u) * 2, lane), wl = hhw_frag(buf[c], (tp * 2 + u) * 2 + 1, lane);
-                HHX_MFMA(wh, xh, a[u]);
-                HHX_MFMA(wl, xh, a[u]);
-                HHX_MFMA(wh, xl, a[u]);
+        for (int tp = 0; tp < 8; tp++) {
+            hh_h8 a[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) a[u] = an[u];
+            hhw_need4(a);
+            if (tp + 1 < 8) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) an[u] = hhw_frag(cb, (tp + 1) * 4 + u, lane);
             }
-            hhx_pair_to_frag(a[0], a[1], zh[c * 8 + tp], zl[c * 8 + tp]);
+            __builtin_amdgcn_sched_barrier(0);
+            hh_f32x4 a0 = hhx_bias_acc(bl + 16 * (c * 16 + tp * 2), g), a1 = hhx_bias_acc(bl + 16 * (c * 16 + tp * 2 + 1), g);
+            HHX_MFMA(a[0], xh, a0); HHX_MFMA(a[2], xh, a1);
+            HHX_MFMA(a[1], xh, a0); HHX_MFMA(a[3], xh, a1);
+            HHX_MFMA(a[0], xl, a0); HHX_MFMA(a[2], xl, a1);
+            hhw_issue_some(gsrc, gdst, tp, 1);
+            hhx_pair_to_frag(a0, a1, zh[c * 8 + tp], zl[c * 8 + tp]);
         }
+        HHX_T(pf, c == 0 ? 1 : 3);
     }
 
     /* ---- fight nets: x <- normalize(x + Wov x + bov) on hidden columns 400..499.  K = fragments 12..15 (columns 384..511, the weights of
-     *      384..399 are zero); output tile j (columns 400 + 16 j ..) is half (25 + j) & 1 of fragment (25 + j) >> 1 ---- */
+     *      384..399 are zero); output tile j (columns 400 + 16 j ..) is half (25 + j) & 1 of fragment (25 + j) >> 1.  Steps of (tile pair, k-block)
+     *      like the shared layer's (two accumulators in turn instead of twelve dependent MFMAs on one), fragments a step ahead ---- */
     if (N.has_att) {
         hh_f32x4 y[7];
         float ssum = 0.0f;
+        auto fold = [&](int j, const hh_f32x4 &acc) {
+            const int f = (25 + j) >> 1, e0 = 4 * ((25 + j) & 1);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const bool ok = 16 * j + 4 * g + r < 100;
+                const float x = (float)zh[f][e0 + r] + (float)zl[f][e0 + r];
+                const float v = ok ? x + acc[r] : 0.0f;
+                y[j][r] = v;
+                ssum += v * v;
+            }
+        };
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             __syncthreads();
-            if (c == 0) { hhx_issue<6>(sp, buf[1], wave, lane); sp += (size_t)(HHX_ATT_PIECES - HHX_CHUNK) * HHW_PIECE; }   /* ATT tiles 4..6 (24 pieces) */
-            else { hhx_issue<8>(sp, buf[0], wave, lane); sp += (size_t)HHX_CHUNK * HHW_PIECE; }                             /* shared layer (0, 0) */
+            const int npw = c == 0 ? 6 : 8; /* ATT tiles 4..6 (24 pieces) | shared layer (0, 0) */
+            const unsigned char *gsrc = sp + (size_t)wave * npw * HHW_PIECE + lane * 16;
+            unsigned char *gdst = buf[c ^ 1] + wave * npw * HHW_PIECE;
+            sp += (size_t)(c == 0 ? HHX_ATT_PIECES - HHX_CHUNK : HHX_CHUNK) * HHW_PIECE;
+            const unsigned char *cb = buf[c];
+            /* tile pairs (0, 1) (2, 3) | (4, 5); piece of (tile jj of the chunk, k-block kb, plane) = (jj * 4 + kb) * 2 + plane */
 #pragma unroll
-            for (int jj = 0; jj < (c == 0 ? 4 : 3); jj++) {
-                const int j = c * 4 + jj;
-                hh_f32x4 acc = hhx_bias_acc(bl + 1024 + 16 * j, g);
+            for (int pr = 0; pr < (c == 0 ? 2 : 1); pr++) {
+                const int j0 = c * 4 + pr * 2;
+                hh_f32x4 acc0 = hhx_bias_acc(bl + 1024 + 16 * j0, g), acc1 = hhx_bias_acc(bl + 1024 + 16 * (j0 + 1), g);
+                hh_h8 an[4];
+                an[0] = hhw_frag(cb, (pr * 2 * 4) * 2, lane); an[1] = hhw_frag(cb, (pr * 2 * 4) * 2 + 1, lane);
+                an[2] = hhw_frag(cb, ((pr * 2 + 1) * 4) * 2, lane); an[3] = hhw_frag(cb, ((pr * 2 + 1) * 4) * 2 + 1, lane);
 #pragma unroll
                 for (int kb = 0; kb < 4; kb++) {
-                    const hh_h8 wh = hhw_frag(buf[c], (jj * 4 + kb) * 2, lane), wl = hhw_frag(buf[c], (jj * 4 + kb) * 2 + 1, lane);
-                    HHX_MFMA(wh, zh[12 + kb], acc);
-                    HHX_MFMA(wl, zh[12 + kb], acc);
-                    HHX_MFMA(wh, zl[12 + kb], acc);
-                }
-                const int f = (25 + j) >> 1, e0 = 4 * ((25 + j) & 1);
+                    hh_h8 a[4];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const bool ok = 16 * j + 4 * g + r < 100;
-                    const float x = (float)zh[f][e0 + r] + (float)zl[f][e0 + r];
-                    const float v = ok ? x + acc[r] : 0.0f;
-                    y[j][r] = v;
-                    ssum += v * v;
+                    for (int u = 0; u < 4; u++) a[u] = an[u];
+                    hhw_need4(a);
+                    if (kb + 1 < 4) {
+                        an[0] = hhw_frag(cb, (pr * 2 * 4 + kb + 1) * 2, lane); an[1] = hhw_frag(cb, (pr * 2 * 4 + kb + 1) * 2 + 1, lane);
+                        an[2] = hhw_frag(cb, ((pr * 2 + 1) * 4 + kb + 1) * 2, lane); an[3] = hhw_frag(cb, ((pr * 2 + 1) * 4 + kb + 1) * 2 + 1, lane);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    HHX_MFMA(a[0], zh[12 + kb], acc0); HHX_MFMA(a[2], zh[12 + kb], acc1);
+                    HHX_MFMA(a[1], zh[12 + kb], acc0); HHX_MFMA(a[3], zh[12 + kb], acc1);
+                    HHX_MFMA(a[0], zl[12 + kb], acc0); HHX_MFMA(a[2], zl[12 + kb], acc1);
+                    if (pr * 4 + kb < npw) hhw_issue_some(gsrc, gdst, pr * 4 + kb, 1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                fold(j0, acc0);
+                fold(j0 + 1, acc1);
+            }
+            if (c == 1) { /* tile 6 on its own */
+                hh_f32x4 acc = hhx_bias_acc(bl + 1024 + 16 * 6, g);
+                hh_h8 w[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) w[u] = hhw_frag(cb, 2 * 4 * 2 + u, lane);
+#pragma unroll
+                for (int kb = 0; kb < 4; kb++) {
+                    HHX_MFMA(w[2 * kb], zh[12 + kb], acc);
+                    HHX_MFMA(w[2 * kb + 1], zh[12 + kb], acc);
+                    HHX_MFMA(w[2 * kb], zl[12 + kb], acc);
+                    hhw_issue_some(gsrc, gdst, 4 + kb, 1);
+                }
+                fold(6, acc);
             }
         }
         ssum += __shfl_xor(ssum, 16);
         ssum += __shfl_xor(ssum, 32); /* the four k groups of a row: (s0 + s1) + (s2 + s3) on every lane */
-        /* F.normalize divides; `y * (1.0f / den)` is NOT a substitute here: hipcc folds 1 / max(sqrt(s), eps) into an approximate reciprocal square
-         * root and 0.2 % of real observation rows then leave the fp32 forward by 2e-5 (found by the world-observation test of tests/test_policy_nets.py) */
-        const float den = fmaxf(sqrtf(ssum), 1e-12f);
+        const float rden = hhx_recip_norm(ssum);
 #pragma unroll
         for (int j = 0; j < 7; j++) {
             const int f = (25 + j) >> 1, e0 = 4 * ((25 + j) & 1);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float v = y[j][r] / den; /* columns >= 500 were zeroed above */
-                const _Float16 h = (_Float16)v;
-                zh[f][e0 + r] = h;
-                zl[f][e0 + r] = (_Float16)(v - (float)h);
-            }
+            hhx_put4(zh[f], zl[f], e0 >> 1, hh_f2{y[j][0] * rden, y[j][1] * rden}, hh_f2{y[j][2] * rden, y[j][3] * rden}); /* columns >= 500 were zeroed above */
         }
     }
 
+    HHX_T(pf, 4);
     /* ---- L2 (shared layer) + the output layer from its registers ---- */
     hh_f32x4 lacc[2];
-    hhx_l2_l3<2>(zh, zl, buf, 0, sp, st + (size_t)(HHX_L1_PIECES + HHX_ATT_PIECES + HHX_L2_PIECES) * HHW_PIECE + lane * 16, bl, wave, lane, g, lacc);
+    hhx_l2_l3<2>(zh, zl, buf, 0, sp, st + (size_t)(HHX_L1_PIECES + HHX_ATT_PIECES + HHX_L2_PIECES) * HHW_PIECE, ldsb + HHX_OFF_L3, bl, wave, lane, g, lacc, pf);
 
     /* ---- logits: lane (row, g) holds output columns 16 t + 4 g + (0..3); they meet in LDS for the decode ---- */
     __syncthreads(); /* every wave is done with the chunk buffers */
@@ -328,6 +434,8 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
             if (sa->logp) sa->logp[r] = lp;
         }
     }
+    HHX_T(pf, 9);
+    HHX_TFLUSH(pf);
 }
 
 /* ---- the value branch as a 64-row tile (hh_policy_sample; see hh_policy_kernel_ppo.h for the reference lines): input row = own observation |
@@ -347,7 +455,8 @@ struct HhpCritBankX {
     HhpCritX c[HH_POLICY_MAX_NETS];
 };
 #define HHXC_OFF_ROWS (HHX_OFF_BIAS + (512 + 512 + 160 + 32) * 4)
-#define HHXC_LDS_BYTES (HHXC_OFF_ROWS + 64 * 4)
+#define HHXC_OFF_L3 (HHXC_OFF_ROWS + 64 * 4)
+#define HHXC_LDS_BYTES (HHXC_OFF_L3 + 8 * HHW_PIECE) /* the value head needs four pieces; both tile kinds of hh_k_policy_w16_ppo share one launch size */
 
 template <bool ATT> /* fight nets (attention block, 13 chunks ahead of the shared layer) | escape nets (8): compile-time, so that the buffer parity is too */
 __device__ __forceinline__ void hhx_critic_tile(const HhpCritX &Cw, const float *__restrict__ obs, int obs_stride, const int *__restrict__ list, int tile, int cnt,
@@ -459,23 +568,19 @@ __device__ __forceinline__ void hhx_critic_tile(const HhpCritX &Cw, const float 
         }
         ssum += __shfl_xor(ssum, 16);
         ssum += __shfl_xor(ssum, 32);
-        const float den = fmaxf(sqrtf(ssum), 1e-12f); /* a true division, as above */
+        const float rden = hhx_recip_norm(ssum);
 #pragma unroll
         for (int j = 0; j < 10; j++) {
             const int f = j >> 1, e0 = 4 * (j & 1);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float v = y[j][r] / den;
-                const _Float16 h = (_Float16)v;
-                zh[f][e0 + r] = h;
-                zl[f][e0 + r] = (_Float16)(v - (float)h);
-            }
+            hhx_put4(zh[f], zl[f], e0 >> 1, hh_f2{y[j][0] * rden, y[j][1] * rden}, hh_f2{y[j][2] * rden, y[j][3] * rden});
         }
     }
 
     /* ---- the shared layer and val_out ---- */
     hh_f32x4 lacc[1];
-    hhx_l2_l3<1>(zh, zl, buf, ck & 1, sp, st + (size_t)(HHXC_L1_PIECES + HHXC_ATT_PIECES + HHX_L2_PIECES) * HHW_PIECE + lane * 16, bl, wave, lane, g, lacc);
+    HhxProf pfc;
+    HHX_T0(pfc);
+    hhx_l2_l3<1>(zh, zl, buf, ck & 1, sp, st + (size_t)(HHXC_L1_PIECES + HHXC_ATT_PIECES + HHX_L2_PIECES) * HHW_PIECE, ldsb + HHXC_OFF_L3, bl, wave, lane, g, lacc, pfc);
     if (g == 0 && row >= 0) sa.vf[row] = lacc[0][0] + bl[1184]; /* output column 0 of the head's tile */
 }
 

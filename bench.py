@@ -501,7 +501,7 @@ def main_policy_rollout(args, R=None):
     issued = useful if fp32_form else 3.0 * useful   # split-fp16: hi*hi + hi*lo + lo*hi = three MFMA passes per product
     peak = MFMA_F32_PEAK_TFLOPS if fp32_form else MFMA_F16_PEAK_TFLOPS
     line["roofline"]["dominant"] = {
-        "kernel": pname + (" (fp32 MFMA)" if fp32_form else " (split-fp16: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16)"), "bound": "mfma", "avg_launch_ms": pol_ms,
+        "kernel": pname + (" (fp32 MFMA)" if fp32_form else " (split-fp16: hi*hi + hi*lo + lo*hi on " + ("v_mfma_f32_16x16x32_f16)" if "w16" in pname else "v_mfma_f32_32x32x16_f16)")), "bound": "mfma", "avg_launch_ms": pol_ms,
         "achieved": useful / (pol_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": useful / (pol_ms * 1e-3) / 1e12 / peak,
         "frac_note": "USEFUL flops (one fp32-equivalent multiply-add per weight and row) over the dense fp16 MFMA peak; the three emulation passes "
                      "that buy fp32 accuracy are matrix-pipe work, not useful work: `issued_frac` counts them",

@@ -369,7 +369,7 @@ struct hh_policy {
     unsigned char *wblob[HH_POLICY_MAX_NETS];
     HhpBankX bankx;           /* the same for hh_k_policy_w16 (16 rows per wave: other fragment shape) */
     unsigned char *xblob[HH_POLICY_MAX_NETS];
-    int wform;                /* HH_POLICY_W: 2 = always hh_k_policy_w16, 1 = always hh_k_policy_w, 0 = the tile forms only, unset (-1) = by row count (hhp_rows_suit_w) */
+    int wform;                /* HH_POLICY_W: 3 / 2 = always hh_k_policy_w16<8> / <4>, 1 = always hh_k_policy_w, 0 = the tile forms only, unset (-1) = by row count (hhp_choose_form) */
     HhpCritBank cbank;        /* hh_policy_set_critic: the value branches of the trainable policies (hh_policy_sample) */
     char *cblob[HH_POLICY_MAX_NETS]; /* one allocation per loaded value branch */
     HhpCritBankX cbankx;      /* the same as fragment streams for hh_k_policy_w16_ppo */
@@ -430,7 +430,8 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_h<2>), hipFuncAttributeMaxDynamicSharedMemorySize, HHPH_LDS_BYTES(2));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_ppo), hipFuncAttributeMaxDynamicSharedMemorySize, HHPP_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_w<4>), hipFuncAttributeMaxDynamicSharedMemorySize, HHW_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_w16), hipFuncAttributeMaxDynamicSharedMemorySize, HHX_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_w16<4>), hipFuncAttributeMaxDynamicSharedMemorySize, HHX_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_w16<8>), hipFuncAttributeMaxDynamicSharedMemorySize, HHX_LDS_BYTES_NB(4));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_w16_ppo), hipFuncAttributeMaxDynamicSharedMemorySize, HHXC_LDS_BYTES);
     if (e != hipSuccess) {
         g_err = std::string("hh_policy_create: ") + hipGetErrorString(e);
@@ -634,24 +635,44 @@ static inline bool hhp_rows_suit_wide_tiles(int n_rows, int n_cu) {
  * A weights-through-LDS tile takes ~31 us however few CUs have one; the tile forms are faster while the rows fit one round of 32-row tiles
  * (two per CU) with room to spare.  So: from 10 k rows that carry a network upwards hh_k_policy_w16, below the tile forms. */
 static inline bool hhp_rows_suit_w(int n_rows, int n_cu) { return (long long)n_rows > (long long)n_cu * 40; }
+/* ... and its eight-wave instance (128-row tiles, one workgroup per CU, the weight stream shared by twice the rows, three chunks ahead) when those tiles come
+ * in whole rounds of one per CU: 59.4 against 61.7 us at 32768 rows, 111.3 against 112.5 at 65536, but 48 against 37 at 16384 (half the CUs idle) */
+static inline bool hhp_rows_suit_w8(int n_rows, int n_cu) {
+    const int tiles = (n_rows + 127) / 128, rem = tiles % n_cu;
+    return tiles >= n_cu && (rem == 0 || rem * 4 > n_cu * 3);
+}
+enum { HHP_FORM_H32, HHP_FORM_H64, HHP_FORM_FP32, HHP_FORM_W, HHP_FORM_W16, HHP_FORM_W16X8 };
+/* the form of a forward over heur_rows rows that carry a network: HH_POLICY_W (3 / 2 / 1 = always hh_k_policy_w16<8> / <4> / hh_k_policy_w, 0 = the tile forms only,
+ * unset = by row count), then HH_POLICY_FP32, then the tile width (hh_policy_set_tile_rows / HH_POLICY_TILE, 0 = by row count) */
+static int hhp_choose_form(const hh_policy *p, int heur_rows) {
+    if (p->wform == 3) return HHP_FORM_W16X8;
+    if (p->wform == 2) return HHP_FORM_W16;
+    if (p->wform == 1) return HHP_FORM_W;
+    if (p->wform < 0 && !p->fp32 && p->tile_rows == 0 && hhp_rows_suit_w(heur_rows, p->n_cu)) return hhp_rows_suit_w8(heur_rows, p->n_cu) ? HHP_FORM_W16X8 : HHP_FORM_W16;
+    if (p->fp32) return HHP_FORM_FP32;
+    if (p->tile_rows == 64 || (p->tile_rows == 0 && hhp_rows_suit_wide_tiles(heur_rows, p->n_cu))) return HHP_FORM_H64;
+    return HHP_FORM_H32;
+}
 /* the forward kernel over the current row lists; consume: the last workgroup to read the counters clears them */
 static int hhp_launch_forward(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, int8_t *actions, float *logits, int consume, hipStream_t st,
                               int32_t live_rows = -1) {
     const int grid = (n_rows + HHP_ROWS - 1) / HHP_ROWS + p->n_nets; /* upper bound of the tiles over all networks */
     /* the form is chosen by the rows that CARRY a network: a bound HighLevelEnv world lists one side's units per call, half of its
      * [N, 6] row buffer at most (a full-buffer count picked 64-row tiles for 1.5 rounds of work: 78 against 67 us at 8192 arenas) */
-    const int heur_rows = live_rows >= 0 ? live_rows : n_rows;
-    const bool auto_w = p->wform < 0 && !p->fp32 && p->tile_rows == 0 && hhp_rows_suit_w(heur_rows, p->n_cu);
-    if (p->wform == 2 || auto_w) { /* weights through LDS, activations in registers, 16 rows per wave: 64-row tiles, two workgroups per CU */
-        hipLaunchKernelGGL(hh_k_policy_w16, dim3((n_rows + 63) / 64 + p->n_nets), dim3(256), HHX_LDS_BYTES, st, p->bank, p->bankx, p->n_nets, obs, obs_stride, p->counts,
+    const int form = hhp_choose_form(p, live_rows >= 0 ? live_rows : n_rows);
+    if (form == HHP_FORM_W16) { /* weights through LDS, activations in registers, 16 rows per wave: 64-row tiles, two workgroups per CU */
+        hipLaunchKernelGGL(hh_k_policy_w16<4>, dim3((n_rows + 63) / 64 + p->n_nets), dim3(256), HHX_LDS_BYTES, st, p->bank, p->bankx, p->n_nets, obs, obs_stride, p->counts,
                            p->lists, p->max_rows, actions, logits, consume);
-    } else if (p->wform == 1) { /* weights through LDS, activations in registers, 32 rows per wave: 128-row tiles, one workgroup per CU (A/B form) */
+    } else if (form == HHP_FORM_W16X8) { /* the same with eight waves per workgroup: 128-row tiles, half the weight stream per row */
+        hipLaunchKernelGGL(hh_k_policy_w16<8>, dim3((n_rows + 127) / 128 + p->n_nets), dim3(512), HHX_LDS_BYTES_NB(4), st, p->bank, p->bankx, p->n_nets, obs, obs_stride, p->counts,
+                           p->lists, p->max_rows, actions, logits, consume);
+    } else if (form == HHP_FORM_W) { /* weights through LDS, activations in registers, 32 rows per wave: 128-row tiles, one workgroup per CU (A/B form) */
         hipLaunchKernelGGL(hh_k_policy_w<4>, dim3((n_rows + 127) / 128 + p->n_nets), dim3(256), HHW_LDS_BYTES, st, p->bank, p->bankw, p->n_nets, obs, obs_stride,
                            p->counts, p->lists, p->max_rows, actions, logits, consume);
-    } else if (p->fp32) {
+    } else if (form == HHP_FORM_FP32) {
         hipLaunchKernelGGL(hh_k_policy, dim3(grid), dim3(256), HHP_LDS_BYTES, st, p->bank, p->n_nets, obs, obs_stride, p->counts, p->lists, p->max_rows,
                            actions, logits, consume);
-    } else if (p->tile_rows == 64 || (p->tile_rows == 0 && hhp_rows_suit_wide_tiles(heur_rows, p->n_cu))) { /* persistent: one workgroup per CU walks the tiles grid-stride */
+    } else if (form == HHP_FORM_H64) { /* persistent: one workgroup per CU walks the tiles grid-stride */
         const int tiles = (n_rows + 63) / 64 + p->n_nets;
         hipLaunchKernelGGL(hh_k_policy_h<2>, dim3(p->persist && tiles > p->n_cu ? p->n_cu : tiles), dim3(512), HHPH_LDS_BYTES(2), st, p->bank, p->bankh, p->n_nets,
                            obs, obs_stride, p->counts, p->lists, p->max_rows, actions, logits, consume);
@@ -665,16 +686,18 @@ static int hhp_launch_forward(hh_policy *p, const float *obs, int32_t n_rows, in
 
 /* which kernel instance a forward over n_rows rows (live_rows of them carrying a network; < 0: all) launches, as a profiler prints it */
 static const char *hhp_form_name(const hh_policy *p, int n_rows, int live_rows) {
-    const int heur_rows = live_rows >= 0 ? live_rows : n_rows;
-    if (p->wform == 2 || (p->wform < 0 && !p->fp32 && p->tile_rows == 0 && hhp_rows_suit_w(heur_rows, p->n_cu))) return "hh_k_policy_w16";
-    if (p->wform == 1) return "hh_k_policy_w<4>";
-    if (p->fp32) return "hh_k_policy";
-    if (p->tile_rows == 64 || (p->tile_rows == 0 && hhp_rows_suit_wide_tiles(heur_rows, p->n_cu))) return "hh_k_policy_h<2>";
-    return "hh_k_policy_h<1>";
+    switch (hhp_choose_form(p, live_rows >= 0 ? live_rows : n_rows)) {
+    case HHP_FORM_W16X8: return "hh_k_policy_w16<8>";
+    case HHP_FORM_W16: return "hh_k_policy_w16<4>";
+    case HHP_FORM_W: return "hh_k_policy_w<4>";
+    case HHP_FORM_FP32: return "hh_k_policy";
+    case HHP_FORM_H64: return "hh_k_policy_h<2>";
+    default: return "hh_k_policy_h<1>";
+    }
 }
 /* hh_policy_sample: the weights-through-LDS form for large calls (HH_POLICY_W = 2 always, 0 / 1 never), the tile form otherwise */
 static bool hhp_sampler_is_w16(const hh_policy *p, int n_rows) {
-    return p->wform == 2 || (p->wform < 0 && !p->fp32 && p->tile_rows == 0 && hhp_rows_suit_w(n_rows, p->n_cu));
+    return p->wform == 2 || p->wform == 3 || (p->wform < 0 && !p->fp32 && p->tile_rows == 0 && hhp_rows_suit_w(n_rows, p->n_cu));
 }
 extern "C" int hh_policy_kernel_name(hh_policy *p, int32_t n_rows, int32_t sampler, char *buf, int32_t len) {
     if (!p || !buf || len <= 0 || n_rows <= 0) { g_err = "bad argument"; return HH_E_ARG; }
@@ -913,7 +936,7 @@ extern "C" int hh_policy_occupancy(int32_t which, int32_t *blocks_per_cu) {
     if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(hh_k_policy_h<1>), 256, HHPH_LDS_BYTES(1));
     else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(hh_k_policy_h<2>), 512, HHPH_LDS_BYTES(2));
     else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(hh_k_policy_w<4>), 256, HHW_LDS_BYTES);
-    else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(hh_k_policy_w16), 256, HHX_LDS_BYTES);
+    else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(hh_k_policy_w16<4>), 256, HHX_LDS_BYTES);
     else if (which == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(hh_k_policy_ppo), 256, HHPP_LDS_BYTES);
     if (e != hipSuccess) { g_err = std::string("hh_policy_occupancy: ") + hipGetErrorString(e); return HH_E_HIP; }
     *blocks_per_cu = n;

@@ -13,7 +13,7 @@
  *   - the same linear stream of 1 KB fragments per network as hh_k_policy_w (other packing), copied by LDS-DMA in chunks of <= 32 pieces
  *     into a double buffer one chunk ahead; the output layer's 64 pieces are read straight from global memory (L2 hits; they would make the
  *     last chunk of a column group 40 pieces).
- * Chunks (pieces): L1 tiles 0..15 (32) | L1 tiles 16..31 (32) | ATT tiles 0..3 (32) | ATT tiles 4..6 (24) | 8 column groups x 4 K quarters
+ * Chunks (pieces): L1 tiles 0..15 (32) | L1 tiles 16..31 (32) | ATT tiles 0..3 (32) | ATT tiles 4..6 (24 + 8 of padding) | 8 column groups x 4 K quarters
  * (32 each: 4 k-blocks x 4 tiles x (hi, lo)) | output layer 64 (8 per column group, side buffer).
  */
 #ifndef HH_POLICY_KERNEL_W16_H
@@ -24,14 +24,19 @@ typedef float hh_f32x4 __attribute__((ext_vector_type(4)));
 #define HHX_CHUNK 32 /* pieces per LDS buffer */
 #define HHX_BUF_BYTES (HHX_CHUNK * HHW_PIECE)
 #define HHX_L1_PIECES 64
-#define HHX_ATT_PIECES 56
+#define HHX_ATT_PIECES 64 /* 7 tiles x 4 k-blocks x (hi, lo) = 56, padded to two whole chunks */
 #define HHX_L2_PIECES 1024
 #define HHX_L3_PIECES 64
 #define HHX_STREAM_PIECES (HHX_L1_PIECES + HHX_ATT_PIECES + HHX_L2_PIECES + HHX_L3_PIECES)
-#define HHX_OFF_BIAS (2 * HHX_BUF_BYTES)
-#define HHX_OFF_ROWS (HHX_OFF_BIAS + (512 + 512 + 128 + 32) * 4)
-#define HHX_OFF_L3 (HHX_OFF_ROWS + 64 * 4) /* the head's eight pieces of one column group */
-#define HHX_LDS_BYTES (HHX_OFF_L3 + 8 * HHW_PIECE)
+/* LDS: a ring of NB chunk buffers (2: one chunk ahead, the 64-row form, two workgroups per CU | 4: three ahead, the 128-row form) | biases b1 512, bs 512,
+ * bov 128, ba 32 floats | row ids (<= 128) | the head's eight pieces of one column group */
+#define HHX_OFF_BIAS_NB(NB) ((NB) * HHX_BUF_BYTES)
+#define HHX_OFF_ROWS_NB(NB) (HHX_OFF_BIAS_NB(NB) + (512 + 512 + 128 + 32) * 4)
+#define HHX_OFF_L3_NB(NB) (HHX_OFF_ROWS_NB(NB) + 128 * 4)
+#define HHX_LDS_BYTES_NB(NB) (HHX_OFF_L3_NB(NB) + 8 * HHW_PIECE)
+#define HHX_OFF_BIAS HHX_OFF_BIAS_NB(2)
+#define HHX_OFF_ROWS HHX_OFF_ROWS_NB(2)
+#define HHX_LDS_BYTES HHX_LDS_BYTES_NB(2)
 
 struct HhpBankX {
     const unsigned char *stream[HH_POLICY_MAX_NETS];
@@ -96,6 +101,15 @@ __device__ __forceinline__ void hhx_split8(const hh_f2 (&p)[4], hh_h8 &fh, hh_h8
     fh = H.h;
     fl = L.h;
 }
+/* The hand-over of a chunk: this wave's LDS-DMA pieces of it have landed — at most NEWER requests issued after them may still be in flight (they complete
+ * in order) —, its LDS reads of the chunk before are back, then everyone's.  __syncthreads() is this with NEWER = 0; a ring deeper than two buffers
+ * needs the count (hipcc does not order LDS reads against LDS-DMA on its own: the explicit wait IS the ordering). */
+template <int NEWER>
+__device__ __forceinline__ void hhx_chunk_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NEWER) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 /* 1 / max(sqrt(s), 1e-12), correctly rounded from the correctly rounded norm: F.normalize divides every element by the norm, and a product with this
  * reciprocal is within 1.5 ulp of that quotient.  The empty asm hides the norm from hipcc, which otherwise folds 1 / max(sqrt(s), eps) into ONE approximate
  * v_rsq_f32: 0.2 % of real observation rows then leave the fp32 forward by 2e-5 (found by the world-observation test of tests/test_policy_nets.py). */
@@ -120,16 +134,22 @@ __device__ __forceinline__ void hhx_pair_to_frag(const hh_f32x4 &a0, const hh_f3
     hhx_split8(p, fh, fl);
 }
 
-/* The shared layer and the head contracted from its registers: 8 groups of four column tiles x 4 K quarters (chunks of 32 pieces, chunk
- * (p, q) in buf[(q + par) & 1], the first one already requested; sp = the next chunk to request), the head's NOUT 16-column output tiles
- * accumulated in lacc.  The head's pieces of group p (2 k-blocks x NOUT x (hi, lo), contiguous at l3 + p x 4 NOUT pieces) travel beside chunk
- * (p, 2) into a side buffer l3buf of their own: read from global memory where they are used, their L2 latency stood in the open eight times a tile
- * (tools/policy_w16_phase_profile.py: 8 k of a tile's 69 k cycles).  bl = the biases in LDS. */
-template <int NOUT>
-__device__ __forceinline__ void hhx_l2_l3(const hh_h8 (&zh)[16], const hh_h8 (&zl)[16], unsigned char *const (&buf)[2], int par, const unsigned char *sp,
+/* The shared layer and the head contracted from its registers: 8 groups of four column tiles x 4 K quarters = 32 chunks of 32 pieces, chunk c in ring
+ * buffer (j0 + c) % NB (j0 = what the caller streamed before), requested D = NB - 1 chunks ahead: on entry chunks 0 .. D - 1 are on their way, chunk c + D is
+ * requested behind the MFMAs of chunk c's first four steps.  l2s = chunk 0 in the stream.  The head's NOUT 16-column output tiles are accumulated in lacc;
+ * its pieces of group p (2 k-blocks x NOUT x (hi, lo), contiguous at l3 + p x 4 NOUT pieces) travel beside the group's first chunk into a side buffer
+ * l3buf of their own: read from global memory where they are used, their L2 latency stood in the open eight times a tile (tools/policy_w16_phase_profile.py:
+ * 8 k of a tile's 69 k cycles).  bl = the biases in LDS. */
+template <int NOUT, int WV, int NB>
+__device__ __forceinline__ void hhx_l2_l3(const hh_h8 (&zh)[16], const hh_h8 (&zl)[16], unsigned char *ring, int j0, const unsigned char *l2s,
                                           const unsigned char *l3, unsigned char *l3buf, const float *__restrict__ bl, int wave, int lane, int g,
                                           hh_f32x4 (&lacc)[NOUT], HhxProf &pf) {
     static_assert(NOUT == 1 || NOUT == 2, "one piece (value head) or two (policy head) per wave and group");
+    static_assert(NB == 2 || NB == 4, "one chunk ahead or three");
+    constexpr int D = NB - 1;
+    constexpr int NPW = HHX_CHUNK / WV;                              /* a wave's pieces of a chunk: 8 (four waves) | 4 (eight) */
+    constexpr int HPW = 4 * NOUT >= WV ? 4 * NOUT / WV : 1;         /* and of a group's 4 NOUT head pieces */
+    const unsigned char *gsrc = l2s + (size_t)D * HHX_BUF_BYTES + (size_t)wave * NPW * HHW_PIECE + lane * 16; /* this wave's pieces of the next chunk to request */
     /* ---- L2 (shared layer): 8 groups of four column tiles x 4 K quarters; the output layer from the group's registers ---- */
 #pragma unroll
     for (int t = 0; t < NOUT; t++) lacc[t] = hh_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -140,16 +160,18 @@ __device__ __forceinline__ void hhx_l2_l3(const hh_h8 (&zh)[16], const hh_h8 (&z
         for (int t = 0; t < 4; t++) acc[t] = hhx_bias_acc(bl + 512 + 64 * p + 16 * t, g);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-#ifndef HHX_ABL_NO_BARRIER /* tuning builds: the shared layer's chunks are not waited for (wrong results): what do the 32 barriers + vmcnt(0) cost? */
-            __syncthreads(); /* chunk (p, q) landed in buf[(q + par) & 1]; the other buffer is free */
+#ifndef HHX_ABL_NO_BARRIER /* tuning builds: the shared layer's chunks are not waited for (wrong results): what do the 32 barriers + waits cost? */
+            /* chunk (p, q) landed in its buffer; the buffer of the chunk before is free.  Newer requests in flight: the chunks up to D - 1 ahead that exist */
+            if (D == 1) hhx_chunk_barrier<0>();
+            else if (p < 7 || q < 2) hhx_chunk_barrier<2 * NPW>();
+            else if (q == 2) hhx_chunk_barrier<NPW>();
+            else hhx_chunk_barrier<0>();
 #endif
             HHX_T(pf, 5);
-            const bool more = p < 7 || q < 3;
-            const unsigned char *gsrc = sp + (size_t)wave * 8 * HHW_PIECE + lane * 16; /* this wave's eight pieces of the next chunk: two per step, behind the */
-            unsigned char *gdst = buf[(q + 1 + par) & 1] + wave * 8 * HHW_PIECE;              /* MFMAs of the first four steps (an LDS-DMA request costs ~60 cycles to issue) */
-            sp += (size_t)HHX_CHUNK * HHW_PIECE;
+            const bool more = p < 7 || q + D < 4; /* chunk (p, q) + D exists */
+            unsigned char *gdst = ring + ((j0 + q + D) & (NB - 1)) * HHX_BUF_BYTES + wave * NPW * HHW_PIECE; /* its requests: a quarter per step, behind the MFMAs of the */
+            const unsigned char *cb = ring + ((j0 + q) & (NB - 1)) * HHX_BUF_BYTES;                           /* first four steps (an LDS-DMA request costs 60 - 100 cycles to issue) */
             { /* eight steps of (k-block kk, tile pair tp) = 4 fragments, 6 MFMAs; the fragments of step s + 1 are requested before the MFMAs of step s */
-                const unsigned char *cb = buf[(q + par) & 1];
                 hh_h8 an[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) an[u] = hhw_frag(cb, u, lane);
@@ -175,15 +197,17 @@ __device__ __forceinline__ void hhx_l2_l3(const hh_h8 (&zh)[16], const hh_h8 (&z
                     HHX_MFMA(a[0], zl[4 * q + kk], acc[2 * tp]); HHX_MFMA(a[2], zl[4 * q + kk], acc[2 * tp + 1]);
 #endif
 #ifndef HHX_ABL_NO_GLDS /* tuning builds: the shared layer's chunks are never copied (wrong results): what does the LDS-DMA stream cost? */
-                    if (s_ < 4 && more) hhw_issue_some(gsrc, gdst, 2 * s_, 2);
-                    if (q == 1 && s_ == 4) { /* every wave is past barrier (p, 1), so past its reads of group p - 1's head pieces; these land before barrier (p, 2) */
-                        const unsigned char *hs = l3 + (size_t)(p * 4 * NOUT + wave * NOUT) * HHW_PIECE + lane * 16;
-                        hhw_issue_some(hs, l3buf + wave * NOUT * HHW_PIECE, 0, NOUT);
+                    if (s_ < 4 && more) hhw_issue_some(gsrc, gdst, NPW / 4 * s_, NPW / 4);
+                    if (q == 0 && s_ == 4 && wave * HPW < 4 * NOUT) { /* every wave is past barrier (p, 0), so past its reads of group p - 1's head pieces; these are older than
+                                                                       * anything barrier (p, 3) lets stay in flight */
+                        const unsigned char *hs = l3 + (size_t)(p * 4 * NOUT + wave * HPW) * HHW_PIECE + lane * 16;
+                        hhw_issue_some(hs, l3buf + wave * HPW * HHW_PIECE, 0, HPW);
                     }
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            gsrc += (size_t)HHX_BUF_BYTES;
             HHX_T(pf, 6);
         }
         /* tanh of the four tiles = two B fragments of the output layer (S columns 64 p .. 64 p + 63 = k-blocks 2 p, 2 p + 1) */
@@ -206,20 +230,27 @@ __device__ __forceinline__ void hhx_l2_l3(const hh_h8 (&zh)[16], const hh_h8 (&z
 
 /* one 64-row tile of one network: four waves of 16 rows.  SAMPLE: the PPO sampler's tail (hh_policy_sample: a Categorical draw per action
  * component, its log-probability) instead of the greedy decode */
-template <bool SAMPLE>
+template <bool SAMPLE, int WV>
 __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned char *__restrict__ st, const float *__restrict__ obs, int obs_stride,
                                                  const int *__restrict__ list, int tile, int cnt, int8_t *__restrict__ actions, float *__restrict__ logits_out,
                                                  unsigned char *ldsb, const HhpSampleArgs *sa = nullptr) {
-    constexpr int NTH = 256, R = 64;
-    unsigned char *const buf[2] = {ldsb, ldsb + HHX_BUF_BYTES};
-    float *bl = reinterpret_cast<float *>(ldsb + HHX_OFF_BIAS);
-    int *rows = reinterpret_cast<int *>(ldsb + HHX_OFF_ROWS);
+    constexpr int NTH = 64 * WV, R = 16 * WV, NPW = HHX_CHUNK / WV;
+    constexpr int NB = WV == 8 ? 4 : 2, D = NB - 1; /* ring buffers; chunks requested ahead */
+    float *bl = reinterpret_cast<float *>(ldsb + HHX_OFF_BIAS_NB(NB));
+    int *rows = reinterpret_cast<int *>(ldsb + HHX_OFF_ROWS_NB(NB));
+    /* the stream in PROCESSING order: chunks 0, 1 = first layer, then (fight nets) 2, 3 = attention block, then the shared layer's 32; chunk j sits in
+     * ring buffer j % NB and is requested while chunk j - D is worked on (the first D up front) */
+    const int att_skip = N.has_att ? 0 : HHX_ATT_PIECES / HHX_CHUNK;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ci = lane & 15, g = lane >> 4;
 
+    auto request = [&](int j, int first, int n) { /* pieces first .. first + n - 1 of this wave's NPW of chunk j */
+        hhw_issue_some(st + (size_t)(j < 2 ? j : j + att_skip) * HHX_BUF_BYTES + (size_t)wave * NPW * HHW_PIECE + lane * 16,
+                       ldsb + (j % NB) * HHX_BUF_BYTES + wave * NPW * HHW_PIECE, first, n);
+    };
     HhxProf pf;
     HHX_T0(pf);
-    hhx_issue<8>(st, buf[0], wave, lane); /* chunk 0: L1 tiles 0..15 */
+    request(0, 0, NPW); /* chunk 0: L1 tiles 0..15 */
     for (int e = tid; e < 512; e += NTH) { bl[e] = N.b1[e]; bl[512 + e] = N.bs[e]; }
     if (tid < 128) bl[1024 + tid] = N.has_att ? N.bov[tid] : 0.0f;
     if (tid < 32) bl[1152 + tid] = N.ba[tid];
@@ -244,7 +275,6 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
             xl[e] = (_Float16)(xv[e] - (float)h);
         }
     }
-    const unsigned char *sp = st + (size_t)HHX_CHUNK * HHW_PIECE; /* the next chunk to request */
     hh_h8 zh[16], zl[16]; /* the hidden row: fragment kb = columns 32 kb .. 32 kb + 31 in hhw16_korder */
 
     /* ---- L1: 32 column tiles of 16, K = one block of 32 observation columns; two chunks of 16 tiles.  Steps of one tile pair = one fragment of
@@ -252,13 +282,10 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
      *      phase), the next chunk's eight LDS-DMA requests of this wave go out one per step ---- */
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-        __syncthreads(); /* chunk c landed; the other buffer is free */
+        if (c == 0) hhx_chunk_barrier<0>(); /* chunk c landed (nothing else is on its way yet: hipcc waits for the observation with vmcnt(0) anyway) */
+        else hhx_chunk_barrier<(D - 1) * NPW>();
         HHX_T(pf, c == 0 ? 0 : 2);
-        if (c == 1 && !N.has_att) sp += (size_t)HHX_ATT_PIECES * HHW_PIECE; /* escape nets: straight to shared layer (0, 0) */
-        const unsigned char *gsrc = sp + (size_t)wave * 8 * HHW_PIECE + lane * 16; /* chunk 1 | ATT tiles 0..3 | shared layer (0, 0) */
-        unsigned char *gdst = buf[c ^ 1] + wave * 8 * HHW_PIECE;
-        sp += (size_t)HHX_CHUNK * HHW_PIECE;
-        const unsigned char *cb = buf[c];
+        const unsigned char *cb = ldsb + c * HHX_BUF_BYTES;
         hh_h8 an[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) an[u] = hhw_frag(cb, u, lane);
@@ -277,7 +304,9 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
             HHX_MFMA(a[0], xh, a0); HHX_MFMA(a[2], xh, a1);
             HHX_MFMA(a[1], xh, a0); HHX_MFMA(a[3], xh, a1);
             HHX_MFMA(a[0], xl, a0); HHX_MFMA(a[2], xl, a1);
-            hhw_issue_some(gsrc, gdst, tp, 1);
+            if (D == 1 || c == 1) { if (tp % (8 / NPW) == 0) request(c + D, tp / (8 / NPW), 1); }
+            else if (tp < 4) request(1 + tp / 2, (tp & 1) * (NPW / 2), NPW / 2); /* the deep ring fills behind chunk 0: chunks 1, 2 whole (in order: they complete in order) ... */
+            else request(D, (tp - 4) * (NPW / 4), NPW / 4);                         /* ... then chunk 3 */
             hhx_pair_to_frag(a0, a1, zh[c * 8 + tp], zl[c * 8 + tp]);
         }
         HHX_T(pf, c == 0 ? 1 : 3);
@@ -302,12 +331,8 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
         };
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            __syncthreads();
-            const int npw = c == 0 ? 6 : 8; /* ATT tiles 4..6 (24 pieces) | shared layer (0, 0) */
-            const unsigned char *gsrc = sp + (size_t)wave * npw * HHW_PIECE + lane * 16;
-            unsigned char *gdst = buf[c ^ 1] + wave * npw * HHW_PIECE;
-            sp += (size_t)(c == 0 ? HHX_ATT_PIECES - HHX_CHUNK : HHX_CHUNK) * HHW_PIECE;
-            const unsigned char *cb = buf[c];
+            hhx_chunk_barrier<(D - 1) * NPW>();
+            const unsigned char *cb = ldsb + ((2 + c) % NB) * HHX_BUF_BYTES;
             /* tile pairs (0, 1) (2, 3) | (4, 5); piece of (tile jj of the chunk, k-block kb, plane) = (jj * 4 + kb) * 2 + plane */
 #pragma unroll
             for (int pr = 0; pr < (c == 0 ? 2 : 1); pr++) {
@@ -330,7 +355,7 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
                     HHX_MFMA(a[0], zh[12 + kb], acc0); HHX_MFMA(a[2], zh[12 + kb], acc1);
                     HHX_MFMA(a[1], zh[12 + kb], acc0); HHX_MFMA(a[3], zh[12 + kb], acc1);
                     HHX_MFMA(a[0], zl[12 + kb], acc0); HHX_MFMA(a[2], zl[12 + kb], acc1);
-                    if (pr * 4 + kb < npw) hhw_issue_some(gsrc, gdst, pr * 4 + kb, 1);
+                    if (pr * 4 + kb < NPW) request(2 + c + D, pr * 4 + kb, 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 fold(j0, acc0);
@@ -346,7 +371,7 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
                     HHX_MFMA(w[2 * kb], zh[12 + kb], acc);
                     HHX_MFMA(w[2 * kb + 1], zh[12 + kb], acc);
                     HHX_MFMA(w[2 * kb], zl[12 + kb], acc);
-                    hhw_issue_some(gsrc, gdst, 4 + kb, 1);
+                    if (4 + kb < NPW) request(2 + c + D, 4 + kb, 1);
                 }
                 fold(6, acc);
             }
@@ -364,11 +389,12 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
     HHX_T(pf, 4);
     /* ---- L2 (shared layer) + the output layer from its registers ---- */
     hh_f32x4 lacc[2];
-    hhx_l2_l3<2>(zh, zl, buf, 0, sp, st + (size_t)(HHX_L1_PIECES + HHX_ATT_PIECES + HHX_L2_PIECES) * HHW_PIECE, ldsb + HHX_OFF_L3, bl, wave, lane, g, lacc, pf);
+    hhx_l2_l3<2, WV, NB>(zh, zl, ldsb, N.has_att ? 4 : 2, st + (size_t)(HHX_L1_PIECES + HHX_ATT_PIECES) * HHW_PIECE,
+                         st + (size_t)(HHX_L1_PIECES + HHX_ATT_PIECES + HHX_L2_PIECES) * HHW_PIECE, ldsb + HHX_OFF_L3_NB(NB), bl, wave, lane, g, lacc, pf);
 
     /* ---- logits: lane (row, g) holds output columns 16 t + 4 g + (0..3); they meet in LDS for the decode ---- */
     __syncthreads(); /* every wave is done with the chunk buffers */
-    float *Lg = reinterpret_cast<float *>(ldsb); /* [64][32] */
+    float *Lg = reinterpret_cast<float *>(ldsb); /* [R][32] */
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const float4 b = *reinterpret_cast<const float4 *>(bl + 1152 + 16 * t + 4 * g);
@@ -580,11 +606,13 @@ __device__ __forceinline__ void hhx_critic_tile(const HhpCritX &Cw, const float 
     hh_f32x4 lacc[1];
     HhxProf pfc;
     HHX_T0(pfc);
-    hhx_l2_l3<1>(zh, zl, buf, ck & 1, sp, st + (size_t)(HHXC_L1_PIECES + HHXC_ATT_PIECES + HHX_L2_PIECES) * HHW_PIECE, ldsb + HHXC_OFF_L3, bl, wave, lane, g, lacc, pfc);
+    hhx_l2_l3<1, 4, 2>(zh, zl, ldsb, ck, st + (size_t)(HHXC_L1_PIECES + HHXC_ATT_PIECES) * HHW_PIECE,
+                       st + (size_t)(HHXC_L1_PIECES + HHXC_ATT_PIECES + HHX_L2_PIECES) * HHW_PIECE, ldsb + HHXC_OFF_L3, bl, wave, lane, g, lacc, pfc);
     if (g == 0 && row >= 0) sa.vf[row] = lacc[0][0] + bl[1184]; /* output column 0 of the head's tile */
 }
 
-__global__ __launch_bounds__(256, 2) void hh_k_policy_w16(HhpBank bank, HhpBankX bankx, int n_nets, const float *__restrict__ obs, int obs_stride, int *counts,
+template <int WV> /* 4: 64-row tiles, two workgroups per CU | 8: 128-row tiles, one workgroup of eight waves per CU whose two waves per SIMD share ONE pass over the weights */
+__global__ __launch_bounds__(64 * WV, 2) void hh_k_policy_w16(HhpBank bank, HhpBankX bankx, int n_nets, const float *__restrict__ obs, int obs_stride, int *counts,
                                                           const int *__restrict__ lists, int max_rows, int8_t *__restrict__ actions, float *__restrict__ logits_out,
                                                           int consume) {
     extern __shared__ __align__(16) unsigned char ldsb[];
@@ -596,8 +624,8 @@ __global__ __launch_bounds__(256, 2) void hh_k_policy_w16(HhpBank bank, HhpBankX
     if ((HHX_STAGGER == 1 && (blockIdx.x & 1)) || (HHX_STAGGER == 2 && blockIdx.x >= gridDim.x / 2))
         for (int i = 0; i < HHX_STAGGER_SLEEPS; i++) __builtin_amdgcn_s_sleep(127);
 #endif
-    if (hhp_locate<64>(cn, (int)blockIdx.x, net, tile, cnt))
-        hhx_forward_tile<false>(bank.net[net], bankx.stream[net], obs, obs_stride, lists + (size_t)net * max_rows, tile, cnt, actions, logits_out, ldsb);
+    if (hhp_locate<16 * WV>(cn, (int)blockIdx.x, net, tile, cnt))
+        hhx_forward_tile<false, WV>(bank.net[net], bankx.stream[net], obs, obs_stride, lists + (size_t)net * max_rows, tile, cnt, actions, logits_out, ldsb);
     hhp_consume_counts(counts, consume);
 }
 
@@ -617,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void hh_k_policy_w16_ppo(HhpBank bank, HhpB
             if (cbank.c[net].has_att) hhx_critic_tile<true>(cbank.c[net], obs, obs_stride, list, tile, cnt, sa, ldsb);
             else hhx_critic_tile<false>(cbank.c[net], obs, obs_stride, list, tile, cnt, sa, ldsb);
         }
-        else hhx_forward_tile<true>(bank.net[net], bankx.stream[net], obs, obs_stride, list, tile, cnt, sa.actions, sa.logits_out, ldsb, &sa);
+        else hhx_forward_tile<true, 4>(bank.net[net], bankx.stream[net], obs, obs_stride, list, tile, cnt, sa.actions, sa.logits_out, ldsb, &sa);
     }
     hhp_consume_counts(counts, consume);
 }
@@ -641,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void hhx_probe_crit(HhpCritBankX cbank, con
 }
 __global__ __launch_bounds__(256, 2) void hhx_probe_actor(HhpBank bank, HhpBankX bankx, const float *obs, int obs_stride, const int *lists, int cnt, HhpSampleArgs sa) {
     extern __shared__ __align__(16) unsigned char ldsb[];
-    hhx_forward_tile<true>(bank.net[0], bankx.stream[0], obs, obs_stride, lists, (int)blockIdx.x, cnt, sa.actions, sa.logits_out, ldsb, &sa);
+    hhx_forward_tile<true, 4>(bank.net[0], bankx.stream[0], obs, obs_stride, lists, (int)blockIdx.x, cnt, sa.actions, sa.logits_out, ldsb, &sa);
 }
 #endif
 

@@ -45,7 +45,8 @@ def _bank(seed, max_rows=1 << 16):
 
 
 FORMS = {"split-fp16": {}, "fp32-mfma": {"HH_POLICY_FP32": "1"}, "split-fp16-64-row-tiles": {"HH_POLICY_TILE": "64"},
-         "weights-through-lds": {"HH_POLICY_W": "1"}, "weights-through-lds-16-rows": {"HH_POLICY_W": "2"}}
+         "weights-through-lds": {"HH_POLICY_W": "1"}, "weights-through-lds-16-rows": {"HH_POLICY_W": "2"},
+         "weights-through-lds-16-rows-8-waves": {"HH_POLICY_W": "3"}}
 
 
 def _form(monkeypatch, form):

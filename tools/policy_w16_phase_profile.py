@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-os.environ["HH_POLICY_W"] = "2"
+os.environ["HH_POLICY_W"] = os.environ.get("W", "2")   # 2: 64-row tiles (two workgroups per CU), 3: 128-row tiles (eight waves)
 from hhmarl_2d_amd import _lib as L, pilots  # noqa: E402
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
@@ -24,7 +24,7 @@ for _ in range(n):
     bank.act(obs, None)
 torch.cuda.synchronize()
 L.lib().hh_policy_prof_read(out, 0)
-tiles = n * R / 64
+tiles = n * R / (128 if os.environ["HH_POLICY_W"] == "3" else 64)
 names = ["prologue: rows, observation, biases, chunk 0 wait", "L1 chunk 0 (16 tiles: MFMA + tanh/split)", "barrier (chunk 1)", "L1 chunk 1", "attention block (2 chunks) + normalisation",
          "shared layer: 32 barriers (chunk waits)", "shared layer: 256 steps (4 reads + 6 MFMAs; LDS-DMA requests)", "shared layer: tanh/split of 16 fragments", "head: 8 x (global fragments + 12 MFMAs)",
          "logits through LDS + decode"]

@@ -150,9 +150,23 @@ __device__ __forceinline__ void hhx_l2_l3(const hh_h8 (&zh)[16], const hh_h8 (&z
     constexpr int NPW = HHX_CHUNK / WV;                              /* a wave's pieces of a chunk: 8 (four waves) | 4 (eight) */
     constexpr int HPW = 4 * NOUT >= WV ? 4 * NOUT / WV : 1;         /* and of a group's 4 NOUT head pieces */
     const unsigned char *gsrc = l2s + (size_t)D * HHX_BUF_BYTES + (size_t)wave * NPW * HHW_PIECE + lane * 16; /* this wave's pieces of the next chunk to request */
-    /* ---- L2 (shared layer): 8 groups of four column tiles x 4 K quarters; the output layer from the group's registers ---- */
+    /* ---- L2 (shared layer): 8 groups of four column tiles x 4 K quarters; the output layer from the group's registers ----
+     * NB = 2: chunk (p, q) is handed over at its top (everyone's pieces landed, the other buffer free), its first fragments are read behind that barrier,
+     *   chunk + 1 is requested in steps 0..3.
+     * NB = 4: the hand-over sits INSIDE the chunk before, after its second step: there every wave makes sure its pieces of chunk + 1 have landed and meets
+     *   the others, which also says that everyone is done with chunk - 1, whose buffer takes the requests of chunk + 3 in steps 2..5.  A chunk therefore
+     *   starts with its data in LDS and its first four fragments already in registers (requested in the last step of the chunk before; across the group's
+     *   epilogue: behind it): no barrier, no LDS round trip in front of its MFMAs — at the top they cost ~600 of a chunk's 2 200 cycles with the matrix
+     *   pipe idle. */
 #pragma unroll
     for (int t = 0; t < NOUT; t++) lacc[t] = hh_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    hh_h8 an[4];
+    if (NB == 4) {
+        hhx_chunk_barrier<2 * NPW>(); /* chunk 0 (chunks 1 and 2 may be on their way); everyone is out of the phase before */
+        HHX_T(pf, 5);
+#pragma unroll
+        for (int u = 0; u < 4; u++) an[u] = hhw_frag(ring + (j0 & (NB - 1)) * HHX_BUF_BYTES, u, lane);
+    }
 #pragma nounroll
     for (int p = 0; p < 8; p++) {
         hh_f32x4 acc[4];
@@ -160,21 +174,19 @@ __device__ __forceinline__ void hhx_l2_l3(const hh_h8 (&zh)[16], const hh_h8 (&z
         for (int t = 0; t < 4; t++) acc[t] = hhx_bias_acc(bl + 512 + 64 * p + 16 * t, g);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-#ifndef HHX_ABL_NO_BARRIER /* tuning builds: the shared layer's chunks are not waited for (wrong results): what do the 32 barriers + waits cost? */
-            /* chunk (p, q) landed in its buffer; the buffer of the chunk before is free.  Newer requests in flight: the chunks up to D - 1 ahead that exist */
-            if (D == 1) hhx_chunk_barrier<0>();
-            else if (p < 7 || q < 2) hhx_chunk_barrier<2 * NPW>();
-            else if (q == 2) hhx_chunk_barrier<NPW>();
-            else hhx_chunk_barrier<0>();
-#endif
-            HHX_T(pf, 5);
+            const unsigned char *cb = ring + ((j0 + q) & (NB - 1)) * HHX_BUF_BYTES;
+            const unsigned char *cbn = ring + ((j0 + q + 1) & (NB - 1)) * HHX_BUF_BYTES;
+            unsigned char *gdst = ring + ((j0 + q + D) & (NB - 1)) * HHX_BUF_BYTES + wave * NPW * HHW_PIECE; /* requests: one at a time behind a step's MFMAs (60 - 100 cycles each to issue) */
             const bool more = p < 7 || q + D < 4; /* chunk (p, q) + D exists */
-            unsigned char *gdst = ring + ((j0 + q + D) & (NB - 1)) * HHX_BUF_BYTES + wave * NPW * HHW_PIECE; /* its requests: a quarter per step, behind the MFMAs of the */
-            const unsigned char *cb = ring + ((j0 + q) & (NB - 1)) * HHX_BUF_BYTES;                           /* first four steps (an LDS-DMA request costs 60 - 100 cycles to issue) */
-            { /* eight steps of (k-block kk, tile pair tp) = 4 fragments, 6 MFMAs; the fragments of step s + 1 are requested before the MFMAs of step s */
-                hh_h8 an[4];
+            if (NB == 2) {
+#ifndef HHX_ABL_NO_BARRIER /* tuning builds: the shared layer's chunks are not waited for (wrong results): what do the 32 barriers + waits cost? */
+                hhx_chunk_barrier<0>();
+#endif
+                HHX_T(pf, 5);
 #pragma unroll
                 for (int u = 0; u < 4; u++) an[u] = hhw_frag(cb, u, lane);
+            }
+            { /* eight steps of (k-block kk, tile pair tp) = 4 fragments, 6 MFMAs; the fragments of step s + 1 are requested before the MFMAs of step s */
 #pragma unroll
                 for (int s_ = 0; s_ < 8; s_++) {
                     const int kk = s_ >> 1, tp = s_ & 1;
@@ -189,6 +201,9 @@ __device__ __forceinline__ void hhx_l2_l3(const hh_h8 (&zh)[16], const hh_h8 (&z
 #pragma unroll
                         for (int u = 0; u < 4; u++) an[u] = hhw_frag(cb, (s_ + 1) * 4 + u, lane);
 #endif
+                    } else if (NB == 4 && q < 3) { /* the chunk after this one is in LDS since this chunk's hand-over */
+#pragma unroll
+                        for (int u = 0; u < 4; u++) an[u] = hhw_frag(cbn, u, lane);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     HHX_MFMA(a[0], zh[4 * q + kk], acc[2 * tp]); HHX_MFMA(a[2], zh[4 * q + kk], acc[2 * tp + 1]);
@@ -196,10 +211,18 @@ __device__ __forceinline__ void hhx_l2_l3(const hh_h8 (&zh)[16], const hh_h8 (&z
                     HHX_MFMA(a[1], zh[4 * q + kk], acc[2 * tp]); HHX_MFMA(a[3], zh[4 * q + kk], acc[2 * tp + 1]);
                     HHX_MFMA(a[0], zl[4 * q + kk], acc[2 * tp]); HHX_MFMA(a[2], zl[4 * q + kk], acc[2 * tp + 1]);
 #endif
+                    if (NB == 4 && s_ == 1) { /* the hand-over of chunk + 1: at most chunk + 2's requests (if it exists) stay in flight */
+#ifndef HHX_ABL_NO_BARRIER
+                        if (p < 7 || q < 2) hhx_chunk_barrier<NPW>();
+                        else hhx_chunk_barrier<0>();
+#endif
+                        HHX_T(pf, 5);
+                    }
 #ifndef HHX_ABL_NO_GLDS /* tuning builds: the shared layer's chunks are never copied (wrong results): what does the LDS-DMA stream cost? */
-                    if (s_ < 4 && more) hhw_issue_some(gsrc, gdst, NPW / 4 * s_, NPW / 4);
-                    if (q == 0 && s_ == 4 && wave * HPW < 4 * NOUT) { /* every wave is past barrier (p, 0), so past its reads of group p - 1's head pieces; these are older than
-                                                                       * anything barrier (p, 3) lets stay in flight */
+                    if (NB == 2) { if (s_ < 4 && more) hhw_issue_some(gsrc, gdst, NPW / 4 * s_, NPW / 4); }
+                    else { if (s_ >= 2 && s_ < 6 && more) hhw_issue_some(gsrc, gdst, NPW / 4 * (s_ - 2), NPW / 4); }
+                    if (q == 0 && s_ == (NB == 2 ? 4 : 6) && wave * HPW < 4 * NOUT) { /* everyone is past the hand-over in (p, 0), so past its reads of group p - 1's head pieces;
+                                                                                        * these are older than anything the hand-over before the group's end lets stay in flight */
                         const unsigned char *hs = l3 + (size_t)(p * 4 * NOUT + wave * HPW) * HHW_PIECE + lane * 16;
                         hhw_issue_some(hs, l3buf + wave * HPW * HHW_PIECE, 0, HPW);
                     }
@@ -224,6 +247,10 @@ __device__ __forceinline__ void hhx_l2_l3(const hh_h8 (&zh)[16], const hh_h8 (&z
                 HHX_MFMA(wh, sl, lacc[t]);
             }
             HHX_T(pf, 8);
+        }
+        if (NB == 4 && p < 7) { /* the next group's first chunk: in LDS since the hand-over inside (p, 3); (j0 + 4) % 4 = j0 % 4 */
+#pragma unroll
+            for (int u = 0; u < 4; u++) an[u] = hhw_frag(ring + (j0 & (NB - 1)) * HHX_BUF_BYTES, u, lane);
         }
     }
 }

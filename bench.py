@@ -506,10 +506,12 @@ def main_policy_rollout(args, R=None):
         "frac_note": "USEFUL flops (one fp32-equivalent multiply-add per weight and row) over the dense fp16 MFMA peak; the three emulation passes "
                      "that buy fp32 accuracy are matrix-pipe work, not useful work: `issued_frac` counts them",
         "issued_tflops": issued / (pol_ms * 1e-3) / 1e12, "issued_frac": issued / (pol_ms * 1e-3) / 1e12 / peak}
-    tr = load_json("latest_policy_traffic.json")
-    line["roofline"]["dominant"]["traffic"] = (int(tr["hbm_bytes_per_launch"]) if tr and tr.get("rows") == 2 * n and pname in str(tr.get("kernel_full", "")) else None)
-    if line["roofline"]["dominant"]["traffic"] is not None:
-        line["roofline"]["dominant"]["traffic_source"] = "profiles/latest_policy_traffic.json (builder's rocprofv3 --pmc run of this kernel instance, not this run)"
+    line["roofline"]["dominant"]["traffic"] = None
+    for tf in ("latest_policy_traffic.json", "latest_policy_ppo_traffic.json"):   # the greedy call's instance | the sampler's
+        tr = load_json(tf)
+        if tr and tr.get("rows") == 2 * n and pname in str(tr.get("kernel_full", "")):
+            line["roofline"]["dominant"]["traffic"] = int(tr["hbm_bytes_per_launch"])
+            line["roofline"]["dominant"]["traffic_source"] = f"profiles/{tf} (builder's rocprofv3 --pmc run of this kernel instance, not this run)"
     if not own:
         return line
     if R.rank == 0:

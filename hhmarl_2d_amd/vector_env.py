@@ -20,6 +20,7 @@ with `env_config["num_envs"] = N` — INTEGRATION.md.
 
 Sub-environment i draws from the keyed RNG as arena `arena_offset + i`, exactly like a single-arena `LowLevelEnv` created with
 `env_config["arena_offset"] = arena_offset + i` and the same seed: tests/test_gpu_vector_env.py drives 64 of each side by side.
+Levels 4-5 (frozen opponent policies, env_base.py:312-398) take `env_config["policy_dir"]` or `["opponent_policy"]` like LowLevelEnv and step in two halves.
 """
 import numpy as np
 
@@ -37,12 +38,21 @@ except Exception:  # noqa: BLE001
 class _GpuBackend:
     """the batched world behind the adapter: numpy in, numpy out, pinned host mirrors, one synchronisation per call"""
 
-    def __init__(self, cfg, device):
+    def __init__(self, cfg, device, args=None, policy_dir=None, opponent_policy=None):
         import torch
         from .world import World
         self.torch = torch
         self.world = World(cfg, device=device)
         w = self.world
+        # levels 4-5: the opponents fly frozen policies between the two halves of the step (env_hetero.py:160-172), exactly as LowLevelEnv does it
+        self.opp = opponent_policy
+        self.args = args
+        self.l5_draw = args is not None and args.level == 5 and args.agent_mode == "fight"
+        self.opp_mode, self.opp_k = "fight", None       # level 5: arrays over the arenas, refreshed after every reset (the world's keyed draw)
+        if args is not None and args.level >= 4 and self.opp is None:   # _get_policies("LowLevel"), env_base.py:312-332
+            from .pilots import OpponentNets, PolicyBank
+            bank = PolicyBank.from_reference_dir(w.device, policy_dir, "LowLevel", args, max_rows=w.N * 2)
+            self.opp = OpponentNets(w, bank=bank, bind=True, skip_first=False)
         self.N, self.n_agents, self.D = w.N, w.n_agents, w.D
         self._act = torch.zeros((w.N, w.n_ctrl, 4), dtype=torch.int8, device=w.device)
         self._act_pin = torch.zeros((w.N, w.n_ctrl, 4), dtype=torch.int8).pin_memory()
@@ -62,12 +72,21 @@ class _GpuBackend:
         self.world.reset(mask=self._mask if masked else None, obs=self._robs)
         self._robs_pin.copy_(self._robs, non_blocking=True)
         self.torch.cuda.current_stream(self.world.device).synchronize()
+        if self.l5_draw:   # env_hetero.py:55-59: k = randint(3, 5) per episode; the opponents observe in escape mode iff k == 5
+            self.opp_k = self.world.opp_policy().cpu().numpy()
+            self.opp_mode = np.where(self.opp_k == 5, "escape", "fight")
         return self._robs_pin.numpy()
 
     def step(self):
         """one hh_step with the actions in act_host -> (obs, reward, valid, done) host arrays"""
         self._act.copy_(self._act_pin, non_blocking=True)
-        self.world.step(self._act, out=self._out)
+        if self.opp is not None:   # agents act, the frozen-policy opponents observe (the agents' same-tick weapon flags included) and act, then the tick
+            w = self.world
+            opp_obs = w.step_begin(self._act[:, : w.n_agents].contiguous(), L.OPP_MODE_EPISODE if self.l5_draw else 0)
+            opp_act = self.opp(opp_obs, self).to(self.torch.int8).contiguous()
+            w.step_finish(opp_act, out=self._out)
+        else:
+            self.world.step(self._act, out=self._out)
         for src, dst in zip(self._out, self._out_pin):
             dst.copy_(src, non_blocking=True)
         self.torch.cuda.current_stream(self.world.device).synchronize()
@@ -82,9 +101,10 @@ class LowLevelVectorEnv(_Base):
 
     def __init__(self, env_config):
         self.args = env_config.get("args", None)
-        if self.args.level >= 4:
-            raise ValueError("LowLevelVectorEnv: levels 4-5 fly frozen opponent policies inside the step; use LowLevelEnv(num_envs = N) with "
-                             "env_config['policy_dir'] for those (the vector adapter covers the scripted curriculum stages 1-3)")
+        if self.args.level >= 4 and env_config.get("opponent_policy") is None and env_config.get("policy_dir") is None and env_config.get("_backend") is None:
+            raise ValueError("levels 4-5 fly frozen opponent policies (envs/env_base.py:312-398); pass env_config['policy_dir'] = the directory of the "
+                             "exported L*_AC*_{fight,escape}.pt files, or env_config['opponent_policy'] = callable(opp_obs f32 [N,2,30] on the device, "
+                             "backend) -> int8 actions [N,2,4] for units 3,4 of every sub-environment (backend.world, .opp_k, .opp_mode as in LowLevelEnv)")
         self.agent_mode = self.args.agent_mode
         fight = self.agent_mode == "fight"
         self.obs_dim_map = {1: OBS_AC1 if fight else OBS_ESC_AC1, 2: OBS_AC2 if fight else OBS_ESC_AC2}
@@ -97,7 +117,7 @@ class LowLevelVectorEnv(_Base):
         if backend is None:
             cfg = config_from_args(self.args, L.ENV_LOWLEVEL, self.num_envs, int(env_config.get("seed", 0)), auto_reset=False,
                                    arena_offset=int(env_config.get("arena_offset", 0)))
-            backend = _GpuBackend(cfg, int(env_config.get("device", 0)))
+            backend = _GpuBackend(cfg, int(env_config.get("device", 0)), self.args, env_config.get("policy_dir"), env_config.get("opponent_policy"))
         self.b = backend
         self._started = False
         self._pending = {}                    # env_id -> (obs, rewards, terminateds, truncateds, infos) not yet polled

@@ -39,3 +39,61 @@ def test_vector_env_equals_single_env_facades(mode):
     venv.stop()
     for s in singles:
         s.close()
+
+
+class _LazyNets:
+    """`opponent_policy` callable for levels 4-5: a random-init bank of the reference architectures (the same weights for every seed-equal instance),
+    built inside its first call — on whatever owns the world: a LowLevelEnv facade or the vector adapter's backend"""
+
+    def __init__(self):
+        self.nets = None
+
+    def __call__(self, opp_obs, env):
+        from hhmarl_2d_amd import pilots
+        if self.nets is None:
+            self.nets = pilots.OpponentNets(env.world, seed=3)
+        return self.nets(opp_obs, env)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [4, 5])
+def test_vector_env_levels_4_and_5_equal_single_env_facades(level):
+    """levels 4-5: the opponents fly frozen policies between the two halves of the step (env_hetero.py:160-172; level 5 draws the policy set per arena and
+    episode, env_hetero.py:55-59): 32 sub-environments behind the BaseEnv surface against 32 single-arena facades, through episode ends and resets"""
+    from hhmarl_2d_amd.env_hetero import LowLevelEnv
+    from hhmarl_2d_amd.vector_env import LowLevelVectorEnv
+    N, args = 32, make_args(level=level, mode="fight", horizon=25)
+    with pytest.raises(ValueError):
+        LowLevelVectorEnv({"args": args, "num_envs": N})
+    venv = LowLevelVectorEnv({"args": args, "num_envs": N, "seed": 9, "arena_offset": 300, "opponent_policy": _LazyNets()})
+    singles = [LowLevelEnv({"args": args, "seed": 9, "arena_offset": 300 + i, "opponent_policy": _LazyNets()}) for i in range(N)]
+    obs, rew, term, trunc, info, _ = venv.poll()
+    for i, s in enumerate(singles):
+        o, _ = s.reset()
+        assert np.array_equal(o[1], obs[i][1]) and np.array_equal(o[2], obs[i][2])
+    if level == 5:
+        assert set(np.unique(venv.b.opp_k)) <= {3, 4, 5} and [s.opp_k for s in singles] == list(venv.b.opp_k)
+    rng = np.random.default_rng(2)
+    dones, ks = 0, set()
+    for it in range(70):
+        acts = sample_actions(rng, range(N))
+        venv.send_actions(acts)
+        obs, rew, term, trunc, info, _ = venv.poll()
+        for i, s in enumerate(singles):
+            o, r, t, tr, inf = s.step(acts[i])
+            assert np.array_equal(o[1], obs[i][1]) and np.array_equal(o[2], obs[i][2]), f"step {it}, sub-environment {i}"
+            assert r == rew[i] and t == term[i] and tr == trunc[i]
+            if t["__all__"]:
+                dones += 1
+                ro, ri = venv.try_reset(i)
+                so, _ = s.reset()
+                assert np.array_equal(so[1], ro[i][1]) and np.array_equal(so[2], ro[i][2])
+                if level == 5:
+                    assert s.opp_k == venv.b.opp_k[i]
+                    ks.add(int(s.opp_k))
+    assert dones >= N
+    if level == 5:
+        assert ks == {3, 4, 5}, "the episodes must cover the three policy sets"
+    venv.stop()
+    for s in singles:
+        s.close()

@@ -263,6 +263,36 @@ def test_policy_abi_misuse_is_reported_through_status_codes():
 
 
 @pytest.mark.gpu
+def test_four_and_eight_wave_instances_of_the_streamed_form_agree_bit_for_bit(monkeypatch):
+    """hh_k_policy_w16<4> (64-row tiles, two workgroups per CU, one chunk ahead) and hh_k_policy_w16<8> (128-row tiles, a ring of four chunk buffers three
+    chunks ahead, the hand-over inside the chunk before) run the same per-wave arithmetic in the same order: identical logits and actions on a mixed batch
+    with ragged last tiles; and the row count picks <8> exactly when 128-row tiles fill whole rounds of the CUs"""
+    from hhmarl_2d_amd import pilots
+    rng = np.random.default_rng(11)
+    sels = np.array([0, pilots.SEL_FIGHT1, pilots.SEL_FIGHT2, pilots.SEL_ESC1, pilots.SEL_ESC2], dtype=np.uint8)
+    R = 20011
+    obs = torch.from_numpy(rng.random((R, 30)).astype(np.float32)).cuda()
+    sel = torch.from_numpy(sels[rng.integers(0, len(sels), R)]).cuda()
+    res = []
+    for w in ("2", "3"):
+        monkeypatch.setenv("HH_POLICY_W", w)
+        bank = _bank(7, max_rows=R)
+        assert bank.kernel_name(R) == ("hh_k_policy_w16<4>" if w == "2" else "hh_k_policy_w16<8>")
+        lg = torch.zeros((R, 32), device="cuda")
+        act = bank.act(obs, sel, logits=lg).clone()
+        torch.cuda.synchronize()
+        res.append((lg, act))
+        bank.close()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    monkeypatch.delenv("HH_POLICY_W", raising=False)
+    bank = _bank(7, max_rows=65536)
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    assert bank.kernel_name(128 * n_cu) == "hh_k_policy_w16<8>" and bank.kernel_name(128 * n_cu + 64 * n_cu) == "hh_k_policy_w16<4>"
+    assert bank.kernel_name(64 * n_cu) == "hh_k_policy_w16<4>" and bank.kernel_name(32 * n_cu) in ("hh_k_policy_h<1>", "hh_k_policy_h<2>")
+    bank.close()
+
+
+@pytest.mark.gpu
 def test_tile_instances_of_the_kernel_agree_bit_for_bit(monkeypatch):
     """the 64-row-tile persistent instance (HH_POLICY_TILE=64, with and without the grid-stride walk) computes every row with the
     same operation order as the default 32-row instance: identical logits and actions on a mixed batch larger than one round of

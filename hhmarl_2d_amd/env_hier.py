@@ -55,7 +55,7 @@ class HighLevelEnv(_Base):
             raise ValueError("HighLevelEnv flies frozen low-level pilot policies (envs/env_base.py:312-398); pass env_config['policy_dir'] "
                              "= the directory of the exported L*_AC*_{fight,escape}.pt files, or env_config['pilot'] = "
                              "callable(pilot_obs, pilot_mode) -> int8 actions [N, 6, 4]")
-        cfg = config_from_args(self.args, L.ENV_HIGHLEVEL, self.num_envs, int(env_config.get("seed", 0)))
+        cfg = config_from_args(self.args, L.ENV_HIGHLEVEL, self.num_envs, int(env_config.get("seed", 0)), arena_offset=int(env_config.get("arena_offset", 0)))
         self.world = World(cfg, device=int(env_config.get("device", 0)))
         if self.pilot is None:   # _get_policies("HighLevel"), env_base.py:333-343
             from .pilots import NetPilot, PolicyBank

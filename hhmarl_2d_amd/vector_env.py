@@ -96,7 +96,133 @@ class _GpuBackend:
         self.world.close()
 
 
-class LowLevelVectorEnv(_Base):
+class _VectorProtocol(_Base):
+    """the BaseEnv call protocol over a backend with reset(masked) / step() / act_host / mask_host; subclasses name the agents, cut the observation rows
+    and pack the actions (`_obs_of`, `_put_action`, `_info_of`)"""
+
+    def _init_protocol(self, backend, num_envs, agent_ids):
+        self.b = backend
+        self.num_envs = num_envs
+        self._agent_ids = set(agent_ids)
+        self._ids = sorted(self._agent_ids)
+        self._started = False
+        self._pending = {}                    # env_id -> (obs, rewards, terminateds, truncateds, infos) not yet polled
+        self._done = set()                    # sub-environments whose episode ended and that were not reset yet
+        self._reset_obs = {}                  # env_id -> the first observation of its next episode (arena already re-sampled)
+        self._fresh = set()                   # sub-environments that were reset and have not stepped since
+
+    def _info_of(self, e):
+        return {}
+
+    def _put_action(self, a, e, k, v):
+        a[e, k - 1, : len(v)] = v
+
+    @property
+    def observation_space(self):
+        return self._observation_space
+
+    @property
+    def action_space(self):
+        return self._action_space
+
+    def get_agent_ids(self):
+        return self._agent_ids
+
+    def get_sub_environments(self, as_dict=False):
+        return {} if as_dict else []          # the arenas live in one device-resident world: there are no per-env Python objects
+
+    def _start(self):
+        self._started = True
+        rows = self.b.reset(False).copy()   # ONE copy out of the backend's reused host mirror; the per-agent observations are views of it
+        for e in range(self.num_envs):
+            self._pending[e] = (self._obs_of(rows[e]), {}, {"__all__": False}, {"__all__": False}, {})
+            self._fresh.add(e)
+
+    def poll(self):
+        """-> (obs, rewards, terminateds, truncateds, infos, off_policy_actions), each {env_id: {agent_id | "__all__": value}}, for every
+        sub-environment with a result nobody polled yet (the first call resets them all)"""
+        if not self._started:
+            self._start()
+        obs, rew, term, trunc, info = {}, {}, {}, {}, {}
+        for e, (o, r, t, tr, i) in self._pending.items():
+            obs[e], rew[e], term[e], trunc[e], info[e] = o, r, t, tr, i
+        self._pending = {}
+        return obs, rew, term, trunc, info, {}
+
+    def send_actions(self, action_dict):
+        """{env_id: {agent_id: action}}: every sub-environment whose episode is running must be there (the arenas step
+        together); one that ended needs try_reset first (RLlib's MultiAgentEnvToBaseEnv raises the same ValueError)"""
+        for e in action_dict:
+            if e in self._done:
+                raise ValueError(f"Env {e} is already done and cannot accept new actions")
+        missing = [e for e in range(self.num_envs) if e not in action_dict and e not in self._done]
+        if missing:
+            raise ValueError(f"send_actions: sub-environments {missing[:8]} have a running episode but no action (the arenas of one world step together)")
+        a = self.b.act_host
+        a[:] = 0
+        for e, ad in action_dict.items():
+            for k, v in ad.items():
+                self._put_action(a, e, k, v)
+        obs, rew, val, done = self.b.step()
+        # the per-sub-environment Python objects are what this surface costs (3 us per sub-environment): one copy of the step's observations (the
+        # agents' arrays are views of it), the small arrays as Python lists once instead of a numpy scalar per access
+        obs = obs.copy()
+        rew_l, val_l, done_l = rew.tolist(), val.tolist(), done.tolist()
+        ids = self._ids
+        fin = []
+        self._fresh.clear()
+        pending, obs_of, info_of = self._pending, self._obs_of, self._info_of
+        for e in action_dict:
+            rl, vl = rew_l[e], val_l[e]
+            r = {i: rl[i - 1] for i in ids if vl[i - 1]}
+            if done_l[e]:
+                dd = {"__all__": True}
+                self._done.add(e)
+                fin.append(e)
+            else:
+                dd = {"__all__": False}
+            pending[e] = (obs_of(obs[e]), r, dd, dd, info_of(e))
+        # a sub-environment that ended earlier and was never try_reset (RLlib's sampler always does that at once) was stepped along with
+        # the rest, on zero actions: its arena is re-sampled again, so that the episode it eventually starts is an untouched one
+        fin += [e for e in self._done if e not in action_dict and e not in fin]
+        if fin:   # ONE masked reset for every arena that just finished; try_reset hands out the cached rows
+            m = self.b.mask_host
+            m[:] = 0
+            m[fin] = 1
+            rows = self.b.reset(True)
+            for e in fin:
+                self._reset_obs[e] = self._obs_of(rows[e].copy())
+
+    def try_reset(self, env_id=None, *, seed=None, options=None):
+        """-> ({env_id: obs dict}, {env_id: {}}) of the sub-environment's next episode"""
+        if env_id is None:
+            env_id = 0
+        if not self._started:
+            self._start()
+        if env_id in self._reset_obs:            # its episode ended: the arena was re-sampled right after that step
+            o = self._reset_obs.pop(env_id)
+        elif env_id in self._fresh and env_id in self._pending:   # reset, not stepped, not polled: that observation is the answer
+            o = self._pending[env_id][0]
+        else:                                    # a reset in the middle of an episode (RLlib does this for episodes it truncates itself)
+            m = self.b.mask_host
+            m[:] = 0
+            m[env_id] = 1
+            o = self._obs_of(self.b.reset(True)[env_id].copy())
+        self._done.discard(env_id)
+        self._pending.pop(env_id, None)
+        self._fresh.add(env_id)
+        return {env_id: o}, {env_id: {}}
+
+    def try_restart(self, env_id=None):
+        return None
+
+    def stop(self):
+        self.b.close()
+
+    close = stop
+
+
+class LowLevelVectorEnv(_VectorProtocol):
     """N LowLevelEnv sub-environments (2-vs-2) behind RLlib's BaseEnv protocol, one MI355X world underneath."""
 
     def __init__(self, env_config):
@@ -118,112 +244,127 @@ class LowLevelVectorEnv(_Base):
             cfg = config_from_args(self.args, L.ENV_LOWLEVEL, self.num_envs, int(env_config.get("seed", 0)), auto_reset=False,
                                    arena_offset=int(env_config.get("arena_offset", 0)))
             backend = _GpuBackend(cfg, int(env_config.get("device", 0)), self.args, env_config.get("policy_dir"), env_config.get("opponent_policy"))
-        self.b = backend
-        self._started = False
-        self._pending = {}                    # env_id -> (obs, rewards, terminateds, truncateds, infos) not yet polled
-        self._done = set()                    # sub-environments whose episode ended and that were not reset yet
-        self._reset_obs = {}                  # env_id -> the first observation of its next episode (arena already re-sampled)
-        self._fresh = set()                   # sub-environments that were reset and have not stepped since
-        self._ids = sorted(self._agent_ids)
-
-    # ---- BaseEnv surface (ray/rllib/env/base_env.py)
-    @property
-    def observation_space(self):
-        return self._observation_space
-
-    @property
-    def action_space(self):
-        return self._action_space
-
-    def get_agent_ids(self):
-        return self._agent_ids
-
-    def get_sub_environments(self, as_dict=False):
-        return {} if as_dict else []          # the arenas live in one device-resident world: there are no per-env Python objects
+        self._init_protocol(backend, self.num_envs, range(1, self.args.num_agents + 1))
 
     def _obs_of(self, rows):
-        return {i: rows[i - 1, : self.obs_dim_map[i]].copy() for i in self._ids}
+        return {i: rows[i - 1, : self.obs_dim_map[i]] for i in self._ids}   # views of the caller's fresh copy
 
-    def _start(self):
-        self._started = True
-        rows = self.b.reset(False)
-        for e in range(self.num_envs):
-            self._pending[e] = (self._obs_of(rows[e]), {}, {"__all__": False}, {"__all__": False}, {})
-            self._fresh.add(e)
 
-    def poll(self):
-        """-> (obs, rewards, terminateds, truncateds, infos, off_policy_actions), each {env_id: {agent_id | "__all__": value}}, for every
-        sub-environment with a result nobody polled yet (the first call resets them all)"""
-        if not self._started:
-            self._start()
-        obs, rew, term, trunc, info = {}, {}, {}, {}, {}
-        for e, (o, r, t, tr, i) in self._pending.items():
-            obs[e], rew[e], term[e], trunc[e], info[e] = o, r, t, tr, i
-        self._pending = {}
-        return obs, rew, term, trunc, info, {}
+class _GpuHierBackend:
+    """the batched 3-vs-3 HighLevelEnv world behind HighLevelVectorEnv: one commander step of every sub-environment per step() — the 66 launches of
+    env_hier.macro_step, replayed from ONE HIP graph when the library's own NetPilot flies the units, eager with the early exit for a handful of arenas"""
+
+    def __init__(self, cfg, device, args, policy_dir=None, pilot=None, graph_from=65):
+        import torch
+        from .env_hier import macro_step
+        from .world import World
+        self.torch, self._macro_step = torch, macro_step
+        self.world = World(cfg, device=device)
+        w = self.world
+        self.N, self.n_agents, self.D = w.N, w.n_agents, w.D
+        self.pilot = pilot
+        if self.pilot is None:   # _get_policies("HighLevel"), env_base.py:333-343
+            from .pilots import NetPilot, PolicyBank
+            bank = PolicyBank.from_reference_dir(w.device, policy_dir, "HighLevel", args, max_rows=w.N * 6)
+            self.pilot = NetPilot(w, bank=bank)
+        self._cmd = torch.zeros((w.N, w.n_agents), dtype=torch.int8, device=w.device)
+        self._cmd_pin = torch.zeros((w.N, w.n_agents), dtype=torch.int8).pin_memory()
+        self.act_host = self._cmd_pin.numpy()
+        self._out, self._pbuf = w.alloc_outputs(), w.alloc_pilot()
+        self._out_pin = [torch.zeros(t.shape, dtype=t.dtype).pin_memory() for t in self._out]
+        self._mask = torch.zeros((w.N,), dtype=torch.uint8, device=w.device)
+        self._mask_pin = torch.zeros((w.N,), dtype=torch.uint8).pin_memory()
+        self.mask_host = self._mask_pin.numpy()
+        self._robs = torch.zeros((w.N, w.n_agents, w.D), dtype=torch.float32, device=w.device)
+        self._robs_pin = torch.zeros((w.N, w.n_agents, w.D), dtype=torch.float32).pin_memory()
+        self._graph, self._graph_gen, self._graph_from = None, -1, graph_from
+
+    def reset(self, masked):
+        if masked:
+            self._mask.copy_(self._mask_pin, non_blocking=True)
+        self.world.reset(mask=self._mask if masked else None, obs=self._robs)
+        self._robs_pin.copy_(self._robs, non_blocking=True)
+        self.torch.cuda.current_stream(self.world.device).synchronize()
+        return self._robs_pin.numpy()
+
+    def _replay(self):
+        from .pilots import NetPilot
+        torch, w = self.torch, self.world
+        if not isinstance(self.pilot, NetPilot):   # a foreign pilot may read things on the host: no capture
+            return self._macro_step(w, self._cmd, self.pilot, out=self._out, pilot_buf=self._pbuf, early_exit=False)
+        gen = getattr(w, "ptr_generation", 0)      # the graph holds device pointers by value (trace ring, bound bank's row lists)
+        if self._graph is None or self._graph_gen != gen:
+            self.pilot.bank.act(torch.zeros((64, 30), device=w.device), torch.zeros((64,), dtype=torch.uint8, device=w.device))   # first launches outside a capture
+            torch.cuda.synchronize(w.device)
+            side = torch.cuda.Stream(device=w.device)
+            side.wait_stream(torch.cuda.current_stream(w.device))
+            with torch.cuda.stream(side):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    self._macro_step(w, self._cmd, self.pilot, out=self._out, pilot_buf=self._pbuf, early_exit=False)
+            torch.cuda.current_stream(w.device).wait_stream(side)
+            self._graph, self._graph_gen = graph, gen
+        self._graph.replay()
+        return self._out
+
+    def step(self):
+        """one commander step (HighLevelEnv.step, env_hier.py:114-140) with the actions in act_host -> (obs, reward, valid, done) host arrays"""
+        self._cmd.copy_(self._cmd_pin, non_blocking=True)
+        if self.N < self._graph_from:   # few arenas: leave the sub-step loop as soon as every macro step is over (a host synchronisation per tick)
+            outs = self._macro_step(self.world, self._cmd, self.pilot, out=self._out, pilot_buf=self._pbuf, early_exit=True)
+        else:
+            outs = self._replay()
+        for src, dst in zip(outs, self._out_pin):
+            dst.copy_(src, non_blocking=True)
+        self.torch.cuda.current_stream(self.world.device).synchronize()
+        return [t.numpy() for t in self._out_pin]
+
+    def eval_info(self):
+        return self.world.eval_info()[0].cpu().numpy()
+
+    def close(self):
+        self.world.close()
+
+
+class HighLevelVectorEnv(_VectorProtocol):
+    """N HighLevelEnv sub-environments (3-vs-3 commander, envs/env_hier.py) behind RLlib's BaseEnv protocol, one MI355X world underneath: what
+    train_hier.py's `env=HighLevelEnv` (one env per rollout worker, train_hier.py:196-199) becomes with thousands of arenas per GPU.  One `send_actions`
+    = one commander step of every sub-environment (up to 16 ticks with the frozen pilot networks in between).  env_config as HighLevelEnv's
+    (`policy_dir` or `pilot`), plus `num_envs`, `seed`, `arena_offset`, `device`; `args.eval_info` puts the reference's win / lose / draw and choice counters
+    (env_base.py:91-107) into every sub-environment's info dict."""
+
+    def __init__(self, env_config):
+        from .env_hier import N_OPP_HL, OBS_HL
+        self.args = env_config.get("args", None)
+        if env_config.get("pilot") is None and env_config.get("policy_dir") is None and env_config.get("_backend") is None:
+            raise ValueError("HighLevelEnv flies frozen low-level pilot policies (envs/env_base.py:312-398); pass env_config['policy_dir'] = the directory of the "
+                             "exported L*_AC*_{fight,escape}.pt files, or env_config['pilot'] = callable(pilot_obs, pilot_mode) -> int8 actions [N, 6, 4]")
+        self.num_envs = int(env_config.get("num_envs", 1))
+        self._observation_space = spaces.Box(low=np.zeros(OBS_HL), high=np.ones(OBS_HL), dtype=np.float32)   # per agent, as the reference declares it (env_hier.py:34-35)
+        self._action_space = spaces.Discrete(N_OPP_HL + 1)
+        backend = env_config.get("_backend", None)
+        if backend is None:
+            cfg = config_from_args(self.args, L.ENV_HIGHLEVEL, self.num_envs, int(env_config.get("seed", 0)), auto_reset=False,
+                                   arena_offset=int(env_config.get("arena_offset", 0)))
+            backend = _GpuHierBackend(cfg, int(env_config.get("device", 0)), self.args, env_config.get("policy_dir"), env_config.get("pilot"))
+        self._init_protocol(backend, self.num_envs, range(1, self.args.num_agents + 1))
+        self._eval = bool(getattr(self.args, "eval_info", False))
+        self._last_eval = None
+
+    def _obs_of(self, rows):
+        return {i: rows[i - 1] for i in self._ids}   # views of the caller's fresh copy
+
+    def _put_action(self, a, e, k, v):
+        if k <= len(self._ids):
+            a[e, k - 1] = int(v)
 
     def send_actions(self, action_dict):
-        """{env_id: {agent_id: MultiDiscrete action}}: every sub-environment whose episode is running must be there (the arenas step
-        together); one that ended needs try_reset first (RLlib's MultiAgentEnvToBaseEnv raises the same ValueError)"""
-        for e in action_dict:
-            if e in self._done:
-                raise ValueError(f"Env {e} is already done and cannot accept new actions")
-        missing = [e for e in range(self.num_envs) if e not in action_dict and e not in self._done]
-        if missing:
-            raise ValueError(f"send_actions: sub-environments {missing[:8]} have a running episode but no action (the arenas of one world step together)")
-        a = self.b.act_host
-        a[:] = 0
-        for e, ad in action_dict.items():
-            for k, v in ad.items():
-                v = np.asarray(v)
-                a[e, k - 1, : v.shape[-1]] = v
-        obs, rew, val, done = self.b.step()
-        n_ag = self.args.num_agents
-        fin = []
-        self._fresh.clear()
-        for e in action_dict:
-            d = bool(done[e])
-            r = {i: float(rew[e, i - 1]) for i in range(1, n_ag + 1) if val[e, i - 1]}
-            dd = {"__all__": d}
-            self._pending[e] = (self._obs_of(obs[e]), r, dd, dd, {})
-            if d:
-                self._done.add(e)
-                fin.append(e)
-        # a sub-environment that ended earlier and was never try_reset (RLlib's sampler always does that at once) was stepped along with
-        # the rest, on zero actions: its arena is re-sampled again, so that the episode it eventually starts is an untouched one
-        fin += [e for e in self._done if e not in action_dict and e not in fin]
-        if fin:   # ONE masked reset for every arena that just finished; try_reset hands out the cached rows
-            m = self.b.mask_host
-            m[:] = 0
-            m[fin] = 1
-            rows = self.b.reset(True)
-            for e in fin:
-                self._reset_obs[e] = self._obs_of(rows[e])
+        self._last_eval = None
+        super().send_actions(action_dict)
 
-    def try_reset(self, env_id=None, *, seed=None, options=None):
-        """-> ({env_id: obs dict}, {env_id: {}}) of the sub-environment's next episode"""
-        if env_id is None:
-            env_id = 0
-        if not self._started:
-            self._start()
-        if env_id in self._reset_obs:            # its episode ended: the arena was re-sampled right after that step
-            o = self._reset_obs.pop(env_id)
-        elif env_id in self._fresh and env_id in self._pending:   # reset, not stepped, not polled: that observation is the answer
-            o = self._pending[env_id][0]
-        else:                                    # a reset in the middle of an episode (RLlib does this for episodes it truncates itself)
-            m = self.b.mask_host
-            m[:] = 0
-            m[env_id] = 1
-            o = self._obs_of(self.b.reset(True)[env_id])
-        self._done.discard(env_id)
-        self._pending.pop(env_id, None)
-        self._fresh.add(env_id)
-        return {env_id: o}, {env_id: {}}
-
-    def try_restart(self, env_id=None):
-        return None
-
-    def stop(self):
-        self.b.close()
-
-    close = stop
+    def _info_of(self, e):
+        if not self._eval:
+            return {}
+        if self._last_eval is None:
+            self._last_eval = self.b.eval_info()
+        return {k: int(self._last_eval[e, i]) for i, k in enumerate(L.EVAL_KEYS)}

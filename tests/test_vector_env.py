@@ -134,3 +134,88 @@ def test_protocol_errors_and_corner_cases(oracle):
     assert sorted(env.poll()[0]) == [0, 1, 2, 3]
     with pytest.raises(ValueError, match="levels 4-5"):
         LowLevelVectorEnv({"args": make_args(level=4), "num_envs": 2})
+
+
+# ------------------------------------------------------------------------------------------------ HighLevelVectorEnv
+def make_hl_args(horizon=60, eval_info=False):
+    return types.SimpleNamespace(level=5, agent_mode="fight", num_agents=3, num_opps=3, horizon=horizon, friendly_kill=True, friendly_punish=False,
+                                 esc_dist_rew=False, map_size=0.5, glob_frac=0.0, rew_scale=1, hier_action_assess=True, hier_opp_fight_ratio=75,
+                                 eval_info=eval_info, eval_hl=True)
+
+
+def row_pilot(pilot_obs, pilot_mode):
+    """a 'frozen pilot' that is a function of the unit's own observation row only, so that it flies a unit the same way in any batch"""
+    h = np.floor(np.abs(pilot_obs.astype(np.float64) @ np.linspace(0.37, 3.1, pilot_obs.shape[-1])) * 9973.0).astype(np.int64)
+    a = np.stack([h % 13, (h // 13) % 9, (h // 117) % 2, (h // 234) % 2], axis=-1).astype(np.int8)
+    a[pilot_mode == 0] = 0
+    return a
+
+
+def oracle_macro_step(w, cmd):
+    """env_hier.py:114-140 on the CPU oracle with row_pilot between the phases"""
+    nA = w.n_agents
+    w.hl_begin(cmd)
+    for sub in range(16):
+        act = row_pilot(*w.hl_pilot_obs(0))
+        w.hl_agents_act(act)
+        act[:, nA:] = row_pilot(*w.hl_pilot_obs(1))[:, nA:]
+        if w.hl_tick(act) == 0:
+            break
+    return w.hl_end()
+
+
+class OracleHierBackend:
+    """the reset / step surface of vector_env._GpuHierBackend on the CPU oracle (test infrastructure)"""
+
+    def __init__(self, oracle, cfg):
+        self.w = oracle.OracleWorld(cfg)
+        self.N, self.n_agents, self.D = self.w.N, self.w.n_agents, self.w.D
+        self.act_host = np.zeros((self.N, self.n_agents), dtype=np.int8)
+        self.mask_host = np.zeros((self.N,), dtype=np.uint8)
+
+    def reset(self, masked):
+        return self.w.reset(self.mask_host.copy() if masked else None)
+
+    def step(self):
+        return oracle_macro_step(self.w, self.act_host.copy())
+
+    def eval_info(self):
+        return self.w.eval_info()[0]
+
+    def close(self):
+        pass
+
+
+def test_highlevel_protocol_against_independent_single_arena_worlds(oracle):
+    """HighLevelVectorEnv: N commander environments behind the BaseEnv surface = N single-arena HighLevelEnv worlds, commander step for commander step
+    (observations of agents 1..3, rewards only for the ids alive at step start, done, the eval counters in the info dict), through episode ends and resets"""
+    from hhmarl_2d_amd.vector_env import HighLevelVectorEnv
+    N, args = 6, make_hl_args(horizon=40, eval_info=True)
+    mk = lambda n, off: config_from_args(args, L.ENV_HIGHLEVEL, n, 11, auto_reset=False, arena_offset=off)
+    with pytest.raises(ValueError, match="frozen low-level pilot"):
+        HighLevelVectorEnv({"args": args, "num_envs": N})
+    env = HighLevelVectorEnv({"args": args, "num_envs": N, "_backend": OracleHierBackend(oracle, mk(N, 40))})
+    assert env.get_agent_ids() == {1, 2, 3} and env.observation_space.shape == (34,) and env.action_space.n == 3
+    singles = [oracle.OracleWorld(mk(1, 40 + i)) for i in range(N)]
+    obs, rew, term, trunc, info, _ = env.poll()
+    for e, w in enumerate(singles):
+        ro = w.reset()
+        assert all(np.array_equal(obs[e][i], ro[0, i - 1]) for i in (1, 2, 3)) and obs[e][1].shape == (34,) and rew[e] == {} and info[e] == {}
+    rng = np.random.default_rng(5)
+    n_done = 0
+    for it in range(40):
+        acts = {e: {i: int(rng.integers(3)) for i in (1, 2, 3)} for e in range(N)}
+        env.send_actions(acts)
+        obs, rew, term, trunc, info, _ = env.poll()
+        assert sorted(obs) == list(range(N))
+        for e, w in enumerate(singles):
+            wo, wr, wv, wd = oracle_macro_step(w, np.array([[acts[e][1], acts[e][2], acts[e][3]]], dtype=np.int8))
+            assert all(np.array_equal(obs[e][i], wo[0, i - 1]) for i in (1, 2, 3)), f"step {it}, sub-environment {e}"
+            assert rew[e] == {i: float(wr[0, i - 1]) for i in (1, 2, 3) if wv[0, i - 1]} and term[e] == trunc[e] == {"__all__": bool(wd[0])}
+            assert info[e] == {k: int(w.eval_info()[0][0, j]) for j, k in enumerate(L.EVAL_KEYS)}
+            if wd[0]:
+                n_done += 1
+                ro, ri = env.try_reset(e)
+                so = w.reset()
+                assert all(np.array_equal(ro[e][i], so[0, i - 1]) for i in (1, 2, 3)) and ri == {e: {}}
+    assert n_done >= 3

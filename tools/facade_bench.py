@@ -68,3 +68,26 @@ if len(sys.argv) > 2 and sys.argv[2] == "vector":   # the BaseEnv surface RLlib'
     dt = (time.perf_counter() - t0) / S
     print(f"LowLevelVectorEnv(num_envs={N}) poll + try_reset + send_actions: {dt * 1e6:.0f} us per iteration -> {N / dt / 1e6:.3f} M env-steps/s "
           f"(RLlib BaseEnv protocol: {2 * N} observation arrays and {N} reward dicts built per iteration)")
+
+if len(sys.argv) > 2 and sys.argv[2] == "hvector":   # the same surface for the 3-vs-3 commander environment, the pilot networks in the loop
+    from hhmarl_2d_amd.pilots import NetPilot
+    from hhmarl_2d_amd.vector_env import HighLevelVectorEnv
+    venv = HighLevelVectorEnv({"args": make_args(1, level=5, horizon=500), "num_envs": N, "seed": 1, "pilot": lambda po, pm: None})
+    venv.b.pilot = NetPilot(venv.b.world, seed=2)
+    rng = np.random.default_rng(0)
+    per_env = [{e: {k: int(rng.integers(3)) for k in (1, 2, 3)} for e in range(N)} for _ in range(4)]
+    def it(k):
+        obs, rew, term, trunc, info, _ = venv.poll()
+        for e in obs:
+            if term[e]["__all__"]:
+                venv.try_reset(e)
+        venv.send_actions(per_env[k % 4])
+    for k in range(4):
+        it(k)
+    S = 100 if N <= 256 else 20
+    t0 = time.perf_counter()
+    for k in range(S):
+        it(k)
+    dt = (time.perf_counter() - t0) / S
+    print(f"HighLevelVectorEnv(num_envs={N}) poll + try_reset + send_actions: {dt * 1e3:.2f} ms per iteration -> {N / dt:.3g} commander-steps/s "
+          f"(RLlib BaseEnv protocol; one commander step = up to 16 ticks with the pilot networks in between)")

@@ -73,13 +73,15 @@ def from_torch_module(module):
     return kind, {k: sd[k] for k in actor_keys(kind)}
 
 
-def torch_forward(kind, sd, obs):
+def torch_forward(kind, sd, obs, dtype=None):
     """plain PyTorch fp32 actor forward (same op as the HIP kernel, statement order of the reference's forward()):
-    obs float32 [R, >= OBS_DIM[kind]] -> logits float32 [R, N_OUT[kind]]"""
+    obs float32 [R, >= OBS_DIM[kind]] -> logits float32 [R, N_OUT[kind]].  dtype = torch.float64: the same arithmetic in double (the
+    yardstick of tools/policy_soak.py: how far the fp32 forward itself is from the real-number result)"""
     import torch
     import torch.nn.functional as F
-    t = {k: torch.as_tensor(v, dtype=torch.float32, device=obs.device) for k, v in sd.items()}
-    x = obs[:, :OBS_DIM[kind]].to(torch.float32)
+    dtype = dtype or torch.float32
+    t = {k: torch.as_tensor(v, dtype=dtype, device=obs.device) for k, v in sd.items()}
+    x = obs[:, :OBS_DIM[kind]].to(dtype)
     h = []
     for n, (c0, c1, _) in zip(("inp1", "inp2", "inp3"), INPUTS[kind]):
         h.append(torch.tanh(F.linear(x[:, c0:c1], t[f"{n}._model.0.weight"], t[f"{n}._model.0.bias"])))
@@ -143,15 +145,16 @@ def critic_from_torch_module(module, kind):
     return {k: sd[k] for k in critic_keys(kind)}
 
 
-def torch_value(kind, sd, csd, obs_own, act_own, obs_2, act_2):
+def torch_value(kind, sd, csd, obs_own, act_own, obs_2, act_2, dtype=None):
     """plain PyTorch fp32 value_function() (statement order of the reference): sd = actor tensors (for the shared layer), csd = value branch"""
     import torch
     import torch.nn.functional as F
     dev = obs_own.device
-    t = {k: torch.as_tensor(v, dtype=torch.float32, device=dev) for k, v in {**sd, **csd}.items()}
+    dtype = dtype or torch.float32
+    t = {k: torch.as_tensor(v, dtype=dtype, device=dev) for k, v in {**sd, **csd}.items()}
     d1, a1, d2, a2 = CRITIC_DIMS[kind]
-    v1 = torch.cat((obs_own[:, :d1], act_own[:, :a1]), dim=1).to(torch.float32)
-    v2 = torch.cat((obs_2[:, :d2], act_2[:, :a2]), dim=1).to(torch.float32)
+    v1 = torch.cat((obs_own[:, :d1], act_own[:, :a1]), dim=1).to(dtype)
+    v2 = torch.cat((obs_2[:, :d2], act_2[:, :a2]), dim=1).to(dtype)
     v3 = torch.cat((v1, v2), dim=1)
     if HAS_ATT[kind]:
         y = torch.cat((torch.tanh(F.linear(v1, t["v1._model.0.weight"], t["v1._model.0.bias"])),

@@ -647,10 +647,6 @@ __global__ __launch_bounds__(64 * WV, 2) void hh_k_policy_w16(HhpBank bank, HhpB
 #pragma unroll
     for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? min(hhp_row_count(counts, n, consume), max_rows) : 0;
     int net, tile, cnt;
-#ifdef HHX_STAGGER /* tuning builds: delay one of the two workgroups that share a CU (1: odd ids, 2: the second half of the grid) by HHX_STAGGER_SLEEPS x 8 k cycles */
-    if ((HHX_STAGGER == 1 && (blockIdx.x & 1)) || (HHX_STAGGER == 2 && blockIdx.x >= gridDim.x / 2))
-        for (int i = 0; i < HHX_STAGGER_SLEEPS; i++) __builtin_amdgcn_s_sleep(127);
-#endif
     if (hhp_locate<16 * WV>(cn, (int)blockIdx.x, net, tile, cnt))
         hhx_forward_tile<false, WV>(bank.net[net], bankx.stream[net], obs, obs_stride, lists + (size_t)net * max_rows, tile, cnt, actions, logits_out, ldsb);
     hhp_consume_counts(counts, consume);
@@ -689,15 +685,5 @@ static inline void hhx_put(std::vector<uint16_t> &S, size_t piece_hi, int k, int
     S[(piece_hi + 1) * (HHW_PIECE / 2) + at] = hhp_f2h(v - hhp_h2f(h));
 }
 
-#ifdef HHX_SPLIT_PROBE /* tuning builds: the two tile kinds as kernels of their own (register budgets) */
-__global__ __launch_bounds__(256, 2) void hhx_probe_crit(HhpCritBankX cbank, const float *obs, int obs_stride, const int *lists, int cnt, HhpSampleArgs sa) {
-    extern __shared__ __align__(16) unsigned char ldsb[];
-    hhx_critic_tile<true>(cbank.c[0], obs, obs_stride, lists, (int)blockIdx.x, cnt, sa, ldsb);
-}
-__global__ __launch_bounds__(256, 2) void hhx_probe_actor(HhpBank bank, HhpBankX bankx, const float *obs, int obs_stride, const int *lists, int cnt, HhpSampleArgs sa) {
-    extern __shared__ __align__(16) unsigned char ldsb[];
-    hhx_forward_tile<true, 4>(bank.net[0], bankx.stream[0], obs, obs_stride, lists, (int)blockIdx.x, cnt, sa.actions, sa.logits_out, ldsb, &sa);
-}
-#endif
 
 #endif /* HH_POLICY_KERNEL_W16_H */

@@ -560,55 +560,85 @@ __device__ __forceinline__ void hhx_critic_tile(const HhpCritX &Cw, const float 
     hh_h8 zh[16], zl[16];
     int ck = 0; /* chunk counter: chunk ck sits in buf[ck & 1] */
 
-    /* ---- first layer: 8 chunks of 4 tiles (two fragments of the hidden row each) ---- */
+    /* ---- first layer: 8 chunks of 4 tiles (two fragments of the hidden row each).  Steps of (tile pair, k-block) = 4 fragments + 6 MFMAs on two accumulators
+     *      in turn, the fragments a step ahead, this wave's requests of the next chunk one per step (the scheme of the actor tile: nine dependent MFMAs per tile
+     *      and an LDS round trip in the open per tile before) ---- */
 #pragma unroll
     for (int c = 0; c < 8; c++, ck++) {
         __syncthreads(); /* chunk ck landed; the other buffer is free */
-        if (c < 7) { hhx_issue<6>(sp, buf[(ck + 1) & 1], wave, lane); sp += (size_t)24 * HHW_PIECE; }
-        else if (ATT) { hhx_issue<5>(sp, buf[(ck + 1) & 1], wave, lane); sp += (size_t)20 * HHW_PIECE; }                            /* attention tiles 0, 1 */
-        else { sp += (size_t)HHXC_ATT_PIECES * HHW_PIECE; hhx_issue<8>(sp, buf[(ck + 1) & 1], wave, lane); sp += (size_t)HHX_CHUNK * HHW_PIECE; } /* escape nets: shared layer (0, 0) */
+        const int npw = c < 7 ? 6 : (ATT ? 5 : 8); /* next: first-layer chunk (24 pieces) | attention tiles 0, 1 (20) | escape nets: shared layer (0, 0) (32) */
+        if (c == 7 && !ATT) sp += (size_t)HHXC_ATT_PIECES * HHW_PIECE;
+        const unsigned char *gsrc = sp + (size_t)wave * npw * HHW_PIECE + lane * 16;
+        unsigned char *gdst = buf[(ck + 1) & 1] + wave * npw * HHW_PIECE;
+        sp += (size_t)(npw * 4) * HHW_PIECE;
+        const unsigned char *cb = buf[ck & 1];
+        /* piece of (tile tt of the chunk, k-block kb, plane) = (tt * 3 + kb) * 2 + plane; step st = (pair tp, kb) */
+        hh_h8 an[4];
+        an[0] = hhw_frag(cb, 0, lane); an[1] = hhw_frag(cb, 1, lane); an[2] = hhw_frag(cb, 6, lane); an[3] = hhw_frag(cb, 7, lane);
+        hh_f32x4 a0, a1;
 #pragma unroll
-        for (int tp = 0; tp < 2; tp++) {
-            hh_f32x4 a[2];
+        for (int st_ = 0; st_ < 6; st_++) {
+            const int tp = st_ / 3, kb = st_ % 3;
+            if (kb == 0) { a0 = hhx_bias_acc(bl + 16 * (c * 4 + tp * 2), g); a1 = hhx_bias_acc(bl + 16 * (c * 4 + tp * 2 + 1), g); }
+            hh_h8 a[4];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int tt = tp * 2 + u, T = c * 4 + tt;
-                a[u] = hhx_bias_acc(bl + 16 * T, g);
-#pragma unroll
-                for (int kb = 0; kb < 3; kb++) {
-                    const hh_h8 wh = hhw_frag(buf[ck & 1], (tt * 3 + kb) * 2, lane), wl = hhw_frag(buf[ck & 1], (tt * 3 + kb) * 2 + 1, lane);
-                    HHX_MFMA(wh, xh[kb], a[u]);
-                    HHX_MFMA(wl, xh[kb], a[u]);
-                    HHX_MFMA(wh, xl[kb], a[u]);
-                }
-                __builtin_amdgcn_sched_barrier(0); /* one tile's six fragments at a time: hipcc otherwise hoists the whole chunk's reads (96 registers) */
+            for (int u = 0; u < 4; u++) a[u] = an[u];
+            hhw_need4(a);
+            if (st_ + 1 < 6) {
+                const int tpn = (st_ + 1) / 3, kbn = (st_ + 1) % 3;
+                an[0] = hhw_frag(cb, ((tpn * 2) * 3 + kbn) * 2, lane); an[1] = hhw_frag(cb, ((tpn * 2) * 3 + kbn) * 2 + 1, lane);
+                an[2] = hhw_frag(cb, ((tpn * 2 + 1) * 3 + kbn) * 2, lane); an[3] = hhw_frag(cb, ((tpn * 2 + 1) * 3 + kbn) * 2 + 1, lane);
             }
-            hhx_pair_to_frag(a[0], a[1], zh[c * 2 + tp], zl[c * 2 + tp]);
+            __builtin_amdgcn_sched_barrier(0);
+            HHX_MFMA(a[0], xh[kb], a0); HHX_MFMA(a[2], xh[kb], a1);
+            HHX_MFMA(a[1], xh[kb], a0); HHX_MFMA(a[3], xh[kb], a1);
+            HHX_MFMA(a[0], xl[kb], a0); HHX_MFMA(a[2], xl[kb], a1);
+            if (npw == 8) hhw_issue_some(gsrc, gdst, st_ < 2 ? 2 * st_ : st_ + 2, st_ < 2 ? 2 : 1); /* 2, 2, 1, 1, 1, 1 */
+            else if (st_ < npw) hhw_issue_some(gsrc, gdst, st_, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb == 2) hhx_pair_to_frag(a0, a1, zh[c * 2 + tp], zl[c * 2 + tp]);
         }
     }
 
-    /* ---- fight nets: y3 <- normalize(y3 + att_val(y3)) on hidden columns 0..149 = fragments 0..4; output tile j = half j & 1 of fragment j >> 1 ---- */
+    /* ---- fight nets: y3 <- normalize(y3 + att_val(y3)) on hidden columns 0..149 = fragments 0..4; output tile j = half j & 1 of fragment j >> 1.  Five chunks
+     *      of one tile pair each, steps of one k-block ---- */
     if constexpr (ATT) {
         hh_f32x4 y[10];
         float ssum = 0.0f;
 #pragma unroll
         for (int c = 0; c < 5; c++, ck++) {
             __syncthreads();
-            if (c < 4) { hhx_issue<5>(sp, buf[(ck + 1) & 1], wave, lane); sp += (size_t)20 * HHW_PIECE; }
-            else { hhx_issue<8>(sp, buf[(ck + 1) & 1], wave, lane); sp += (size_t)HHX_CHUNK * HHW_PIECE; }                           /* shared layer (0, 0) */
+            const int npw = c < 4 ? 5 : 8; /* next: attention tiles (20 pieces) | shared layer (0, 0) (32) */
+            const unsigned char *gsrc = sp + (size_t)wave * npw * HHW_PIECE + lane * 16;
+            unsigned char *gdst = buf[(ck + 1) & 1] + wave * npw * HHW_PIECE;
+            sp += (size_t)(npw * 4) * HHW_PIECE;
+            const unsigned char *cb = buf[ck & 1];
+            /* piece of (tile jj of the chunk, k-block kb, plane) = (jj * 5 + kb) * 2 + plane */
+            hh_f32x4 acc0 = hhx_bias_acc(bl + 1024 + 16 * (c * 2), g), acc1 = hhx_bias_acc(bl + 1024 + 16 * (c * 2 + 1), g);
+            hh_h8 an[4];
+            an[0] = hhw_frag(cb, 0, lane); an[1] = hhw_frag(cb, 1, lane); an[2] = hhw_frag(cb, 10, lane); an[3] = hhw_frag(cb, 11, lane);
+#pragma unroll
+            for (int kb = 0; kb < 5; kb++) {
+                hh_h8 a[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) a[u] = an[u];
+                hhw_need4(a);
+                if (kb + 1 < 5) {
+                    an[0] = hhw_frag(cb, (kb + 1) * 2, lane); an[1] = hhw_frag(cb, (kb + 1) * 2 + 1, lane);
+                    an[2] = hhw_frag(cb, (5 + kb + 1) * 2, lane); an[3] = hhw_frag(cb, (5 + kb + 1) * 2 + 1, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                HHX_MFMA(a[0], zh[kb], acc0); HHX_MFMA(a[2], zh[kb], acc1);
+                HHX_MFMA(a[1], zh[kb], acc0); HHX_MFMA(a[3], zh[kb], acc1);
+                HHX_MFMA(a[0], zl[kb], acc0); HHX_MFMA(a[2], zl[kb], acc1);
+                if (npw == 8) hhw_issue_some(gsrc, gdst, kb < 3 ? 2 * kb : kb + 3, kb < 3 ? 2 : 1); /* 2, 2, 2, 1, 1 */
+                else hhw_issue_some(gsrc, gdst, kb, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int jj = 0; jj < 2; jj++) {
                 const int j = c * 2 + jj;
-                hh_f32x4 acc = hhx_bias_acc(bl + 1024 + 16 * j, g);
-#pragma unroll
-                for (int kb = 0; kb < 5; kb++) {
-                    const hh_h8 wh = hhw_frag(buf[ck & 1], (jj * 5 + kb) * 2, lane), wl = hhw_frag(buf[ck & 1], (jj * 5 + kb) * 2 + 1, lane);
-                    HHX_MFMA(wh, zh[kb], acc);
-                    HHX_MFMA(wl, zh[kb], acc);
-                    HHX_MFMA(wh, zl[kb], acc);
-                    if (kb == 2) __builtin_amdgcn_sched_barrier(0); /* at most six fragments in flight beside the 168 registers of hidden row and tile outputs */
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                const hh_f32x4 &acc = jj ? acc1 : acc0;
                 const int f = j >> 1, e0 = 4 * (j & 1);
 #pragma unroll
                 for (int r = 0; r < 4; r++) { /* columns 150..159 are padding: zero first-layer outputs, zero weights, zero biases -> v = 0 */

@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hhmarl_2d_amd import _lib as L, pilots  # noqa: E402
 
-R = 32768
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 bank = pilots.PolicyBank.random_init(torch.device("cuda", 0), seed=3, max_rows=R)
 obs = torch.rand((R, 26), device="cuda")
 sel = torch.tensor([pilots.SEL_FIGHT1, pilots.SEL_FIGHT2], dtype=torch.uint8, device="cuda").repeat(R // 2).contiguous()

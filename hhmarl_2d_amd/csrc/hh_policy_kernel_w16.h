@@ -237,7 +237,12 @@ __device__ __forceinline__ void hhx_l2_l3(const hh_h8 (&zh)[16], const hh_h8 (&z
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             hh_h8 sh, sl;
+#ifdef HHX_ABL_SKIP_EPI /* tuning builds: no tanh / split behind a column group (wrong results) */
+            sh = zh[u]; sl = zl[u];
+            asm volatile("" :: "v"(acc[2 * u]), "v"(acc[2 * u + 1]));
+#else
             hhx_pair_to_frag(acc[2 * u], acc[2 * u + 1], sh, sl);
+#endif
             HHX_T(pf, 7);
 #pragma unroll
             for (int t = 0; t < NOUT; t++) {
@@ -263,11 +268,16 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
                                                  unsigned char *ldsb, const HhpSampleArgs *sa = nullptr) {
     constexpr int NTH = 64 * WV, R = 16 * WV, NPW = HHX_CHUNK / WV;
     constexpr int NB = WV == 8 ? 4 : 2, D = NB - 1; /* ring buffers; chunks requested ahead */
+#ifdef HHX_ABL_SKIP_P
+    const int has_att = 0;
+#else
+    const int has_att = N.has_att;
+#endif
     float *bl = reinterpret_cast<float *>(ldsb + HHX_OFF_BIAS_NB(NB));
     int *rows = reinterpret_cast<int *>(ldsb + HHX_OFF_ROWS_NB(NB));
     /* the stream in PROCESSING order: chunks 0, 1 = first layer, then (fight nets) 2, 3 = attention block, then the shared layer's 32; chunk j sits in
      * ring buffer j % NB and is requested while chunk j - D is worked on (the first D up front) */
-    const int att_skip = N.has_att ? 0 : HHX_ATT_PIECES / HHX_CHUNK;
+    const int att_skip = has_att ? 0 : HHX_ATT_PIECES / HHX_CHUNK;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ci = lane & 15, g = lane >> 4;
 
@@ -279,7 +289,7 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
     HHX_T0(pf);
     request(0, 0, NPW); /* chunk 0: L1 tiles 0..15 */
     for (int e = tid; e < 512; e += NTH) { bl[e] = N.b1[e]; bl[512 + e] = N.bs[e]; }
-    if (tid < 128) bl[1024 + tid] = N.has_att ? N.bov[tid] : 0.0f;
+    if (tid < 128) bl[1024 + tid] = has_att ? N.bov[tid] : 0.0f;
     if (tid < 32) bl[1152 + tid] = N.ba[tid];
     const int q_ = tile * R + wave * 16 + ci;
     const int row = q_ < cnt ? list[q_] : -1;
@@ -334,7 +344,12 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
             if (D == 1 || c == 1) { if (tp % (8 / NPW) == 0) request(c + D, tp / (8 / NPW), 1); }
             else if (tp < 4) request(1 + tp / 2, (tp & 1) * (NPW / 2), NPW / 2); /* the deep ring fills behind chunk 0: chunks 1, 2 whole (in order: they complete in order) ... */
             else request(D, (tp - 4) * (NPW / 4), NPW / 4);                         /* ... then chunk 3 */
+#ifdef HHX_ABL_SKIP_P /* tuning builds: no tanh / split behind the first layer, no attention block (wrong results): what does the shared layer take when nothing precedes it? */
+            zh[c * 8 + tp] = a[0]; zl[c * 8 + tp] = a[1];
+            asm volatile("" :: "v"(a0), "v"(a1));
+#else
             hhx_pair_to_frag(a0, a1, zh[c * 8 + tp], zl[c * 8 + tp]);
+#endif
         }
         HHX_T(pf, c == 0 ? 1 : 3);
     }
@@ -342,7 +357,7 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
     /* ---- fight nets: x <- normalize(x + Wov x + bov) on hidden columns 400..499.  K = fragments 12..15 (columns 384..511, the weights of
      *      384..399 are zero); output tile j (columns 400 + 16 j ..) is half (25 + j) & 1 of fragment (25 + j) >> 1.  Steps of (tile pair, k-block)
      *      like the shared layer's (two accumulators in turn instead of twelve dependent MFMAs on one), fragments a step ahead ---- */
-    if (N.has_att) {
+    if (has_att) {
         hh_f32x4 y[7];
         float ssum = 0.0f;
         auto fold = [&](int j, const hh_f32x4 &acc) {
@@ -416,7 +431,7 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
     HHX_T(pf, 4);
     /* ---- L2 (shared layer) + the output layer from its registers ---- */
     hh_f32x4 lacc[2];
-    hhx_l2_l3<2, WV, NB>(zh, zl, ldsb, N.has_att ? 4 : 2, st + (size_t)(HHX_L1_PIECES + HHX_ATT_PIECES) * HHW_PIECE,
+    hhx_l2_l3<2, WV, NB>(zh, zl, ldsb, has_att ? 4 : 2, st + (size_t)(HHX_L1_PIECES + HHX_ATT_PIECES) * HHW_PIECE,
                          st + (size_t)(HHX_L1_PIECES + HHX_ATT_PIECES + HHX_L2_PIECES) * HHW_PIECE, ldsb + HHX_OFF_L3_NB(NB), bl, wave, lane, g, lacc, pf);
 
     /* ---- logits: lane (row, g) holds output columns 16 t + 4 g + (0..3); they meet in LDS for the decode ---- */

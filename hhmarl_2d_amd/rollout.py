@@ -99,16 +99,24 @@ class PPORollout:
     per action component from the keyed RNG, its log-probability, and the centralised value branch on central_critic_observer's row —
     the other agent's observation, action inputs zero while sampling) and the world takes one `hh_step`; after T ticks `hh_gae` turns
     the rewards and value predictions into advantages and value targets (gamma 0.99, lambda 0.95: train_hetero.py:216), bootstrapping
-    the unfinished tail of every arena from one more value evaluation.  The 2 T + 2 launches of a collect are one HIP graph.
+    the unfinished tail of every arena from one more value evaluation.  The 2 T + 2 launches of a collect are one HIP graph (4 T + 2 at
+    curriculum levels 4-5, where the frozen opponents' networks run between the two halves of every step).
 
     Buffers (device, overwritten by every `collect`):  obs f32 [T+1, N, 2, D] (row t = what the policy saw at tick t), actions i8
     [T, N, 2, 4], logp f32 [T, N, 2], vf f32 [T+1, N, 2], reward f32 [T, N, 2], valid u8 [T, N, 2], done u8 [T, N], adv / target f32
     [T, N, 2].  `critic_rows(agent)` gives the flattened CUR_OBS rows the reference's critic is trained on (actions filled in the way
     on_postprocess_trajectory does)."""
 
-    def __init__(self, world, bank, T, gamma=0.99, lam=0.95, use_graph=True):
+    def __init__(self, world, bank, T, gamma=0.99, lam=0.95, use_graph=True, opponents=None):
+        """opponents: levels 4-5 only (env_hetero.py:160-172: frozen-policy opponents observe and act between the agents' actions and the tick) —
+        a `pilots.OpponentNets` of this world (its bank bound, so that hh_step_begin lists the opponents' rows itself) or any
+        callable(opp_obs f32 [N, 2, 30] on the device, None) -> int8 [N, 2, 4] that only enqueues work on the current stream"""
         from . import pilots
         assert world.cfg.env_kind == L.ENV_LOWLEVEL and world.n_agents == 2 and world.cfg.auto_reset, "PPORollout drives an auto-resetting LowLevelEnv world"
+        self.split = bool(world.cfg.ext_opp_actions)
+        if self.split and opponents is None:
+            raise ValueError("levels 4-5 fly frozen opponent policies (envs/env_base.py:312-398): pass opponents = pilots.OpponentNets(world, bank = ...)")
+        self.opponents = opponents
         self.w, self.bank, self.T, self.gamma, self.lam = world, bank, int(T), float(gamma), float(lam)
         N, D, dev = world.N, world.D, world.device
         esc = world.cfg.agent_mode == L.MODE_ESCAPE
@@ -125,6 +133,9 @@ class PPORollout:
         self.adv = z((self.T, N, 2), torch.float32)
         self.target = z((self.T, N, 2), torch.float32)
         self._tmp_act, self._tmp_logp = z((N, 2, 4), torch.int8), z((N, 2), torch.float32)
+        self._opp_obs = z((N, world.A - 2, 30), torch.float32) if self.split else None
+        # level 5 in fight mode: every arena observes in the mode of its own episode's draw (HH_OPP_MODE_EPISODE); otherwise fight mode
+        self._opp_mode = L.OPP_MODE_EPISODE if (world.cfg.level == 5 and world.cfg.agent_mode == L.MODE_FIGHT) else 0
         self.use_graph = use_graph
         self._graph = None
         self._started = False
@@ -141,7 +152,12 @@ class PPORollout:
         self.obs[0].copy_(self.obs[T])      # where the previous collect (or start) left every arena
         for t in range(T):                  # every launch reads and writes its tick's rows of the [T, ...] buffers in place
             self.bank.sample(self.obs[t], None, world=self.w, actions=self.actions[t], logp=self.logp[t], vf=self.vf[t])
-            self.w.step(self.actions[t], out=(self.obs[t + 1], self.reward[t], self.valid[t], self.done[t]))
+            out = (self.obs[t + 1], self.reward[t], self.valid[t], self.done[t])
+            if self.split:   # agents act -> the frozen opponents observe (the agents' same-tick weapon flags included) and act -> tick
+                self.w.step_begin(self.actions[t], self._opp_mode, opp_obs=self._opp_obs)
+                self.w.step_finish(self.opponents(self._opp_obs, None).contiguous(), out=out)
+            else:
+                self.w.step(self.actions[t], out=out)
         # bootstrap value of the observation after the last tick (an arena that just finished starts a new episode there: hh_gae cuts at done)
         self.bank.sample(self.obs[T], None, greedy=True, actions=self._tmp_act, logp=self._tmp_logp, vf=self.vf[T])
         st = C.c_void_p(torch.cuda.current_stream(self.w.device).cuda_stream)

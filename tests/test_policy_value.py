@@ -226,3 +226,46 @@ def test_ppo_rollout_driver_equals_a_step_by_step_replay():
     # the critic's training rows carry the stored actions (central_critic_rows: pinned against the reference's callbacks elsewhere)
     rows = ro.critic_rows(1)
     assert rows.shape == (T, N, 57) and torch.equal(rows[..., 0], second["actions"][:, :, 0, 0].double().div(12.0).float())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [4, 5])
+def test_ppo_rollout_at_the_self_play_levels_equals_a_step_by_step_replay(level):
+    """curriculum levels 4-5: the opponents fly frozen networks between the two halves of every step (env_hetero.py:160-172; level 5 draws the policy set per
+    arena and episode).  PPORollout with a pilots.OpponentNets (one HIP graph per collect) against the same ticks driven call by call on a second world"""
+    from hhmarl_2d_amd import _lib as L, pilots
+    from hhmarl_2d_amd.world import World, make_config
+    from hhmarl_2d_amd.rollout import PPORollout, gae
+    N, T = 1024, 20
+    kw = dict(n_arenas=N, level=level, seed=13, auto_reset=True, horizon=18, ext_opp_actions=True)
+    wa, wb = World(make_config(**kw), device=0), World(make_config(**kw), device=0)
+    bank = _trainable(9, max_rows=2 * N)
+    with pytest.raises(ValueError):
+        PPORollout(wa, bank, T)
+    ro = PPORollout(wa, bank, T, opponents=pilots.OpponentNets(wa, seed=4, skip_first=False))
+    ro.collect()
+    first = {k: getattr(ro, k).clone() for k in ("obs", "actions", "logp", "vf", "reward", "valid", "done", "adv", "target")}
+    ro.collect()
+    second = {k: getattr(ro, k).clone() for k in first}
+    assert first["done"].sum() > N // 2
+    nets_b = pilots.OpponentNets(wb, seed=4, skip_first=False)
+    mode = L.OPP_MODE_EPISODE if level == 5 else 0
+    sel = _sel("fight", N)
+    obs = wb.reset()
+    ks = set()
+    for rec in (first, second):
+        assert torch.equal(rec["obs"][0], obs)
+        for t in range(T):
+            a, lp, vf = bank.sample(obs, sel, world=wb)
+            assert torch.equal(a, rec["actions"][t]) and torch.equal(lp, rec["logp"][t]) and torch.equal(vf, rec["vf"][t])
+            oo = wb.step_begin(a, mode)
+            if level == 5:
+                ks |= set(wb.opp_policy().cpu().numpy().tolist())
+            obs, r, v, d = wb.step_finish(nets_b(oo, None).contiguous())
+            assert torch.equal(obs, rec["obs"][t + 1]) and torch.equal(r, rec["reward"][t]) and torch.equal(v, rec["valid"][t]) and torch.equal(d, rec["done"][t])
+        _, _, vfT = bank.sample(obs, sel, greedy=True)
+        assert torch.equal(vfT, rec["vf"][T])
+        adv, ret = gae(rec["reward"], rec["vf"], rec["valid"], rec["done"], 0.99, 0.95)
+        assert torch.equal(adv, rec["adv"]) and torch.equal(ret, rec["target"])
+    if level == 5:
+        assert ks == {3, 4, 5}

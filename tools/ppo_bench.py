@@ -1,6 +1,6 @@
 """hh_policy_sample alone and inside the device-resident PPO rollout (BASELINE configs[2]): microseconds per call with / without the
 value branch, greedy hh_policy_act beside it, and env-steps/s of `PPORollout.collect` (2 T + 2 launches in one HIP graph).
-    python tools/ppo_bench.py [arenas] [T]"""
+    python tools/ppo_bench.py [arenas] [T] [level: 3 | 4 | 5 — at 4 and 5 the frozen opponents' networks run between the two halves of every step]"""
 import os
 import sys
 import time
@@ -29,7 +29,8 @@ def timed(fn, n=50, warm=5):
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-    w = World(make_config(n_arenas=N, level=3, seed=1, auto_reset=True), device=0)
+    level = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    w = World(make_config(n_arenas=N, level=level, seed=1, auto_reset=True, ext_opp_actions=level >= 4), device=0)
     bank = pilots.PolicyBank.trainable_init(w.device, seed=0, max_rows=2 * N)
     obs = w.reset()
     sel = torch.tensor([pilots.SEL_FIGHT1, pilots.SEL_FIGHT2], dtype=torch.uint8, device=w.device).repeat(N, 1).contiguous()
@@ -41,7 +42,7 @@ def main():
     bank.act(obs, sel, act)
     us_greedy = timed(lambda: bank.act(obs, None, act))
     print(f"{2 * N} rows: hh_policy_sample actor + value {us_full:.1f} us | actor + draw only {us_actor:.1f} us | hh_policy_act (greedy, frozen form) {us_greedy:.1f} us")
-    ro = PPORollout(w, bank, T)
+    ro = PPORollout(w, bank, T, opponents=pilots.OpponentNets(w, seed=2, skip_first=False) if level >= 4 else None)
     ro.collect(); ro.collect()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -50,7 +51,7 @@ def main():
         ro.collect()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    print(f"PPORollout.collect: {N} arenas x {T} ticks in {dt * 1e3:.2f} ms = {N * T / dt:.3e} env-steps/s ({dt / T * 1e6:.1f} us per tick)")
+    print(f"PPORollout.collect (level {level}): {N} arenas x {T} ticks in {dt * 1e3:.2f} ms = {N * T / dt:.3e} env-steps/s ({dt / T * 1e6:.1f} us per tick)")
 
 
 if __name__ == "__main__":

@@ -68,8 +68,6 @@ def parse_args():
                                                         "log-probability + the centralised value branch on central_critic_observer's rows, then hh_step")
     ap.add_argument("--no-graph", action="store_true", help="hier/rollout: launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--phases", action="store_true", help="hier with --pilot tape: the 34-launch phase path instead of the one-launch macro step")
-    ap.add_argument("--coop", action="store_true", help="hier with --pilot net: the whole commander step as ONE cooperative launch (hh_hl_step_nets: world phases + policy "
-                                                         "tiles behind grid barriers) instead of the 66-launch graph — correct (tests/test_gpu_hier_nets.py) but 3x slower: A/B only")
     ap.add_argument("--streams", type=int, default=0, help="rollout / hier --pilot net: split the arenas into this many sub-worlds (disjoint global arena ids, "
                                                                  "bit-identical to one world) stepped on as many HIP streams inside the one graph, so that one sub-world's world "
                                                                  "launches run under another's policy kernel (0 = the workload's default)")
@@ -534,7 +532,7 @@ def main_hier(args, R=None):
     from hhmarl_2d_amd.pilots import MLPPilot, NetPilot, RandomPilot, TapePilot
     from hhmarl_2d_amd.sharding import ShardedWorld
     N = args.arenas or 8192
-    K = (args.streams or DEFAULT_STREAMS["hier_net"]) if (args.pilot == "net" and not getattr(args, "coop", False)) else 1
+    K = (args.streams or DEFAULT_STREAMS["hier_net"]) if args.pilot == "net" else 1
     assert N % K == 0, "--streams must divide the arena count"
     n_sub = N // K
     if K > 1:
@@ -546,10 +544,6 @@ def main_hier(args, R=None):
         pilot = TapePilot(R.dev, N, 6, seed=args.seed + R.rank)
     elif args.pilot == "random":
         pilot = RandomPilot(R.dev, args.seed + R.rank)
-    elif args.pilot == "net" and args.coop:
-        from hhmarl_2d_amd.pilots import PolicyBank
-        pilot = None
-        coop_bank = PolicyBank.random_init(R.dev, seed=args.seed, max_rows=N * 6)   # the whole commander step is ONE cooperative launch
     elif args.pilot == "net":
         pilot = NetPilot(w, seed=args.seed, bind=os.environ.get("HH_BENCH_NO_BIND", "0") != "1")   # HH_BENCH_NO_BIND=1: binning pass per call (A/B)
     else:
@@ -564,8 +558,7 @@ def main_hier(args, R=None):
     # actions from a resident tape: the whole commander step is ONE persistent launch (hh_hl_rollout).
     cmd_static = cmds[0].clone()
     graph = None
-    coop = args.pilot == "net" and getattr(args, "coop", False)
-    one_launch = (args.pilot == "tape" and not args.phases) or coop
+    one_launch = args.pilot == "tape" and not args.phases
     if not args.no_graph and not one_launch:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -582,12 +575,6 @@ def main_hier(args, R=None):
     def run(n):
         for _ in range(n):
             k = state["k"]
-            if coop:
-                w.hl_step_nets(coop_bank, cmds[k % 64], out=out)
-                state["k"] = k + 1
-                if state["k"] % 16 == 0:
-                    sw.log_episode_stats(log_side)
-                continue
             if one_launch:
                 w.hl_rollout(cmds[k % 64], pilot.bank[k % pilot.bank.shape[0]], out=out)
                 state["k"] = k + 1
@@ -623,7 +610,7 @@ def main_hier(args, R=None):
     gpu_s = e0.elapsed_time(e1) * 1e-3
     steps = args.steps
     value = N * R.world * steps / dt
-    tape_launch = one_launch and not coop
+    tape_launch = one_launch
     tick_bytes = ALGO_BYTES_3V3_TICK_TAPE if tape_launch else ALGO_BYTES_3V3_TICK
     algo_bytes = tick_bytes * ticks + ALGO_BYTES_3V3_CMD_FIXED * N * steps
     achieved = algo_bytes / gpu_s / 1e9
@@ -637,8 +624,7 @@ def main_hier(args, R=None):
                                f"pilots = {PILOT_DESC[args.pilot]}, auto-reset (BASELINE configs[{3 if R.world == 1 else 4}])", "arenas_per_gpu": N,
                    "parallelism": f"arena-sharded x{R.world}, no data-path collective; logging all-gather of [N, 3] episode statistics every 16 commander steps on a side stream"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": ("hh_k_hier_nets (one cooperative launch per commander step: world phases + policy tiles behind grid barriers)" if coop else
-                                                 f"{w.kernel_instance(1)} (one persistent launch per commander step)" if one_launch else
+                     "traffic": None, "kernel": (f"{w.kernel_instance(1)} (one persistent launch per commander step)" if one_launch else
                                                  f"{w.kernel_name()} (every phase launch of the macro step, plus the pilots' kernels if any)"),
                      "algorithmic_bytes": algo_bytes,
                      "note": (f"{tick_bytes} B per arena-tick actually run + 424 B per commander step (SURVEY.md 8d" +
@@ -657,10 +643,6 @@ def main_hier(args, R=None):
             line["roofline"]["traffic_source"] = "profiles/r03_hier8192_traffic.json: builder's rocprofv3 --pmc passes of this kernel instance (bytes per commander step), NOT measured by this run"
     if not one_launch:
         line["launches_per_step"] = 2 + 16 * (4 if args.pilot in ("net", "mlp", "random") else 2)
-    if coop:
-        assert w.hl_step_nets_ok(), "a grid barrier of the cooperative step timed out"
-        line["launches_per_step"] = 1
-        coop_bank.close()
     if hasattr(pilot, "close"):
         pilot.close()
     if not own:
@@ -814,7 +796,7 @@ def configs4(args, R):
         first = None if sw.last_stats is None else [float(sw.last_stats[i * N4, 0]) for i in range(R.world)]   # DryWorld reports the global arena id: ranks in order
         return {"dry_run": True, "arenas_per_gpu": N4, "n_gpus": R.world, "gathered_rows": rows, "first_global_arena_of_each_block": first}
     a = copy.copy(args)
-    a.workload, a.pilot, a.arenas, a.steps, a.warmup, a.spinup, a.phases, a.coop, a.streams = "hier", "tape", N4, 30, 6, 0.3, False, False, 0
+    a.workload, a.pilot, a.arenas, a.steps, a.warmup, a.spinup, a.phases, a.streams = "hier", "tape", N4, 30, 6, 0.3, False, 0
     try:
         line = main_hier(a, R)
     except Exception as e:   # noqa: BLE001 — reported, never silently dropped

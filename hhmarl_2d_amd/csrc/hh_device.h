@@ -78,6 +78,7 @@ struct DevPtrs {
     int *last_len;                                       /* [N] */
     int8_t *last_outcome;                                /* [N] */
     uint32_t *ev_mask;                                   /* [N] */
+    uint32_t *act_fault;                                 /* [N] sticky: a step of this arena ran on a sanitised action word (hh_action_faults) */
     double *acc_rew;                                     /* [U] rewards accumulated over a HighLevelEnv macro step */
     int *eval_last, *eval_tot;                           /* [N][HH_EVAL_K] eval_info of the last commander step / summed since cleared */
     /* optional trajectory ring buffer (hh_trace_enable; cmano_simulator.py:125-130,159-162 record_unit_trace): the first trace_K
@@ -151,6 +152,21 @@ __device__ __forceinline__ HhBinTicket hh_bin_rows_issue(int *__restrict__ count
 __device__ __forceinline__ void hh_bin_rows_finish(const HhBinTicket &t, int *__restrict__ lists, int max_rows, int row, int slot) {
     const int base = __shfl(t.base, slot > 0 ? slot - 1 : 0);
     if (slot > 0 && base + t.rank < max_rows) lists[(size_t)(slot - 1) * max_rows + base + t.rank] = row;
+}
+
+/* The lane's action word -> its four components, sanitised where it is loaded (hh_spec.h: hh_action_sanitize — heading / speed component
+ * clamped to their ranges, fire components as booleans); `fault` collects "a component of a CONSUMED word was out of range" for
+ * hh_act_fault_commit.  consumed = the lane's unit is alive in a running arena and it is its side's turn: exactly the rows the reference
+ * hands to _take_base_action (rows of dead units / finished arenas / the other side may hold anything and never raise a fault). */
+__device__ __forceinline__ void hh_act_unpack(int w, int8_t (&act)[4], int &fault, bool consumed) {
+    int bad = 0;
+    const uint32_t q = hh_action_sanitize((uint32_t)w, &bad);
+    fault |= consumed ? bad : 0;
+    act[0] = (int8_t)(q & 0xff); act[1] = (int8_t)((q >> 8) & 0xff); act[2] = (int8_t)((q >> 16) & 0xff); act[3] = (int8_t)((q >> 24) & 0xff);
+}
+/* once per launch, rare body: the arena's sticky flag (never cleared by a step; hh_action_faults reads / clears it) */
+__device__ __forceinline__ void hh_act_fault_commit(const DevPtrs &P, int n, bool owner, int fault) {
+    if (owner && fault) atomicOr(&P.act_fault[n], 1u);
 }
 
 /* one trace row of the lane's unit: lat, lon, heading, speed, alive, rocket lat, rocket lon, rocket alive + 16 * episode */

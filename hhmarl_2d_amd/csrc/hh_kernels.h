@@ -1129,6 +1129,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
     if (run == HH_RUN_RESET && P.pol_lut && blockIdx.x == 0 && tid <= 8) P.pol_counts[tid * HH_BIN_STRIDE] = 0; /* rows nobody consumed */
     bool need_reset = run == HH_RUN_RESET && active && (mask == nullptr || mask[n]);
     uint32_t evm_last = 0;
+    int act_fault = 0; /* some action word of this lane was out of range and ran sanitised (hh_act_unpack) */
     int tcur = (P.trace != nullptr && active && n < P.trace_K) ? P.trace_pos[n] : 0; /* trace cursor of the lane's arena */
     if (run == HH_RUN_ROLLOUT || run >= HH_RUN_LL_BEGIN) { /* pair table of the pre-tick state */
         publish_obs(c, sh, tid, m);
@@ -1145,7 +1146,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
             int8_t act[4] = {0, 0, 0, 0};
             if (active && s < c.nA) {
                 int w = *reinterpret_cast<const int *>(actions + ((size_t)n * c.nA + s) * 4);
-                act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
+                hh_act_unpack(w, act, act_fault, running && m.alive);
             }
             double pre = 0.0, os0 = 0.0;
             int valid = 0;
@@ -1201,14 +1202,14 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
             if (has_act) {
                 int w = act_next;
                 if (t + 1 < T) act_next = *reinterpret_cast<const int *>(actions + (((size_t)(t + 1) * c.N + n) * c.n_ctrl + s) * 4);
-                act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
+                hh_act_unpack(w, act, act_fault, !ar.done && m.alive);
             }
             const bool was_running = active && !ar.done;
             if constexpr (SPLIT) {
                 if (run == HH_RUN_LL_FINISH) {
                     if (active && s >= c.nA) {
                         int w = *reinterpret_cast<const int *>(actions + ((size_t)n * c.nO + (s - c.nA)) * 4);
-                        act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
+                        hh_act_unpack(w, act, act_fault, was_running && m.alive);
                     }
                     double pre = 0.0, os0 = 0.0;
                     int vl = 0;
@@ -1303,6 +1304,7 @@ __global__ __launch_bounds__(B, W) void hh_k_world(DevPtrs P, DevCfg c, int run,
         /* OR-reduce the per-lane event bits of the last tick into the arena word */
         __syncthreads();
         if (active && evm_last) atomicOr(&P.ev_mask[n], evm_last);
+        hh_act_fault_commit(P, n, active, act_fault);
     }
 }
 

@@ -169,11 +169,12 @@ struct HlLane {
     int tcur;       /* trace cursor of the lane's arena (hh_trace_enable) */
 };
 
-__device__ __forceinline__ void hl_load_act(const int8_t *__restrict__ actions, size_t row, bool active, int8_t (&act)[4]) {
+/* consumed: the row is one the reference hands to _take_base_action in this phase (hh_device.h: hh_act_unpack) */
+__device__ __forceinline__ void hl_load_act(const int8_t *__restrict__ actions, size_t row, bool active, int8_t (&act)[4], int &fault, bool consumed) {
     act[0] = act[1] = act[2] = act[3] = 0;
     if (active) {
         const int w = *reinterpret_cast<const int *>(actions + row * 4);
-        act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
+        hh_act_unpack(w, act, fault, consumed);
     }
 }
 
@@ -391,6 +392,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
     }
     HH_HPROF(2); /* pair table */
     int obs_side = -1; /* which side's pilot observations this launch emits */
+    int act_fault = 0;  /* a consumed action word was out of range and ran sanitised (hh_act_unpack) */
     /* a bound policy bank (hh_bind_policy): this launch's pilot rows are binned by network here.  The selector of a row is known
      * as soon as the phase body is through (policy type from the commander's / the opponent's own choice, env_hier.py:100-112) — for
      * HL_AGENTS_ACT, which kills nobody, before it — so the list slot is REQUESTED there and used after the observation tile has
@@ -410,13 +412,13 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
         if (P.pol_lut && pilot_obs) bin_issue(0);
     } else if (phase == HH_HL_AGENTS_ACT) {
         int8_t act[4];
-        hl_load_act(actions, u, active, act);
+        hl_load_act(actions, u, active, act, act_fault, ar.hl_run && m.alive && agent);
         if (P.pol_lut && pilot_obs) bin_issue(1);
         hl_do_agents_act<A, B, W>(c, sh, tid, base, s, active, L, act);
         obs_side = 1;
     } else if (phase == HH_HL_TICK) {
         int8_t act[4];
-        hl_load_act(actions, u, active, act);
+        hl_load_act(actions, u, active, act, act_fault, ar.hl_run && m.alive && !agent);
         const int ran = hl_do_tick<A, B, W, false>(P, c, sh, tid, g, base, s, n, active, L, act);
         if (s == 0 && ran && ar.hl_run && running_count) atomicAdd(running_count, 1);
         {   /* cumulative arena-ticks of this world (hh_hl_tick_count): one atomic per wave */
@@ -513,6 +515,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
         if (active && s == 0 && phase == HH_HL_AGENTS_ACT && ar.hl_run) P.ev_mask[n] = 0;
         __syncthreads();
         if (active && L.evm) atomicOr(&P.ev_mask[n], L.evm);
+        hh_act_fault_commit(P, n, active, act_fault);
     }
 }
 
@@ -560,6 +563,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier_macro(DevPtrs P, DevCfg c_in, 
     hl_do_begin<A, B>(c, sh, tid, base, s, n, active, L, cmd);
     int ticks = 0;
     uint32_t evm_last = 0;
+    int act_fault = 0;
     /* the action word of the next sub-step is requested a sub-step ahead (one wave per SIMD cannot hide the round trip) */
     int act_next = active ? *reinterpret_cast<const int *>(tape + u * 4) : 0;
     for (int sub = 0; sub < 16; sub++) {
@@ -567,8 +571,8 @@ __global__ __launch_bounds__(B, W) void hh_k_hier_macro(DevPtrs P, DevCfg c_in, 
         const int w = act_next;
         if (active && sub + 1 < 16) act_next = *reinterpret_cast<const int *>(tape + ((size_t)(sub + 1) * U + u) * 4);
         int8_t act[4];
-        act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
         const bool running = active && L.ar.hl_run;
+        hh_act_unpack(w, act, act_fault, running && L.m.alive);
         if (running) L.evm = 0;
         hl_do_agents_act<A, B, W>(c, sh, tid, base, s, active, L, act);
         ticks += hl_do_tick<A, B, W, true>(P, c, sh, tid, g, base, s, n, active, L, act);
@@ -594,6 +598,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier_macro(DevPtrs P, DevCfg c_in, 
     if (active && s == 0 && ticks) P.ev_mask[n] = 0;
     __syncthreads();
     if (active && ticks && evm_last) atomicOr(&P.ev_mask[n], evm_last);
+    hh_act_fault_commit(P, n, active, act_fault);
 }
 
 #endif /* HH_KERNELS_HIER_H */

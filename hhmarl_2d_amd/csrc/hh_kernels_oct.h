@@ -925,6 +925,7 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_macro_oct(DevPtrs P, DevCfg c
     oct_do_begin(c, tb, L, n, active, H, cmd);
     int ticks = 0;
     uint32_t evm_last = 0;
+    int act_fault = 0; /* a consumed action word was out of range and ran sanitised (hh_act_unpack) */
     /* the action word of the next sub-step is requested a sub-step ahead (one wave per SIMD cannot hide the round trip) */
     int act_next = L.exists ? *reinterpret_cast<const int *>(tape + u * 4) : 0;
     o_wave_sync();
@@ -934,8 +935,8 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_macro_oct(DevPtrs P, DevCfg c
         const int w = act_next;
         if (L.exists && sub + 1 < 16) act_next = *reinterpret_cast<const int *>(tape + ((size_t)(sub + 1) * U + u) * 4);
         int8_t act[4];
-        act[0] = (int8_t)(w & 0xff); act[1] = (int8_t)((w >> 8) & 0xff); act[2] = (int8_t)((w >> 16) & 0xff); act[3] = (int8_t)((w >> 24) & 0xff);
         const bool running = active && H.ar.hl_run;
+        hh_act_unpack(w, act, act_fault, running && L.exists && H.m.alive);
         if (running) H.evm = 0;
         /* both sides' _take_base_action in one pass: a side's action reads nothing the other side's action writes (positions do not
          * move, the missile_wait draws are keyed by unit), and launches are numbered in unit id order either way */
@@ -972,6 +973,7 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_macro_oct(DevPtrs P, DevCfg c
     if (active && L.p == 0 && ticks) P.ev_mask[n] = 0;
     __syncthreads();
     if (L.exists && ticks && evm_last) atomicOr(&P.ev_mask[n], evm_last);
+    hh_act_fault_commit(P, n, L.exists, act_fault);
 }
 
 /* env_hier.py:100-112 lowlevel_state of the lane's unit -> 30 floats (zero padded) + policy type (hl_pilot_obs of hh_kernels_hier.h) */
@@ -1023,8 +1025,7 @@ __device__ __forceinline__ int oct_pilot_obs(const DevCfg &c, const OTab &t, con
 /* ---- the phases one launch each, for callers whose pilot networks run BETWEEN them (hh_k_hier of hh_kernels_hier.h on the
  * register table): HL_BEGIN / HL_AGENTS_ACT / HL_TICK / HL_END.  Same results, bit for bit; HL_REFRESH / HL_RESET stay on the
  * generic kernel (the state in HBM is the same). ---- */
-/* one phase for the eight arenas grp * 8 .. grp * 8 + 7, executed by ONE wave (tid = lane): the body of hh_k_hier_oct, also called by the
- * one-launch commander step with the networks inside (hh_kernels_coop.h), where several waves of a workgroup run it side by side */
+/* one phase for the eight arenas grp * 8 .. grp * 8 + 7, executed by ONE wave (tid = lane): the body of hh_k_hier_oct */
 template <int W>
 __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c, int phase, int grp, int tid, OctShared &sh, const int8_t *__restrict__ cmd,
                                                const int8_t *__restrict__ actions, float *__restrict__ pilot_obs, uint8_t *__restrict__ pilot_mode,
@@ -1069,6 +1070,7 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
     else oct_tables<true>(m, pub, L, tb);
     o_wave_sync();
     int obs_side = -1; /* which side's pilot observations this launch emits */
+    int act_fault = 0;  /* a consumed action word was out of range and ran sanitised (hh_act_unpack) */
     /* a bound policy bank (hh_bind_policy): this launch's pilot rows are binned by network here (see hh_k_hier) */
     int pslot = 0;
     HhBinTicket bt{0, 0};
@@ -1084,7 +1086,7 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
         if (P.pol_lut && pilot_obs) bin_issue(0);
     } else if (phase == HH_HL_AGENTS_ACT) {
         int8_t act[4];
-        hl_load_act(actions, u, L.exists, act);
+        hl_load_act(actions, u, L.exists, act, act_fault, active && ar.hl_run && m.alive && agent);
         if (P.pol_lut && pilot_obs) bin_issue(1);
         const bool running = active && ar.hl_run;
         act_oct<(W >= 2), true>(c, sh, tid, L, running, m, ar, act, agent, tb, pub, H.evm);
@@ -1092,7 +1094,7 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
         obs_side = 1;
     } else if (phase == HH_HL_TICK) {
         int8_t act[4];
-        hl_load_act(actions, u, L.exists, act);
+        hl_load_act(actions, u, L.exists, act, act_fault, active && ar.hl_run && m.alive && !agent);
         const bool running = active && ar.hl_run;
         act_oct<(W >= 2), false>(c, sh, tid, L, running, m, ar, act, !agent, tb, pub, H.evm);
         const int ran = oct_do_tick<(W >= 2), true>(P, c, sh, tid, L, n, active, H, tb, pub);
@@ -1156,6 +1158,7 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
         if (active && L.p == 0 && phase == HH_HL_AGENTS_ACT && ar.hl_run) P.ev_mask[n] = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the clear is acknowledged before this wave's atomics leave (one wave per arena group) */
         if (L.exists && H.evm) atomicOr(&P.ev_mask[n], H.evm);
+        hh_act_fault_commit(P, n, L.exists, act_fault);
     }
 }
 

@@ -1022,6 +1022,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         ar.done = 1;
     }
     uint32_t evm_last = 0;
+    int act_fault = 0; /* a consumed action word was out of range and ran sanitised (hh_act_unpack) */
     {
         const double speed_table[11] = HH_ROCKET_SPEED_TABLE;
         if (tid < 11) sh.rk_speed[tid] = speed_table[tid];
@@ -1045,8 +1046,8 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
     for (int t = 0; t < T; t++) {
         StepOut so;
         int8_t act[4];
-        act[0] = (int8_t)(act_cur & 0xff); act[1] = (int8_t)((act_cur >> 8) & 0xff); act[2] = (int8_t)((act_cur >> 16) & 0xff); act[3] = (int8_t)((act_cur >> 24) & 0xff);
         const bool was_running = active && !ar.done;
+        hh_act_unpack(act_cur, act, act_fault, has_act & was_running & (m.alive != 0));
         tick_quad<(W >= 2), DUAL>(c, sh, tid, g, s, base, active, helper, m, ar, act, tb, pub, nbc, so, evm_last HH_PROF_PASS);
         const int done_now = ar.done;
         if constexpr (TWO) { /* post the agents' rows as early as they exist: the LDS stores drain behind the work below */
@@ -1133,6 +1134,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
     }
     q_wave_sync();
     if (active && evm_last) atomicOr(&P.ev_mask[n], evm_last);
+    hh_act_fault_commit(P, n, active, act_fault);
 }
 
 #endif /* HH_KERNELS_QUAD_H */

@@ -247,7 +247,7 @@ __device__ __forceinline__ bool hhp_locate(const int (&cn)[HH_POLICY_MAX_NETS], 
  * out level.  Kept as an A/B instance; what separates both forms from the matrix pipe's 30 k cycles per 64 rows is that a tile's
  * epilogues (tanh, hi/lo split, 2-byte LDS scatter) and GEMMs alternate instead of overlapping. */
 /* the forward over the tiles first_tile, first_tile + tile_stride, ... of the row lists (cn = rows per network): the body of
- * hh_k_policy_h, also called by the one-launch commander step (hh_kernels_coop.h) between two grid barriers */
+ * hh_k_policy_h */
 template <int RH>
 __device__ __forceinline__ void hhp_forward_tiles(const HhpBank &bank, const HhpBankH &bankh, const int (&cn)[HH_POLICY_MAX_NETS], const float *__restrict__ obs,
                                                   int obs_stride, const int *__restrict__ lists, int max_rows, int8_t *__restrict__ actions,

@@ -65,9 +65,6 @@ struct hh_world {
     int apw;      /* HH_APW=16: never pick the 8-arenas-per-wave form of the two-wave kernel */
     void *trace_mem; /* trajectory ring buffer + cursors (hh_trace_enable), separate allocation */
     struct hh_policy *bound_policy; /* hh_bind_policy: the bank whose row lists P.pol_* point into (it points back at this world) */
-    void *coop_mem;  /* hh_hl_step_nets: pilot rows [N,6,30] f32 | pilot actions [N,6,4] i8 | barrier, error flag, running counts, two counter sets */
-    int coop_grid;   /* workgroups of the cooperative launch (co-resident by construction) */
-    int coop_timed_out; /* hh_hl_step_nets_status saw the error flag: the next hh_hl_step_nets clears it */
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -125,7 +122,6 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     w->block = HH_BLOCK;
     w->trace_mem = nullptr;
     w->bound_policy = nullptr;
-    w->coop_mem = nullptr; w->coop_grid = 0; w->coop_timed_out = 0;
     { const char *fw = getenv("HH_FORCE_W"); w->force_w = fw ? atoi(fw) : 0; }
     { const char *e = getenv("HH_APW"); w->apw = e ? atoi(e) : 0; }
     { const char *nq = getenv("HH_NO_QUAD"); w->no_quad = nq ? atoi(nq) : 0; }
@@ -142,7 +138,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     size_t o_rk[4]; for (int k = 0; k < 4; k++) o_rk[k] = take(U * 8);
     size_t o_rkp = take(U * 8), o_ar = take(N * 16), o_ep = take(N * 8), o_lr = take(N * 4), o_ll = take(N * 4);
     size_t o_lo = take(N), o_ev = take(N * 4), o_acc = take(U * 8), o_cnt = take(256);
-    size_t o_el = take(N * HH_EVAL_K * 4), o_et = take(N * HH_EVAL_K * 4);
+    size_t o_el = take(N * HH_EVAL_K * 4), o_et = take(N * HH_EVAL_K * 4), o_af = take(N * 4);
     w->slab_bytes = off;
     {
         hipError_t e = hipMalloc(&w->slab, off);
@@ -163,6 +159,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     P.rk_pack = (int2 *)(b + o_rkp); P.ar_pack = (int4 *)(b + o_ar); P.ep_ret = (double *)(b + o_ep);
     P.last_ret = (float *)(b + o_lr); P.last_len = (int *)(b + o_ll); P.last_outcome = (int8_t *)(b + o_lo);
     P.ev_mask = (uint32_t *)(b + o_ev);
+    P.act_fault = (uint32_t *)(b + o_af);
     P.acc_rew = (double *)(b + o_acc);
     P.eval_last = (int *)(b + o_el); P.eval_tot = (int *)(b + o_et);
     w->counter = (int *)(b + o_cnt);
@@ -185,7 +182,6 @@ extern "C" int hh_world_destroy(hh_world *w) {
     DeviceGuard guard_(w->device);
     (void)hipFree(w->slab);
     if (w->trace_mem) (void)hipFree(w->trace_mem);
-    if (w->coop_mem) (void)hipFree(w->coop_mem);
     delete w;
     return HH_OK;
 }
@@ -450,6 +446,22 @@ extern "C" int hh_get_event_masks(hh_world *w, uint32_t *masks, void *stream) {
     hipStream_t st = (hipStream_t)stream; /* ordered after the step on the caller's stream; waits for that stream only */
     HIPCHK(hipMemcpyAsync(masks, w->P.ev_mask, (size_t)w->dc.N * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    return HH_OK;
+}
+
+/* sticky per-arena "a step ran on a sanitised action word" flags (hh_abi.h) */
+__global__ __launch_bounds__(256) void hh_k_action_faults(int N, uint32_t *__restrict__ flags, uint8_t *__restrict__ out, int clear) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    if (out) out[n] = flags[n] ? 1 : 0;
+    if (clear) flags[n] = 0;
+}
+
+extern "C" int hh_action_faults(hh_world *w, uint8_t *out, int32_t clear, void *stream) {
+    if (!w || (!out && !clear)) { g_err = "hh_action_faults: nothing to do (no output buffer, no clear)"; return HH_E_ARG; }
+    HH_GUARD(w);
+    hipLaunchKernelGGL(hh_k_action_faults, dim3((w->dc.N + 255) / 256), dim3(256), 0, (hipStream_t)stream, w->dc.N, w->P.act_fault, out, clear);
+    HIPCHK(hipGetLastError());
     return HH_OK;
 }
 
@@ -740,98 +752,3 @@ extern "C" int hh_hl_commands(hh_world *w, int8_t *out /* [host] [N, A] */) {
 
 /* ---- frozen pilot / opponent networks (C ABI in include/hh_policy.h) ---- */
 #include "hh_policy_kernel.h"
-
-/* ---- HighLevelEnv.step with the pilot networks inside: one cooperative launch per commander step (hh_kernels_coop.h) ---- */
-#include "hh_kernels_coop.h"
-
-struct CoopLayout { size_t o_obs, o_act, o_ctl, total; };
-static CoopLayout hh_coop_layout(int N) {
-    CoopLayout L;
-    L.o_obs = 0;
-    L.o_act = align_up((size_t)N * 6 * 30 * sizeof(float), 256);
-    L.o_ctl = align_up(L.o_act + (size_t)N * 6 * 4, 256);
-    L.total = L.o_ctl + (128 + 2 * HH_COOP_SET_INTS) * sizeof(int) + 256;
-    return L;
-}
-
-extern "C" int hh_hl_step_nets(hh_world *w, hh_policy *p, const int8_t *commander_actions, float *obs, float *reward, uint8_t *reward_valid,
-                               uint8_t *done, void *stream) {
-    if (!w || !p || !commander_actions) { g_err = "null argument"; return HH_E_ARG; }
-    const DevCfg &c = w->dc;
-    if (w->cfg.env_kind != HH_ENV_HIGHLEVEL || c.A != 6) { g_err = "not a HighLevelEnv (3-vs-3) world"; return HH_E_ARG; }
-    if (p->device != w->device) { g_err = "hh_hl_step_nets: world and policy bank live on different devices"; return HH_E_ARG; }
-    if (p->n_nets == 0) { g_err = "hh_hl_step_nets: no network loaded"; return HH_E_ARG; }
-    if ((long long)p->max_rows < (long long)c.N * 6) { g_err = "hh_hl_step_nets: the bank's max_rows is smaller than n_arenas x 6"; return HH_E_ARG; }
-    if (p->fp32) { g_err = "hh_hl_step_nets runs the split-fp16 policy tiles (unset HH_POLICY_FP32)"; return HH_E_ARG; } /* the bank's tile width does not matter: the step always walks 32-row tiles */
-    HH_GUARD(w);
-    const CoopLayout Lt = hh_coop_layout(c.N);
-    if (!w->coop_mem) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_hier_nets), hipFuncAttributeMaxDynamicSharedMemorySize, HHPH_LDS_BYTES(1)));
-        int per_cu = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(hh_k_hier_nets), 256, HHPH_LDS_BYTES(1)));
-        if (per_cu < 1) { g_err = "hh_hl_step_nets: the kernel does not fit a compute unit"; return HH_E_HIP; }
-        w->coop_grid = per_cu * (w->n_simd / 4);
-        void *m = nullptr;
-        HIPCHK(hipMalloc(&m, Lt.total));
-        HIPCHK(hipMemset(m, 0, Lt.total));
-        w->coop_mem = m;
-    }
-    char *base = (char *)w->coop_mem;
-    int *ctl_i = reinterpret_cast<int *>(base + Lt.o_ctl);
-    CoopCtl ctl;
-    ctl.bar_cnt = reinterpret_cast<unsigned *>(ctl_i); ctl.bar_gen = reinterpret_cast<unsigned *>(ctl_i + 32);   /* own cache lines */
-    ctl.err = ctl_i + 16; ctl.run_cnt = ctl_i + 48 /* 16 used (+ 3 of the profiling build) */; ctl.counts = ctl_i + 128;
-    CoopParams prm;
-    prm.P = w->P;
-    prm.P.pol_lut = p->lut; prm.P.pol_lists = p->lists; prm.P.pol_max_rows = p->max_rows; prm.P.pol_counts = ctl.counts;
-    prm.c = c;
-    prm.bank = p->bank; prm.bankh = p->bankh; prm.n_nets = p->n_nets;
-    prm.ctl = ctl;
-    prm.cmd = commander_actions;
-    prm.pilot_obs = reinterpret_cast<float *>(base + Lt.o_obs);
-    prm.actions = reinterpret_cast<int8_t *>(base + Lt.o_act);
-    prm.obs_out = obs; prm.reward_out = reward; prm.valid_out = reward_valid; prm.done_out = done;
-    prm.counters = w->counter;
-    /* no more workgroups than there is work for: a world phase has ceil(N / 8) wave-sized groups, a policy phase at most N * 3 / 32 + n_nets tiles */
-    int grid = w->coop_grid;
-    const int tiles = (c.N * 3 + 31) / 32 + p->n_nets, groups = (c.N + 7) / 8;
-    const int want = tiles > (groups + 3) / 4 ? tiles : (groups + 3) / 4;
-    if (grid > want) grid = want;
-    if (grid < 1) grid = 1;
-    /* a barrier that timed out in an earlier step leaves the error flag set and the arrival count / generation out of step: every step starts
-     * after a reported timeout (hh_hl_step_nets_status) starts from a clean control block (three words on the stream, ahead of the launch) */
-    if (w->coop_timed_out) {
-        HIPCHK(hipMemsetAsync(ctl.bar_cnt, 0, sizeof(unsigned), (hipStream_t)stream));
-        HIPCHK(hipMemsetAsync(ctl.bar_gen, 0, sizeof(unsigned), (hipStream_t)stream));
-        HIPCHK(hipMemsetAsync(ctl.err, 0, sizeof(int), (hipStream_t)stream));
-        w->coop_timed_out = 0;
-    }
-    void *args[] = {&prm};
-    HIPCHK(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(hh_k_hier_nets), dim3(grid), dim3(256), args, HHPH_LDS_BYTES(1), (hipStream_t)stream));
-    return HH_OK;
-}
-
-#ifdef HH_COOP_PROFILE
-extern "C" int hh_coop_prof_read(hh_world *w, int32_t *out3) {
-    if (!w || !w->coop_mem) return HH_E_ARG;
-    HH_GUARD(w);
-    HIPCHK(hipDeviceSynchronize());
-    const CoopLayout Lt = hh_coop_layout(w->dc.N);
-    HIPCHK(hipMemcpy(out3, (char *)w->coop_mem + Lt.o_ctl + (48 + 16) * sizeof(int), 3 * sizeof(int), hipMemcpyDeviceToHost));
-    return HH_OK;
-}
-#endif
-
-/* 0: every cooperative step so far completed; 1: a grid barrier timed out (the results of that step are invalid).  Synchronises `stream`. */
-extern "C" int hh_hl_step_nets_status(hh_world *w, int32_t *err_out, void *stream) {
-    if (!w || !err_out) { g_err = "null argument"; return HH_E_ARG; }
-    *err_out = 0;
-    if (!w->coop_mem) return HH_OK;
-    HH_GUARD(w);
-    const CoopLayout Lt = hh_coop_layout(w->dc.N);
-    HIPCHK(hipMemcpyAsync(err_out, (char *)w->coop_mem + Lt.o_ctl + 16 * sizeof(int), sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    if (*err_out) w->coop_timed_out = 1; /* the next step resets the barrier words and the flag */
-    return HH_OK;
-}
-

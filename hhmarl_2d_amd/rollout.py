@@ -97,25 +97,46 @@ class PPORollout:
     """What RLlib's rollout workers produce for train_hetero.py's PPO (train_hetero.py:206-243), for every arena of a `World` at once and
     without leaving the device: per tick the two trainable policies are sampled by `hh_policy_sample` (actor forward, Categorical draw
     per action component from the keyed RNG, its log-probability, and the centralised value branch on central_critic_observer's row —
-    the other agent's observation, action inputs zero while sampling) and the world takes one `hh_step`; after T ticks `hh_gae` turns
-    the rewards and value predictions into advantages and value targets (gamma 0.99, lambda 0.95: train_hetero.py:216), bootstrapping
-    the unfinished tail of every arena from one more value evaluation.  The 2 T + 2 launches of a collect are one HIP graph (4 T + 2 at
-    curriculum levels 4-5, where the frozen opponents' networks run between the two halves of every step).
+    the other agent's observation, action inputs zero while sampling) and the world takes one `hh_step`; after T ticks the rewards and
+    value predictions become advantages and value targets (gamma 0.99, lambda 0.95: train_hetero.py:216).  The 2 T + 2 launches of a
+    collect are one HIP graph (4 T + 2 at curriculum levels 4-5, where the frozen opponents' networks run between the two halves of
+    every step).
+
+    semantics = "rllib" (default) — the batch RLlib 2.4 hands the reference's learner (ray's sampler + compute_advantages as restated in
+    oracle/gae_ref.py; include/hh_abi.h: hh_gae_rllib):
+      * every agent's trajectory spans the whole episode: the rows of an agent that died earlier STAY IN with reward 0.0 (the reference
+        returns an observation for every agent id, zeros for dead ones, and a reward only for ids alive at step start; RLlib fills
+        `rewards.get(agent_id, 0.0)`) — nothing is masked, `valid` is only reported;
+      * last_r = 0.0 at every episode end (terminateds["__all__"] also at the horizon, env_base.py:108): the recursion is cut there and
+        no value is bootstrapped across it; float64 delta and discounted sum, float32 results;
+      * train_hetero.py:212 batch_mode = "complete_episodes": RLlib trains on whole episodes only.  `complete` (bool [T, N]) marks the
+        rows of episodes that END inside this collect — the rows of that batch; the trailing fragment of every arena (its episode is still
+        running after tick T - 1) gets RLlib's truncated-trajectory bootstrap from one more value evaluation and is flagged
+        complete = False, so that a learner either drops it or keeps it for the next batch (`segments` numbers the episodes per arena).
+    semantics = "masked": the pre-round-5 convention (`hh_gae`): rows without a reward key have advantage = target = 0 and do not
+    propagate, float32 throughout — for learners that cut dead agents' rows out.
 
     Buffers (device, overwritten by every `collect`):  obs f32 [T+1, N, 2, D] (row t = what the policy saw at tick t), actions i8
-    [T, N, 2, 4], logp f32 [T, N, 2], vf f32 [T+1, N, 2], reward f32 [T, N, 2], valid u8 [T, N, 2], done u8 [T, N], adv / target f32
-    [T, N, 2].  `critic_rows(agent)` gives the flattened CUR_OBS rows the reference's critic is trained on (actions filled in the way
-    on_postprocess_trajectory does)."""
+    [T, N, 2, 4], logp f32 [T, N, 2], vf f32 [T+1, N, 2], reward f32 [T, N, 2] (0.0 where valid = 0), valid u8 [T, N, 2], done u8
+    [T, N], adv / target f32 [T, N, 2]; `complete` / `segments` are derived from `done` on demand.  `critic_rows(agent)` gives the
+    flattened CUR_OBS rows the reference's critic is trained on (actions filled in the way on_postprocess_trajectory does)."""
 
-    def __init__(self, world, bank, T, gamma=0.99, lam=0.95, use_graph=True, opponents=None):
+    def __init__(self, world, bank, T, gamma=0.99, lam=0.95, use_graph=True, opponents=None, semantics="rllib"):
         """opponents: levels 4-5 only (env_hetero.py:160-172: frozen-policy opponents observe and act between the agents' actions and the tick) —
-        a `pilots.OpponentNets` of this world (its bank bound, so that hh_step_begin lists the opponents' rows itself) or any
+        a `pilots.OpponentNets(world, skip_first=False)` (its bank bound, so that hh_step_begin lists the opponents' rows itself) or any
         callable(opp_obs f32 [N, 2, 30] on the device, None) -> int8 [N, 2, 4] that only enqueues work on the current stream"""
         from . import pilots
         assert world.cfg.env_kind == L.ENV_LOWLEVEL and world.n_agents == 2 and world.cfg.auto_reset, "PPORollout drives an auto-resetting LowLevelEnv world"
+        if semantics not in ("rllib", "masked"):
+            raise ValueError("semantics: 'rllib' (RLlib 2.4's trajectory view, the reference's) or 'masked' (rows without a reward key cut out)")
+        self.semantics = semantics
         self.split = bool(world.cfg.ext_opp_actions)
         if self.split and opponents is None:
-            raise ValueError("levels 4-5 fly frozen opponent policies (envs/env_base.py:312-398): pass opponents = pilots.OpponentNets(world, bank = ...)")
+            raise ValueError("levels 4-5 fly frozen opponent policies (envs/env_base.py:312-398): pass opponents = pilots.OpponentNets(world, skip_first=False)")
+        if getattr(opponents, "_skip", 0):
+            # OpponentNets(skip_first=True) serves a facade whose reset() already ran one step_begin: its one-shot path re-bins rows that
+            # hh_step_begin listed, and captured into the collect's graph it would do so on every replay (every row evaluated twice)
+            opponents._skip = 0
         self.opponents = opponents
         self.w, self.bank, self.T, self.gamma, self.lam = world, bank, int(T), float(gamma), float(lam)
         N, D, dev = world.N, world.D, world.device
@@ -158,11 +179,17 @@ class PPORollout:
                 self.w.step_finish(self.opponents(self._opp_obs, None).contiguous(), out=out)
             else:
                 self.w.step(self.actions[t], out=out)
-        # bootstrap value of the observation after the last tick (an arena that just finished starts a new episode there: hh_gae cuts at done)
+        # value of the observation after the last tick: the bootstrap of every arena's unfinished tail (an arena that just finished starts a
+        # new episode there: both recursions cut at done and never read it)
         self.bank.sample(self.obs[T], None, greedy=True, actions=self._tmp_act, logp=self._tmp_logp, vf=self.vf[T])
         st = C.c_void_p(torch.cuda.current_stream(self.w.device).cuda_stream)
-        L.check(L.lib().hh_gae(T, self.w.N, 2, _p(self.reward), _p(self.vf), _p(self.valid), _p(self.done), self.gamma, self.lam,
-                               _p(self.adv), _p(self.target), st))
+        if self.semantics == "rllib":
+            # the world writes reward 0.0 wherever it reports valid = 0 (a dead agent's row): exactly RLlib's rewards.get(agent_id, 0.0)
+            L.check(L.lib().hh_gae_rllib(T, self.w.N, 2, _p(self.reward), _p(self.vf), _p(self.done), self.gamma, self.lam,
+                                         _p(self.adv), _p(self.target), st))
+        else:
+            L.check(L.lib().hh_gae(T, self.w.N, 2, _p(self.reward), _p(self.vf), _p(self.valid), _p(self.done), self.gamma, self.lam,
+                                   _p(self.adv), _p(self.target), st))
 
     def collect(self):
         """T ticks of every arena -> self (the buffers above): 2 T + 2 launches, replayed from ONE HIP graph; no host synchronisation."""
@@ -178,6 +205,16 @@ class PPORollout:
                     self._run()
             self._graph.replay()
         return self
+
+    @property
+    def segments(self):
+        """int64 [T, N]: index of the episode a row belongs to, counted per arena from the start of this collect (episode_segments)"""
+        return episode_segments(self.done)[0]
+
+    @property
+    def complete(self):
+        """bool [T, N]: the row's episode ends inside this collect — batch_mode = "complete_episodes" (train_hetero.py:212) trains on these"""
+        return episode_segments(self.done)[1]
 
     def critic_rows(self, agent):
         """the CUR_OBS rows of `agent` (1 | 2) for the T collected ticks with both agents' actions filled in (central_critic_rows)"""

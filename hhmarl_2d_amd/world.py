@@ -197,6 +197,13 @@ class World:
         L.check(L.lib().hh_eval_info(self.h, _p(last), _p(tot), int(clear_total), self._stream()))
         return last, tot
 
+    def action_faults(self, clear=False, out=None):
+        """uint8 [N]: 1 where a step consumed an out-of-range action word since the last clear (it ran on the sanitised word:
+        heading / speed component clamped, fire components as booleans) — the batched stand-in for the reference's raising guards"""
+        out = out if out is not None else torch.zeros((self.N,), dtype=torch.uint8, device=self.device)
+        L.check(L.lib().hh_action_faults(self.h, _p(out), int(bool(clear)), self._stream()))
+        return out
+
     def arena_status(self):
         """int32 [N, 4] on the device: steps, alive_agents, alive_opps, done"""
         out = torch.empty((self.N, 4), dtype=torch.int32, device=self.device)
@@ -232,20 +239,6 @@ class World:
             r[:, :, 7] = r[:, :, 7] % 16
             out.append((r, ep))
         return out
-
-    def hl_step_nets(self, bank, commander_actions, out=None):
-        """HighLevelEnv.step with the pilot networks inside, ONE cooperative launch (hh_hl_step_nets): commander_actions int8
-        [N, n_agents], bank = pilots.PolicyBank with the Fight / Esc networks and selector LUT -> (obs, reward, valid, done)"""
-        assert commander_actions.dtype == torch.int8 and commander_actions.is_contiguous()
-        obs, rew, val, done = out if out is not None else self.alloc_outputs()
-        L.check(L.lib().hh_hl_step_nets(self.h, bank.h, _p(commander_actions), _p(obs), _p(rew), _p(val), _p(done), self._stream()))
-        return obs, rew, val, done
-
-    def hl_step_nets_ok(self):
-        """False if a grid barrier of a cooperative step ever timed out (synchronises the current stream)"""
-        e = C.c_int32(0)
-        L.check(L.lib().hh_hl_step_nets_status(self.h, C.byref(e), self._stream()))
-        return e.value == 0
 
     def hl_tick_count(self):
         """cumulative arena-ticks run by macro steps on this world (synchronises the current stream)"""

@@ -101,8 +101,11 @@ int hh_reset(hh_world *w, const uint8_t *mask, float *obs, void *stream);
 /* step() (env_base.py:79-109 -> env_hetero.py:105-186 _take_action -> cmano_simulator.py:138-157
  * do_tick -> env_hetero.py:188-225 rewards -> env_hetero.py:65-103 state).
  *   actions      [dev] i8 [N, n_ctrl, 4]   MultiDiscrete([13,9,2,2]); 4th ignored for type 2.  Components outside their ranges (the
- *                                          reference's spaces never emit them: env_hetero.py:37-43) are UNDEFINED — the heading's one-turn
- *                                          modulo assumes |(a0 - 6) * 15| <= 90 deg; validate untrusted actions before the call
+ *                                          reference's spaces never emit them, env_hetero.py:37-43; its guards would raise, ac1.py:58-66)
+ *                                          are SANITISED where the word is loaded — heading component clamped to [0, 12], speed component
+ *                                          to [0, 8], fire components read as non-zero = fire (hh_spec.h: hh_action_sanitize) — and the
+ *                                          arena's sticky fault flag is set (hh_action_faults).  Only CONSUMED words count: rows of dead
+ *                                          units and of finished arenas may hold anything
  *   obs          [dev] f32[N, n_agents, D] observation after the tick (all agents, zeros if dead)
  *   reward       [dev] f32[N, n_agents]
  *   reward_valid [dev] u8 [N, n_agents]    1 iff the reference's rewards dict has the key
@@ -189,6 +192,13 @@ int hh_eval_info(hh_world *w, int32_t *last, int32_t *total, int32_t clear_total
 
 /* steps, alive_agents, alive_opps, done of every arena -> [dev] i32 [N, 4] (what step({}) needs: env_base.py:87-90) */
 int hh_arena_status(hh_world *w, int32_t *out, void *stream);
+
+/* The device-side replacement of the reference's raising guards (ac1.py:58-66 set_heading / set_speed; SURVEY.md section 5 "invalid-state
+ * flag per arena instead of raising"): out [dev] u8 [N] (nullable) = 1 for every arena in which, since the flags were last cleared, a step
+ * (hh_step / hh_rollout / hh_step_begin / hh_step_finish / hh_hl_agents_act / hh_hl_tick / hh_hl_rollout) consumed an action word with a
+ * component outside MultiDiscrete([13,9,2,2]); that step ran on the sanitised word (see hh_step).  clear != 0 zeroes the flags after
+ * copying them.  Resets do not clear them.  Ordered on `stream`, no host synchronisation. */
+int hh_action_faults(hh_world *w, uint8_t *out, int32_t clear, void *stream);
 
 /* Trajectory ring buffer on the device (rendering / trace export; cmano_simulator.py:125-130,159-162 record_unit_trace,
  * env_base.py:587-645 plot): after hh_trace_enable the first n_arenas arenas append one row per unit after every reset and every

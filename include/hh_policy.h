@@ -144,24 +144,6 @@ int hh_policy_sample(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs
                      const double *uniforms, const float *crit_act, int32_t greedy, int8_t *actions, float *logp, float *vf, float *logits,
                      void *stream);
 
-/* HighLevelEnv.step with the pilot networks INSIDE, one cooperative launch per commander step (envs/env_hier.py:114-140 with
- * env_base.py:349-398 evaluated where the reference evaluates it): the same result as
- *     hh_hl_begin; 16 x { hh_policy_act_binned; hh_hl_agents_act; hh_policy_act_binned; hh_hl_tick }; hh_hl_end
- * on a bound bank whose calls run a tile form (HH_POLICY_W=0, or a world small enough that the row count picks one), bit for bit (no
- * early exit while any arena of the world is still inside its macro step; against the weights-through-LDS forms the logits agree to
- * the last bits only, so an argmax on a near-tie can differ), but the world phases and
- * the policy tiles run inside ONE persistent kernel separated by grid barriers: nothing is dispatched, drained or re-fetched
- * between them.  commander_actions [dev] i8 [N, n_agents]; obs / reward / reward_valid / done like hh_hl_end.  The bank needs its
- * networks and LUT loaded, max_rows >= n_arenas x 6 and the split-fp16 form (the step walks 32-row tiles whatever width the bank is set
- * to); it does NOT have to be bound (the step uses the bank's row lists with counters of its own).  The world keeps the pilots'
- * observation / action scratch.  hh_hl_step_nets only ENQUEUES the launch on `stream` (no host synchronisation).
- * hh_hl_step_nets_status synchronises `stream` and reports 0 unless a grid barrier timed out since the last report (a workgroup gives up
- * after ~0.5 s of polling instead of hanging the device; the results of that step are then invalid); after a reported timeout the next
- * hh_hl_step_nets resets the barrier words and the flag, so later steps are valid again. */
-int hh_hl_step_nets(struct hh_world *w, hh_policy *p, const int8_t *commander_actions, float *obs, float *reward, uint8_t *reward_valid,
-                    uint8_t *done, void *stream);
-int hh_hl_step_nets_status(struct hh_world *w, int32_t *err_out, void *stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,30 @@
 
 #define HH_MAX_AIRCRAFT 8 /* 2v2 -> 4, 3v3 -> 6 */
 
+/* Action words: MultiDiscrete([13, 9, 2, 2]) = relative heading, speed level, fire cannon, fire missile (envs/env_hetero.py:37-43,
+ * env_base.py:214-238).  The reference's spaces never emit anything else, and its guards would raise on most of what lies outside
+ * (ac1.py:58-66: set_speed refuses a speed outside [100, max]; set_heading is unreachable behind `% 360`).  A batched world cannot
+ * raise for one arena, so an untrusted action word is SANITISED where it is loaded — heading component clamped to [0, 12], speed
+ * component to [0, 8], the two fire components read as "non-zero = fire" (the reference's bool()) — and the caller is told through a
+ * sticky per-arena flag (hh_action_faults, hh_abi.h) that the step ran on the sanitised action.  The kernels and the oracle share this
+ * one definition.  w = the four int8 components packed little-endian (a0 in bits 0..7).  Returns the sanitised word; *bad is OR-ed
+ * with 1 when any component was outside its range. */
+#define HH_ACT_HEADING_MAX 12
+#define HH_ACT_SPEED_MAX 8
+#if defined(__HIPCC__)
+#define HH_SPEC_FN __host__ __device__ __forceinline__
+#else
+#define HH_SPEC_FN static inline
+#endif
+HH_SPEC_FN uint32_t hh_action_sanitize(uint32_t w, int *bad) {
+    const int a0 = (int)(int8_t)(w & 0xffu), a1 = (int)(int8_t)((w >> 8) & 0xffu);
+    const int c0 = a0 < 0 ? 0 : (a0 > HH_ACT_HEADING_MAX ? HH_ACT_HEADING_MAX : a0);
+    const int c1 = a1 < 0 ? 0 : (a1 > HH_ACT_SPEED_MAX ? HH_ACT_SPEED_MAX : a1);
+    const uint32_t f2 = (w & 0x00ff0000u) != 0u, f3 = (w & 0xff000000u) != 0u;
+    *bad |= (c0 != a0) | (c1 != a1) | ((w & 0xfefe0000u) != 0u);
+    return (uint32_t)c0 | ((uint32_t)c1 << 8) | (f2 << 16) | (f3 << 24);
+}
+
 /* Keyed-RNG draw sites.  One id per reference call site family. */
 enum {
     HH_SITE_RESET_SIDE = 1,   /* envs/env_base.py:555  randint(1,2)                       */

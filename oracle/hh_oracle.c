@@ -67,6 +67,7 @@ typedef struct {
     int reward_valid[MAXA];
     float obs[MAXA][OBS_MAX];
     uint32_t ev_mask;
+    int act_fault; /* sticky: some consumed action word of this arena was out of range and ran sanitised */
     /* HighLevelEnv macro step (env_hier.py:114-140) */
     int hl_s, hl_running, hl_kill, hl_situ;
     int cmd_act[MAXA]; /* self.commander_actions[i]: 0 escape, k>0 fight stored target k (agents and opponents) */
@@ -481,8 +482,15 @@ static int do_tick(const o_world *w, o_arena *a, o_event *ev) {
 
 /* ------------------------------------------------------------------ actions */
 /* env_base.py:214-238 _take_base_action; returns 0 or error */
-static void take_base_action(const o_world *w, o_arena *a, int hl, int id, int opp_id, const int8_t *act) {
+static void take_base_action(const o_world *w, o_arena *a, int hl, int id, int opp_id, const int8_t *act_in) {
     o_ac *u = &a->ac[id - 1];
+    /* an action outside MultiDiscrete([13,9,2,2]) (the reference would raise at ac1.py:62-66 for the speed component): run on the
+     * sanitised word and remember it per arena (hh_spec.h: hh_action_sanitize, hh_abi.h: hh_action_faults) */
+    int bad = 0;
+    const uint32_t aw = hh_action_sanitize((uint32_t)(uint8_t)act_in[0] | ((uint32_t)(uint8_t)act_in[1] << 8) | ((uint32_t)(uint8_t)act_in[2] << 16) |
+                                           ((uint32_t)(uint8_t)act_in[3] << 24), &bad);
+    const int8_t act[4] = {(int8_t)(aw & 0xff), (int8_t)((aw >> 8) & 0xff), (int8_t)((aw >> 16) & 0xff), (int8_t)((aw >> 24) & 0xff)};
+    a->act_fault |= bad;
     double nh = hh_pymod(u->hdg + (double)((act[0] - 6) * 15), 360.0);
     if (nh >= 360.0 || nh < 0.0) nh = 0.0; /* ac1.py:59-60 would raise (unreachable) */
     u->cmd_hdg = nh;
@@ -1081,6 +1089,16 @@ API int hho_episode_stats(void *h, float *ret, int32_t *len, int8_t *outcome) {
         if (ret) ret[n] = w->ar[n].last_ret;
         if (len) len[n] = w->ar[n].last_len;
         if (outcome) outcome[n] = (int8_t)w->ar[n].last_outcome;
+    }
+    return HH_OK;
+}
+
+/* hh_abi.h: hh_action_faults */
+API int hho_action_faults(void *h, uint8_t *out, int clear) {
+    o_world *w = (o_world *)h;
+    for (int n = 0; n < w->cfg.n_arenas; n++) {
+        if (out) out[n] = (uint8_t)(w->ar[n].act_fault != 0);
+        if (clear) w->ar[n].act_fault = 0;
     }
     return HH_OK;
 }

@@ -197,6 +197,12 @@ class OracleWorld:
         lib().hho_get_event_masks(self.h, _ptr(m, C.c_uint32))
         return m
 
+    def action_faults(self, clear=False):
+        """u8 [N]: a consumed action word of the arena was out of range and ran sanitised (sticky until cleared)"""
+        m = np.zeros((self.N,), dtype=np.uint8)
+        lib().hho_action_faults(self.h, _ptr(m, C.c_uint8), int(bool(clear)))
+        return m
+
     # ---- HighLevelEnv macro step (env_hier.py:114-140), split so that pilot inference runs between ticks
     def hl_begin(self, cmd):
         cmd = np.ascontiguousarray(cmd, dtype=np.int8).reshape(self.N, self.n_agents)

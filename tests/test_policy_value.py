@@ -198,7 +198,7 @@ def test_ppo_rollout_driver_equals_a_step_by_step_replay():
     """PPORollout (one HIP graph per collect) against the same ticks driven call by call: identical buffers; the buffers are consistent
     with each other (obs[t+1] = step(actions[t]), vf / logp of obs[t], GAE of the stored rewards / values / dones)"""
     from hhmarl_2d_amd.world import World, make_config
-    from hhmarl_2d_amd.rollout import PPORollout, gae
+    from hhmarl_2d_amd.rollout import PPORollout, gae_rllib
     N, T = 2048, 24
     kw = dict(n_arenas=N, level=3, seed=11, auto_reset=True, horizon=20)    # short horizon: episodes end (and restart) inside the rollout
     wa, wb = World(make_config(**kw), device=0), World(make_config(**kw), device=0)
@@ -221,7 +221,7 @@ def test_ppo_rollout_driver_equals_a_step_by_step_replay():
             assert torch.equal(obs, rec["obs"][t + 1]) and torch.equal(r, rec["reward"][t]) and torch.equal(v, rec["valid"][t]) and torch.equal(d, rec["done"][t])
         _, _, vfT = bank.sample(obs, sel, greedy=True)
         assert torch.equal(vfT, rec["vf"][T])
-        adv, ret = gae(rec["reward"], rec["vf"], rec["valid"], rec["done"], 0.99, 0.95)
+        adv, ret = gae_rllib(rec["reward"], rec["vf"], rec["done"], 0.99, 0.95)     # the default semantics: RLlib's trajectory view
         assert torch.equal(adv, rec["adv"]) and torch.equal(ret, rec["target"])
     # the critic's training rows carry the stored actions (central_critic_rows: pinned against the reference's callbacks elsewhere)
     rows = ro.critic_rows(1)
@@ -235,7 +235,7 @@ def test_ppo_rollout_at_the_self_play_levels_equals_a_step_by_step_replay(level)
     arena and episode).  PPORollout with a pilots.OpponentNets (one HIP graph per collect) against the same ticks driven call by call on a second world"""
     from hhmarl_2d_amd import _lib as L, pilots
     from hhmarl_2d_amd.world import World, make_config
-    from hhmarl_2d_amd.rollout import PPORollout, gae
+    from hhmarl_2d_amd.rollout import PPORollout, gae_rllib
     N, T = 1024, 20
     kw = dict(n_arenas=N, level=level, seed=13, auto_reset=True, horizon=18, ext_opp_actions=True)
     wa, wb = World(make_config(**kw), device=0), World(make_config(**kw), device=0)
@@ -265,7 +265,59 @@ def test_ppo_rollout_at_the_self_play_levels_equals_a_step_by_step_replay(level)
             assert torch.equal(obs, rec["obs"][t + 1]) and torch.equal(r, rec["reward"][t]) and torch.equal(v, rec["valid"][t]) and torch.equal(d, rec["done"][t])
         _, _, vfT = bank.sample(obs, sel, greedy=True)
         assert torch.equal(vfT, rec["vf"][T])
-        adv, ret = gae(rec["reward"], rec["vf"], rec["valid"], rec["done"], 0.99, 0.95)
+        adv, ret = gae_rllib(rec["reward"], rec["vf"], rec["done"], 0.99, 0.95)     # the default semantics: RLlib's trajectory view
         assert torch.equal(adv, rec["adv"]) and torch.equal(ret, rec["target"])
     if level == 5:
         assert ks == {3, 4, 5}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level,mode", [(3, "fight"), (3, "escape"), (4, "fight")], ids=["L3-fight", "L3-escape", "L4-self-play"])
+def test_ppo_rollout_buffers_are_the_batch_rllib_would_build(level, mode):
+    """The DRIVER'S OWN buffers: advantages / value targets of `PPORollout.collect` against the restatement
+    of ray 2.4's sampler + compute_advantages (oracle/gae_ref.py: rllib_stream) run on the rewards, reward keys, value predictions and done
+    flags the driver left on the device — bit for bit (float64 delta and discounted sum on both sides).  Short horizon and real combat, so
+    that agents die before their episode ends: their rows stay in the trajectory with reward 0.0 and non-zero advantages (RLlib masks
+    nothing), last_r = 0 at every episode end, the trailing fragment bootstraps from the extra value evaluation and is flagged incomplete
+    (batch_mode = "complete_episodes", train_hetero.py:212)."""
+    import gae_ref
+    from hhmarl_2d_amd import pilots
+    from hhmarl_2d_amd.world import World, make_config
+    from hhmarl_2d_amd.rollout import PPORollout
+    N, T = 1536, 48
+    kw = dict(n_arenas=N, level=level, seed=23, auto_reset=True, horizon=30, agent_mode=1 if mode == "escape" else 0)
+    if level >= 4:
+        kw["ext_opp_actions"] = True
+    w = World(make_config(**kw), device=0)
+    bank = _trainable(5, mode=mode, max_rows=2 * N)
+    opp = pilots.OpponentNets(w, seed=4, skip_first=False) if level >= 4 else None
+    ro = PPORollout(w, bank, T, opponents=opp)
+    assert ro.semantics == "rllib"
+    for it in range(2):
+        ro.collect()
+        torch.cuda.synchronize()
+        r, v, vf, d = (x.cpu().numpy() for x in (ro.reward, ro.valid, ro.vf, ro.done))
+        assert not r[v == 0].any(), "the world writes reward 0.0 where it reports no reward key (RLlib's rewards.get(agent_id, 0.0))"
+        adv, ret = gae_ref.rllib_stream(r, v, vf, d, 0.99, 0.95)
+        assert np.array_equal(ro.adv.cpu().numpy(), adv), f"collect {it}: advantages"
+        assert np.array_equal(ro.target.cpu().numpy(), ret), f"collect {it}: value targets"
+        # what the masked recursion would have given differs exactly where an agent died before the end of its episode
+        dead_rows = (v == 0)
+        assert dead_rows.any() and np.abs(adv[dead_rows]).max() > 0, "dead agents' rows carry advantages in RLlib's view"
+        madv, _ = gae_ref.masked_stream(r, v, vf, d, 0.99, 0.95)
+        assert not np.array_equal(madv, adv)
+        # complete_episodes: rows up to an arena's last done; every arena finishes at least one 30-step episode in 48 ticks
+        comp = ro.complete.cpu().numpy()
+        last_done = T - 1 - np.argmax(d[::-1] != 0, axis=0)
+        want = np.arange(T)[:, None] <= last_done[None, :]
+        assert d.any(axis=0).all() and np.array_equal(comp, want)
+        seg = ro.segments.cpu().numpy()
+        assert np.array_equal(seg[0], np.zeros(N, dtype=np.int64)) and np.array_equal(seg[-1], d[:-1].sum(axis=0))
+    if level < 4:   # the other convention stays available: rows without a reward key cut out (hh_gae)
+        masked = PPORollout(World(make_config(**kw), device=0), bank, T, semantics="masked")
+        masked.collect()
+        torch.cuda.synchronize()
+        a2, t2 = gae_ref.masked_stream(*(x.cpu().numpy() for x in (masked.reward, masked.valid, masked.vf, masked.done)), 0.99, 0.95)
+        assert np.allclose(masked.adv.cpu().numpy(), a2, atol=2e-6) and np.allclose(masked.target.cpu().numpy(), t2, atol=2e-6)
+    with pytest.raises(ValueError):
+        PPORollout(w, bank, T, opponents=opp, semantics="truncate")

@@ -474,6 +474,11 @@ static int hhp_set_net(hh_policy *p, int32_t slot, const hh_net_weights *w) {
     }
     for (int k = 0; k < 3; k++) if (!w->inp_w[k] || !w->inp_b[k]) { g_err = "hh_policy_set_net: missing input layer"; return HH_E_ARG; }
     HH_GUARD(p);
+    /* the slot's value branch holds its own permuted copy of the shared layer and the input widths of the kind it was loaded for: a new
+     * actor makes both stale.  hh_policy_sample refuses vf for the slot until hh_policy_set_critic is called again (set_net + set_critic
+     * are a pair; the old copy stays allocated and is simply never read) */
+    p->cbank.c[slot].loaded = 0;
+    p->cbankx.c[slot].loaded = 0;
     const int n_out = (w->kind == HH_NET_FIGHT1 || w->kind == HH_NET_ESC1) ? 26 : 24;
     /* blob: w1p | b1 | wovp | bov | wsp | bs | wap | ba   (float counts; every section 16-byte aligned) */
     const size_t n_w1 = 4 * 2 * HHP_H * 4, n_wov = 13 * 2 * HHP_ATT_J * 4, n_ws = 64 * 2 * HHP_H * 4, n_wa = 64 * 2 * HHP_OUT * 4;

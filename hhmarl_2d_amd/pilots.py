@@ -23,6 +23,15 @@ SEL_FIGHT1, SEL_ESC1, SEL_FIGHT2, SEL_ESC2 = 5, 6, 9, 10
 SEL_OPP_SIDE = 64   # HH_SEL_OPP_SIDE: an opponent's fight row of a world created with opp_side_selector (eval_hl = False)
 
 
+def tie_shared_layer(sds):
+    """make every state dict of `sds` carry the FIRST one's shared_layer tensors (models/ac_models_hetero.py:21: one module-level
+    SHARED_LAYER serves Fight1, Fight2, Esc1 and Esc2, so every policy of a trainer holds the same 500 x 500 layer)"""
+    for sd in sds[1:]:
+        for k in ("shared_layer._model.0.weight", "shared_layer._model.0.bias"):
+            sd[k] = sds[0][k]
+    return sds
+
+
 class PolicyBank:
     """Up to 8 frozen actor networks resident on one GPU (hh_policy_* of include/hh_policy.h)."""
     FIGHT1, FIGHT2, ESC1, ESC2 = PN.FIGHT1, PN.FIGHT2, PN.ESC1, PN.ESC2
@@ -117,17 +126,29 @@ class PolicyBank:
         return actions, logp, vf
 
     @classmethod
-    def trainable_init(cls, device, mode="fight", seed=0, max_rows=1 << 20):
+    def trainable_init(cls, device, mode="fight", seed=0, max_rows=1 << 20, tie_shared=True):
         """the two trainable policies of train_hetero.py (ac1_policy = Fight1 | Esc1 in slot 0, ac2_policy = Fight2 | Esc2 in slot 1) with
-        synthetic actor AND value-branch weights; selector bytes as the agents' aircraft types: SEL_FIGHT1 / SEL_FIGHT2 (| SEL_ESC*)"""
+        synthetic actor AND value-branch weights; selector bytes as the agents' aircraft types: SEL_FIGHT1 / SEL_FIGHT2 (| SEL_ESC*).
+        tie_shared (default): both slots carry ONE shared_layer tensor — in the reference `SHARED_LAYER` is one module-level SlimFC used by
+        Fight1, Fight2, Esc1 and Esc2 (models/ac_models_hetero.py:21), so ac1_policy and ac2_policy train the same 500 x 500 layer.
+        tie_shared = False draws one per slot (what the committed policy_value.npz vectors were recorded with)."""
         b = cls(device, max_rows)
         kinds = (PN.FIGHT1, PN.FIGHT2) if mode == "fight" else (PN.ESC1, PN.ESC2)
-        for slot, kind in enumerate(kinds):
-            sd = PN.random_weights(kind, seed)
+        sds = [PN.random_weights(kind, seed) for kind in kinds]
+        if tie_shared:
+            tie_shared_layer(sds)
+        for slot, (kind, sd) in enumerate(zip(kinds, sds)):
             b.set_net(slot, kind, sd)
             b.set_critic(slot, kind, sd, PN.random_critic_weights(kind, seed))
         b.set_lut({(SEL_FIGHT1 if mode == "fight" else SEL_ESC1): 0, (SEL_FIGHT2 if mode == "fight" else SEL_ESC2): 1})
         return b
+
+    def load_trainable(self, slot, kind, sd, csd):
+        """one policy of a PPO iteration into `slot`: actor and value branch TOGETHER (hh_policy_set_net invalidates the slot's value branch,
+        whose private copy of the shared layer would otherwise go stale).  When syncing weights back from a learner, pass the same
+        shared_layer tensors for every slot (tie_shared_layer): the reference has one SHARED_LAYER for all four architectures."""
+        self.set_net(slot, kind, sd)
+        self.set_critic(slot, kind, sd, csd)
 
     def kernel_name(self, n_rows, sampler=False):
         """the forward kernel instance a call of n_rows rows launches (hh_policy_kernel_name)"""

@@ -22,6 +22,8 @@ Sub-environment i draws from the keyed RNG as arena `arena_offset + i`, exactly 
 `env_config["arena_offset"] = arena_offset + i` and the same seed: tests/test_gpu_vector_env.py drives 64 of each side by side.
 Levels 4-5 (frozen opponent policies, env_base.py:312-398) take `env_config["policy_dir"]` or `["opponent_policy"]` like LowLevelEnv and step in two halves.
 """
+import gc
+
 import numpy as np
 
 from . import _lib as L
@@ -96,26 +98,62 @@ class _GpuBackend:
         self.world.close()
 
 
+class _NoCyclicGC:
+    """The bulk builds below create tens of thousands of small dicts per call, none of them part of a cycle.  CPython's generational collector
+    counts container allocations and runs a pass every 700 of them, promoting the survivors — with N = 4096 sub-environments that is what made
+    the per-sub-environment cost GROW with N (2.5 us against 1.3 us at N = 256, same code).  Collection is paused for the duration of a build and
+    the caller's setting restored afterwards (reference counting frees everything here anyway)."""
+
+    def __enter__(self):
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        if self.was:
+            gc.enable()
+        return False
+
+
 class _VectorProtocol(_Base):
     """the BaseEnv call protocol over a backend with reset(masked) / step() / act_host / mask_host; subclasses name the agents, cut the observation rows
-    and pack the actions (`_obs_of`, `_put_action`, `_info_of`)"""
+    and pack the actions (`_obs_dicts`, `_pack_all`, `_put_action`, `_info_of`).
+
+    What this surface costs is Python objects — RLlib's protocol wants {env_id: {agent_id: value}} dicts for observations, rewards, terminateds,
+    truncateds and infos of every sub-environment on every step — so everything per sub-environment is built in bulk: the action dicts are packed with
+    one concatenate per agent id, the observation rows of an agent are cut with one slice and iterated once, rewards / done flags cross into Python as
+    lists, and the five result dicts are kept as they will be polled (poll hands them over, it does not rebuild them).  Measured per iteration
+    (poll + try_reset of the finished + send_actions) in profiles/r05_vector_env_rates.json."""
 
     def _init_protocol(self, backend, num_envs, agent_ids):
         self.b = backend
         self.num_envs = num_envs
         self._agent_ids = set(agent_ids)
         self._ids = sorted(self._agent_ids)
+        self._all = dict.fromkeys(range(num_envs)).keys()   # every env id: `action_dict.keys() == self._all` is one C-speed comparison
         self._started = False
-        self._pending = {}                    # env_id -> (obs, rewards, terminateds, truncateds, infos) not yet polled
+        self._new_pending()
         self._done = set()                    # sub-environments whose episode ended and that were not reset yet
         self._reset_obs = {}                  # env_id -> the first observation of its next episode (arena already re-sampled)
         self._fresh = set()                   # sub-environments that were reset and have not stepped since
+
+    def _new_pending(self):
+        # results nobody polled yet, as the five dicts poll returns: env_id -> obs dict | reward dict | terminateds | truncateds | infos
+        self._p_obs, self._p_rew, self._p_term, self._p_trunc, self._p_info = {}, {}, {}, {}, {}
 
     def _info_of(self, e):
         return {}
 
     def _put_action(self, a, e, k, v):
         a[e, k - 1, : len(v)] = v
+
+    def _pack_all(self, a, dicts):
+        """actions of ALL sub-environments (dicts in env order) into the host mirror `a`; False = not applicable (odd shapes): per-row path"""
+        return False
+
+    def _obs_dicts(self, obs, envs):
+        """observation dicts of the sub-environments `envs` (a range or a list) from the step's rows obs [N, n_agents, D] (a fresh copy: the
+        per-agent arrays are views of it)"""
+        raise NotImplementedError
 
     @property
     def observation_space(self):
@@ -132,84 +170,125 @@ class _VectorProtocol(_Base):
         return {} if as_dict else []          # the arenas live in one device-resident world: there are no per-env Python objects
 
     def _start(self):
+        with _NoCyclicGC():
+            self._start_inner()
+
+    def _start_inner(self):
         self._started = True
         rows = self.b.reset(False).copy()   # ONE copy out of the backend's reused host mirror; the per-agent observations are views of it
-        for e in range(self.num_envs):
-            self._pending[e] = (self._obs_of(rows[e]), {}, {"__all__": False}, {"__all__": False}, {})
-            self._fresh.add(e)
+        envs = range(self.num_envs)
+        od = self._obs_dicts(rows, envs)
+        self._p_obs = dict(zip(envs, od))
+        self._p_rew = {e: {} for e in envs}
+        self._p_term = {e: {"__all__": False} for e in envs}
+        self._p_trunc = dict(self._p_term)   # terminateds is truncateds, per sub-environment (env_base.py:108)
+        self._p_info = {e: {} for e in envs}
+        self._fresh = set(envs)
 
     def poll(self):
         """-> (obs, rewards, terminateds, truncateds, infos, off_policy_actions), each {env_id: {agent_id | "__all__": value}}, for every
         sub-environment with a result nobody polled yet (the first call resets them all)"""
         if not self._started:
             self._start()
-        obs, rew, term, trunc, info = {}, {}, {}, {}, {}
-        for e, (o, r, t, tr, i) in self._pending.items():
-            obs[e], rew[e], term[e], trunc[e], info[e] = o, r, t, tr, i
-        self._pending = {}
-        return obs, rew, term, trunc, info, {}
+        out = (self._p_obs, self._p_rew, self._p_term, self._p_trunc, self._p_info, {})
+        self._new_pending()
+        return out
 
     def send_actions(self, action_dict):
-        """{env_id: {agent_id: action}}: every sub-environment whose episode is running must be there (the arenas step
-        together); one that ended needs try_reset first (RLlib's MultiAgentEnvToBaseEnv raises the same ValueError)"""
-        for e in action_dict:
-            if e in self._done:
-                raise ValueError(f"Env {e} is already done and cannot accept new actions")
-        missing = [e for e in range(self.num_envs) if e not in action_dict and e not in self._done]
-        if missing:
-            raise ValueError(f"send_actions: sub-environments {missing[:8]} have a running episode but no action (the arenas of one world step together)")
+        """{env_id: {agent_id: action}}: every sub-environment whose episode is running must be there (the arenas of one world step
+        together); one that ended needs try_reset first (RLlib's MultiAgentEnvToBaseEnv raises the same ValueError).
+
+        A sub-environment that ended and was NOT try_reset before this call (RLlib's sampler always resets at once) has no action here: its
+        arena — already re-sampled when its episode ended — moves along with the rest on an all-zero action, and is re-sampled once more
+        after the step, so that the episode try_reset eventually hands out is an untouched one.  That costs the arena one episode number
+        of the keyed RNG per skipped step: the equivalence with a single-arena LowLevelEnv at arena_offset + i holds for the call order
+        poll -> try_reset(finished) -> send_actions, the one RLlib uses."""
+        with _NoCyclicGC():
+            self._send_actions(action_dict)
+
+    def _send_actions(self, action_dict):
+        n = self.num_envs
+        full = not self._done and len(action_dict) == n and action_dict.keys() == self._all
+        if not full:
+            for e in action_dict:
+                if e in self._done:
+                    raise ValueError(f"Env {e} is already done and cannot accept new actions")
+            missing = [e for e in range(n) if e not in action_dict and e not in self._done]
+            if missing:
+                raise ValueError(f"send_actions: sub-environments {missing[:8]} have a running episode but no action (the arenas of one world step together)")
         a = self.b.act_host
-        a[:] = 0
-        for e, ad in action_dict.items():
-            for k, v in ad.items():
-                self._put_action(a, e, k, v)
+        packed = False
+        if full:
+            try:
+                packed = self._pack_all(a, [action_dict[e] for e in range(n)])
+            except (ValueError, TypeError, KeyError, IndexError):
+                packed = False
+        if not packed:
+            a[:] = 0
+            for e, ad in action_dict.items():
+                for k, v in ad.items():
+                    self._put_action(a, e, k, v)
         obs, rew, val, done = self.b.step()
-        # the per-sub-environment Python objects are what this surface costs (3 us per sub-environment): one copy of the step's observations (the
-        # agents' arrays are views of it), the small arrays as Python lists once instead of a numpy scalar per access
-        obs = obs.copy()
-        rew_l, val_l, done_l = rew.tolist(), val.tolist(), done.tolist()
+        obs = obs.copy()                           # one copy of the step's observations: the agents' arrays are views of it
+        envs = range(n) if full else list(action_dict)
+        sel = slice(None) if full else envs
         ids = self._ids
-        fin = []
-        self._fresh.clear()
-        pending, obs_of, info_of = self._pending, self._obs_of, self._info_of
-        for e in action_dict:
-            rl, vl = rew_l[e], val_l[e]
-            r = {i: rl[i - 1] for i in ids if vl[i - 1]}
-            if done_l[e]:
-                dd = {"__all__": True}
-                self._done.add(e)
-                fin.append(e)
-            else:
-                dd = {"__all__": False}
-            pending[e] = (obs_of(obs[e]), r, dd, dd, info_of(e))
-        # a sub-environment that ended earlier and was never try_reset (RLlib's sampler always does that at once) was stepped along with
-        # the rest, on zero actions: its arena is re-sampled again, so that the episode it eventually starts is an untouched one
+        rew_l, done_l = rew[sel].tolist(), done[sel].tolist()
+        if len(ids) == 2:
+            i0, i1 = ids
+            rd = [{i0: r[0], i1: r[1]} for r in rew_l]
+        elif len(ids) == 3:
+            i0, i1, i2 = ids
+            rd = [{i0: r[0], i1: r[1], i2: r[2]} for r in rew_l]
+        else:
+            rd = [dict(zip(ids, r)) for r in rew_l]
+        vsel = val[sel][:, : len(ids)]
+        if not vsel.all():                          # rewards only for ids alive at step start: rebuild the few rows that lost a key
+            for k in np.nonzero(~vsel.all(axis=1))[0].tolist():
+                rd[k] = {i: rew_l[k][i - 1] for i in ids if vsel[k, i - 1]}
+        dd = [{"__all__": bool(d)} for d in done_l]
+        od = self._obs_dicts(obs, envs)
+        self._fresh = set()
+        if self._p_obs:                             # results of earlier steps nobody polled: the newer ones replace them per sub-environment
+            self._p_obs.update(zip(envs, od)); self._p_rew.update(zip(envs, rd)); self._p_term.update(zip(envs, dd)); self._p_trunc.update(zip(envs, dd))
+            self._p_info.update((e, self._info_of(e)) for e in envs)
+        else:
+            self._p_obs, self._p_rew, self._p_term = dict(zip(envs, od)), dict(zip(envs, rd)), dict(zip(envs, dd))
+            self._p_trunc = dict(self._p_term)
+            self._p_info = {e: self._info_of(e) for e in envs}
+        fin = np.nonzero(done)[0].tolist() if full else [e for e, d in zip(envs, done_l) if d]
+        self._done.update(fin)
+        # see the docstring: sub-environments that ended earlier and were never try_reset were stepped along on zero actions
         fin += [e for e in self._done if e not in action_dict and e not in fin]
         if fin:   # ONE masked reset for every arena that just finished; try_reset hands out the cached rows
             m = self.b.mask_host
             m[:] = 0
             m[fin] = 1
-            rows = self.b.reset(True)
-            for e in fin:
-                self._reset_obs[e] = self._obs_of(rows[e].copy())
+            rows = self.b.reset(True).copy()
+            self._reset_obs.update(zip(fin, self._obs_dicts(rows, fin)))
 
     def try_reset(self, env_id=None, *, seed=None, options=None):
-        """-> ({env_id: obs dict}, {env_id: {}}) of the sub-environment's next episode"""
+        """-> ({env_id: obs dict}, {env_id: {}}) of the sub-environment's next episode.  RLlib's MultiAgentEnvToBaseEnv.try_reset calls
+        env.reset(), i.e. EVERY try_reset starts a new episode; so does this one, with two cases in which the new episode already exists and no
+        device call is made: the sub-environment's episode just ended (its arena was re-sampled by the step's one masked reset), or it was reset
+        and that first observation has not even been polled yet.  Anything else — a reset in the middle of an episode, a second reset without a
+        step in between — re-samples the arena (one masked hh_reset), exactly as calling reset() again on a single-arena LowLevelEnv would."""
         if env_id is None:
             env_id = 0
         if not self._started:
             self._start()
         if env_id in self._reset_obs:            # its episode ended: the arena was re-sampled right after that step
             o = self._reset_obs.pop(env_id)
-        elif env_id in self._fresh and env_id in self._pending:   # reset, not stepped, not polled: that observation is the answer
-            o = self._pending[env_id][0]
+        elif env_id in self._fresh and env_id in self._p_obs:   # reset, not stepped, not polled: that observation is the answer
+            o = self._p_obs[env_id]
         else:                                    # a reset in the middle of an episode (RLlib does this for episodes it truncates itself)
             m = self.b.mask_host
             m[:] = 0
             m[env_id] = 1
-            o = self._obs_of(self.b.reset(True)[env_id].copy())
+            o = self._obs_dicts(self.b.reset(True).copy(), [env_id])[0]
         self._done.discard(env_id)
-        self._pending.pop(env_id, None)
+        for p in (self._p_obs, self._p_rew, self._p_term, self._p_trunc, self._p_info):
+            p.pop(env_id, None)
         self._fresh.add(env_id)
         return {env_id: o}, {env_id: {}}
 
@@ -222,11 +301,19 @@ class _VectorProtocol(_Base):
     close = stop
 
 
+def _require_args(env_config, what):
+    args = env_config.get("args", None)
+    if args is None:
+        raise ValueError(f"{what}: env_config['args'] is missing — pass the reference's config.Config(mode).get_arguments namespace (or "
+                         "hhmarl_2d_amd.config.make_args(mode, level=..., ...)), exactly what train_hetero.py / train_hier.py put there")
+    return args
+
+
 class LowLevelVectorEnv(_VectorProtocol):
     """N LowLevelEnv sub-environments (2-vs-2) behind RLlib's BaseEnv protocol, one MI355X world underneath."""
 
     def __init__(self, env_config):
-        self.args = env_config.get("args", None)
+        self.args = _require_args(env_config, "LowLevelVectorEnv")
         if self.args.level >= 4 and env_config.get("opponent_policy") is None and env_config.get("policy_dir") is None and env_config.get("_backend") is None:
             raise ValueError("levels 4-5 fly frozen opponent policies (envs/env_base.py:312-398); pass env_config['policy_dir'] = the directory of the "
                              "exported L*_AC*_{fight,escape}.pt files, or env_config['opponent_policy'] = callable(opp_obs f32 [N,2,30] on the device, "
@@ -246,8 +333,22 @@ class LowLevelVectorEnv(_VectorProtocol):
             backend = _GpuBackend(cfg, int(env_config.get("device", 0)), self.args, env_config.get("policy_dir"), env_config.get("opponent_policy"))
         self._init_protocol(backend, self.num_envs, range(1, self.args.num_agents + 1))
 
-    def _obs_of(self, rows):
-        return {i: rows[i - 1, : self.obs_dim_map[i]] for i in self._ids}   # views of the caller's fresh copy
+    def _obs_dicts(self, obs, envs):
+        d1, d2 = self.obs_dim_map[1], self.obs_dim_map[2]
+        if isinstance(envs, range):   # all of them: one slice per agent id, iterated once (row views of the caller's fresh copy)
+            return [{1: x, 2: y} for x, y in zip(obs[:, 0, :d1], obs[:, 1, :d2])]
+        return [{1: obs[e, 0, :d1], 2: obs[e, 1, :d2]} for e in envs]
+
+    def _pack_all(self, a, dicts):
+        n = len(dicts)
+        a1 = np.concatenate([d[1] for d in dicts])   # agent 1: MultiDiscrete([13, 9, 2, 2]); agent 2 (type 2, no missile): ([13, 9, 2])
+        a2 = np.concatenate([d[2] for d in dicts])
+        if a1.size != 4 * n or a2.size != 3 * n or len(dicts[0]) != 2:
+            return False
+        a[:, 0, :] = a1.reshape(n, 4)
+        a[:, 1, :3] = a2.reshape(n, 3)
+        a[:, 1, 3] = 0
+        return True
 
 
 class _GpuHierBackend:
@@ -335,7 +436,7 @@ class HighLevelVectorEnv(_VectorProtocol):
 
     def __init__(self, env_config):
         from .env_hier import N_OPP_HL, OBS_HL
-        self.args = env_config.get("args", None)
+        self.args = _require_args(env_config, "HighLevelVectorEnv")
         if env_config.get("pilot") is None and env_config.get("policy_dir") is None and env_config.get("_backend") is None:
             raise ValueError("HighLevelEnv flies frozen low-level pilot policies (envs/env_base.py:312-398); pass env_config['policy_dir'] = the directory of the "
                              "exported L*_AC*_{fight,escape}.pt files, or env_config['pilot'] = callable(pilot_obs, pilot_mode) -> int8 actions [N, 6, 4]")
@@ -351,12 +452,24 @@ class HighLevelVectorEnv(_VectorProtocol):
         self._eval = bool(getattr(self.args, "eval_info", False))
         self._last_eval = None
 
-    def _obs_of(self, rows):
-        return {i: rows[i - 1] for i in self._ids}   # views of the caller's fresh copy
+    def _obs_dicts(self, obs, envs):
+        ids = self._ids
+        if isinstance(envs, range) and len(ids) == 3:
+            return [{1: x, 2: y, 3: z} for x, y, z in zip(obs[:, 0], obs[:, 1], obs[:, 2])]   # row views of the caller's fresh copy
+        return [{i: obs[e, i - 1] for i in ids} for e in envs]
 
     def _put_action(self, a, e, k, v):
         if k <= len(self._ids):
             a[e, k - 1] = int(v)
+
+    def _pack_all(self, a, dicts):
+        n, ids = len(dicts), self._ids
+        if len(dicts[0]) != len(ids):
+            return False
+        a[:] = 0
+        for i in ids:   # Discrete(3) per agent id
+            a[:, i - 1] = np.fromiter((d[i] for d in dicts), dtype=np.int64, count=n)
+        return True
 
     def send_actions(self, action_dict):
         self._last_eval = None

@@ -118,7 +118,10 @@ typedef struct hh_critic_weights {
     const float *val_w, *val_b;                                        /* val_out._model.0 [1,500], [1] */
 } hh_critic_weights;
 
-/* load (or replace) the value branch of network `slot` (its actor must be loaded: hh_policy_set_net).  Synchronous. */
+/* load (or replace) the value branch of network `slot` (its actor must be loaded: hh_policy_set_net).  Synchronous.
+ * hh_policy_set_net and hh_policy_set_critic are a PAIR: the value branch keeps its own permuted copy of the shared layer (the reference
+ * has ONE module-level SHARED_LAYER, models/ac_models_hetero.py:21) and the input widths of its kind, so loading a new actor into the slot
+ * invalidates it — hh_policy_sample then refuses a value output (HH_E_ARG) until the value branch is loaded again. */
 int hh_policy_set_critic(hh_policy *p, int32_t slot, const hh_critic_weights *w);
 
 /* One sampler step for n_rows units = [n_arenas, 2] rows of LowLevelEnv agents (row r's partner — "the other agent" of

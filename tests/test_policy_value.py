@@ -71,7 +71,8 @@ def test_critic_tables_are_consistent():
 # ---------------------------------------------------------------------------------------------- GPU: hh_policy_sample
 def _trainable(seed, mode="fight", max_rows=1 << 16):
     from hhmarl_2d_amd.pilots import PolicyBank
-    return PolicyBank.trainable_init(torch.device("cuda", 0), mode=mode, seed=seed, max_rows=max_rows)
+    # per-slot shared layers: what policy_value.npz and the per-kind restatements below were made with (tying them is a host-side choice)
+    return PolicyBank.trainable_init(torch.device("cuda", 0), mode=mode, seed=seed, max_rows=max_rows, tie_shared=False)
 
 
 def _sel(mode, n_arenas):
@@ -321,3 +322,46 @@ def test_ppo_rollout_buffers_are_the_batch_rllib_would_build(level, mode):
         assert np.allclose(masked.adv.cpu().numpy(), a2, atol=2e-6) and np.allclose(masked.target.cpu().numpy(), t2, atol=2e-6)
     with pytest.raises(ValueError):
         PPORollout(w, bank, T, opponents=opp, semantics="truncate")
+
+
+@pytest.mark.gpu
+def test_one_shared_layer_for_both_policies_and_set_net_invalidates_the_value_branch():
+    """(a) the reference has ONE module-level SHARED_LAYER (models/ac_models_hetero.py:21) — `trainable_init` ties the two
+    policies' shared layers by default, and both the actor and the value branch of slot 1 then evaluate slot 0's tensor; (b) the value
+    branch keeps a private permuted copy of the shared layer, so hh_policy_set_net must invalidate it: vf is refused until
+    hh_policy_set_critic is called again, and after `load_trainable` both halves see the new layer."""
+    from hhmarl_2d_amd import pilots
+    from hhmarl_2d_amd.pilots import PolicyBank
+    R = 96
+    bank = PolicyBank.trainable_init(torch.device("cuda", 0), seed=3, max_rows=2 * R)            # tie_shared = True
+    sds = pilots.tie_shared_layer([PN.random_weights(k, 3) for k in (PN.FIGHT1, PN.FIGHT2)])
+    assert sds[1]["shared_layer._model.0.weight"] is sds[0]["shared_layer._model.0.weight"]
+    g = torch.Generator().manual_seed(1)
+    obs = (torch.rand((R, 2, 26), generator=g) * 2 - 1).cuda()
+    obs[:, 1, 24:] = 0
+    sel = _sel("fight", R)
+    zeros4 = torch.zeros((R, 4))
+
+    def check(bank, sds, csds):
+        logits = torch.zeros((R, 2, 32), dtype=torch.float32, device="cuda")
+        _, _, vf = bank.sample(obs, sel, greedy=True, logits=logits)
+        o = obs.cpu()
+        for slot, kind in enumerate((PN.FIGHT1, PN.FIGHT2)):
+            assert (logits[:, slot, : PN.N_OUT[kind]].cpu() - PN.torch_forward(kind, sds[slot], o[:, slot])).abs().max() <= TOL
+            assert (vf[:, slot].cpu() - PN.torch_value(kind, sds[slot], csds[slot], o[:, slot], zeros4, o[:, 1 - slot], zeros4)).abs().max() <= TOL
+    csds = [PN.random_critic_weights(k, 3) for k in (PN.FIGHT1, PN.FIGHT2)]
+    check(bank, sds, csds)
+    # a PPO iteration reloads slot 1's actor only: its value branch would evaluate the OLD shared layer — refused instead
+    new = pilots.tie_shared_layer([PN.random_weights(k, 8) for k in (PN.FIGHT1, PN.FIGHT2)])
+    bank.set_net(1, PN.FIGHT2, new[1])
+    with pytest.raises(RuntimeError, match="value branch"):
+        bank.sample(obs, sel, greedy=True)
+    _, _, none = bank.sample(obs, sel, greedy=True, want_vf=False)                                # the actor alone still runs
+    assert none is None
+    bank.set_critic(1, PN.FIGHT2, new[1], csds[1])
+    bank.load_trainable(0, PN.FIGHT1, new[0], csds[0])
+    check(bank, new, csds)
+    # another kind into the slot: the old kind's value branch cannot be used with it
+    bank.set_net(1, PN.ESC2, PN.random_weights(PN.ESC2, 8))
+    with pytest.raises(RuntimeError):
+        bank.set_critic(1, PN.FIGHT2, new[1], csds[1])

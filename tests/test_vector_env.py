@@ -134,6 +134,8 @@ def test_protocol_errors_and_corner_cases(oracle):
     assert sorted(env.poll()[0]) == [0, 1, 2, 3]
     with pytest.raises(ValueError, match="levels 4-5"):
         LowLevelVectorEnv({"args": make_args(level=4), "num_envs": 2})
+    with pytest.raises(ValueError, match="env_config\\['args'\\] is missing"):
+        LowLevelVectorEnv({"num_envs": 2})                           # a clear error instead of an AttributeError on None
 
 
 # ------------------------------------------------------------------------------------------------ HighLevelVectorEnv

@@ -49,17 +49,23 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=8, help="untimed launches after the clock spin-up")
     ap.add_argument("--arenas", type=int, default=None, help="arenas per GPU (configs[1]: 4096; rollout: 16384; hier: 8192)")
     ap.add_argument("--level", type=int, default=3)
-    ap.add_argument("--chunk", type=int, default=250, help="ticks per persistent-kernel launch (= per step)")
+    ap.add_argument("--chunk", type=int, default=500, help="ticks per persistent-kernel launch (= per step).  500: the driver's --steps 20 --warmup 5 then "
+                                                            "times 10 000 ticks of every arena after 2 500 warm-up ticks (SURVEY.md 8d asks >= 10 000 after 1 000)")
+    ap.add_argument("--one-gpu-value", type=float, default=None, help="--gpus N > 1: the `value` of a 1-GPU line of the same command; the N-GPU line then carries "
+                                                                       "scaling_efficiency = value_N / (N x value_1) (weak scaling, SURVEY.md 8e)")
+    ap.add_argument("--tape", choices=["keyed", "torch"], default="keyed", help="action tapes: keyed = hh_action_tape_uniform, i.i.d. uniform over MultiDiscrete([13,9,2,2]) from the "
+                                                                                  "keyed RNG, key = (seed, global arena, step, agent) (SURVEY.md 8d); torch = torch.rand with a per-rank seed")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--spinup", type=float, default=0.6, help="seconds of untimed launches before the warm-up (GPU clocks ramp from idle)")
     ap.add_argument("--log-every", type=int, default=8, help="launches between logging all-gathers of episode statistics (side stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU plumbing check of the multi-rank path (gloo, no world, no kernel): ranks, barriers, max-over-ranks, gather")
-    ap.add_argument("--workload", choices=["low", "rollout", "hier"], default="low",
+    ap.add_argument("--workload", choices=["low", "rollout", "hier", "collect"], default="low",
                     help="low: BASELINE configs[1] (default, the headline).  rollout: configs[2], every tick a fight policy with the "
                          "reference's Fight1/Fight2 architecture maps the observations to the next actions (--arenas 16384).  hier: "
-                         "configs[3], 3-vs-3 HighLevelEnv commander steps (--arenas 8192); a step is one commander step")
+                         "configs[3], 3-vs-3 HighLevelEnv commander steps (--arenas 8192); a step is one commander step.  collect: configs[2] as a whole "
+                         "PPO batch — PPORollout.collect of --chunk ticks (sampler + step per tick, bootstrap value, hh_gae_rllib): a step is one collect")
     ap.add_argument("--pilot", choices=["tape", "random", "mlp", "net"], default="tape",
                     help="hier: uniform actions from a pre-resident tape (default), drawn by torch kernels inside the step, random-init "
                          "MLP stand-ins in torch, or the reference's Fight/Esc architectures in the fused HIP kernel (net)")
@@ -186,11 +192,8 @@ def cpu_baseline(n_arenas, level, seed, budget_s=12.0):
     cores = len(os.sched_getaffinity(0))
     w = O.OracleWorld(O.make_config(n_arenas=n_arenas, level=level, seed=seed, auto_reset=True))
     w.reset()
-    rng = np.random.default_rng(seed)
     T = 50
-    act = np.zeros((T, n_arenas, w.n_ctrl, 4), dtype=np.int8)
-    act[..., 0] = rng.integers(0, 13, act.shape[:-1]); act[..., 1] = rng.integers(0, 9, act.shape[:-1])
-    act[..., 2] = rng.integers(0, 2, act.shape[:-1]); act[..., 3] = rng.integers(0, 2, act.shape[:-1])
+    act = O.action_tape_uniform(seed, 0, 0, T, n_arenas, w.n_ctrl)   # the first T steps of the same keyed tape the GPU run consumes
     w.rollout(act[:4])  # warm
     steps = 0
     t0 = time.perf_counter()
@@ -200,7 +203,7 @@ def cpu_baseline(n_arenas, level, seed, budget_s=12.0):
     dt = time.perf_counter() - t0
     out = {"value": n_arenas * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
            "note": "unoptimised scalar C restatement (statement order of the reference, no SIMD): a reported baseline, not a tuned CPU implementation",
-           "sample": f"{n_arenas} arenas x {steps} ticks, same config/seed/action distribution, one OpenMP team, arenas outer / ticks inner"}
+           "sample": f"{n_arenas} arenas x {steps} ticks, same config / seed / keyed action tape (its first {T} steps, cycled), one OpenMP team, arenas outer / ticks inner"}
     ref = load_json("reference_cpu_rate.json")
     if ref:
         out["reference_python"] = {
@@ -225,12 +228,12 @@ def counter_evidence(instance, n_arenas, ticks, units_per_s_per_gpu, lanes_per_a
     instance: evidence whose profiled kernel name does not contain `instance` (hh_kernel_instance: the template instance this world
     launches, as a profiler prints it) is stale and is not quoted (traffic / fp64 stay null)."""
     traffic, fp64, issue = None, None, None
-    quoted = "builder's rocprofv3 --pmc run of this kernel instance at this arena count (tools/prof_pmc.sh), NOT measured by this run"
-    tj = load_json("latest_traffic.json")
+    quoted = "builder's rocprofv3 --pmc run of this kernel instance at this arena count (tools/prof_pmc.sh -> profiles/latest_*[_<arenas>].json), NOT measured by this run"
+    tj = load_json(f"latest_traffic_{n_arenas}.json") or load_json("latest_traffic.json")
     if tj and tj.get("arenas") == n_arenas and tj.get("hbm_bytes_per_launch") and instance in str(tj.get("kernel_full", tj.get("kernel", ""))):
         per = tj.get("hbm_bytes_per_arena_tick") or tj["hbm_bytes_per_launch"] / (tj["arenas"] * tj["ticks_per_launch"])
         traffic = int(per * n_arenas * ticks)
-    pj = load_json("latest_pmc.json")
+    pj = load_json(f"latest_pmc_{n_arenas}.json") or load_json("latest_pmc.json")
     if pj and pj.get("arenas") == n_arenas and instance in str(pj.get("kernel", "")):
         valu = pj["insts_valu_per_wave_tick"]
         # every VALU instruction of a wave counted as one issue slot for each lane that carries an aircraft (idle lanes of the
@@ -277,6 +280,24 @@ def launch_traffic(fname, instance, n_arenas):
     return None
 
 
+def make_tape(args, R, T, N, n_units, step0=0):
+    """[T, N, n_units, 4] int8 actions resident in HBM before the timed region.  keyed (default): i.i.d. uniform over
+    MultiDiscrete([13,9,2,2]) from the keyed RNG, key = (seed, GLOBAL arena, step, agent) — rank r's tape is the slice of the one global
+    tape its arenas select (hh_action_tape_uniform, pinned against the oracle's in tests/test_gpu_parity.py)"""
+    torch = R.torch
+    if args.tape == "keyed":
+        from hhmarl_2d_amd.world import action_tape_uniform
+        return action_tape_uniform(args.seed, R.rank * N, step0, T, N, n_units, device=R.dev)
+    gen = torch.Generator(device=R.dev)
+    gen.manual_seed(args.seed + R.rank + 7919 * step0)
+    hi = torch.tensor([13, 9, 2, 2], device=R.dev)
+    return (torch.rand((T, N, n_units, 4), device=R.dev, generator=gen) * hi).to(torch.int8).contiguous()
+
+
+TAPE_DESC = {"keyed": "actions i.i.d. uniform over MultiDiscrete([13,9,2,2]) from the keyed RNG, key = (seed, global arena, step, agent)",
+             "torch": "actions i.i.d. uniform over MultiDiscrete([13,9,2,2]) from torch.rand (per-rank seed)"}
+
+
 # ------------------------------------------------------------------------------------------------ configs[1]: the headline
 def main_low(args, R=None):
     own = R is None
@@ -290,13 +311,10 @@ def main_low(args, R=None):
     w = sw.world
     w.reset()
     tape, out, side = None, w.alloc_outputs(chunk), None
-    n_tape = 4  # distinct chunks of actions, cycled
+    n_tape = 4 if N * chunk <= (1 << 26) else 2  # distinct chunks of actions, cycled (8 B per arena-tick: 1 GB per chunk at 262144 arenas x 500 ticks)
     if not R.dry:
         # action tape resident in HBM before the timed region: i.i.d. uniform MultiDiscrete([13,9,2,2])
-        gen = torch.Generator(device=R.dev)
-        gen.manual_seed(args.seed + R.rank)
-        hi = torch.tensor([13, 9, 2, 2], device=R.dev)
-        tape = (torch.rand((n_tape, chunk, N, w.n_ctrl, 4), device=R.dev, generator=gen) * hi).to(torch.int8).contiguous()
+        tape = make_tape(args, R, n_tape * chunk, N, w.n_ctrl).view(n_tape, chunk, N, w.n_ctrl, 4)
         side = torch.cuda.Stream()
     state = {"k": 0}
 
@@ -339,10 +357,15 @@ def main_low(args, R=None):
         "agent_steps_per_s": value * 2, "per_rank_env_steps_per_s": per_rank,
         "config": {"workload": f"{N} arenas/GPU x 2-vs-2 fight L{args.level} (scripted opponent), random actions, auto-reset "
                                f"(BASELINE configs[1])", "arenas_per_gpu": N, "ticks_per_step": chunk,
+                   "actions": TAPE_DESC[args.tape] + f"; {n_tape} chunks of {chunk} steps resident in HBM, cycled",
+                   "timed_ticks_per_arena": chunk * args.steps, "warmup_ticks_per_arena": chunk * args.warmup,
                    "env_steps_per_step": N * chunk * R.world,
                    "step": "one hh_rollout launch = ticks_per_step consecutive LowLevelEnv.step() calls of every arena",
                    "parallelism": f"arena-sharded x{R.world}, no data-path collective; logging all-gather every {args.log_every} launches on a side stream"},
     }
+    if R.world > 1 and args.one_gpu_value:
+        line["scaling_efficiency"] = value / (R.world * args.one_gpu_value)
+        line["one_gpu_value"] = args.one_gpu_value
     if R.dry:
         line["dry_run"] = True
         line["gathered_rows"] = None if sw.last_stats is None else int(sw.last_stats.shape[0])
@@ -517,9 +540,72 @@ def main_policy_rollout(args, R=None):
     R.close()
 
 
+def main_collect(args, R=None):
+    """BASELINE configs[2] as a whole PPO batch: one step = one `PPORollout.collect` of T = --chunk ticks of N arenas — per tick the sampler
+    (actor, keyed Categorical draw, logp, centralised value branch: hh_policy_sample) and hh_step, then the bootstrap value evaluation and
+    hh_gae_rllib over the [T, N, 2] buffers (RLlib's trajectory semantics, rollout.py) — replayed from ONE HIP graph; everything stays on
+    the device.  value = N x T x steps / wall time."""
+    own = R is None
+    R = R or Ranks(args)
+    torch = R.torch
+    from hhmarl_2d_amd.pilots import PolicyBank
+    from hhmarl_2d_amd.rollout import PPORollout
+    from hhmarl_2d_amd.sharding import ShardedWorld
+    N, T = args.arenas or 16384, max(1, args.chunk)
+    sw = ShardedWorld(dict(n_arenas=N, level=args.level, seed=args.seed, auto_reset=True), rank=R.rank, world_size=R.world, device=R.local_rank)
+    w = sw.world
+    bank = PolicyBank.trainable_init(R.dev, seed=args.seed, max_rows=2 * N)
+    ro = PPORollout(w, bank, T, use_graph=not args.no_graph)
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup:
+        ro.collect()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        ro.collect()
+    R.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        ro.collect()
+    e1.record()
+    R.barrier()
+    dt = R.max_over_ranks(time.perf_counter() - t0)
+    gpu_s = e0.elapsed_time(e1) * 1e-3
+    value = N * T * R.world * args.steps / dt
+    comp = float(ro.complete.float().mean())
+    achieved = ALGO_BYTES_2V2_STEP * N * T * args.steps / gpu_s / 1e9
+    line = {
+        "metric": "env-steps/sec (2v2, whole PPO batch: sampler + step per tick, bootstrap, GAE)", "value": value, "unit": "env-steps/s", "n_gpus": R.world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 world + f32 policy, f64 GAE recursion", "data": "synthetic", "agent_steps_per_s": value * 2, "gpu_ms_per_step": gpu_s / args.steps * 1e3,
+        "collect": {"ticks": T, "launches": 2 * T + 2, "semantics": ro.semantics, "gae": "hh_gae_rllib (gamma 0.99, lambda 0.95)",
+                    "rows_in_complete_episodes": comp, "buffers": "obs, actions, logp, vf, reward, valid, done, adv, target of T x N x 2 rows, resident in HBM"},
+        "config": {"workload": f"{N} arenas/GPU x 2-vs-2 fight L{args.level}: PPORollout.collect of {T} ticks = what RLlib's rollout workers hand train_hetero.py's learner "
+                               f"(train_hetero.py:206-243: sampler every tick, complete-episode mask, GAE gamma 0.99 / lambda 0.95), random-init Fight1/Fight2 with ONE tied "
+                               f"shared layer, one HIP graph per collect, auto-reset (BASELINE configs[2])",
+                   "arenas_per_gpu": N, "ticks_per_step": T, "parallelism": f"arena-sharded x{R.world}, no data-path collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": f"{bank.kernel_name(2 * N, sampler=True)} + {w.kernel_instance()} (T = 1 per launch) + hh_k_gae_rllib, one HIP graph per collect",
+                     "note": "1 113 algorithmic bytes per env step (SURVEY.md 8d); the batch is policy-bound: see extra.configs2.roofline.dominant for the sampler kernel's MFMA fraction"},
+    }
+    bank.close()
+    if not own:
+        return line
+    if R.rank == 0:
+        print(json.dumps(line), flush=True)
+    R.close()
+
+
 # ------------------------------------------------------------------------------------------------ configs[3]/[4]: HighLevelEnv
 PILOT_DESC = {"tape": "uniform action tape resident in HBM", "random": "uniform actions drawn by torch kernels inside the step",
               "mlp": "random-init MLP stand-ins (torch)", "net": "random-init Fight1/Fight2/Esc1/Esc2 actors (reference architecture) in the fused HIP kernel"}
+
+
+def commander_tape(args, R, N):
+    """64 commander steps of uniform {0,1,2} actions [64, N, 3] int8: the speed component (uniform over 0..8) of the keyed action word mod 3, at step
+    indices far from the pilots' tape (or torch.rand with --tape torch)"""
+    return (make_tape(args, R, 64, N, 3, step0=1 << 20)[..., 1] % 3).to(R.torch.int8).contiguous()
 
 
 def main_hier(args, R=None):
@@ -541,16 +627,14 @@ def main_hier(args, R=None):
     w = sw.world
     w.reset()
     if args.pilot == "tape":
-        pilot = TapePilot(R.dev, N, 6, seed=args.seed + R.rank)
+        pilot = TapePilot(R.dev, N, 6, seed=args.seed + R.rank, bank=make_tape(args, R, 4 * 16, N, 6).view(4, 16, N, 6, 4))
     elif args.pilot == "random":
         pilot = RandomPilot(R.dev, args.seed + R.rank)
     elif args.pilot == "net":
         pilot = NetPilot(w, seed=args.seed, bind=os.environ.get("HH_BENCH_NO_BIND", "0") != "1")   # HH_BENCH_NO_BIND=1: binning pass per call (A/B)
     else:
         pilot = MLPPilot(R.dev, seed=args.seed)
-    gen = torch.Generator(device=R.dev)
-    gen.manual_seed(args.seed + 17 + R.rank)
-    cmds = (torch.rand((64, N, 3), device=R.dev, generator=gen) * 3).to(torch.int8).contiguous()
+    cmds = commander_tape(args, R, N)
     out, pbuf = w.alloc_outputs(), w.alloc_pilot()
 
     # pilot networks in the loop: the macro step is a fixed sequence of world launches + the pilots' kernels: capture it once
@@ -670,9 +754,7 @@ def main_hier_split(args, R, own, N, K):
     if "HH_POLICY_TILE" not in os.environ and n * 3 <= 10240:
         for pl in pilots_:   # small calls on concurrent streams stay on the tile forms: wide tiles, the other streams fill what a partial round leaves idle
             pl.bank.set_tile_rows(64)
-    gen = torch.Generator(device=R.dev)
-    gen.manual_seed(args.seed + 17 + R.rank)
-    cmds = (torch.rand((64, N, 3), device=R.dev, generator=gen) * 3).to(torch.int8).contiguous()
+    cmds = commander_tape(args, R, N)
     cmd_static = [cmds[0, k * n:(k + 1) * n].clone() for k in range(K)]
     outs = [w.alloc_outputs() for w in worlds]
     pbufs = [w.alloc_pilot() for w in worlds]
@@ -751,6 +833,8 @@ def main_hier_split(args, R, own, N, K):
 
 def main():
     args = parse_args()
+    if args.workload == "collect" and args.chunk == 500:
+        args.chunk = 64     # T of a collect unless given
     if args.dry_run and args.workload != "low":
         sys.exit("--dry-run exercises the rank plumbing of the default workload on a CPU box (gloo); the other workloads need the GPU")
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -759,6 +843,8 @@ def main():
         return main_hier(args)
     if args.workload == "rollout":
         return main_policy_rollout(args)
+    if args.workload == "collect":
+        return main_collect(args)
     single = args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1
     if not single and not args.no_extra:
         # N ranks: configs[1] per rank stays the headline `value`; BASELINE configs[4] (8192 arenas x 3-vs-3 HighLevelEnv per rank, the episode
@@ -816,15 +902,20 @@ def extra_configs(args, R):
     there — an exception, a crash — costs the headline nothing but an `error` entry."""
     def brief(line):
         keys = ("metric", "value", "unit", "steps", "ms_per_step", "gpu_ms_per_step", "dtype", "kernels_ms", "launches_per_step", "sim_ticks_per_s",
-                "ticks_per_commander_step", "streams")
+                "ticks_per_commander_step", "streams", "collect", "agent_steps_per_s")
         out = {k: line[k] for k in keys if k in line}
         out["workload"] = line["config"]["workload"]
+        for k in ("actions", "ticks_per_step", "timed_ticks_per_arena"):
+            if k in line["config"]:
+                out[k] = line["config"][k]
         out["roofline"] = line["roofline"]
         return out
 
     extra = {}
     R.torch.cuda.synchronize()
-    for name, flags in (("configs2", ["--workload", "rollout", "--ppo", "--steps", "300", "--warmup", "30"]),
+    for name, flags in (("configs1_saturated", ["--workload", "low", "--arenas", "262144", "--chunk", "125", "--steps", "8", "--warmup", "2", "--no-extra"]),
+                        ("configs2", ["--workload", "rollout", "--ppo", "--steps", "300", "--warmup", "30"]),
+                        ("configs2_collect", ["--workload", "collect", "--chunk", "64", "--steps", "6", "--warmup", "2"]),
                         ("configs2_greedy_inference", ["--workload", "rollout", "--steps", "300", "--warmup", "30"]),
                         ("configs3", ["--workload", "hier", "--pilot", "tape", "--steps", "40", "--warmup", "8"]),
                         ("configs3_networks_in_loop", ["--workload", "hier", "--pilot", "net", "--steps", "12", "--warmup", "3"])):

@@ -449,6 +449,26 @@ extern "C" int hh_get_event_masks(hh_world *w, uint32_t *masks, void *stream) {
     return HH_OK;
 }
 
+/* the keyed synthetic action tape (hh_abi.h): one lane per action word, unit-stride 4-byte stores */
+__global__ __launch_bounds__(256) void hh_k_action_tape(uint64_t seed, uint64_t arena_offset, int step0, int T, int N, int nU, int *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per_t = (size_t)N * nU;
+    if (i >= per_t * (size_t)T) return;
+    const size_t t = i / per_t, r = i - t * per_t;
+    const size_t n = r / (size_t)nU;
+    const int s = (int)(r - n * (size_t)nU);
+    out[i] = (int)hh_rng_action_word(seed, arena_offset + n, (uint32_t)(step0 + (int)t), (uint32_t)(s + 1));
+}
+
+extern "C" int hh_action_tape_uniform(uint64_t seed, uint64_t arena_offset, int32_t step0, int32_t T, int32_t N, int32_t n_units, int8_t *out, void *stream) {
+    if (T <= 0 || N <= 0 || n_units <= 0 || step0 < 0 || !out || (reinterpret_cast<uintptr_t>(out) & 3)) { g_err = "hh_action_tape_uniform: bad argument"; return HH_E_ARG; }
+    const size_t words = (size_t)T * N * n_units;
+    hipLaunchKernelGGL(hh_k_action_tape, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, arena_offset, step0, T, N, n_units,
+                       reinterpret_cast<int *>(out));
+    HIPCHK(hipGetLastError());
+    return HH_OK;
+}
+
 /* sticky per-arena "a step ran on a sanitised action word" flags (hh_abi.h) */
 __global__ __launch_bounds__(256) void hh_k_action_faults(int N, uint32_t *__restrict__ flags, uint8_t *__restrict__ out, int clear) {
     const int n = blockIdx.x * 256 + threadIdx.x;

@@ -351,11 +351,16 @@ class TapePilot:
     calls hand out, one slice per sub-step (the agents' call and the opponents' call of a sub-step get the same tensor —
     each side's rows are read by its own launch).  No kernel runs inside the macro step."""
 
-    def __init__(self, device, n_arenas, n_units, seed=0, depth=16, chunks=4):
-        g = torch.Generator(device=device)
-        g.manual_seed(seed)
-        hi = torch.tensor([13, 9, 2, 2], device=device)
-        self.bank = (torch.rand((chunks, depth, n_arenas, n_units, 4), device=device, generator=g) * hi).to(torch.int8).contiguous()
+    def __init__(self, device, n_arenas, n_units, seed=0, depth=16, chunks=4, bank=None):
+        """bank: a ready int8 tape [chunks, depth, n_arenas, n_units, 4] (e.g. world.action_tape_uniform: the keyed synthetic actions); else torch.rand"""
+        if bank is not None:
+            assert bank.dtype == torch.int8 and bank.is_contiguous() and tuple(bank.shape[1:]) == (depth, n_arenas, n_units, 4)
+            self.bank = bank
+        else:
+            g = torch.Generator(device=device)
+            g.manual_seed(seed)
+            hi = torch.tensor([13, 9, 2, 2], device=device)
+            self.bank = (torch.rand((chunks, depth, n_arenas, n_units, 4), device=device, generator=g) * hi).to(torch.int8).contiguous()
         self.static = self.bank[0].clone()
         self.depth, self.calls = depth, 0
 

@@ -33,6 +33,18 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def action_tape_uniform(seed, arena_offset, step0, T, N, n_units=2, device=0, out=None):
+    """the keyed synthetic action tape of the benchmark workloads (hh_action_tape_uniform: i.i.d. uniform over MultiDiscrete([13,9,2,2]),
+    key = (seed, global arena, step, agent)) -> int8 [T, N, n_units, 4] on `device`"""
+    dev = torch.device("cuda", device) if isinstance(device, int) else device
+    out = out if out is not None else torch.empty((T, N, n_units, 4), dtype=torch.int8, device=dev)
+    assert out.is_contiguous() and out.dtype == torch.int8 and out.numel() == T * N * n_units * 4
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(L.lib().hh_action_tape_uniform(int(seed), int(arena_offset), int(step0), int(T), int(N), int(n_units), _p(out), st))
+    return out
+
+
 class World:
     """N independent arenas resident on one GPU."""
 

@@ -193,6 +193,12 @@ int hh_eval_info(hh_world *w, int32_t *last, int32_t *total, int32_t clear_total
 /* steps, alive_agents, alive_opps, done of every arena -> [dev] i32 [N, 4] (what step({}) needs: env_base.py:87-90) */
 int hh_arena_status(hh_world *w, int32_t *out, void *stream);
 
+/* Synthetic action tape of the benchmark workloads (BASELINE configs[1] "random actions": i.i.d. uniform over
+ * MultiDiscrete([13,9,2,2]) from the keyed RNG, key = (seed, global arena, step, agent)): fills out [dev] i8 [T, N, n_units, 4]: the word at (t, n, s) is
+ * hh_rng.h's `hh_rng_action_word` of seed, global arena arena_offset + n, step step0 + t, unit s + 1.  No world needed: the tape of a shard is the
+ * slice of the global tape its arena_offset selects.  n_units = 2 for LowLevelEnv agents, 6 for a HighLevelEnv pilot tape. */
+int hh_action_tape_uniform(uint64_t seed, uint64_t arena_offset, int32_t step0, int32_t T, int32_t N, int32_t n_units, int8_t *out, void *stream);
+
 /* The device-side replacement of the reference's raising guards (ac1.py:58-66 set_heading / set_speed; SURVEY.md section 5 "invalid-state
  * flag per arena instead of raising"): out [dev] u8 [N] (nullable) = 1 for every arena in which, since the flags were last cleared, a step
  * (hh_step / hh_rollout / hh_step_begin / hh_step_finish / hh_hl_agents_act / hh_hl_tick / hh_hl_rollout) consumed an action word with a

@@ -61,4 +61,16 @@ HH_HD int hh_l5_policy_pick(uint64_t arena_key, uint32_t episode) {
     return hh_rng_randint(hh_rng_u01(hh_rng_tick_key(arena_key, episode, 0u), 0u, HH_SITE_RESET_L5K, 0u), 3, 5);
 }
 
+/* One word of the synthetic action tape (BASELINE configs[1]: "random actions"): the four components of agent `unit`
+ * (1-based) of global arena `arena` at step index `step`, i.i.d. uniform over MultiDiscrete([13, 9, 2, 2]), keyed — the same word on any
+ * device, shard or host.  Returns the packed little-endian int8 word (a0 in bits 0..7). */
+HH_HD uint32_t hh_rng_action_word(uint64_t seed, uint64_t arena, uint32_t step, uint32_t unit) {
+    const uint64_t tk = hh_rng_tick_key(hh_rng_arena_key(seed, arena), 0u, step);
+    const uint32_t a0 = (uint32_t)hh_rng_randint(hh_rng_u01(tk, unit, HH_SITE_ACTION_TAPE, 0u), 0, 12);
+    const uint32_t a1 = (uint32_t)hh_rng_randint(hh_rng_u01(tk, unit, HH_SITE_ACTION_TAPE, 1u), 0, 8);
+    const uint32_t a2 = (uint32_t)hh_rng_randint(hh_rng_u01(tk, unit, HH_SITE_ACTION_TAPE, 2u), 0, 1);
+    const uint32_t a3 = (uint32_t)hh_rng_randint(hh_rng_u01(tk, unit, HH_SITE_ACTION_TAPE, 3u), 0, 1);
+    return a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
+}
+
 #endif /* HH_RNG_H */

@@ -110,7 +110,9 @@ enum {
     HH_SITE_HL_PICK = 24,     /* env_hier.py:181  randint(2, k)                           */
     HH_SITE_POLICY_SAMPLE = 25, /* hh_policy_sample (hh_policy.h): the Categorical draw RLlib's sampler makes per action component
                                    (TorchMultiCategorical.sample -> torch.multinomial, unseeded in the reference); sub = component */
-    HH_SITE_COUNT = 26
+    HH_SITE_ACTION_TAPE = 26,   /* hh_action_tape_uniform (hh_abi.h): the synthetic "random actions" of the benchmark workloads (SURVEY.md 8d:
+                                   i.i.d. uniform over MultiDiscrete([13,9,2,2]) keyed by (arena, step, agent)); sub = component; episode key 0 */
+    HH_SITE_COUNT = 27
 };
 
 #endif /* HH_SPEC_H */

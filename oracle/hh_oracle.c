@@ -1516,6 +1516,17 @@ API void hho_cannon_cone_planar(int n, int ac_type, const double *lat1, const do
         exact[i] = km < HH_AC_CANNON_KM(ac_type) && hh_fabs(signed_heading_diff(hdg[i], brg)) <= HH_AC_CANNON_HALF(ac_type);
     }
 }
+/* hh_abi.h: hh_action_tape_uniform (the benchmark's keyed synthetic actions), out [T, N, n_units, 4] */
+API int hho_action_tape_uniform(uint64_t seed, uint64_t arena_offset, int step0, int T, int N, int n_units, int8_t *out) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)T * N * n_units; i++) {
+        const long per_t = (long)N * n_units, t = i / per_t, r = i - t * per_t, n = r / n_units, s = r - n * n_units;
+        const uint32_t w = hh_rng_action_word(seed, arena_offset + (uint64_t)n, (uint32_t)(step0 + (int)t), (uint32_t)(s + 1));
+        out[4 * i] = (int8_t)(w & 0xff); out[4 * i + 1] = (int8_t)((w >> 8) & 0xff); out[4 * i + 2] = (int8_t)((w >> 16) & 0xff); out[4 * i + 3] = (int8_t)((w >> 24) & 0xff);
+    }
+    return HH_OK;
+}
+
 API double hho_rng_u01(uint64_t seed, uint64_t arena, uint32_t episode, uint32_t tick, uint32_t unit, uint32_t site, uint32_t sub) {
     return hh_rng_u01(hh_rng_tick_key(hh_rng_arena_key(seed, arena), episode, tick), unit, site, sub);
 }

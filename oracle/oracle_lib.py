@@ -252,6 +252,15 @@ class OracleWorld:
         return ret, ln, oc
 
 
+def action_tape_uniform(seed, arena_offset, step0, T, N, n_units=2):
+    """hh_action_tape_uniform on the host: int8 [T, N, n_units, 4], the benchmark's keyed uniform MultiDiscrete([13,9,2,2]) actions"""
+    out = np.zeros((T, N, n_units, 4), dtype=np.int8)
+    L = lib()
+    L.hho_action_tape_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.hho_action_tape_uniform(int(seed), int(arena_offset), int(step0), int(T), int(N), int(n_units), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def math_eval(fn, a, b=None):
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(a if b is None else b, dtype=np.float64)

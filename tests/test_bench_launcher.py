@@ -26,7 +26,7 @@ def test_gpus_2_self_spawns_two_ranks():
     assert line["n_gpus"] == 2 and line["dry_run"] is True
     assert len(line["per_rank_env_steps_per_s"]) == 2
     assert line["gathered_rows"] == 16                      # both ranks' blocks arrived in the all-gather
-    assert line["config"]["env_steps_per_step"] == 8 * 250 * 2
+    assert line["config"]["env_steps_per_step"] == 8 * 500 * 2
     assert line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
 
 
@@ -39,6 +39,23 @@ def test_two_rank_line_carries_configs4():
     assert c4["gathered_rows"] == 2 * 8192
     assert c4["first_global_arena_of_each_block"] == [0.0, 8192.0]
     assert line["metric"].startswith("env-steps/sec") and line["n_gpus"] == 2   # the headline is still configs[1]
+
+
+def test_gpus_8_dry_run_is_the_scale_table_the_driver_will_fill():
+    """8-rank readiness without hardware: `bench.py --gpus 8` self-spawns eight ranks (gloo here, RCCL on the
+    node), weak scaling, per-rank rates, the configs[4] branch with 8 x 8192 rows gathered in global arena order — and, given the 1-GPU line's
+    value, the line carries scaling_efficiency = value_8 / (8 x value_1) so that the first real SCALE run yields the table with no edits"""
+    line = _run(["--gpus", "8", "--one-gpu-value", "1000.0"])
+    assert line["n_gpus"] == 8 and line["dry_run"] is True and line["scaling"] == "weak"
+    assert len(line["per_rank_env_steps_per_s"]) == 8 and all(v > 0 for v in line["per_rank_env_steps_per_s"])
+    assert line["gathered_rows"] == 8 * 8
+    assert line["config"]["env_steps_per_step"] == 8 * 500 * 8
+    assert abs(line["scaling_efficiency"] - line["value"] / (8 * 1000.0)) < 1e-12 and line["one_gpu_value"] == 1000.0
+    c4 = line["extra"]["configs4"]
+    assert c4["dry_run"] is True and c4["n_gpus"] == 8 and c4["arenas_per_gpu"] == 8192
+    assert c4["gathered_rows"] == 8 * 8192                                                   # BASELINE configs[4]: 65536 arenas over 8 ranks
+    assert c4["first_global_arena_of_each_block"] == [float(8192 * r) for r in range(8)]    # blocks in global arena order
+    assert "scaling_efficiency" not in _run(["--gpus", "2"])                                 # only when a 1-GPU value was supplied
 
 
 def test_single_rank_line_contract():

@@ -215,6 +215,51 @@ def test_full_size_rollout_parity(oracle, monkeypatch, N, T, force_w):
         assert np.array_equal(a, b)
 
 
+def test_keyed_action_tape_equals_the_oracles(oracle):
+    """hh_action_tape_uniform (the benchmark's "random actions": SURVEY.md 8d, key = (seed, global arena, step, agent)) on the device = the
+    oracle's, word for word; a shard's tape is a slice of the global one; every component covers exactly its MultiDiscrete range"""
+    from hhmarl_2d_amd.world import action_tape_uniform
+    t = action_tape_uniform(1234, 4096, 7, 20, 3001).cpu().numpy()
+    assert np.array_equal(t, oracle.action_tape_uniform(1234, 4096, 7, 20, 3001))
+    whole = action_tape_uniform(1234, 0, 0, 30, 8192).cpu().numpy()
+    assert np.array_equal(t[:, :3001], whole[7:27, 4096:4096 + 3001])
+    for c, hi in enumerate((13, 9, 2, 2)):
+        assert whole[..., c].min() == 0 and whole[..., c].max() == hi - 1 and len(np.unique(whole[..., c])) == hi
+    six = action_tape_uniform(5, 100, 0, 16, 777, n_units=6).cpu().numpy()
+    assert np.array_equal(six, oracle.action_tape_uniform(5, 100, 0, 16, 777, 6)) and np.array_equal(six[:, :, :2], action_tape_uniform(5, 100, 0, 16, 777).cpu().numpy())
+
+
+@pytest.mark.parametrize("N", [131072, 262144], ids=["131072", "262144-saturated"])
+def test_saturated_world_parity(oracle, N):
+    """The W = 2 instance at the sizes where it saturates the chip (bench.py extra.configs1_saturated: 262144 arenas; VERDICT r4 weak 1.iii:
+    nothing above 40 000 arenas was oracle-checked inside the suite): the first ticks after reset, then — after 170 unchecked ticks on the
+    bench's keyed tape, by which time rockets fly, cannons burst and episodes have ended — the state is handed to the oracle and the next
+    ticks are compared: every output row, the event masks and the whole final state, bit for bit."""
+    import torch
+    from hhmarl_2d_amd.world import action_tape_uniform
+    kw = dict(n_arenas=N, level=3, seed=1234, auto_reset=True, horizon=150)
+    g, o = _worlds(oracle, **kw)
+    assert "hh_k_world_quad<2, 1, false, 16" in g.kernel_instance()
+    assert np.array_equal(g.reset().cpu().numpy(), o.reset())
+    tape = action_tape_uniform(1234, 0, 0, 180, N)
+    host = tape[:4].cpu().numpy()
+    for a, b, name in zip([x.cpu().numpy() for x in g.rollout(tape[:4])], o.rollout(host), ("obs", "reward", "valid", "done")):
+        assert np.array_equal(a, b), f"first ticks: {name}"
+    _assert_same_state(g.get_state(), o.get_state(), "after the first ticks")
+    for k in range(4, 174, 34):   # unchecked stretch in pieces: the stacked output buffers of one call stay below 2 GB
+        g.rollout(tape[k:k + 34], want_obs=False)
+    st = g.get_state()
+    assert (st["rk_i"][:, :, 0] != 0).any() and (st["ar_i"][:, 5] >= 2).any(), "rockets in flight, second episodes running"
+    g.set_state(st); o.set_state(st)
+    host = tape[174:180].cpu().numpy()
+    outs = [x.cpu().numpy() for x in g.rollout(tape[174:180])]
+    for a, b, name in zip(outs, o.rollout(host), ("obs", "reward", "valid", "done")):
+        assert np.array_equal(a, b), f"mid-run ticks: {name}"
+    assert np.array_equal(g.event_masks(), o.event_masks())
+    _assert_same_state(g.get_state(), o.get_state(), "final")
+    assert outs[3].any(), "episodes ended inside the compared ticks"
+
+
 @pytest.mark.parametrize("kw", [dict(level=3), dict(level=3, agent_mode=1, esc_dist_rew=1), dict(level=5, ext_opp_actions=1)],
                          ids=["L3-fight", "L3-escape", "L5-external-opponents"])
 def test_register_exchange_kernel_equals_lds_kernel(monkeypatch, kw):

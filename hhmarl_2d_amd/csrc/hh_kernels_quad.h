@@ -82,18 +82,39 @@ struct QTab {
     int amask;                                /* alive bits by ABSOLUTE slot, own bit included */
 };
 
-/* position / speed / heading part (final once the aircraft has moved) and the status flags (final at the end of the tick) */
-__device__ __forceinline__ void quad_publish_motion(const DevCfg &c, const Unit &m, QPub &p) {
+/* position / speed / heading part (final once the aircraft has moved) and the status flags (final at the end of the tick).
+ * _vec: the heading unit vector — read by the tick itself (cannon prefilter, launch test) and by the pair table; _norm: the normalised
+ * observation entries — read only by whoever formats observation rows */
+__device__ __forceinline__ void quad_publish_vec(const Unit &m, QPub &p) {
     double sn, cs;
     hh_sincos(hh_pymod360(90.0 - m.hdg) * (HH_PI / 180.0), &sn, &cs);
     p.uc = cs;
     p.us = sn;
     p.un = hh_sqrt(cs * cs + sn * sn);
+}
+__device__ __forceinline__ void quad_publish_norm(const DevCfg &c, const Unit &m, QPub &p) {
     p.nlat = (float)hh_clip(hh_div_known(m.lat - HH_MAP_LAT0, c.ext_lat, c.inv_ext_lat), 0.0, 1.0);
     p.nlon = (float)hh_clip(hh_div_known(m.lon - HH_MAP_LON0, c.ext_lon, c.inv_ext_lon), 0.0, 1.0);
     p.nspd = (float)hh_clip(hh_div_known(m.spd, HH_AC_MAX_SPEED(m.ac_type), HH_AC_INV_MAX_SPEED(m.ac_type)), 0.0, 1.0);
     p.nhdg = (float)hh_clip(HH_DIVC(hh_pymod359(m.hdg), 359.0), 0.0, 1.0);
 }
+__device__ __forceinline__ void quad_publish_motion(const DevCfg &c, const Unit &m, QPub &p) {
+    quad_publish_vec(m, p);
+    quad_publish_norm(c, m, p);
+}
+
+/* ---- the pair table on the OUTPUT wave (two-wave forms compiled for a preset configuration, OWT below) ----
+ * What a tick's post-move pair table needs — four positions and heading vectors — is final at the end of phase B, a third of the way
+ * into the tick, and nothing the simulation wave does between there and the end of the tick (envelope tests, kill resolution, rewards)
+ * reads it.  So the simulation wave hands the moved positions to the output wave at a workgroup barrier (X), goes on with the envelope
+ * phases, and takes the finished distances and focus angles back at the second barrier of the tick (Y), while the output wave — on
+ * another SIMD of the CU — runs the table's two square roots and four acos chains (16 % of a tick) and then formats the observation
+ * rows from ITS copy of the table.  Only integers cross at Y in the other direction (status flags, ammunition, reward, done).
+ * All three mailboxes are indexed by lane and single-buffered: every write is separated from every read of the other wave by one of
+ * the two barriers. */
+struct QPosMail { double lat[64], lon[64], uc[64], us[64], un[64], spd[64], hdg[64]; int ac_type[64]; };   /* sim -> out at X */
+struct QTabMail { double dist[3][64], foc[3][64], focr[3][64]; };                                            /* out -> sim at Y */
+struct QSlimMail { int flags[64], w5[64], w6[64], w7[64]; float rew[64]; int full; };                        /* sim -> out at Y */
 __device__ __forceinline__ void quad_publish_flags(const Unit &m, QPub &p) {
     int shot = m.burst > 0 || (m.ac_type == 1 && m.has_missile);
     p.flags = (m.alive ? FL_ALIVE : 0) | ((m.ac_type & 3) << 1) | (shot ? FL_SHOT : 0);
@@ -290,10 +311,13 @@ __device__ __forceinline__ void q_wave_sync() { asm volatile("s_waitcnt lgkmcnt(
 
 /* one fused LowLevelEnv step of the lane's arena; `tb`/`pub` hold the pre-tick table on entry and the post-tick
  * table on return.  Line-by-line counterpart of tick<4, 64>(tmode 0) in hh_kernels.h. */
-template <bool IX, bool DUAL>
+template <bool IX, bool DUAL, bool OWT = false>
 __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, int tid, int g, int s, int base, bool active, bool helper, Unit &m,
                                           Arena &ar, const int8_t *act, QTab &tb, QPub &pub, Near2 &nbc, StepOut &out,
-                                          uint32_t &ev_mask_out HH_PROF_ARGS) {
+                                          uint32_t &ev_mask_out, QPosMail *pos HH_PROF_ARGS) {
+    /* OWT: the post-tick pair table is built by the output wave (QPosMail above).  This function then posts the moved positions and meets the
+     * output wave at barrier X after phase B, and returns with tb.lat / lon / amask refreshed but tb.dist / foc / focr and nbc still the PRE-tick
+     * ones: the caller takes the new ones from the output wave at barrier Y. */
     /* nbc: _nearby_object of the lane against `tb` — the pre-tick table on entry (what the scripts and the target refresh of this tick
      * read), the post-tick table on return: computed once per tick, straight-line on every lane, instead of once per reader */
     constexpr int A = 4;
@@ -554,7 +578,16 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     /* position, speed and heading are final for this tick: their published form is computed here, where it also
      * serves the cannon prefilter (heading vector after the turn) and overlaps the envelope phases */
     QPub pn;
-    quad_publish_motion(c, m, pn);
+    if constexpr (OWT) {
+        quad_publish_vec(m, pn);
+        pn.nlat = pn.nlon = pn.nspd = pn.nhdg = 0.0f; /* formatted by the output wave from the raw values */
+        /* every lane posts (the helpers' slots are never read): no exec-mask region */
+        pos->lat[tid] = m.lat; pos->lon[tid] = m.lon; pos->uc[tid] = pn.uc; pos->us[tid] = pn.us; pos->un[tid] = pn.un;
+        pos->spd[tid] = m.spd; pos->hdg[tid] = m.hdg; pos->ac_type[tid] = m.ac_type;
+        __syncthreads(); /* barrier X: the output wave starts on the post-tick table */
+    } else {
+        quad_publish_motion(c, m, pn);
+    }
     /* positions of the other aircraft after their move (registers, by relative slot) */
     double lat1[3], lon1[3];
     lat1[0] = q_rot_d<1>(m.lat); lon1[0] = q_rot_d<1>(m.lon);
@@ -828,8 +861,15 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     quad_publish_flags(m, pn);
     pub = pn;
     HH_PROF(6);
-    quad_tables<DUAL>(m, pub, s, helper, tb);
-    quad_nearby(c, tb, s, nbc);
+    if constexpr (OWT) {
+        /* what of the post-tick table this wave can tell by itself: where the others stand now and who is alive */
+#pragma unroll
+        for (int k = 0; k < 3; k++) { tb.lat[k] = lat1[k]; tb.lon[k] = lon1[k]; }
+        tb.amask = (int)(__ballot(m.alive != 0) >> base) & 0xf;
+    } else {
+        quad_tables<DUAL>(m, pub, s, helper, tb);
+        quad_nearby(c, tb, s, nbc);
+    }
     HH_PROF(7);
     {
         const int ag = __popc(tb.amask & 3), op = __popc(tb.amask & 12);
@@ -838,7 +878,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         out.kill_event = running ? ke : out.kill_event;
         ar.done = running ? dn : ar.done;
     }
-    if (c.agent_mode == HH_MODE_ESCAPE && c.esc_dist_rew) { /* wave-uniform: configuration */
+    if (!OWT && c.agent_mode == HH_MODE_ESCAPE && c.esc_dist_rew) { /* wave-uniform: configuration (OWT instances are presets: no escape shaping) */
         if (running && agent && m.alive) { /* env_hetero.py:198-214 */
             const Near2 nb = nbc;
             const double dr[2] = {nb.r0, nb.r1};
@@ -916,6 +956,9 @@ __device__ __forceinline__ void mail_take(const ObsMail &mb, int r, QTab &t, QPu
 template <bool TWO> struct QuadMailbox { /* LDS of the two-wave form only */
     ObsMail mail[2];
     alignas(16) float tile[16 * 2 * HH_OBS_ESC_AC1];
+    QPosMail pos;   /* the three mailboxes of the preset instances (pair table on the output wave) */
+    QTabMail tab;
+    QSlimMail slim;
 };
 template <> struct QuadMailbox<false> {};
 
@@ -965,7 +1008,72 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
     __shared__ QuadMailbox<TWO> mbx;
     const int tid = threadIdx.x & 63;
     const int D = c.D;
-    if constexpr (TWO) {
+    /* OWT: the post-tick pair table is computed by the output wave (QPosMail above).  Preset instances only: the general instance may carry
+     * the escape distance shaping (env_hetero.py:198-214), whose reward needs the post-tick distances before the tick's rows are posted. */
+    constexpr bool OWT = TWO && PRE != 0;
+    if constexpr (OWT) {
+        if (threadIdx.x >= 64) { /* ---------------- the output wave: pair table, then the observation rows ---------------- */
+            const bool helper = DUAL && tid >= 32;
+            const int mt = DUAL ? (tid & 31) : tid;
+            const int g = mt >> 2, s = mt & 3; /* the simulation wave's lane layout: one lane per aircraft, helpers above */
+            const int n = blockIdx.x * GPB + g;
+            const bool row = !helper && s < 2 && g < GPB && n < c.N;
+            for (int t = 0; t < T; t++) {
+                __syncthreads(); /* barrier X: the moved positions are posted */
+                Unit m = Unit{};
+                QPub pub;
+                m.lat = mbx.pos.lat[tid]; m.lon = mbx.pos.lon[tid]; m.spd = mbx.pos.spd[tid]; m.hdg = mbx.pos.hdg[tid];
+                m.ac_type = mbx.pos.ac_type[tid];
+                pub.uc = mbx.pos.uc[tid]; pub.us = mbx.pos.us[tid]; pub.un = mbx.pos.un[tid];
+                pub.flags = 0;
+                quad_publish_norm(c, m, pub);
+                QTab tb;
+                quad_tables<DUAL>(m, pub, s, helper, tb); /* the same expressions on the same operands as the simulation wave's own (reset ticks) */
+#pragma unroll
+                for (int k = 0; k < 3; k++) { mbx.tab.dist[k][tid] = tb.dist[k]; mbx.tab.foc[k][tid] = tb.foc[k]; mbx.tab.focr[k][tid] = tb.focr[k]; }
+                __syncthreads(); /* barrier Y: the table is there for the simulation wave; its integers are here */
+                int valid = 0, done = 0;
+                float rew = 0.0f;
+                if (mbx.slim.full) { /* a reset in this tick (wave-uniform): the rows come from the simulation wave's own table of the new episodes */
+                    if (row) mail_take(mbx.mail[0], g * 2 + s, tb, pub, m, valid, done, rew);
+                } else {
+                    pub.flags = mbx.slim.flags[tid];
+                    tb.fl[0] = q_rot_i<1>(pub.flags); tb.fl[1] = q_rot_i<2>(pub.flags); tb.fl[2] = q_rot_i<3>(pub.flags);
+                    tb.amask = ((pub.flags & FL_ALIVE) << s) | ((tb.fl[0] & FL_ALIVE) << ((s + 1) & 3)) | ((tb.fl[1] & FL_ALIVE) << ((s + 2) & 3)) |
+                               ((tb.fl[2] & FL_ALIVE) << ((s + 3) & 3));
+                    const int w5 = mbx.slim.w5[tid], w6 = mbx.slim.w6[tid], w7 = mbx.slim.w7[tid];
+                    m.cannon_remain = w5 & 0xffff; m.cannon_max = (w5 >> 16) & 0xffff;
+                    m.missile_remain = w6 & 0xff; m.rocket_max = (w6 >> 8) & 0xff; m.missile_wait = (w6 >> 16) & 0xff; m.burst = (w6 >> 24) & 0xff;
+                    m.ac_type = w7 & 0xff; m.alive = (w7 >> 8) & 0xff; m.has_missile = (w7 >> 16) & 0xff;
+                    valid = (w7 >> 24) & 1;
+                    done = (w7 >> 25) & 1;
+                    rew = mbx.slim.rew[tid];
+                }
+                if (row) {
+                    quad_lowlevel_obs(c, tb, pub, s, c.agent_mode, m, &mbx.tile[(g * 2 + s) * D], D);
+                    const size_t o = ((size_t)t * c.N + n) * 2 + s;
+                    if (reward_out) reward_out[o] = rew;
+                    if (valid_out) valid_out[o] = (uint8_t)valid;
+                    if (s == 0 && done_out) done_out[(size_t)t * c.N + n] = (uint8_t)done;
+                }
+                q_wave_sync();
+                if (obs_out) {
+                    const int rows = min(GPB, c.N - (int)blockIdx.x * GPB);
+                    const int cnt = rows * 2 * D;
+                    float *dst = obs_out + ((size_t)t * c.N + (size_t)blockIdx.x * GPB) * 2 * D;
+                    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0) {
+                        const float4 *src4 = reinterpret_cast<const float4 *>(mbx.tile);
+                        float4 *dst4 = reinterpret_cast<float4 *>(dst);
+                        for (int k = tid; k < (cnt >> 2); k += 64) dst4[k] = src4[k];
+                    } else {
+                        for (int k = tid; k < cnt; k += 64) dst[k] = mbx.tile[k];
+                    }
+                }
+                q_wave_sync(); /* the tile is free again */
+            }
+            return;
+        }
+    } else if constexpr (TWO) {
         if (threadIdx.x >= 64) { /* ---------------- the output wave ---------------- */
             const int g = tid >> 1, s = tid & 1; /* lanes 0..31: one agent row each */
             const int n = blockIdx.x * GPB + g;
@@ -1048,9 +1156,11 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         int8_t act[4];
         const bool was_running = active && !ar.done;
         hh_act_unpack(act_cur, act, act_fault, has_act & was_running & (m.alive != 0));
-        tick_quad<(W >= 2), DUAL>(c, sh, tid, g, s, base, active, helper, m, ar, act, tb, pub, nbc, so, evm_last HH_PROF_PASS);
+        QPosMail *posmail = nullptr;
+        if constexpr (OWT) posmail = &mbx.pos;
+        tick_quad<(W >= 2), DUAL, OWT>(c, sh, tid, g, s, base, active, helper, m, ar, act, tb, pub, nbc, so, evm_last, posmail HH_PROF_PASS);
         const int done_now = ar.done;
-        if constexpr (TWO) { /* post the agents' rows as early as they exist: the LDS stores drain behind the work below */
+        if constexpr (TWO && !OWT) { /* post the agents' rows as early as they exist: the LDS stores drain behind the work below */
             if (!helper && s < 2) mail_post(mbx.mail[t & 1], g * 2 + s, tb, pub, m, so, done_now);
         }
         asm volatile("" : "+v"(act_next)); /* take the word of tick t+1 HERE (see above) ... */
@@ -1079,7 +1189,8 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         }
         if (!TWO && active && s == 0 && done_out) done_out[(size_t)t * c.N + n] = (uint8_t)ar.done;
         const bool need_reset = active && ar.done && c.auto_reset;
-        if (q_any(need_reset)) { /* K3, wave-uniform */
+        const bool reset_tick = q_any(need_reset);
+        if (reset_tick) { /* K3, wave-uniform */
             if (need_reset) {
                 reset_arena_scalars(ar);
                 reset_unit<A>(c, s, m, ar);
@@ -1088,12 +1199,36 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
             quad_publish(c, m, pub);
             quad_tables<DUAL>(m, pub, s, helper, tb);
             quad_nearby(c, tb, s, nbc);
-            if constexpr (TWO) { /* the first observation of the new episode replaces the posted rows */
+            if constexpr (OWT) { /* the rows of this tick come from THIS table (the first observation of the new episodes) */
+                if (!helper && s < 2) mail_post(mbx.mail[0], g * 2 + s, tb, pub, m, so, done_now);
+            } else if constexpr (TWO) { /* the first observation of the new episode replaces the posted rows */
                 if (!helper && s < 2) mail_post(mbx.mail[t & 1], g * 2 + s, tb, pub, m, so, done_now);
             }
         }
         HH_PROF(9);
-        if constexpr (TWO) {
+        if constexpr (OWT) {
+            /* the integers of the agents' rows (every lane posts its own words: no exec-mask region), then barrier Y */
+            mbx.slim.flags[tid] = pub.flags;
+            mbx.slim.w5[tid] = (m.cannon_remain & 0xffff) | ((m.cannon_max & 0xffff) << 16);
+            mbx.slim.w6[tid] = (m.missile_remain & 0xff) | ((m.rocket_max & 0xff) << 8) | ((m.missile_wait & 0xff) << 16) | ((m.burst & 0xff) << 24);
+            mbx.slim.w7[tid] = (m.ac_type & 0xff) | ((m.alive & 0xff) << 8) | ((m.has_missile & 0xff) << 16) | ((so.valid & 1) << 24) | ((done_now & 1) << 25);
+            mbx.slim.rew[tid] = (float)so.reward;
+            if (tid == 0) mbx.slim.full = reset_tick ? 1 : 0;
+            __syncthreads(); /* barrier Y */
+            if (!reset_tick) { /* wave-uniform: take the post-tick table the output wave built while this wave ran the envelope phases */
+#pragma unroll
+                for (int k = 0; k < 3; k++) { tb.dist[k] = mbx.tab.dist[k][tid]; tb.foc[k] = mbx.tab.foc[k][tid]; tb.focr[k] = mbx.tab.focr[k][tid]; }
+                quad_nearby(c, tb, s, nbc);
+            }
+            { /* env_hetero.py:99-101: the observation refreshes opp_to_attack (straight-line on every lane, kept by the agents') */
+                Unit mr = m;
+                quad_target_refresh(nbc, mr);
+                const bool keep = active & (s < 2);
+                m.n_tgt = keep ? mr.n_tgt : m.n_tgt; m.tgt0 = keep ? mr.tgt0 : m.tgt0; m.tgt_d0 = keep ? mr.tgt_d0 : m.tgt_d0;
+            }
+            HH_PROF(10);
+            continue;
+        } else if constexpr (TWO) {
             /* hand the agents' rows to the output wave and go on */
             { /* straight-line on every lane, kept by the agents' */
                 Unit mr = m;

@@ -38,12 +38,13 @@
 /* phase timers for tuning builds only (-DHH_PROFILE_PHASES): s_memtime deltas per phase, summed per wave
  * into hh_prof_cycles[]; compiled out of the product */
 #ifdef HH_PROFILE_PHASES
-__device__ unsigned long long hh_prof_cycles[16];
-#define HH_PROF_DECL unsigned long long prof_t0_ = __builtin_readcyclecounter(), prof_acc_[12] = {0}
+__device__ unsigned long long hh_prof_cycles[24]; /* 0..11 phases, 12..15 queue statistics, 16..19 output wave (wait X, table, wait Y, rows), 20 / 21 barrier X / Y waits of the simulation wave */
+#define HH_PROF_DECL unsigned long long prof_t0_ = __builtin_readcyclecounter(), prof_acc_[14] = {0}
 #define HH_PROF(k) do { unsigned long long t_ = __builtin_readcyclecounter(); prof_acc_[k] += t_ - prof_t0_; prof_t0_ = t_; } while (0)
 #define HH_PROF_ARGS , unsigned long long &prof_t0_, unsigned long long *prof_acc_
 #define HH_PROF_PASS , prof_t0_, prof_acc_
-#define HH_PROF_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 12; k_++) atomicAdd(&hh_prof_cycles[k_], prof_acc_[k_]); } while (0)
+#define HH_PROF_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 12; k_++) atomicAdd(&hh_prof_cycles[k_], prof_acc_[k_]); \
+                                                          atomicAdd(&hh_prof_cycles[20], prof_acc_[12]); atomicAdd(&hh_prof_cycles[21], prof_acc_[13]); } } while (0)
 #else
 #define HH_PROF_DECL
 #define HH_PROF(k)

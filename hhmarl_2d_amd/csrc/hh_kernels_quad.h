@@ -112,9 +112,19 @@ __device__ __forceinline__ void quad_publish_motion(const DevCfg &c, const Unit 
  * rows from ITS copy of the table.  Only integers cross at Y in the other direction (status flags, ammunition, reward, done).
  * All three mailboxes are indexed by lane and single-buffered: every write is separated from every read of the other wave by one of
  * the two barriers. */
-struct QPosMail { double lat[64], lon[64], uc[64], us[64], un[64], spd[64], hdg[64]; int ac_type[64]; };   /* sim -> out at X */
-struct QTabMail { double dist[3][64], foc[3][64], focr[3][64]; };                                            /* out -> sim at Y */
+struct QPosMail { double lat[64], lon[64], uc[64], us[64], un[64], spd[64], hdg[64]; int ac_type[64], steps[64], episode[64]; };   /* sim -> out at X */
+struct QTabMail { double dist[3][64], foc[3][64], focr[3][64]; double sx[64], sy[64], ue[64], uh[64]; unsigned long long tk[64]; };   /* out -> sim at Y */
 struct QSlimMail { int flags[64], w5[64], w6[64], w7[64]; float rew[64]; int full; };                        /* sim -> out at Y */
+/* The output wave also runs AHEAD of the simulation wave: between X and Y of tick t it computes what tick t + 1 will need that depends only on
+ * what tick t has already fixed — the keyed-RNG tick key of (episode, steps + 1), this lane's script draw from it in both variants (escaping /
+ * pursuing: which one applies is decided in tick t + 1), and the rounded sine / cosine of the heading after the turn that _correct_angle_sign
+ * (env_base.py:464-487) takes.  `ok` is wave-uniform: false on the first tick of a launch and after a tick that reset an arena of the wave
+ * (episode / steps / heading changed behind the prediction); the tick then computes them itself, the same expressions. */
+struct QPre {
+    bool ok;
+    unsigned long long tkey;
+    double ue, uh, sx, sy;
+};
 __device__ __forceinline__ void quad_publish_flags(const Unit &m, QPub &p) {
     int shot = m.burst > 0 || (m.ac_type == 1 && m.has_missile);
     p.flags = (m.alive ? FL_ALIVE : 0) | ((m.ac_type & 3) << 1) | (shot ? FL_SHOT : 0);
@@ -314,7 +324,7 @@ __device__ __forceinline__ void q_wave_sync() { asm volatile("s_waitcnt lgkmcnt(
 template <bool IX, bool DUAL, bool OWT = false>
 __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, int tid, int g, int s, int base, bool active, bool helper, Unit &m,
                                           Arena &ar, const int8_t *act, QTab &tb, QPub &pub, Near2 &nbc, StepOut &out,
-                                          uint32_t &ev_mask_out, QPosMail *pos HH_PROF_ARGS) {
+                                          uint32_t &ev_mask_out, QPosMail *pos, const QPre &pre HH_PROF_ARGS) {
     /* OWT: the post-tick pair table is built by the output wave (QPosMail above).  This function then posts the moved positions and meets the
      * output wave at barrier X after phase B, and returns with tb.lat / lon / amask refreshed but tb.dist / foc / focr and nbc still the PRE-tick
      * ones: the caller takes the new ones from the output wave at barrier Y. */
@@ -328,7 +338,9 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     out.valid = 0;
     out.kill_event = 0;
     uint32_t evm = 0;
-    if (running) { ar.steps += 1; arena_rekey(ar); }
+    if (OWT && pre.ok) { /* wave-uniform: the key of this tick was computed by the output wave during the last one */
+        if (running) { ar.steps += 1; ar.tkey = pre.tkey; }
+    } else if (running) { ar.steps += 1; arena_rekey(ar); }
     const bool snap = running && m.alive;
     const int amask0 = tb.amask; /* alive at tick start, by absolute slot */
     /* rocket_unit.py:25-35 speed profile of this slot's rocket (a launch in this tick starts at age 0).  Looked up
@@ -431,17 +443,25 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         {
             const int du = (s | 2) + 1;                           /* unit id of the opponent this lane draws for */
             const bool desc = (s & 1) ? escj[1] : escj[0];
-            uint64_t key = ar.tkey;
             int role = agent ? 1 : 0, de = desc ? 1 : 0;
             if (DUAL) {
-                const int klo = q_down_i((int)(uint32_t)key), khi = q_down_i((int)(uint32_t)(key >> 32)), deh = q_down_i(de);
-                key = helper ? (((uint64_t)(uint32_t)khi << 32) | (uint64_t)(uint32_t)klo) : key;
+                const int deh = q_down_i(de);
                 de = helper ? deh : de;
                 role = helper ? 2 : role;
             }
-            const int site_e = role == 0 ? HH_SITE_ESC_HDG : (role == 1 ? HH_SITE_ESC_SPEED : HH_SITE_ESC_FIRE);
-            const int site_h = role == 0 ? HH_SITE_HC_SPEED1 : (role == 1 ? HH_SITE_HC_R : HH_SITE_HC_SPEED2);
-            const double u = hh_rng_u01(key, (uint32_t)du, (uint32_t)(de ? site_e : site_h), 0u);
+            double u;
+            if (OWT && pre.ok) { /* wave-uniform: both variants of this lane's draw are there */
+                u = de ? pre.ue : pre.uh;
+            } else {
+                uint64_t key = ar.tkey;
+                if (DUAL) {
+                    const int klo = q_down_i((int)(uint32_t)key), khi = q_down_i((int)(uint32_t)(key >> 32));
+                    key = helper ? (((uint64_t)(uint32_t)khi << 32) | (uint64_t)(uint32_t)klo) : key;
+                }
+                const int site_e = role == 0 ? HH_SITE_ESC_HDG : (role == 1 ? HH_SITE_ESC_SPEED : HH_SITE_ESC_FIRE);
+                const int site_h = role == 0 ? HH_SITE_HC_SPEED1 : (role == 1 ? HH_SITE_HC_R : HH_SITE_HC_SPEED2);
+                u = hh_rng_u01(key, (uint32_t)du, (uint32_t)(de ? site_e : site_h), 0u);
+            }
             u0 = u;
             u1 = q_perm_d<HH_QP(0, 1, 0, 1)>(u); /* slot 2 <- slot 0, slot 3 <- slot 1 */
             if (DUAL) u2 = q_up_d(u);
@@ -467,9 +487,14 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                 if (nb.n) {
                     const double ag_lat = q_sel(tb.lat, nb.k0), ag_lon = q_sel(tb.lon, nb.k0);
                     /* env_base.py:464-487 _correct_angle_sign */
-                    double sn, cs;
-                    hh_sincos(hh_pymod360(m.hdg) * (HH_PI / 180.0), &sn, &cs);
-                    double x1 = m.lon + hh_round3(sn), y1 = m.lat + hh_round3(cs);
+                    double rs, rc;
+                    if (OWT && pre.ok) { rs = pre.sx; rc = pre.sy; } /* wave-uniform */
+                    else {
+                        double sn, cs;
+                        hh_sincos(hh_pymod360(m.hdg) * (HH_PI / 180.0), &sn, &cs);
+                        rs = hh_round3(sn); rc = hh_round3(cs);
+                    }
+                    double x1 = m.lon + rs, y1 = m.lat + rc;
                     double val = (x1 - m.lon) * (ag_lat - m.lat) - (ag_lon - m.lon) * (y1 - m.lat);
                     double sign = val < 0.0 ? 1.0 : -1.0;
                     double r = hh_rng_uniform(u1, 0.7, 1.3);
@@ -584,7 +609,10 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         /* every lane posts (the helpers' slots are never read): no exec-mask region */
         pos->lat[tid] = m.lat; pos->lon[tid] = m.lon; pos->uc[tid] = pn.uc; pos->us[tid] = pn.us; pos->un[tid] = pn.un;
         pos->spd[tid] = m.spd; pos->hdg[tid] = m.hdg; pos->ac_type[tid] = m.ac_type;
+        pos->steps[tid] = ar.steps; pos->episode[tid] = ar.episode;
+        HH_PROF(1);
         __syncthreads(); /* barrier X: the output wave starts on the post-tick table */
+        HH_PROF(12);
     } else {
         quad_publish_motion(c, m, pn);
     }
@@ -1018,8 +1046,16 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
             const int g = mt >> 2, s = mt & 3; /* the simulation wave's lane layout: one lane per aircraft, helpers above */
             const int n = blockIdx.x * GPB + g;
             const bool row = !helper && s < 2 && g < GPB && n < c.N;
+#ifdef HH_PROFILE_PHASES
+            unsigned long long ot0_ = __builtin_readcyclecounter(), oacc_[4] = {0, 0, 0, 0};
+#define HH_OPROF(k) do { unsigned long long t_ = __builtin_readcyclecounter(); oacc_[k] += t_ - ot0_; ot0_ = t_; } while (0)
+#else
+#define HH_OPROF(k)
+#endif
+            const unsigned long long akey = hh_rng_arena_key(c.seed, c.arena_offset + (uint64_t)n);
             for (int t = 0; t < T; t++) {
                 __syncthreads(); /* barrier X: the moved positions are posted */
+                HH_OPROF(0);
                 Unit m = Unit{};
                 QPub pub;
                 m.lat = mbx.pos.lat[tid]; m.lon = mbx.pos.lon[tid]; m.spd = mbx.pos.spd[tid]; m.hdg = mbx.pos.hdg[tid];
@@ -1031,7 +1067,21 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                 quad_tables<DUAL>(m, pub, s, helper, tb); /* the same expressions on the same operands as the simulation wave's own (reset ticks) */
 #pragma unroll
                 for (int k = 0; k < 3; k++) { mbx.tab.dist[k][tid] = tb.dist[k]; mbx.tab.foc[k][tid] = tb.foc[k]; mbx.tab.focr[k][tid] = tb.focr[k]; }
+                { /* ahead of the simulation wave (QPre): the next tick's key, this lane's script draw in both variants, the script's rounded sine / cosine */
+                    const unsigned long long tk1 = hh_rng_tick_key(akey, (uint32_t)mbx.pos.episode[mt], (uint32_t)(mbx.pos.steps[mt] + 1));
+                    const int du = (s | 2) + 1, role = helper ? 2 : (s < 2 ? 1 : 0); /* tick_quad's assignment of the three draws to lanes */
+                    const int site_e = role == 0 ? HH_SITE_ESC_HDG : (role == 1 ? HH_SITE_ESC_SPEED : HH_SITE_ESC_FIRE);
+                    const int site_h = role == 0 ? HH_SITE_HC_SPEED1 : (role == 1 ? HH_SITE_HC_R : HH_SITE_HC_SPEED2);
+                    mbx.tab.tk[tid] = tk1;
+                    mbx.tab.ue[tid] = hh_rng_u01(tk1, (uint32_t)du, (uint32_t)site_e, 0u);
+                    mbx.tab.uh[tid] = hh_rng_u01(tk1, (uint32_t)du, (uint32_t)site_h, 0u);
+                    double sn, cs;
+                    hh_sincos(hh_pymod360(m.hdg) * (HH_PI / 180.0), &sn, &cs);
+                    mbx.tab.sx[tid] = hh_round3(sn); mbx.tab.sy[tid] = hh_round3(cs);
+                }
+                HH_OPROF(1);
                 __syncthreads(); /* barrier Y: the table is there for the simulation wave; its integers are here */
+                HH_OPROF(2);
                 int valid = 0, done = 0;
                 float rew = 0.0f;
                 if (mbx.slim.full) { /* a reset in this tick (wave-uniform): the rows come from the simulation wave's own table of the new episodes */
@@ -1070,7 +1120,12 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                     }
                 }
                 q_wave_sync(); /* the tile is free again */
+                HH_OPROF(3);
             }
+#ifdef HH_PROFILE_PHASES
+            if (tid == 0) for (int k_ = 0; k_ < 4; k_++) atomicAdd(&hh_prof_cycles[16 + k_], oacc_[k_]);
+#endif
+#undef HH_OPROF
             return;
         }
     } else if constexpr (TWO) {
@@ -1146,6 +1201,8 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
      * for) right after tick t's compute and BEFORE tick t's output stores, when the load is a whole tick old and
      * the previous tick's stores have long been acknowledged; the request for tick t+2 goes out at the same place. */
     const bool has_act = active && s < c.n_ctrl;
+    QPre pre;
+    pre.ok = false; pre.tkey = 0ULL; pre.ue = pre.uh = pre.sx = pre.sy = 0.0;
     const size_t act_stride = (size_t)c.N * c.n_ctrl * 4;
     const int8_t *act_ptr = has_act ? actions + ((size_t)n * c.n_ctrl + s) * 4 : actions; /* lanes without a row re-read row 0, unused */
     int act_cur = *reinterpret_cast<const int *>(act_ptr);
@@ -1158,7 +1215,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         hh_act_unpack(act_cur, act, act_fault, has_act & was_running & (m.alive != 0));
         QPosMail *posmail = nullptr;
         if constexpr (OWT) posmail = &mbx.pos;
-        tick_quad<(W >= 2), DUAL, OWT>(c, sh, tid, g, s, base, active, helper, m, ar, act, tb, pub, nbc, so, evm_last, posmail HH_PROF_PASS);
+        tick_quad<(W >= 2), DUAL, OWT>(c, sh, tid, g, s, base, active, helper, m, ar, act, tb, pub, nbc, so, evm_last, posmail, pre HH_PROF_PASS);
         const int done_now = ar.done;
         if constexpr (TWO && !OWT) { /* post the agents' rows as early as they exist: the LDS stores drain behind the work below */
             if (!helper && s < 2) mail_post(mbx.mail[t & 1], g * 2 + s, tb, pub, m, so, done_now);
@@ -1214,10 +1271,14 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
             mbx.slim.w7[tid] = (m.ac_type & 0xff) | ((m.alive & 0xff) << 8) | ((m.has_missile & 0xff) << 16) | ((so.valid & 1) << 24) | ((done_now & 1) << 25);
             mbx.slim.rew[tid] = (float)so.reward;
             if (tid == 0) mbx.slim.full = reset_tick ? 1 : 0;
+            HH_PROF(9);
             __syncthreads(); /* barrier Y */
-            if (!reset_tick) { /* wave-uniform: take the post-tick table the output wave built while this wave ran the envelope phases */
+            HH_PROF(13);
+            pre.ok = !reset_tick;
+            if (!reset_tick) { /* wave-uniform: take the post-tick table the output wave built while this wave ran the envelope phases, and what it computed ahead */
 #pragma unroll
                 for (int k = 0; k < 3; k++) { tb.dist[k] = mbx.tab.dist[k][tid]; tb.foc[k] = mbx.tab.foc[k][tid]; tb.focr[k] = mbx.tab.focr[k][tid]; }
+                pre.tkey = mbx.tab.tk[tid]; pre.ue = mbx.tab.ue[tid]; pre.uh = mbx.tab.uh[tid]; pre.sx = mbx.tab.sx[tid]; pre.sy = mbx.tab.sy[tid];
                 quad_nearby(c, tb, s, nbc);
             }
             { /* env_hetero.py:99-101: the observation refreshes opp_to_attack (straight-line on every lane, kept by the agents') */

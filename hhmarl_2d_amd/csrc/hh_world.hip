@@ -675,8 +675,8 @@ extern "C" int hh_hl_rollout(hh_world *w, const int8_t *commander_actions, const
 #ifdef HH_PROFILE_PHASES
 extern "C" int hh_prof_read(unsigned long long *out16, int reset) {
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(hh_prof_cycles), 16 * 8));
-    if (reset) { unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(hh_prof_cycles), z, 16 * 8)); }
+    HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(hh_prof_cycles), 24 * 8)); /* [host] 24 counters (hh_kernels.h) */
+    if (reset) { unsigned long long z[24] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(hh_prof_cycles), z, 24 * 8)); }
     return HH_OK;
 }
 #endif

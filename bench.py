@@ -720,11 +720,12 @@ def main_hier(args, R=None):
                                         "note": "bytes the one-launch schedule needs (state stays in registers across the sub-steps): the figure the counter traffic should be compared with"}
     line["gpu_ms_per_step"] = gpu_s / steps * 1e3
     if tape_launch:   # HBM bytes per commander step of the one-launch kernel, from the committed PMC passes
-        tr = launch_traffic("r03_hier8192_traffic.json", w.kernel_instance(1), N)
+        tf = "latest_hier_traffic.json" if load_json("latest_hier_traffic.json") else "r03_hier8192_traffic.json"
+        tr = launch_traffic(tf, w.kernel_instance(1), N)
         line["roofline"]["traffic"] = tr
         if tr is not None:
             line["roofline"]["traffic_frac"] = tr / (gpu_s / steps) / 1e9 / HBM_PEAK_GBS
-            line["roofline"]["traffic_source"] = "profiles/r03_hier8192_traffic.json: builder's rocprofv3 --pmc passes of this kernel instance (bytes per commander step), NOT measured by this run"
+            line["roofline"]["traffic_source"] = f"profiles/{tf}: builder's rocprofv3 --pmc passes of this kernel instance (bytes per commander step), NOT measured by this run"
     if not one_launch:
         line["launches_per_step"] = 2 + 16 * (4 if args.pilot in ("net", "mlp", "random") else 2)
     if hasattr(pilot, "close"):

@@ -1,12 +1,12 @@
 #!/bin/bash
 # rocprofv3 passes for the bench kernel: kernel-trace stats, then PMC counter passes (separate runs: gpurun refuses --pmc
 # together with trace domains other than --kernel-trace, and the TCC counters cannot share a pass).
-# env: ARENAS (4096), CHUNK (250), BENCH_ARGS, KERNEL (hh_k_world_quad), TAG (name under gpurun_out/)
+# env: ARENAS (4096), CHUNK (500), BENCH_ARGS, KERNEL (hh_k_world_quad), TAG (name under gpurun_out/)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${TAG:-prof}
 rm -rf $OUT; mkdir -p $OUT
-A=${ARENAS:-4096}; C=${CHUNK:-250}; K=${KERNEL:-hh_k_world_quad}
+A=${ARENAS:-4096}; C=${CHUNK:-500}; K=${KERNEL:-hh_k_world_quad}
 ARGS="--steps 8 --warmup 2 --spinup 0.3 --no-cpu-baseline --no-extra --arenas $A --chunk $C ${BENCH_ARGS}"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $R/bench.py $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/pmc1 -o pmc1 -- python $R/bench.py $ARGS > $OUT/pmc1.log 2>&1

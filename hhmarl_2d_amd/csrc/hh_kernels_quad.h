@@ -1022,7 +1022,9 @@ inline int hh_cfg_preset(const DevCfg &c) { /* which preset equals this configur
 /* APW = arenas per simulation wave: 16 fills the 64 lanes; 8 (lanes 32..63 idle) is for worlds so small that half the SIMDs would
  * otherwise sit empty: a wave's tick costs the instructions of every branch ANY of its arenas takes (rocket in flight, cannon
  * burst, events, reset ...), so half the arenas per wave means fewer instructions per wave-tick at the same number of ticks. */
-template <int W, int PRE, bool TWO, int APW = 16, bool DUAL = false>
+/* SHAPE = false: a general (PRE = 0) two-wave instance for configurations WITHOUT the escape distance shaping (env_hetero.py:198-214), the one
+ * reward term that reads the post-tick distances inside the tick: such worlds can hand the pair table to the output wave like the presets. */
+template <int W, int PRE, bool TWO, int APW = 16, bool DUAL = false, bool SHAPE = true>
 __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_eu(W, W))) void hh_k_world_quad(DevPtrs P, DevCfg c_in, int T, const int8_t *__restrict__ actions,
                                                                   float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                                   uint8_t *__restrict__ valid_out, uint8_t *__restrict__ done_out) {
@@ -1036,9 +1038,11 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
     __shared__ QuadMailbox<TWO> mbx;
     const int tid = threadIdx.x & 63;
     const int D = c.D;
-    /* OWT: the post-tick pair table is computed by the output wave (QPosMail above).  Preset instances only: the general instance may carry
-     * the escape distance shaping (env_hetero.py:198-214), whose reward needs the post-tick distances before the tick's rows are posted. */
-    constexpr bool OWT = TWO && PRE != 0;
+    /* OWT: the post-tick pair table is computed by the output wave (QPosMail above).  Not with the escape distance shaping (env_hetero.py:198-214),
+     * whose reward needs the post-tick distances before the tick's rows are posted: the presets never have it, the general instance only when
+     * the launcher picked its SHAPE = false form (hh_world.hip). */
+    static_assert(SHAPE || (PRE == 0 && TWO), "SHAPE = false names the general two-wave instance without escape shaping");
+    constexpr bool OWT = TWO && (PRE != 0 || !SHAPE);
     if constexpr (OWT) {
         if (threadIdx.x >= 64) { /* ---------------- the output wave: pair table, then the observation rows ---------------- */
             const bool helper = DUAL && tid >= 32;

@@ -63,6 +63,7 @@ struct hh_world {
     int no_dual;  /* HH_NO_DUAL=1: the 8-arenas-per-wave 2-vs-2 form without helper lanes (A/B) */
     int no_oct;   /* HH_NO_OCT=1: HighLevelEnv macro steps on the LDS-exchange kernel instead of the register-exchange one (A/B) */
     int apw;      /* HH_APW=16: never pick the 8-arenas-per-wave form of the two-wave kernel */
+    int no_owt;   /* HH_NO_OWT=1: general two-wave instances keep the pair table on the simulation wave (A/B; the presets always hand it to the output wave) */
     void *trace_mem; /* trajectory ring buffer + cursors (hh_trace_enable), separate allocation */
     struct hh_policy *bound_policy; /* hh_bind_policy: the bank whose row lists P.pol_* point into (it points back at this world) */
 };
@@ -129,6 +130,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     { const char *nt = getenv("HH_NO_TWO"); w->no_two = nt ? atoi(nt) : 0; }
     { const char *no = getenv("HH_NO_OCT"); w->no_oct = no ? atoi(no) : 0; }
     { const char *nd = getenv("HH_NO_DUAL"); w->no_dual = nd ? atoi(nd) : 0; }
+    { const char *e = getenv("HH_NO_OWT"); w->no_owt = e ? atoi(e) : 0; }
     /* one slab, 256-byte aligned sub-arrays */
     size_t U = (size_t)d.N * A, N = (size_t)d.N;
     size_t off = 0;
@@ -267,18 +269,29 @@ static int launch(hh_world *w, int run, int T, const int8_t *actions, const uint
 #define HH_QLAUNCH(Wv, Pv, TWOv) hipLaunchKernelGGL((hh_k_world_quad<Wv, Pv, TWOv>), dim3(grid), dim3(TWOv ? 128 : 64), 0, st, w->P, c, T, actions, obs, reward, valid, done)
 #define HH_QLAUNCH8(Pv) do { if (w->no_dual) hipLaunchKernelGGL((hh_k_world_quad<1, Pv, true, 8>), dim3(grid8), dim3(128), 0, st, w->P, c, T, actions, obs, reward, valid, done); \
                             else hipLaunchKernelGGL((hh_k_world_quad<1, Pv, true, 8, true>), dim3(grid8), dim3(128), 0, st, w->P, c, T, actions, obs, reward, valid, done); } while (0)
+        /* general two-wave instances without the escape distance shaping: the pair table goes to the output wave like in the presets (hh_kernels_quad.h: SHAPE) */
+        const bool noshape = pre == 0 && !w->no_owt && !(c.esc_dist_rew && c.agent_mode == HH_MODE_ESCAPE);
+#define HH_QLAUNCH8_NS() do { if (w->no_dual) hipLaunchKernelGGL((hh_k_world_quad<1, 0, true, 8, false, false>), dim3(grid8), dim3(128), 0, st, w->P, c, T, actions, obs, reward, valid, done); \
+                              else hipLaunchKernelGGL((hh_k_world_quad<1, 0, true, 8, true, false>), dim3(grid8), dim3(128), 0, st, w->P, c, T, actions, obs, reward, valid, done); } while (0)
 #define HH_QPRE(LAUNCH) switch (pre) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; case 4: LAUNCH(4); break; default: LAUNCH(0); }
 #define HH_Q2(Pv) HH_QLAUNCH(2, Pv, false)
 #define HH_Q1(Pv) HH_QLAUNCH(1, Pv, false)
         if (two) { HH_QPRE(HH_Q2) }
+        else if (half && noshape) { HH_QLAUNCH8_NS(); }
         else if (half) { HH_QPRE(HH_QLAUNCH8) }
-        else if (pair) { if (pre == 1) HH_QLAUNCH(1, 1, true); else HH_QLAUNCH(1, 0, true); } /* 4097..8192 arenas: the benchmark's preset only */
+        else if (pair) { /* 4097..8192 arenas: the benchmark's preset only */
+            if (pre == 1) HH_QLAUNCH(1, 1, true);
+            else if (!w->no_owt && !(c.esc_dist_rew && c.agent_mode == HH_MODE_ESCAPE))
+                hipLaunchKernelGGL((hh_k_world_quad<1, 0, true, 16, false, false>), dim3(grid), dim3(128), 0, st, w->P, c, T, actions, obs, reward, valid, done);
+            else HH_QLAUNCH(1, 0, true);
+        }
         else { HH_QPRE(HH_Q1) }
 #undef HH_Q2
 #undef HH_Q1
 #undef HH_QPRE
 #undef HH_QLAUNCH
 #undef HH_QLAUNCH8
+#undef HH_QLAUNCH8_NS
     } else if (run >= HH_RUN_LL_BEGIN)
         hipLaunchKernelGGL((hh_k_world<4, B, 1, true>), dim3(grid), dim3(B), 0, st, w->P, c, run, T, actions, mask, obs, reward, valid, done);
     else if (two)
@@ -346,7 +359,9 @@ extern "C" int hh_kernel_instance(hh_world *w, int32_t which, char *buf, int32_t
     if (w->no_quad || w->P.trace) snprintf(buf, (size_t)len, "hh_k_world<4, 64, %d, false>", two ? 2 : 1);
     else {
         if (pair && !half && pre != 1) pre = 0;
-        if (half && !w->no_dual) snprintf(buf, (size_t)len, "hh_k_world_quad<1, %d, true, 8, true>", pre);
+        const bool noshape = pair && pre == 0 && !w->no_owt && !(c.esc_dist_rew && c.agent_mode == HH_MODE_ESCAPE);
+        if (noshape) snprintf(buf, (size_t)len, "hh_k_world_quad<1, 0, true, %d, %s, false>", half ? 8 : 16, (half && !w->no_dual) ? "true" : "false");
+        else if (half && !w->no_dual) snprintf(buf, (size_t)len, "hh_k_world_quad<1, %d, true, 8, true>", pre);
         else snprintf(buf, (size_t)len, "hh_k_world_quad<%d, %d, %s, %d, false>", two ? 2 : 1, pre, pair ? "true" : "false", half ? 8 : 16);
     }
     return HH_OK;

@@ -302,15 +302,26 @@ def test_two_wave_form_equals_single_wave(monkeypatch, kw):
     for N, T in ((4096, 330), (8189, 90), (37, 200), (2045, 150)):
         cfg = dict(n_arenas=N, seed=99, auto_reset=True, **kw)
         worlds = []
-        for no_two, no_quad, no_spec, apw in (("0", "0", "0", "0"), ("0", "0", "0", "16"), ("1", "0", "0", "0"), ("0", "0", "1", "0"), ("1", "1", "0", "0")):
+        # two-wave preset (pair table on the output wave), 16 arenas per wave, single wave, the general two-wave instance (its pair table on
+        # the output wave too unless the configuration has the escape distance shaping), the same with the table kept on the simulation
+        # wave (HH_NO_OWT), the general instance at 16 arenas per wave, the LDS-exchange kernel
+        for no_two, no_quad, no_spec, apw, no_owt in (("0", "0", "0", "0", "0"), ("0", "0", "0", "16", "0"), ("1", "0", "0", "0", "0"), ("0", "0", "1", "0", "0"),
+                                                      ("0", "0", "1", "0", "1"), ("0", "0", "1", "16", "0"), ("1", "1", "0", "0", "0")):
             monkeypatch.setenv("HH_APW", apw)
             monkeypatch.setenv("HH_NO_TWO", no_two)
             monkeypatch.setenv("HH_NO_QUAD", no_quad)
             monkeypatch.setenv("HH_NO_SPEC", no_spec)
+            monkeypatch.setenv("HH_NO_OWT", no_owt)
             monkeypatch.setenv("HH_FORCE_W", "0")
             worlds.append(World(make_config(**cfg)))
         if N <= 4096:
             assert "8 arenas per wave" in worlds[0].kernel_name() and "8 arenas per wave" not in worlds[1].kernel_name()
+        if N <= 8192:   # which general two-wave instance runs: six template arguments = SHAPE false = pair table on the output wave
+            shaping = bool(kw.get("esc_dist_rew"))
+            half = N <= 4096
+            old = "hh_k_world_quad<1, 0, true, 8, true>" if half else "hh_k_world_quad<1, 0, true, 16, false>"
+            assert worlds[4].kernel_instance() == old
+            assert worlds[3].kernel_instance() == (old if shaping else old[:-1] + ", false>")
         obs0 = [w.reset() for w in worlds]
         assert all(torch.equal(obs0[0], o) for o in obs0[1:])
         rng = np.random.default_rng(N)

@@ -112,8 +112,12 @@ __device__ __forceinline__ void quad_publish_motion(const DevCfg &c, const Unit 
  * rows from ITS copy of the table.  Only integers cross at Y in the other direction (status flags, ammunition, reward, done).
  * All three mailboxes are indexed by lane and single-buffered: every write is separated from every read of the other wave by one of
  * the two barriers. */
-struct QPosMail { double lat[64], lon[64], uc[64], us[64], un[64], spd[64], hdg[64]; int ac_type[64], steps[64], episode[64]; };   /* sim -> out at X */
-struct QTabMail { double dist[3][64], foc[3][64], focr[3][64]; double sx[64], sy[64], ue[64], uh[64]; unsigned long long tk[64]; };   /* out -> sim at Y */
+struct QPosMail { double lat[64], lon[64], spd[64], hdg[64]; int ac_type[64], steps[64], episode[64]; };   /* sim -> out at X */
+struct QTabMail { double dist[3][64], foc[3][64], focr[3][64]; double uc[64], us[64], sx[64], sy[64], ue[64], uh[64]; unsigned long long tk[64]; };   /* out -> sim at Y */
+/* The heading unit vector after the turn (a sincos and a square root) is computed by the OUTPUT wave too: the table needs it exactly, the simulation wave
+ * needs it inside the tick only for the cannon prefilter (hh_envelope.h: hh_cannon_cone_planar_outside, a one-sided test with a 0.3 deg margin of which the
+ * planar-vs-geodesic bound uses 0.26), for which the exact vector of the tick before, rotated by the turn just made (<= 5 deg: cos / sin by their Taylor
+ * polynomials, error < 1e-9 rad), is as good — and it takes the exact one back at Y for the next tick (launch test, next rotation). */
 struct QSlimMail { int flags[64], w5[64], w6[64], w7[64]; float rew[64]; int full; };                        /* sim -> out at Y */
 /* The output wave also runs AHEAD of the simulation wave: between X and Y of tick t it computes what tick t + 1 will need that depends only on
  * what tick t has already fixed — the keyed-RNG tick key of (episode, steps + 1), this lane's script draw from it in both variants (escaping /
@@ -528,14 +532,18 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     const int rk_pre = m.rk_alive;
     const int has_missile_pre = m.has_missile;
     const bool try_launch = want_launch && !m.has_missile && m.missile_remain > 0; /* ac1.py:73 */
+    double turn_deg = 0.0;
     if (snap) {
         int t = m.ac_type;
         {
             const double delta = d_signed_heading_diff(m.hdg, m.cmd_hdg);
             const double max_deg = HH_AC_TURN_RATE(t) * 1.0;
-            const double stepped = hh_pymod360(m.hdg + (delta >= 0.0 ? max_deg : -max_deg));
-            const double nh = hh_fabs(delta) <= max_deg ? m.cmd_hdg : stepped;
-            m.hdg = m.hdg != m.cmd_hdg ? nh : m.hdg;
+            const double turn = delta >= 0.0 ? max_deg : -max_deg;
+            const double stepped = hh_pymod360(m.hdg + turn);
+            const bool reach = hh_fabs(delta) <= max_deg, moved = m.hdg != m.cmd_hdg;
+            const double nh = reach ? m.cmd_hdg : stepped;
+            turn_deg = moved ? (reach ? delta : turn) : 0.0; /* the turn actually made, signed [deg] (OWT: rotates the heading vector below) */
+            m.hdg = moved ? nh : m.hdg;
         }
         {
             const double delta = m.cmd_spd - m.spd;
@@ -604,10 +612,17 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
      * serves the cannon prefilter (heading vector after the turn) and overlaps the envelope phases */
     QPub pn;
     if constexpr (OWT) {
-        quad_publish_vec(m, pn);
+        { /* the exact heading vector of the tick before (pub), rotated by the turn just made: QTabMail's comment */
+            const double th = turn_deg * (HH_PI / 180.0), t2 = th * th;
+            const double cd = 1.0 + t2 * (-0.5 + t2 * (1.0 / 24.0));
+            const double sd = th * (1.0 + t2 * ((-1.0 / 6.0) + t2 * (1.0 / 120.0)));
+            pn.uc = pub.uc * cd + pub.us * sd; /* east  = sin(h + d) */
+            pn.us = pub.us * cd - pub.uc * sd; /* north = cos(h + d) */
+            pn.un = 1.0;
+        }
         pn.nlat = pn.nlon = pn.nspd = pn.nhdg = 0.0f; /* formatted by the output wave from the raw values */
         /* every lane posts (the helpers' slots are never read): no exec-mask region */
-        pos->lat[tid] = m.lat; pos->lon[tid] = m.lon; pos->uc[tid] = pn.uc; pos->us[tid] = pn.us; pos->un[tid] = pn.un;
+        pos->lat[tid] = m.lat; pos->lon[tid] = m.lon;
         pos->spd[tid] = m.spd; pos->hdg[tid] = m.hdg; pos->ac_type[tid] = m.ac_type;
         pos->steps[tid] = ar.steps; pos->episode[tid] = ar.episode;
         HH_PROF(1);
@@ -1064,9 +1079,8 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                 QPub pub;
                 m.lat = mbx.pos.lat[tid]; m.lon = mbx.pos.lon[tid]; m.spd = mbx.pos.spd[tid]; m.hdg = mbx.pos.hdg[tid];
                 m.ac_type = mbx.pos.ac_type[tid];
-                pub.uc = mbx.pos.uc[tid]; pub.us = mbx.pos.us[tid]; pub.un = mbx.pos.un[tid];
                 pub.flags = 0;
-                quad_publish_norm(c, m, pub);
+                quad_publish_motion(c, m, pub); /* heading vector and normalised entries: the expressions the simulation wave uses on reset ticks */
                 QTab tb;
                 quad_tables<DUAL>(m, pub, s, helper, tb); /* the same expressions on the same operands as the simulation wave's own (reset ticks) */
 #pragma unroll
@@ -1076,6 +1090,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                     const int du = (s | 2) + 1, role = helper ? 2 : (s < 2 ? 1 : 0); /* tick_quad's assignment of the three draws to lanes */
                     const int site_e = role == 0 ? HH_SITE_ESC_HDG : (role == 1 ? HH_SITE_ESC_SPEED : HH_SITE_ESC_FIRE);
                     const int site_h = role == 0 ? HH_SITE_HC_SPEED1 : (role == 1 ? HH_SITE_HC_R : HH_SITE_HC_SPEED2);
+                    mbx.tab.uc[tid] = pub.uc; mbx.tab.us[tid] = pub.us;
                     mbx.tab.tk[tid] = tk1;
                     mbx.tab.ue[tid] = hh_rng_u01(tk1, (uint32_t)du, (uint32_t)site_e, 0u);
                     mbx.tab.uh[tid] = hh_rng_u01(tk1, (uint32_t)du, (uint32_t)site_h, 0u);
@@ -1283,6 +1298,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
 #pragma unroll
                 for (int k = 0; k < 3; k++) { tb.dist[k] = mbx.tab.dist[k][tid]; tb.foc[k] = mbx.tab.foc[k][tid]; tb.focr[k] = mbx.tab.focr[k][tid]; }
                 pre.tkey = mbx.tab.tk[tid]; pre.ue = mbx.tab.ue[tid]; pre.uh = mbx.tab.uh[tid]; pre.sx = mbx.tab.sx[tid]; pre.sy = mbx.tab.sy[tid];
+                pub.uc = mbx.tab.uc[tid]; pub.us = mbx.tab.us[tid]; /* the exact heading vector (the tick carried a rotated one) */
                 quad_nearby(c, tb, s, nbc);
             }
             { /* env_hetero.py:99-101: the observation refreshes opp_to_attack (straight-line on every lane, kept by the agents') */

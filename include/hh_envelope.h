@@ -44,6 +44,8 @@ HH_HD int hh_missile_cone_planar(double lat1, double lon1, double lat2, double l
  * relative bearing by the same terms as above (no focus quotient here: no 1e-10 guard), < 0.26 deg for |lat| <= 10 deg
  * and |dlat|, |dlon| <= 0.06 deg.  Returns 1 only when the planar angle exceeds w + HH_PLANAR_CONE_MARGIN: the target is
  * certainly outside the cone and the exact test can be skipped; 0 means "not decided here". */
+/* (he, hn) need not be the exactly rounded heading vector: the two-wave 2-vs-2 kernel passes the exact vector of the tick before rotated by the turn
+ * just made, whose direction is within 1e-9 rad = 6e-8 deg of the exact one — inside the 0.04 deg the margin below leaves over the 0.26 deg bound. */
 #define HH_PLANAR_CONE_MARGIN 0.3
 #define HH_COS_5P3_DEG 0.9957246981845821 /* cos((10 / 2 + 0.3) deg) */
 #define HH_COS_3P8_DEG 0.99780146829205   /* cos((7 / 2 + 0.3) deg) */

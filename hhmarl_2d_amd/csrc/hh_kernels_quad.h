@@ -118,7 +118,10 @@ struct QTabMail { double dist[3][64], foc[3][64], focr[3][64]; double uc[64], us
  * needs it inside the tick only for the cannon prefilter (hh_envelope.h: hh_cannon_cone_planar_outside, a one-sided test with a 0.3 deg margin of which the
  * planar-vs-geodesic bound uses 0.26), for which the exact vector of the tick before, rotated by the turn just made (<= 5 deg: cos / sin by their Taylor
  * polynomials, error < 1e-9 rad), is as good — and it takes the exact one back at Y for the next tick (launch test, next rotation). */
-struct QSlimMail { int flags[64], w5[64], w6[64], w7[64]; float rew[64]; int full; };                        /* sim -> out at Y */
+struct QSlimMail { int flags[64], w5[64], w6[64], w7[64]; double rew[64]; int full; };                       /* sim -> out at Y */
+/* w7: aircraft type, alive, has_missile (8 bits each) | reward key << 24 | done << 25 | "the arena ran this tick" << 26 | alive bits of the arena
+ * after the tick and BEFORE a reset (4 bits) << 27.  The reward crosses as the double the tick computed: the output wave also keeps the episode
+ * statistics (return summed in agent order, length, outcome: what the logging all-gather moves), one more thing the next tick does not read. */
 /* The output wave also runs AHEAD of the simulation wave: between X and Y of tick t it computes what tick t + 1 will need that depends only on
  * what tick t has already fixed — the keyed-RNG tick key of (episode, steps + 1), this lane's script draw from it in both variants (escaping /
  * pursuing: which one applies is decided in tick t + 1), and the rounded sine / cosine of the heading after the turn that _correct_angle_sign
@@ -351,7 +354,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
      * here, a whole phase before its use, so the table read is off the critical path. */
     const int rk_age0 = (m.rk_alive && m.rk_life <= HH_ROCKET_MAX_LIFE) ? m.rk_life : 0;
     const double rk_speed0 = sh.rk_speed[rk_age0];
-    double opp_stat0 = 0.0;
+    const int tgt_at_act = m.n_tgt ? m.tgt0 : 0; /* an agent's opp_to_attack when it acts (its lane never changes it inside the tick) */
     int want_launch = 0, launch_tgt = 0;
     int wait_after = -1;
     bool base_gate = false;
@@ -369,13 +372,9 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                 m.n_tgt = nb.n ? 1 : 0; m.tgt0 = nb.n ? nb.j0 + 1 : 0; m.tgt_d0 = nb.n ? nb.d0 : 0.0;
                 t = m.tgt0;
             }
-            {
-                const int t1 = t ? t - 1 : 0;
-                const double os = norm180(q_sel(tb.focr, (t1 - s) & 3)); /* env_hetero.py:169-170 */
-                const bool os_ok = agent & (t != 0) & (((amask0 >> t1) & 1) != 0);
-                out.valid = agent ? 1 : out.valid;
-                opp_stat0 = os_ok ? os : opp_stat0;
-            }
+            out.valid = agent ? 1 : out.valid;
+            /* env_hetero.py:169-170 opp_stats[i][0] (the target's focus on the agent when it acted) is read by ONE reward term, the cannon kill:
+             * evaluated there (phase E), from the same pre-tick table and target */
             /* env_base.py:214-238 _take_base_action */
             double nh = hh_pymod360(m.hdg + (double)(((int)act[0] - 6) * 15));
             if (nh >= 360.0 || nh < 0.0) nh = 0.0;
@@ -878,6 +877,10 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                             rews += (1.0 + ((1.5 - 1.0) / (1.0 - 0.0)) * ((double)m.missile_remain / (double)m.rocket_max - 0.0)) * sc;
                         } else {
                             double r1 = 0.5 + ((1.0 - 0.5) / (1.0 - 0.0)) * ((double)m.cannon_remain / (double)m.cannon_max - 0.0);
+                            /* the killer acted in this tick (it was alive at tick start), `tb` still holds the pre-tick table here */
+                            const int t1 = tgt_at_act ? tgt_at_act - 1 : 0;
+                            const bool os_ok = (tgt_at_act != 0) & (((amask0 >> t1) & 1) != 0);
+                            const double opp_stat0 = os_ok ? norm180(q_sel(tb.focr, (t1 - s) & 3)) : 0.0;
                             double r2 = 0.5 + ((1.0 - 0.5) / (1.0 - 0.0)) * (opp_stat0 - 0.0);
                             rews += (r1 + r2) * sc;
                         }
@@ -1072,6 +1075,8 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
 #define HH_OPROF(k)
 #endif
             const unsigned long long akey = hh_rng_arena_key(c.seed, c.arena_offset + (uint64_t)n);
+            const bool stat_lane = row && s == 0; /* one lane per arena keeps the episode statistics */
+            double ep_ret = stat_lane ? P.ep_ret[n] : 0.0;
             for (int t = 0; t < T; t++) {
                 __syncthreads(); /* barrier X: the moved positions are posted */
                 HH_OPROF(0);
@@ -1082,11 +1087,13 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                 pub.flags = 0;
                 quad_publish_motion(c, m, pub); /* heading vector and normalised entries: the expressions the simulation wave uses on reset ticks */
                 QTab tb;
+                int steps_t = 0;
                 quad_tables<DUAL>(m, pub, s, helper, tb); /* the same expressions on the same operands as the simulation wave's own (reset ticks) */
 #pragma unroll
                 for (int k = 0; k < 3; k++) { mbx.tab.dist[k][tid] = tb.dist[k]; mbx.tab.foc[k][tid] = tb.foc[k]; mbx.tab.focr[k][tid] = tb.focr[k]; }
                 { /* ahead of the simulation wave (QPre): the next tick's key, this lane's script draw in both variants, the script's rounded sine / cosine */
-                    const unsigned long long tk1 = hh_rng_tick_key(akey, (uint32_t)mbx.pos.episode[mt], (uint32_t)(mbx.pos.steps[mt] + 1));
+                    steps_t = mbx.pos.steps[mt]; /* read HERE: after Y the simulation wave posts the next tick's */
+                    const unsigned long long tk1 = hh_rng_tick_key(akey, (uint32_t)mbx.pos.episode[mt], (uint32_t)(steps_t + 1));
                     const int du = (s | 2) + 1, role = helper ? 2 : (s < 2 ? 1 : 0); /* tick_quad's assignment of the three draws to lanes */
                     const int site_e = role == 0 ? HH_SITE_ESC_HDG : (role == 1 ? HH_SITE_ESC_SPEED : HH_SITE_ESC_FIRE);
                     const int site_h = role == 0 ? HH_SITE_HC_SPEED1 : (role == 1 ? HH_SITE_HC_R : HH_SITE_HC_SPEED2);
@@ -1103,6 +1110,22 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                 HH_OPROF(2);
                 int valid = 0, done = 0;
                 float rew = 0.0f;
+                { /* episode statistics (the simulation wave's own code in the other forms): return summed in agent order, then length and outcome */
+                    const int w7s = mbx.slim.w7[tid];
+                    const double rv = ((w7s >> 24) & 1) ? mbx.slim.rew[tid] : 0.0;
+                    const double r1 = q_rot_d<1>(rv); /* agent 2's, as lane s = 0 sees it */
+                    const bool ran = ((w7s >> 26) & 1) != 0, dn = ((w7s >> 25) & 1) != 0;
+                    const double e2 = (ep_ret + rv) + r1;
+                    ep_ret = ran ? e2 : ep_ret;
+                    if (stat_lane && ran && dn) { /* an episode ended */
+                        const int am = (w7s >> 27) & 0xf, steps = steps_t;
+                        const int ag = __popc(am & 3), op = __popc(am & 12);
+                        P.last_ret[n] = (float)ep_ret;
+                        P.last_len[n] = steps;
+                        P.last_outcome[n] = (op <= 0 && steps < c.horizon) ? 1 : ((ag <= 0 && steps < c.horizon) ? -1 : 0);
+                    }
+                    if (dn && c.auto_reset) ep_ret = 0.0; /* the arena starts a new episode (K3 of the simulation wave) */
+                }
                 if (mbx.slim.full) { /* a reset in this tick (wave-uniform): the rows come from the simulation wave's own table of the new episodes */
                     if (row) mail_take(mbx.mail[0], g * 2 + s, tb, pub, m, valid, done, rew);
                 } else {
@@ -1116,7 +1139,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                     m.ac_type = w7 & 0xff; m.alive = (w7 >> 8) & 0xff; m.has_missile = (w7 >> 16) & 0xff;
                     valid = (w7 >> 24) & 1;
                     done = (w7 >> 25) & 1;
-                    rew = mbx.slim.rew[tid];
+                    rew = (float)mbx.slim.rew[tid];
                 }
                 if (row) {
                     quad_lowlevel_obs(c, tb, pub, s, c.agent_mode, m, &mbx.tile[(g * 2 + s) * D], D);
@@ -1141,6 +1164,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                 q_wave_sync(); /* the tile is free again */
                 HH_OPROF(3);
             }
+            if (stat_lane) P.ep_ret[n] = ep_ret;
 #ifdef HH_PROFILE_PHASES
             if (tid == 0) for (int k_ = 0; k_ < 4; k_++) atomicAdd(&hh_prof_cycles[16 + k_], oacc_[k_]);
 #endif
@@ -1247,8 +1271,9 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
             if (reward_out) reward_out[o] = (float)so.reward;
             if (valid_out) valid_out[o] = (uint8_t)so.valid;
         }
-        /* episode statistics in agent order (every lane of the arena keeps the same running sum) */
-        {
+        const int amask_stats = tb.amask; /* who is alive after the tick, before a reset */
+        /* episode statistics in agent order (every lane of the arena keeps the same running sum); OWT: kept by the output wave */
+        if constexpr (!OWT) {
             const double rv = so.valid ? so.reward : 0.0;
             const double r0 = q_bc_d<0>(rv), r1 = q_bc_d<1>(rv);
             {
@@ -1287,8 +1312,9 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
             mbx.slim.flags[tid] = pub.flags;
             mbx.slim.w5[tid] = (m.cannon_remain & 0xffff) | ((m.cannon_max & 0xffff) << 16);
             mbx.slim.w6[tid] = (m.missile_remain & 0xff) | ((m.rocket_max & 0xff) << 8) | ((m.missile_wait & 0xff) << 16) | ((m.burst & 0xff) << 24);
-            mbx.slim.w7[tid] = (m.ac_type & 0xff) | ((m.alive & 0xff) << 8) | ((m.has_missile & 0xff) << 16) | ((so.valid & 1) << 24) | ((done_now & 1) << 25);
-            mbx.slim.rew[tid] = (float)so.reward;
+            mbx.slim.w7[tid] = (m.ac_type & 0xff) | ((m.alive & 0xff) << 8) | ((m.has_missile & 0xff) << 16) | ((so.valid & 1) << 24) | ((done_now & 1) << 25) |
+                               ((was_running ? 1 : 0) << 26) | ((amask_stats & 0xf) << 27);
+            mbx.slim.rew[tid] = so.reward;
             if (tid == 0) mbx.slim.full = reset_tick ? 1 : 0;
             HH_PROF(9);
             __syncthreads(); /* barrier Y */
@@ -1344,7 +1370,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         unit_store(P, U, u, m);
         if (s == 0) {
             arena_store(P, n, ar);
-            P.ep_ret[n] = ep_ret;
+            if constexpr (!OWT) P.ep_ret[n] = ep_ret; /* OWT: the output wave keeps and stores it */
             P.ev_mask[n] = 0;
         }
     }

@@ -113,7 +113,8 @@ __device__ __forceinline__ void quad_publish_motion(const DevCfg &c, const Unit 
  * All three mailboxes are indexed by lane and single-buffered: every write is separated from every read of the other wave by one of
  * the two barriers. */
 struct QPosMail { double lat[64], lon[64], spd[64], hdg[64]; int ac_type[64], steps[64], episode[64]; };   /* sim -> out at X */
-struct QTabMail { double dist[3][64], foc[3][64], focr[3][64]; double uc[64], us[64], sx[64], sy[64], ue[64], uh[64]; unsigned long long tk[64]; };   /* out -> sim at Y */
+struct QTabMail { double dist[3][64], foc[3][64], focr[3][64]; double uc[64], us[64], sx[64], sy[64], ue[64], uh[64]; unsigned long long tk[64];
+                  double g[6][64]; };   /* out -> sim at Y; g: hh_geo_short_lat_terms of the lane's posted latitude (S0, C0, U0, W0, iC, hW) */
 /* The heading unit vector after the turn (a sincos and a square root) is computed by the OUTPUT wave too: the table needs it exactly, the simulation wave
  * needs it inside the tick only for the cannon prefilter (hh_envelope.h: hh_cannon_cone_planar_outside, a one-sided test with a 0.3 deg margin of which the
  * planar-vs-geodesic bound uses 0.26), for which the exact vector of the tick before, rotated by the turn just made (<= 5 deg: cos / sin by their Taylor
@@ -131,6 +132,8 @@ struct QPre {
     bool ok;
     unsigned long long tkey;
     double ue, uh, sx, sy;
+    hh_geo_lat_terms lt; /* DUAL: the latitude terms of this lane's next move (hh_geodesic.h): the aircraft's on a main lane; on a helper lane its
+                            rocket's if one is in flight after the tick, else the aircraft's again (a rocket launched in the next tick starts there) */
 };
 __device__ __forceinline__ void quad_publish_flags(const Unit &m, QPub &p) {
     int shot = m.burst > 0 || (m.ac_type == 1 && m.has_missile);
@@ -565,6 +568,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     /* aircraft move + speculative move of this slot's rocket (in flight, or the one a pending launch creates) */
     const bool rk_spec = running && (rk_pre ? m.rk_life <= HH_ROCKET_MAX_LIFE : try_launch);
     double rk_nlat = 0.0, rk_nlon = 0.0, rk_nhdg = 0.0, rk_ncmd = 0.0;
+    double helper_lat = 0.0; /* DUAL: where this lane's move ended (a helper lane: its rocket) */
     {
         const bool mv_a = snap && m.spd > 0.0;
         const bool any_rk = __ballot(rk_spec) != 0ULL;
@@ -593,9 +597,11 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                 x_lat = helper ? h_lat : x_lat; x_lon = helper ? h_lon : x_lon; x_hdg = helper ? h_hdg : x_hdg; x_s = helper ? h_s : x_s;
             }
             double o_lat, o_lon;
-            d_geo_move(x_lat, x_lon, x_hdg, x_s, o_lat, o_lon);
+            if (OWT && pre.ok) d_geo_move_pre(x_lat, x_lon, x_hdg, x_s, pre.lt, o_lat, o_lon); /* wave-uniform: the start latitude's terms came from the output wave */
+            else d_geo_move(x_lat, x_lon, x_hdg, x_s, o_lat, o_lon);
             if (mv_a) { m.lat = o_lat; m.lon = o_lon; }
             if (any_rk) { rk_nlat = q_up_d(o_lat); rk_nlon = q_up_d(o_lon); }
+            helper_lat = o_lat;
         } else if (any_rk) {
             const double r_spd = rk_speed0;
             double a_lat, a_lon;
@@ -621,7 +627,8 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         }
         pn.nlat = pn.nlon = pn.nspd = pn.nhdg = 0.0f; /* formatted by the output wave from the raw values */
         /* every lane posts (the helpers' slots are never read): no exec-mask region */
-        pos->lat[tid] = m.lat; pos->lon[tid] = m.lon;
+        pos->lat[tid] = (DUAL && helper) ? helper_lat : m.lat; /* a helper lane: its rocket's new latitude (QPre.lt) */
+        pos->lon[tid] = m.lon;
         pos->spd[tid] = m.spd; pos->hdg[tid] = m.hdg; pos->ac_type[tid] = m.ac_type;
         pos->steps[tid] = ar.steps; pos->episode[tid] = ar.episode;
         HH_PROF(1);
@@ -1082,7 +1089,8 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                 HH_OPROF(0);
                 Unit m = Unit{};
                 QPub pub;
-                m.lat = mbx.pos.lat[tid]; m.lon = mbx.pos.lon[tid]; m.spd = mbx.pos.spd[tid]; m.hdg = mbx.pos.hdg[tid];
+                const double lat_posted = mbx.pos.lat[tid];
+                m.lat = lat_posted; m.lon = mbx.pos.lon[tid]; m.spd = mbx.pos.spd[tid]; m.hdg = mbx.pos.hdg[tid];
                 m.ac_type = mbx.pos.ac_type[tid];
                 pub.flags = 0;
                 quad_publish_motion(c, m, pub); /* heading vector and normalised entries: the expressions the simulation wave uses on reset ticks */
@@ -1098,6 +1106,10 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                     const int site_e = role == 0 ? HH_SITE_ESC_HDG : (role == 1 ? HH_SITE_ESC_SPEED : HH_SITE_ESC_FIRE);
                     const int site_h = role == 0 ? HH_SITE_HC_SPEED1 : (role == 1 ? HH_SITE_HC_R : HH_SITE_HC_SPEED2);
                     mbx.tab.uc[tid] = pub.uc; mbx.tab.us[tid] = pub.us;
+                    if constexpr (DUAL) { /* the latitude terms of the next move from where this one ended (a helper lane: its rocket) */
+                        const hh_geo_lat_terms lt = hh_geo_short_lat_terms(lat_posted);
+                        mbx.tab.g[0][tid] = lt.S0; mbx.tab.g[1][tid] = lt.C0; mbx.tab.g[2][tid] = lt.U0; mbx.tab.g[3][tid] = lt.W0; mbx.tab.g[4][tid] = lt.iC; mbx.tab.g[5][tid] = lt.hW;
+                    }
                     mbx.tab.tk[tid] = tk1;
                     mbx.tab.ue[tid] = hh_rng_u01(tk1, (uint32_t)du, (uint32_t)site_e, 0u);
                     mbx.tab.uh[tid] = hh_rng_u01(tk1, (uint32_t)du, (uint32_t)site_h, 0u);
@@ -1246,6 +1258,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
     const bool has_act = active && s < c.n_ctrl;
     QPre pre;
     pre.ok = false; pre.tkey = 0ULL; pre.ue = pre.uh = pre.sx = pre.sy = 0.0;
+    pre.lt = hh_geo_lat_terms{0.0, 1.0, 1.0, 1.0, 1.0, 0.5};
     const size_t act_stride = (size_t)c.N * c.n_ctrl * 4;
     const int8_t *act_ptr = has_act ? actions + ((size_t)n * c.n_ctrl + s) * 4 : actions; /* lanes without a row re-read row 0, unused */
     int act_cur = *reinterpret_cast<const int *>(act_ptr);
@@ -1325,6 +1338,12 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                 for (int k = 0; k < 3; k++) { tb.dist[k] = mbx.tab.dist[k][tid]; tb.foc[k] = mbx.tab.foc[k][tid]; tb.focr[k] = mbx.tab.focr[k][tid]; }
                 pre.tkey = mbx.tab.tk[tid]; pre.ue = mbx.tab.ue[tid]; pre.uh = mbx.tab.uh[tid]; pre.sx = mbx.tab.sx[tid]; pre.sy = mbx.tab.sy[tid];
                 pub.uc = mbx.tab.uc[tid]; pub.us = mbx.tab.us[tid]; /* the exact heading vector (the tick carried a rotated one) */
+                if constexpr (DUAL) {
+                    const int rk_main = q_down_i(m.rk_alive); /* a helper lane: is its main lane's rocket in flight after this tick? */
+                    const int gi = (helper && !rk_main) ? tid - 32 : tid;
+                    pre.lt.S0 = mbx.tab.g[0][gi]; pre.lt.C0 = mbx.tab.g[1][gi]; pre.lt.U0 = mbx.tab.g[2][gi]; pre.lt.W0 = mbx.tab.g[3][gi];
+                    pre.lt.iC = mbx.tab.g[4][gi]; pre.lt.hW = mbx.tab.g[5][gi];
+                }
                 quad_nearby(c, tb, s, nbc);
             }
             { /* env_hetero.py:99-101: the observation refreshes opp_to_attack (straight-line on every lane, kept by the agents') */

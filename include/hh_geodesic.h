@@ -228,15 +228,25 @@ HH_HD void hh_geo_direct(double lat1, double lon1, double azi1, double s12, doub
 #define HH_GEO_SHORT_MAX_M 4000.0
 #define HH_GEO_SHORT_MAX_LAT 70.0
 
-HH_HD void hh_geo_direct_short(double lat1, double lon1, double azi1, double s12, double *lat2, double *lon2) {
+/* The terms of the series that depend on the START LATITUDE only (a sincosd, a square root, two divisions: the long dependent chains of the
+ * function).  Split out so that a caller who knows the start latitude a tick ahead can have them computed off its critical path (the two-wave 2-vs-2
+ * kernel's output wave, hh_kernels_quad.h); hh_geo_direct_short = these terms + hh_geo_direct_short_core: the same operations on the same operands. */
+typedef struct { double S0, C0, U0, W0, iC, hW; } hh_geo_lat_terms;
+HH_HD hh_geo_lat_terms hh_geo_short_lat_terms(double lat1) {
+    hh_geo_lat_terms t;
+    hh_sincosd_small(lat1, &t.S0, &t.C0);
+    t.U0 = hh_fma(-HH_GEO_E2 * t.S0, t.S0, 1.0);
+    t.W0 = hh_sqrt(t.U0);
+    t.iC = 1.0 / t.C0;
+    t.hW = 0.5 / t.W0;
+    return t;
+}
+HH_HD void hh_geo_direct_short_core(double lat1, double lon1, double azi1, double s12, hh_geo_lat_terms lt, double *lat2, double *lon2) {
     const double E2 = HH_GEO_E2, K1 = 1.0 / (1.0 - HH_GEO_E2), TH = 1.0 / 3.0, M2E2 = -2.0 * HH_GEO_E2;
-    double S0, C0, Sa0, Ca0;
-    hh_sincosd_small(lat1, &S0, &C0);
+    const double S0 = lt.S0, C0 = lt.C0, U0 = lt.U0, W0 = lt.W0, iC = lt.iC, hW = lt.hW;
+    double Sa0, Ca0;
     hh_sincosd_small(azi1, &Sa0, &Ca0);
     const double h = s12 * (1.0 / HH_GEO_A);
-    const double U0 = hh_fma(-E2 * S0, S0, 1.0);
-    const double W0 = hh_sqrt(U0);
-    const double iC = 1.0 / C0, hW = 0.5 / W0;
     const double Q0 = W0 * iC, P0 = W0 * U0 * K1;
     /* every Cauchy sum below is one multiply followed by fused multiply-adds (hh_fma on both sides of the parity) */
     /* order 1 */
@@ -282,6 +292,9 @@ HH_HD void hh_geo_direct_short(double lat1, double lon1, double azi1, double s12
     const double dlam = h * hh_fma(h, hh_fma(h, hh_fma(h, l4, l3), l2), l1);
     *lat2 = hh_fma(dphi, HH_RAD2DEG, lat1);
     *lon2 = hh_fma(dlam, HH_RAD2DEG, lon1);
+}
+HH_HD void hh_geo_direct_short(double lat1, double lon1, double azi1, double s12, double *lat2, double *lon2) {
+    hh_geo_direct_short_core(lat1, lon1, azi1, s12, hh_geo_short_lat_terms(lat1), lat2, lon2);
 }
 
 /* position update used by the simulator tick (cmano_simulator.py:65-72) */

@@ -379,11 +379,15 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
             /* env_hetero.py:169-170 opp_stats[i][0] (the target's focus on the agent when it acted) is read by ONE reward term, the cannon kill:
              * evaluated there (phase E), from the same pre-tick table and target */
             /* env_base.py:214-238 _take_base_action */
+#ifdef HHQ_ABL_DECODE /* tuning builds only (tools/build_variant.sh): WRONG RESULTS on purpose, timing of what a piece costs */
+            m.cmd_hdg = m.hdg; m.cmd_spd = 300.0;
+#else
             double nh = hh_pymod360(m.hdg + (double)(((int)act[0] - 6) * 15));
             if (nh >= 360.0 || nh < 0.0) nh = 0.0;
             m.cmd_hdg = nh;
             double mx = HH_AC_MAX_SPEED(m.ac_type);
             m.cmd_spd = 100.0 + ((mx - 100.0) / 8.0) * (double)act[1];
+#endif
             if (act[2] && m.cannon_remain > 0) {
                 arm_cannon(m);
                 if (agent && c.agent_mode == HH_MODE_ESCAPE && m.cannon_remain < 90) out.reward -= 0.1;
@@ -474,9 +478,15 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
             else u2 = hh_rng_u01(ar.tkey, (uint32_t)id, (uint32_t)(my_escaping ? HH_SITE_ESC_FIRE : HH_SITE_HC_SPEED2), 0u);
         }
     }
+#ifdef HHQ_ABL_SCRIPT
+    if (false) {
+        if (snap && !agent) {
+            int opp = -1, fire = 0, fire_m = 0;
+#else
     if (running && !c.ext_opp && c.level >= 3) {
         if (snap && !agent) {
             int opp = -1, fire = 0, fire_m = 0;
+#endif
             double heading, speed;
             if (my_escaping) { /* env_hetero.py:227-245 _escaping_opp */
                 double y = hh_clip(hh_div_known(m.lat - HH_MAP_LAT0, c.ext_lat, c.inv_ext_lat), 0.0, 1.0);
@@ -597,8 +607,12 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                 x_lat = helper ? h_lat : x_lat; x_lon = helper ? h_lon : x_lon; x_hdg = helper ? h_hdg : x_hdg; x_s = helper ? h_s : x_s;
             }
             double o_lat, o_lon;
+#ifdef HHQ_ABL_MOVE
+            o_lat = x_lat + 1e-5 * x_s; o_lon = x_lon + 1e-5 * x_hdg;
+#else
             if (OWT && pre.ok) d_geo_move_pre(x_lat, x_lon, x_hdg, x_s, pre.lt, o_lat, o_lon); /* wave-uniform: the start latitude's terms came from the output wave */
             else d_geo_move(x_lat, x_lon, x_hdg, x_s, o_lat, o_lon);
+#endif
             if (mv_a) { m.lat = o_lat; m.lon = o_lon; }
             if (any_rk) { rk_nlat = q_up_d(o_lat); rk_nlon = q_up_d(o_lon); }
             helper_lat = o_lat;
@@ -674,8 +688,12 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
             const double to = j < s ? lon1[k - 1] : tb.lon[k - 1];
             /* every clause is a handful of compares and products and almost every tick SOME lane of the wave has fired: evaluated
              * unconditionally (&, not &&) — at one wave per SIMD an exec-mask region costs ~45 cycles whether or not it is entered */
+#ifdef HHQ_ABL_PREFILTER
+            push[k] = 0;
+#else
             push[k] = (int)fired & (int)snap_j & ((int)(c.friendly_kill != 0) | (int)enemy) & (int)d_maybe_within_km(lat_old, lon_old, tl, to, HH_AC_CANNON_KM(t)) &
                       (int)!hh_cannon_cone_planar_outside(lat_old, lon_old, tl, to, pn.uc, pn.us, t);
+#endif
             code[k] = tid | (1 << 8) | (j << 10);
         }
         {
@@ -1344,7 +1362,9 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                     pre.lt.S0 = mbx.tab.g[0][gi]; pre.lt.C0 = mbx.tab.g[1][gi]; pre.lt.U0 = mbx.tab.g[2][gi]; pre.lt.W0 = mbx.tab.g[3][gi];
                     pre.lt.iC = mbx.tab.g[4][gi]; pre.lt.hW = mbx.tab.g[5][gi];
                 }
+#ifndef HHQ_ABL_NEARBY
                 quad_nearby(c, tb, s, nbc);
+#endif
             }
             { /* env_hetero.py:99-101: the observation refreshes opp_to_attack (straight-line on every lane, kept by the agents') */
                 Unit mr = m;

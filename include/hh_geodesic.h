@@ -215,17 +215,19 @@ HH_HD void hh_geo_direct(double lat1, double lon1, double azi1, double s12, doub
  * geodesic equations on the ellipsoid,
  *     dphi/dt = cos(alp) W^3 / (1-e^2),  dlam/dt = sin(alp) W / cos(phi),  dalp/dt = sin(alp) tan(phi) W,
  *     W = sqrt(1 - e^2 sin^2 phi),
- * are solved by their TAYLOR SERIES in t to 4th order.  The coefficients come from the standard
+ * are solved by their TAYLOR SERIES in t to 3rd order (rounds 1-4 carried the 4th: in the domain below its term is at most one unit in the last
+ * place of the result — measured: 8.9e-16 deg against the 4th-order form over 2e6 arena-scale samples, the same 4.4e-15 / 1.7e-14 deg against
+ * Karney — for 32 of the function's ~150 operations on the tick's critical path).  The coefficients come from the standard
  * power-series recurrences of the auxiliary functions S = sin phi, C = cos phi, Sa = sin alp, Ca = cos alp,
  * U = 1 - e^2 S^2, W = sqrt(U), Q = W/C, P = W U/(1-e^2)   (S' = C phi', C' = -S phi', W_k from W^2 = U,
  * Q_k from Q C = W, products by Cauchy sums), all evaluated at the start point only.  The truncation
- * error is ~ t^5 < 2e-19 rad (< 1e-16 rad at the 4 km domain limit) — below double rounding — and the
+ * error is ~ t^4 |f4| < 1e-15 rad at the 1.1 km domain limit at arena latitudes (a few 1e-14 deg at 60 deg: tests/test_geodesic.py) — at double rounding — and the
  * dependency chain is ~30 operations deep instead of the ~160 of a Runge-Kutta step or the several
  * hundred of the general series solution: this is the per-tick latency that matters at one wave per
- * SIMD.  Cost: 2 division-free sincosd, 1 sqrt, 2 divisions, ~170 multiply-adds.
+ * SIMD.  Cost: 2 division-free sincosd, 1 sqrt, 2 divisions, ~120 multiply-adds.
  * tests/test_geodesic.py pins it to hh_geo_direct (Karney) and to the mpmath ODE vectors at <= 2e-14 deg.
- * Outside its domain (s > 4 km or |lat| > 70) callers fall back to hh_geo_direct. */
-#define HH_GEO_SHORT_MAX_M 4000.0
+ * Outside its domain (s > 1.1 km: beyond one tick of the fastest unit, a 2000 kn rocket; or |lat| > 70) callers fall back to hh_geo_direct. */
+#define HH_GEO_SHORT_MAX_M 1100.0
 #define HH_GEO_SHORT_MAX_LAT 70.0
 
 /* The terms of the series that depend on the START LATITUDE only (a sincosd, a square root, two divisions: the long dependent chains of the
@@ -271,25 +273,12 @@ HH_HD void hh_geo_direct_short_core(double lat1, double lon1, double azi1, doubl
     const double W2 = hh_fma(-W1, W1, U2) * hW;
     const double Q2 = hh_fma(-C2, Q0, hh_fma(-C1, Q1, W2)) * iC;
     const double P2 = hh_fma(W0, U2, hh_fma(W1, U1, W2 * U0)) * K1;
-    /* order 3: g3 = 3 f3, h3 = 3 a3 */
+    /* order 3: g3 = 3 f3 (the azimuth's third coefficient feeds the fourth order only: not needed) */
     const double g3 = hh_fma(Ca0, P2, hh_fma(Ca1, P1, Ca2 * P0));
     const double f3 = TH * g3;
-    const double SS2 = hh_fma(Sa0, S2, hh_fma(Sa1, S1, Sa2 * S0));
-    const double h3 = hh_fma(SS0, Q2, hh_fma(SS1, Q1, SS2 * Q0));
     const double l3 = TH * hh_fma(Sa0, Q2, hh_fma(Sa1, Q1, Sa2 * Q0));
-    const double S3 = TH * hh_fma(C0, g3, hh_fma(C1, g2, C2 * f1));
-    const double C3 = -TH * hh_fma(S0, g3, hh_fma(S1, g2, S2 * f1));
-    const double Sa3 = TH * hh_fma(Ca0, h3, hh_fma(Ca1, h2, Ca2 * a1));
-    const double Ca3 = -TH * hh_fma(Sa0, h3, hh_fma(Sa1, h2, Sa2 * a1));
-    const double U3 = M2E2 * hh_fma(S0, S3, S1 * S2);
-    const double W3 = hh_fma(-2.0 * W1, W2, U3) * hW;
-    const double Q3 = hh_fma(-C3, Q0, hh_fma(-C2, Q1, hh_fma(-C1, Q2, W3))) * iC;
-    const double P3 = hh_fma(W0, U3, hh_fma(W1, U2, hh_fma(W2, U1, W3 * U0))) * K1;
-    /* order 4 */
-    const double f4 = 0.25 * hh_fma(Ca0, P3, hh_fma(Ca1, P2, hh_fma(Ca2, P1, Ca3 * P0)));
-    const double l4 = 0.25 * hh_fma(Sa0, Q3, hh_fma(Sa1, Q2, hh_fma(Sa2, Q1, Sa3 * Q0)));
-    const double dphi = h * hh_fma(h, hh_fma(h, hh_fma(h, f4, f3), f2), f1);
-    const double dlam = h * hh_fma(h, hh_fma(h, hh_fma(h, l4, l3), l2), l1);
+    const double dphi = h * hh_fma(h, hh_fma(h, f3, f2), f1);
+    const double dlam = h * hh_fma(h, hh_fma(h, l3, l2), l1);
     *lat2 = hh_fma(dphi, HH_RAD2DEG, lat1);
     *lon2 = hh_fma(dlam, HH_RAD2DEG, lon1);
 }

@@ -301,18 +301,6 @@ __device__ __forceinline__ void d_geo_move(double lat1, double lon1, double azi1
     lon2 = b;
 }
 
-/* d_geo_move with the start latitude's terms supplied by the caller (hh_geodesic.h: hh_geo_short_lat_terms of lat1, computed a tick ahead by the
- * two-wave 2-vs-2 kernel's output wave): the same selection and the same operations */
-__device__ __forceinline__ void d_geo_move_pre(double lat1, double lon1, double azi1, double s12, const hh_geo_lat_terms &lt, double &lat2, double &lon2) {
-    double a, b;
-    if (s12 <= HH_GEO_SHORT_MAX_M && hh_fabs(lat1) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon1) < 170.0 && hh_fabs(azi1) <= 360.0)
-        hh_geo_direct_short_core(lat1, lon1, azi1, s12, lt, &a, &b);
-    else
-        d_geo_direct_general(lat1, lon1, azi1, s12, &a, &b);
-    lat2 = a;
-    lon2 = b;
-}
-
 /* two independent short-step moves in one basic block so that their RK4 chains interleave (ILP); each
  * result is bit-identical to d_geo_move of the same arguments */
 __device__ __forceinline__ void d_geo_move2(double lat_a, double lon_a, double azi_a, double s_a, double &lat2_a, double &lon2_a,

@@ -112,9 +112,10 @@ __device__ __forceinline__ void quad_publish_motion(const DevCfg &c, const Unit 
  * rows from ITS copy of the table.  Only integers cross at Y in the other direction (status flags, ammunition, reward, done).
  * All three mailboxes are indexed by lane and single-buffered: every write is separated from every read of the other wave by one of
  * the two barriers. */
-struct QPosMail { double lat[64], lon[64], spd[64], hdg[64]; int ac_type[64], steps[64], episode[64]; };   /* sim -> out at X */
-struct QTabMail { double dist[3][64], foc[3][64], focr[3][64]; double uc[64], us[64], sx[64], sy[64], ue[64], uh[64]; unsigned long long tk[64];
-                  double g[6][64]; };   /* out -> sim at Y; g: hh_geo_short_lat_terms of the lane's posted latitude (S0, C0, U0, W0, iC, hW) */
+struct QPosMail { double lat[64], lon[64], spd[64], hdg[64]; int ac_type[64], steps[64], episode[64], escw[64]; };   /* sim -> out at X; escw: the arena's
+                                                                      escape flag | timer << 8 after this tick's script | alive mask at tick start << 16 */
+struct QTabMail { double dist[3][64], foc[3][64], focr[3][64]; double uc[64], us[64], sx[64], sy[64]; unsigned long long tk[64];
+                  double sp_hdg[64], sp_spd[64]; int sp_w[64]; };   /* out -> sim at Y; sp_*: QPre */
 /* The heading unit vector after the turn (a sincos and a square root) is computed by the OUTPUT wave too: the table needs it exactly, the simulation wave
  * needs it inside the tick only for the cannon prefilter (hh_envelope.h: hh_cannon_cone_planar_outside, a one-sided test with a 0.3 deg margin of which the
  * planar-vs-geodesic bound uses 0.26), for which the exact vector of the tick before, rotated by the turn just made (<= 5 deg: cos / sin by their Taylor
@@ -130,10 +131,11 @@ struct QSlimMail { int flags[64], w5[64], w6[64], w7[64]; double rew[64]; int fu
  * (episode / steps / heading changed behind the prediction); the tick then computes them itself, the same expressions. */
 struct QPre {
     bool ok;
+    bool spec;            /* wave-uniform: ok, and the tick before changed no alive mask in this wave — the prediction the output wave ran the level-3 script on */
+    double sp_hdg, sp_spd; /* the script's commanded heading / speed for this lane's opponent */
+    int sp_w;             /* fire | fire_m << 1 | (target slot + 1) << 2 | arena escape flag << 8 | escape timer << 16 (after the script's tick) */
     unsigned long long tkey;
-    double ue, uh, sx, sy;
-    hh_geo_lat_terms lt; /* DUAL: the latitude terms of this lane's next move (hh_geodesic.h): the aircraft's on a main lane; on a helper lane its
-                            rocket's if one is in flight after the tick, else the aircraft's again (a rocket launched in the next tick starts there) */
+    double sx, sy;
 };
 __device__ __forceinline__ void quad_publish_flags(const Unit &m, QPub &p) {
     int shot = m.burst > 0 || (m.ac_type == 1 && m.has_missile);
@@ -149,17 +151,28 @@ __device__ __forceinline__ void quad_publish(const DevCfg &c, const Unit &m, QPu
  * fetches then deliver the same neighbours to both halves, and the four acos chains of a lane are split two and two — the main lane
  * computes the focus towards slots +1 and +2, its helper the focus towards slot +3 and the heading difference — the same expressions
  * on the same operands, handed up afterwards: half the table's arithmetic per lane for 14 lane swaps. */
-template <bool DUAL>
+/* the entries of the others that only observation rows read (and the alive mask): WAVE-UNIFORM control flow only */
+__device__ __forceinline__ void quad_tables_obs(const QPub &p, int s, QTab &t) {
+#define HH_QFETCHO(K)                                                                 \
+    t.nlat[K - 1] = q_rot_f<K>(p.nlat); t.nlon[K - 1] = q_rot_f<K>(p.nlon);               \
+    t.nspd[K - 1] = q_rot_f<K>(p.nspd); t.nhdg[K - 1] = q_rot_f<K>(p.nhdg);               \
+    t.fl[K - 1] = q_rot_i<K>(p.flags);
+    HH_QFETCHO(1)
+    HH_QFETCHO(2)
+    HH_QFETCHO(3)
+#undef HH_QFETCHO
+    t.amask = ((p.flags & FL_ALIVE) << s) | ((t.fl[0] & FL_ALIVE) << ((s + 1) & 3)) | ((t.fl[1] & FL_ALIVE) << ((s + 2) & 3)) |
+              ((t.fl[2] & FL_ALIVE) << ((s + 3) & 3));
+}
+/* OBS = false: the geometry only (positions, distances, focus angles, heading differences); the caller adds quad_tables_obs when it has the flags */
+template <bool DUAL, bool OBS = true>
 __device__ __forceinline__ void quad_tables(const Unit &m, const QPub &p, int s, bool helper, QTab &t) {
     double lat = m.lat, lon = m.lon, c1 = p.uc, s1 = p.us, n1 = p.un;
     if (DUAL) { lat = q_down_d(lat); lon = q_down_d(lon); c1 = q_down_d(c1); s1 = q_down_d(s1); n1 = q_down_d(n1); }
     double ouc[3], ous[3], oun[3];
 #define HH_QFETCH(K)                                                                  \
     t.lat[K - 1] = q_rot_d<K>(lat); t.lon[K - 1] = q_rot_d<K>(lon);                       \
-    ouc[K - 1] = q_rot_d<K>(c1); ous[K - 1] = q_rot_d<K>(s1); oun[K - 1] = q_rot_d<K>(n1); \
-    t.nlat[K - 1] = q_rot_f<K>(p.nlat); t.nlon[K - 1] = q_rot_f<K>(p.nlon);               \
-    t.nspd[K - 1] = q_rot_f<K>(p.nspd); t.nhdg[K - 1] = q_rot_f<K>(p.nhdg);               \
-    t.fl[K - 1] = q_rot_i<K>(p.flags);
+    ouc[K - 1] = q_rot_d<K>(c1); ous[K - 1] = q_rot_d<K>(s1); oun[K - 1] = q_rot_d<K>(n1);
     HH_QFETCH(1)
     HH_QFETCH(2)
     HH_QFETCH(3)
@@ -218,8 +231,7 @@ __device__ __forceinline__ void quad_tables(const Unit &m, const QPub &p, int s,
     t.focr[0] = q_rot_d<1>(t.foc[2]);
     t.focr[1] = q_rot_d<2>(t.foc[1]);
     t.focr[2] = q_rot_d<3>(t.foc[0]);
-    t.amask = ((p.flags & FL_ALIVE) << s) | ((t.fl[0] & FL_ALIVE) << ((s + 1) & 3)) | ((t.fl[1] & FL_ALIVE) << ((s + 2) & 3)) |
-              ((t.fl[2] & FL_ALIVE) << ((s + 3) & 3));
+    if constexpr (OBS) quad_tables_obs(p, s, t);
 }
 
 /* env_base.py:400-422 _nearby_object for the OTHER side of a 2-vs-2 arena: live opponents, stable-sorted by
@@ -329,6 +341,71 @@ __device__ __forceinline__ bool q_any(bool x) {
  * __syncthreads() inside the simulation wave — that would be a workgroup barrier the output wave does not take */
 __device__ __forceinline__ void q_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+/* ---- the level-3 opponent script (env_hetero.py:138-158 + 227-271) as functions: the simulation wave runs them inside the tick; the output wave
+ * of the two-wave forms runs the SAME functions a tick ahead on a prediction (QPre.spec) ---- */
+/* the arena-level escape flag for the tick with counter `steps` and key `tkey`: consumed once per live opponent in id order.  esc / esc_t:
+ * the arena's flag and timer, updated in place.  Call from code every lane of the arena takes (a ballot inside). */
+__device__ __forceinline__ void quad_l3_flags(int steps, unsigned long long tkey, int amask0, int s, int &esc, int &esc_t, bool &my_escaping, bool (&escj)[2]) {
+    const bool draw_tick = steps % 60 == 0; /* one tick in sixty per arena: the draws sit behind a wave-uniform test */
+    const bool any_draw = q_any(draw_tick);
+#pragma unroll
+    for (int j = 2; j < 4; j++) {
+        const bool aj = ((amask0 >> j) & 1) != 0;
+        if (any_draw) { /* wave-uniform */
+            if (aj & draw_tick & (esc == 0)) {
+                esc = hh_rng_randint(hh_rng_u01(tkey, (uint32_t)(j + 1), HH_SITE_L3_ESC_COIN, 0u), 0, 1);
+                if (esc) esc_t = (int)hh_rng_uniform(hh_rng_u01(tkey, (uint32_t)(j + 1), HH_SITE_L3_ESC_TIME, 0u), 20.0, 30.0);
+            }
+        }
+        const bool mine = aj & (j == s), upd = aj & (esc != 0);
+        my_escaping = mine ? (esc != 0) : my_escaping;
+        escj[j - 2] = aj & (esc != 0);
+        const int esc_t1 = esc_t - 1;
+        esc_t = upd ? esc_t1 : esc_t;
+        esc = (upd & (esc_t <= 0)) ? 0 : esc;
+    }
+}
+/* what the script decides for one opponent; opp = target slot or -1.  rs / rc: round(sin(hdg), 3), round(cos(hdg), 3) (_correct_angle_sign) */
+struct QScriptOut { double heading, speed; int fire, fire_m, opp; };
+__device__ __forceinline__ void quad_l3_script(const DevCfg &c, double lat, double lon, double hdg, int ac_type, bool my_escaping, double u0, double u1, double u2,
+                                               const Near2 &nb, const QTab &tb, double rs, double rc, QScriptOut &o) {
+    int opp = -1, fire = 0, fire_m = 0;
+    double heading, speed;
+    if (my_escaping) { /* env_hetero.py:227-245 _escaping_opp */
+        double y = hh_clip(hh_div_known(lat - HH_MAP_LAT0, c.ext_lat, c.inv_ext_lat), 0.0, 1.0);
+        double x = hh_clip(hh_div_known(lon - HH_MAP_LON0, c.ext_lon, c.inv_ext_lon), 0.0, 1.0);
+        double uh = u0;
+        double lo_h = y < 0.5 ? (x < 0.5 ? 30.0 : 300.0) : (x < 0.5 ? 120.0 : 210.0);
+        heading = (double)(int)hh_rng_uniform(uh, lo_h, lo_h + 30.0);
+        speed = (double)(int)hh_rng_uniform(u1, 300.0, 600.0);
+        fire = hh_rng_randint(u2, 0, 1);
+    } else { /* env_hetero.py:247-271 _hardcoded_opp */
+        heading = hdg;
+        speed = (double)(int)hh_rng_uniform(u0, 100.0, 400.0);
+        if (nb.n) {
+            const double ag_lat = q_sel(tb.lat, nb.k0), ag_lon = q_sel(tb.lon, nb.k0);
+            /* env_base.py:464-487 _correct_angle_sign */
+            double x1 = lon + rs, y1 = lat + rc;
+            double val = (x1 - lon) * (ag_lat - lat) - (ag_lon - lon) * (y1 - lat);
+            double sign = val < 0.0 ? 1.0 : -1.0;
+            double r = hh_rng_uniform(u1, 0.7, 1.3);
+            double focus = q_sel(tb.foc, nb.k0);
+            const double turned = hh_pymod360(heading + r * sign * focus);
+            heading = ((nb.d0 > 0.008) & (focus > 4.0)) ? turned : heading;
+            const double us = u2;
+            const double sp_near = (double)(int)hh_rng_uniform(us, 500.0, 800.0), sp_far = (double)(int)hh_rng_uniform(us, 100.0, 500.0);
+            const double sp2 = focus < 30.0 ? sp_near : sp_far;
+            speed = nb.d0 > 0.05 ? sp2 : speed;
+            fire = nb.d0 < 0.03 && focus < 10.0;
+            fire_m = nb.d0 < 0.09 && focus < 5.0;
+            opp = nb.j0;
+        }
+        if (ac_type == 2) speed = hh_clip(speed, 0.0, 600.0);
+    }
+    if (heading >= 360.0 || heading < 0.0) heading = 0.0;
+    o.heading = heading; o.speed = speed; o.fire = fire; o.fire_m = fire_m; o.opp = opp;
+}
+
 /* one fused LowLevelEnv step of the lane's arena; `tb`/`pub` hold the pre-tick table on entry and the post-tick
  * table on return.  Line-by-line counterpart of tick<4, 64>(tmode 0) in hh_kernels.h. */
 template <bool IX, bool DUAL, bool OWT = false>
@@ -417,29 +494,16 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         }
     }
     HH_PROF(11);
+    /* OWT: the whole level-3 script of this tick may have been run a tick ahead by the output wave, on the prediction that the last tick changed no
+     * alive mask in this wave (QPre.spec, wave-uniform): then its decisions are applied below and the flag / draws / script blocks are skipped */
+    const bool spec = OWT && pre.ok && pre.spec && !c.ext_opp && c.level >= 3;
     /* env_hetero.py:138-158 level 3: the arena-level escape flag, consumed once per live opponent in id order */
     bool my_escaping = false;
     bool escj[2] = {false, false}; /* the flag as opponent slot 2 / 3 consumes it (every lane of the arena computes both) */
+    if (!spec) {
     if (running && !c.ext_opp && c.level >= 3) {
         int esc = ar.escaping, esc_t = ar.escaping_time;
-        const bool draw_tick = ar.steps % 60 == 0; /* one tick in sixty per arena: the draws sit behind a wave-uniform test */
-        const bool any_draw = q_any(draw_tick);
-#pragma unroll
-        for (int j = 2; j < A; j++) {
-            const bool aj = ((amask0 >> j) & 1) != 0;
-            if (any_draw) { /* wave-uniform */
-                if (aj & draw_tick & (esc == 0)) {
-                    esc = hh_rng_randint(d_rng(ar, j + 1, HH_SITE_L3_ESC_COIN, 0), 0, 1);
-                    if (esc) esc_t = (int)hh_rng_uniform(d_rng(ar, j + 1, HH_SITE_L3_ESC_TIME, 0), 20.0, 30.0);
-                }
-            }
-            const bool mine = aj & (j == s), upd = aj & (esc != 0);
-            my_escaping = mine ? (esc != 0) : my_escaping;
-            escj[j - 2] = aj & (esc != 0);
-            const int esc_t1 = esc_t - 1;
-            esc_t = upd ? esc_t1 : esc_t;
-            esc = (upd & (esc_t <= 0)) ? 0 : esc;
-        }
+        quad_l3_flags(ar.steps, ar.tkey, amask0, s, esc, esc_t, my_escaping, escj);
         ar.escaping = esc;
         ar.escaping_time = esc_t;
     }
@@ -459,19 +523,14 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                 de = helper ? deh : de;
                 role = helper ? 2 : role;
             }
-            double u;
-            if (OWT && pre.ok) { /* wave-uniform: both variants of this lane's draw are there */
-                u = de ? pre.ue : pre.uh;
-            } else {
-                uint64_t key = ar.tkey;
-                if (DUAL) {
-                    const int klo = q_down_i((int)(uint32_t)key), khi = q_down_i((int)(uint32_t)(key >> 32));
-                    key = helper ? (((uint64_t)(uint32_t)khi << 32) | (uint64_t)(uint32_t)klo) : key;
-                }
-                const int site_e = role == 0 ? HH_SITE_ESC_HDG : (role == 1 ? HH_SITE_ESC_SPEED : HH_SITE_ESC_FIRE);
-                const int site_h = role == 0 ? HH_SITE_HC_SPEED1 : (role == 1 ? HH_SITE_HC_R : HH_SITE_HC_SPEED2);
-                u = hh_rng_u01(key, (uint32_t)du, (uint32_t)(de ? site_e : site_h), 0u);
+            uint64_t key = ar.tkey;
+            if (DUAL) {
+                const int klo = q_down_i((int)(uint32_t)key), khi = q_down_i((int)(uint32_t)(key >> 32));
+                key = helper ? (((uint64_t)(uint32_t)khi << 32) | (uint64_t)(uint32_t)klo) : key;
             }
+            const int site_e = role == 0 ? HH_SITE_ESC_HDG : (role == 1 ? HH_SITE_ESC_SPEED : HH_SITE_ESC_FIRE);
+            const int site_h = role == 0 ? HH_SITE_HC_SPEED1 : (role == 1 ? HH_SITE_HC_R : HH_SITE_HC_SPEED2);
+            const double u = hh_rng_u01(key, (uint32_t)du, (uint32_t)(de ? site_e : site_h), 0u);
             u0 = u;
             u1 = q_perm_d<HH_QP(0, 1, 0, 1)>(u); /* slot 2 <- slot 0, slot 3 <- slot 1 */
             if (DUAL) u2 = q_up_d(u);
@@ -480,59 +539,39 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     }
 #ifdef HHQ_ABL_SCRIPT
     if (false) {
-        if (snap && !agent) {
-            int opp = -1, fire = 0, fire_m = 0;
 #else
     if (running && !c.ext_opp && c.level >= 3) {
-        if (snap && !agent) {
-            int opp = -1, fire = 0, fire_m = 0;
 #endif
-            double heading, speed;
-            if (my_escaping) { /* env_hetero.py:227-245 _escaping_opp */
-                double y = hh_clip(hh_div_known(m.lat - HH_MAP_LAT0, c.ext_lat, c.inv_ext_lat), 0.0, 1.0);
-                double x = hh_clip(hh_div_known(m.lon - HH_MAP_LON0, c.ext_lon, c.inv_ext_lon), 0.0, 1.0);
-                double uh = u0;
-                double lo_h = y < 0.5 ? (x < 0.5 ? 30.0 : 300.0) : (x < 0.5 ? 120.0 : 210.0);
-                heading = (double)(int)hh_rng_uniform(uh, lo_h, lo_h + 30.0);
-                speed = (double)(int)hh_rng_uniform(u1, 300.0, 600.0);
-                fire = hh_rng_randint(u2, 0, 1);
-            } else { /* env_hetero.py:247-271 _hardcoded_opp */
-                const Near2 nb = nbc;
-                heading = m.hdg;
-                speed = (double)(int)hh_rng_uniform(u0, 100.0, 400.0);
-                if (nb.n) {
-                    const double ag_lat = q_sel(tb.lat, nb.k0), ag_lon = q_sel(tb.lon, nb.k0);
-                    /* env_base.py:464-487 _correct_angle_sign */
-                    double rs, rc;
-                    if (OWT && pre.ok) { rs = pre.sx; rc = pre.sy; } /* wave-uniform */
-                    else {
-                        double sn, cs;
-                        hh_sincos(hh_pymod360(m.hdg) * (HH_PI / 180.0), &sn, &cs);
-                        rs = hh_round3(sn); rc = hh_round3(cs);
-                    }
-                    double x1 = m.lon + rs, y1 = m.lat + rc;
-                    double val = (x1 - m.lon) * (ag_lat - m.lat) - (ag_lon - m.lon) * (y1 - m.lat);
-                    double sign = val < 0.0 ? 1.0 : -1.0;
-                    double r = hh_rng_uniform(u1, 0.7, 1.3);
-                    double focus = q_sel(tb.foc, nb.k0);
-                    const double turned = hh_pymod360(heading + r * sign * focus);
-                    heading = ((nb.d0 > 0.008) & (focus > 4.0)) ? turned : heading;
-                    const double us = u2;
-                    const double sp_near = (double)(int)hh_rng_uniform(us, 500.0, 800.0), sp_far = (double)(int)hh_rng_uniform(us, 100.0, 500.0);
-                    const double sp2 = focus < 30.0 ? sp_near : sp_far;
-                    speed = nb.d0 > 0.05 ? sp2 : speed;
-                    fire = nb.d0 < 0.03 && focus < 10.0;
-                    fire_m = nb.d0 < 0.09 && focus < 5.0;
-                    opp = nb.j0;
-                }
-                if (m.ac_type == 2) speed = hh_clip(speed, 0.0, 600.0);
+        if (snap && !agent) {
+            double rs, rc;
+            if (OWT && pre.ok) { rs = pre.sx; rc = pre.sy; } /* wave-uniform */
+            else {
+                double sn, cs;
+                hh_sincos(hh_pymod360(m.hdg) * (HH_PI / 180.0), &sn, &cs);
+                rs = hh_round3(sn); rc = hh_round3(cs);
             }
-            if (heading >= 360.0 || heading < 0.0) heading = 0.0;
-            m.cmd_hdg = heading;
-            m.cmd_spd = speed;
-            if (fire) arm_cannon(m);
-            if (fire_m && opp >= 0 && !m.has_missile && m.missile_wait == 0 && m.ac_type == 1) {
-                want_launch = 1; launch_tgt = opp; wait_after = 10;
+            QScriptOut so_;
+            quad_l3_script(c, m.lat, m.lon, m.hdg, m.ac_type, my_escaping, u0, u1, u2, nbc, tb, rs, rc, so_);
+            m.cmd_hdg = so_.heading;
+            m.cmd_spd = so_.speed;
+            if (so_.fire) arm_cannon(m);
+            if (so_.fire_m && so_.opp >= 0 && !m.has_missile && m.missile_wait == 0 && m.ac_type == 1) {
+                want_launch = 1; launch_tgt = so_.opp; wait_after = 10;
+            }
+        }
+    }
+    } else { /* spec: apply what the output wave decided (same functions, same operands) */
+        if (running) {
+            ar.escaping = (pre.sp_w >> 8) & 0xff;
+            ar.escaping_time = (int)(int8_t)((pre.sp_w >> 16) & 0xff);
+            if (snap && !agent) {
+                const int opp = ((pre.sp_w >> 2) & 7) - 1;
+                m.cmd_hdg = pre.sp_hdg;
+                m.cmd_spd = pre.sp_spd;
+                if (pre.sp_w & 1) arm_cannon(m);
+                if ((pre.sp_w & 2) && opp >= 0 && !m.has_missile && m.missile_wait == 0 && m.ac_type == 1) {
+                    want_launch = 1; launch_tgt = opp; wait_after = 10;
+                }
             }
         }
     }
@@ -578,7 +617,6 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     /* aircraft move + speculative move of this slot's rocket (in flight, or the one a pending launch creates) */
     const bool rk_spec = running && (rk_pre ? m.rk_life <= HH_ROCKET_MAX_LIFE : try_launch);
     double rk_nlat = 0.0, rk_nlon = 0.0, rk_nhdg = 0.0, rk_ncmd = 0.0;
-    double helper_lat = 0.0; /* DUAL: where this lane's move ended (a helper lane: its rocket) */
     {
         const bool mv_a = snap && m.spd > 0.0;
         const bool any_rk = __ballot(rk_spec) != 0ULL;
@@ -610,12 +648,10 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
 #ifdef HHQ_ABL_MOVE
             o_lat = x_lat + 1e-5 * x_s; o_lon = x_lon + 1e-5 * x_hdg;
 #else
-            if (OWT && pre.ok) d_geo_move_pre(x_lat, x_lon, x_hdg, x_s, pre.lt, o_lat, o_lon); /* wave-uniform: the start latitude's terms came from the output wave */
-            else d_geo_move(x_lat, x_lon, x_hdg, x_s, o_lat, o_lon);
+            d_geo_move(x_lat, x_lon, x_hdg, x_s, o_lat, o_lon);
 #endif
             if (mv_a) { m.lat = o_lat; m.lon = o_lon; }
             if (any_rk) { rk_nlat = q_up_d(o_lat); rk_nlon = q_up_d(o_lon); }
-            helper_lat = o_lat;
         } else if (any_rk) {
             const double r_spd = rk_speed0;
             double a_lat, a_lon;
@@ -641,10 +677,11 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         }
         pn.nlat = pn.nlon = pn.nspd = pn.nhdg = 0.0f; /* formatted by the output wave from the raw values */
         /* every lane posts (the helpers' slots are never read): no exec-mask region */
-        pos->lat[tid] = (DUAL && helper) ? helper_lat : m.lat; /* a helper lane: its rocket's new latitude (QPre.lt) */
+        pos->lat[tid] = m.lat;
         pos->lon[tid] = m.lon;
         pos->spd[tid] = m.spd; pos->hdg[tid] = m.hdg; pos->ac_type[tid] = m.ac_type;
         pos->steps[tid] = ar.steps; pos->episode[tid] = ar.episode;
+        pos->escw[tid] = (ar.escaping & 0xff) | ((ar.escaping_time & 0xff) << 8) | ((amask0 & 0xf) << 16);
         HH_PROF(1);
         __syncthreads(); /* barrier X: the output wave starts on the post-tick table */
         HH_PROF(12);
@@ -1107,14 +1144,13 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                 HH_OPROF(0);
                 Unit m = Unit{};
                 QPub pub;
-                const double lat_posted = mbx.pos.lat[tid];
-                m.lat = lat_posted; m.lon = mbx.pos.lon[tid]; m.spd = mbx.pos.spd[tid]; m.hdg = mbx.pos.hdg[tid];
+                m.lat = mbx.pos.lat[tid]; m.lon = mbx.pos.lon[tid]; m.spd = mbx.pos.spd[tid]; m.hdg = mbx.pos.hdg[tid];
                 m.ac_type = mbx.pos.ac_type[tid];
                 pub.flags = 0;
-                quad_publish_motion(c, m, pub); /* heading vector and normalised entries: the expressions the simulation wave uses on reset ticks */
+                quad_publish_vec(m, pub); /* the heading vector now; the normalised entries after Y (only rows read them): the expressions of the simulation wave's reset ticks */
                 QTab tb;
                 int steps_t = 0;
-                quad_tables<DUAL>(m, pub, s, helper, tb); /* the same expressions on the same operands as the simulation wave's own (reset ticks) */
+                quad_tables<DUAL, false>(m, pub, s, helper, tb); /* the same expressions on the same operands as the simulation wave's own (reset ticks) */
 #pragma unroll
                 for (int k = 0; k < 3; k++) { mbx.tab.dist[k][tid] = tb.dist[k]; mbx.tab.foc[k][tid] = tb.foc[k]; mbx.tab.focr[k][tid] = tb.focr[k]; }
                 { /* ahead of the simulation wave (QPre): the next tick's key, this lane's script draw in both variants, the script's rounded sine / cosine */
@@ -1124,16 +1160,34 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                     const int site_e = role == 0 ? HH_SITE_ESC_HDG : (role == 1 ? HH_SITE_ESC_SPEED : HH_SITE_ESC_FIRE);
                     const int site_h = role == 0 ? HH_SITE_HC_SPEED1 : (role == 1 ? HH_SITE_HC_R : HH_SITE_HC_SPEED2);
                     mbx.tab.uc[tid] = pub.uc; mbx.tab.us[tid] = pub.us;
-                    if constexpr (DUAL) { /* the latitude terms of the next move from where this one ended (a helper lane: its rocket) */
-                        const hh_geo_lat_terms lt = hh_geo_short_lat_terms(lat_posted);
-                        mbx.tab.g[0][tid] = lt.S0; mbx.tab.g[1][tid] = lt.C0; mbx.tab.g[2][tid] = lt.U0; mbx.tab.g[3][tid] = lt.W0; mbx.tab.g[4][tid] = lt.iC; mbx.tab.g[5][tid] = lt.hW;
-                    }
                     mbx.tab.tk[tid] = tk1;
-                    mbx.tab.ue[tid] = hh_rng_u01(tk1, (uint32_t)du, (uint32_t)site_e, 0u);
-                    mbx.tab.uh[tid] = hh_rng_u01(tk1, (uint32_t)du, (uint32_t)site_h, 0u);
                     double sn, cs;
                     hh_sincos(hh_pymod360(m.hdg) * (HH_PI / 180.0), &sn, &cs);
-                    mbx.tab.sx[tid] = hh_round3(sn); mbx.tab.sy[tid] = hh_round3(cs);
+                    const double rs = hh_round3(sn), rc = hh_round3(cs);
+                    mbx.tab.sx[tid] = rs; mbx.tab.sy[tid] = rc;
+                    if (!c.ext_opp && c.level >= 3) { /* configuration: the level-3 script of tick t + 1, on the prediction that tick t removes nobody (QPre.spec) */
+                        const int ew = mbx.pos.escw[mt];
+                        int esc = ew & 0xff, esc_t = (int)(int8_t)((ew >> 8) & 0xff);
+                        const int am = (ew >> 16) & 0xf;
+                        bool my_escaping = false, escj[2] = {false, false};
+                        quad_l3_flags(steps_t + 1, tk1, am, s, esc, esc_t, my_escaping, escj);
+                        /* the three draws, as tick_quad spreads them over the lanes */
+                        const bool desc = (s & 1) ? escj[1] : escj[0];
+                        int de = desc ? 1 : 0;
+                        if (DUAL) { const int deh = q_down_i(de); de = helper ? deh : de; }
+                        const double u = hh_rng_u01(tk1, (uint32_t)du, (uint32_t)(de ? site_e : site_h), 0u);
+                        const double u0 = u, u1 = q_perm_d<HH_QP(0, 1, 0, 1)>(u);
+                        double u2;
+                        if (DUAL) u2 = q_up_d(u);
+                        else u2 = hh_rng_u01(tk1, (uint32_t)(s + 1), (uint32_t)(my_escaping ? HH_SITE_ESC_FIRE : HH_SITE_HC_SPEED2), 0u);
+                        tb.amask = am;
+                        Near2 nb;
+                        quad_nearby(c, tb, s, nb);
+                        QScriptOut so_;
+                        quad_l3_script(c, m.lat, m.lon, m.hdg, m.ac_type, my_escaping, u0, u1, u2, nb, tb, rs, rc, so_);
+                        mbx.tab.sp_hdg[tid] = so_.heading; mbx.tab.sp_spd[tid] = so_.speed;
+                        mbx.tab.sp_w[tid] = (so_.fire & 1) | ((so_.fire_m & 1) << 1) | (((so_.opp + 1) & 7) << 2) | ((esc & 0xff) << 8) | ((esc_t & 0xff) << 16);
+                    }
                 }
                 HH_OPROF(1);
                 __syncthreads(); /* barrier Y: the table is there for the simulation wave; its integers are here */
@@ -1160,9 +1214,8 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                     if (row) mail_take(mbx.mail[0], g * 2 + s, tb, pub, m, valid, done, rew);
                 } else {
                     pub.flags = mbx.slim.flags[tid];
-                    tb.fl[0] = q_rot_i<1>(pub.flags); tb.fl[1] = q_rot_i<2>(pub.flags); tb.fl[2] = q_rot_i<3>(pub.flags);
-                    tb.amask = ((pub.flags & FL_ALIVE) << s) | ((tb.fl[0] & FL_ALIVE) << ((s + 1) & 3)) | ((tb.fl[1] & FL_ALIVE) << ((s + 2) & 3)) |
-                               ((tb.fl[2] & FL_ALIVE) << ((s + 3) & 3));
+                    quad_publish_norm(c, m, pub);
+                    quad_tables_obs(pub, s, tb);
                     const int w5 = mbx.slim.w5[tid], w6 = mbx.slim.w6[tid], w7 = mbx.slim.w7[tid];
                     m.cannon_remain = w5 & 0xffff; m.cannon_max = (w5 >> 16) & 0xffff;
                     m.missile_remain = w6 & 0xff; m.rocket_max = (w6 >> 8) & 0xff; m.missile_wait = (w6 >> 16) & 0xff; m.burst = (w6 >> 24) & 0xff;
@@ -1275,8 +1328,8 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
      * the previous tick's stores have long been acknowledged; the request for tick t+2 goes out at the same place. */
     const bool has_act = active && s < c.n_ctrl;
     QPre pre;
-    pre.ok = false; pre.tkey = 0ULL; pre.ue = pre.uh = pre.sx = pre.sy = 0.0;
-    pre.lt = hh_geo_lat_terms{0.0, 1.0, 1.0, 1.0, 1.0, 0.5};
+    pre.ok = false; pre.spec = false; pre.sp_hdg = pre.sp_spd = 0.0; pre.sp_w = 0;
+    pre.tkey = 0ULL; pre.sx = pre.sy = 0.0;
     const size_t act_stride = (size_t)c.N * c.n_ctrl * 4;
     const int8_t *act_ptr = has_act ? actions + ((size_t)n * c.n_ctrl + s) * 4 : actions; /* lanes without a row re-read row 0, unused */
     int act_cur = *reinterpret_cast<const int *>(act_ptr);
@@ -1289,6 +1342,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         hh_act_unpack(act_cur, act, act_fault, has_act & was_running & (m.alive != 0));
         QPosMail *posmail = nullptr;
         if constexpr (OWT) posmail = &mbx.pos;
+        const int amask_before = tb.amask; /* alive at tick start: QPre.spec holds when the tick leaves it as it is */
         tick_quad<(W >= 2), DUAL, OWT>(c, sh, tid, g, s, base, active, helper, m, ar, act, tb, pub, nbc, so, evm_last, posmail, pre HH_PROF_PASS);
         const int done_now = ar.done;
         if constexpr (TWO && !OWT) { /* post the agents' rows as early as they exist: the LDS stores drain behind the work below */
@@ -1351,17 +1405,13 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
             __syncthreads(); /* barrier Y */
             HH_PROF(13);
             pre.ok = !reset_tick;
+            pre.spec = !reset_tick && !q_any(active && tb.amask != amask_before);
             if (!reset_tick) { /* wave-uniform: take the post-tick table the output wave built while this wave ran the envelope phases, and what it computed ahead */
 #pragma unroll
                 for (int k = 0; k < 3; k++) { tb.dist[k] = mbx.tab.dist[k][tid]; tb.foc[k] = mbx.tab.foc[k][tid]; tb.focr[k] = mbx.tab.focr[k][tid]; }
-                pre.tkey = mbx.tab.tk[tid]; pre.ue = mbx.tab.ue[tid]; pre.uh = mbx.tab.uh[tid]; pre.sx = mbx.tab.sx[tid]; pre.sy = mbx.tab.sy[tid];
+                pre.tkey = mbx.tab.tk[tid]; pre.sx = mbx.tab.sx[tid]; pre.sy = mbx.tab.sy[tid];
                 pub.uc = mbx.tab.uc[tid]; pub.us = mbx.tab.us[tid]; /* the exact heading vector (the tick carried a rotated one) */
-                if constexpr (DUAL) {
-                    const int rk_main = q_down_i(m.rk_alive); /* a helper lane: is its main lane's rocket in flight after this tick? */
-                    const int gi = (helper && !rk_main) ? tid - 32 : tid;
-                    pre.lt.S0 = mbx.tab.g[0][gi]; pre.lt.C0 = mbx.tab.g[1][gi]; pre.lt.U0 = mbx.tab.g[2][gi]; pre.lt.W0 = mbx.tab.g[3][gi];
-                    pre.lt.iC = mbx.tab.g[4][gi]; pre.lt.hW = mbx.tab.g[5][gi];
-                }
+                pre.sp_hdg = mbx.tab.sp_hdg[tid]; pre.sp_spd = mbx.tab.sp_spd[tid]; pre.sp_w = mbx.tab.sp_w[tid];
 #ifndef HHQ_ABL_NEARBY
                 quad_nearby(c, tb, s, nbc);
 #endif

@@ -231,8 +231,8 @@ HH_HD void hh_geo_direct(double lat1, double lon1, double azi1, double s12, doub
 #define HH_GEO_SHORT_MAX_LAT 70.0
 
 /* The terms of the series that depend on the START LATITUDE only (a sincosd, a square root, two divisions: the long dependent chains of the
- * function).  Split out so that a caller who knows the start latitude a tick ahead can have them computed off its critical path (the two-wave 2-vs-2
- * kernel's output wave, hh_kernels_quad.h); hh_geo_direct_short = these terms + hh_geo_direct_short_core: the same operations on the same operands. */
+ * function), split from the rest: hh_geo_direct_short = these terms + hh_geo_direct_short_core, the same operations on the same operands.  (Round 5
+ * tried computing them a tick ahead on the 2-vs-2 kernel's output wave: +0.6 %, and the room in that wave's window went to the opponents' script.) */
 typedef struct { double S0, C0, U0, W0, iC, hW; } hh_geo_lat_terms;
 HH_HD hh_geo_lat_terms hh_geo_short_lat_terms(double lat1) {
     hh_geo_lat_terms t;

@@ -1147,47 +1147,61 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                 m.lat = mbx.pos.lat[tid]; m.lon = mbx.pos.lon[tid]; m.spd = mbx.pos.spd[tid]; m.hdg = mbx.pos.hdg[tid];
                 m.ac_type = mbx.pos.ac_type[tid];
                 pub.flags = 0;
-                quad_publish_vec(m, pub); /* the heading vector now; the normalised entries after Y (only rows read them): the expressions of the simulation wave's reset ticks */
+                /* the heading vector now; the normalised entries after Y (only rows read them): the expressions of the simulation wave's reset ticks.  The
+                 * 8-arena form evaluates the tick's TWO sincos in one pass: the main lane its heading vector (of 90 - hdg), its helper lane the sine /
+                 * cosine of hdg that the opponents' script rounds (_correct_angle_sign), handed up afterwards */
+                double rs_ahead = 0.0, rc_ahead = 0.0;
+                if constexpr (DUAL) {
+                    const double hmain = q_down_d(m.hdg);
+                    double sn, cs;
+                    hh_sincos((helper ? hh_pymod360(hmain) : hh_pymod360(90.0 - hmain)) * (HH_PI / 180.0), &sn, &cs);
+                    pub.uc = cs; pub.us = sn; pub.un = hh_sqrt(cs * cs + sn * sn);
+                    rs_ahead = q_up_d(hh_round3(sn)); rc_ahead = q_up_d(hh_round3(cs));
+                } else {
+                    quad_publish_vec(m, pub);
+                    double sn, cs;
+                    hh_sincos(hh_pymod360(m.hdg) * (HH_PI / 180.0), &sn, &cs);
+                    rs_ahead = hh_round3(sn); rc_ahead = hh_round3(cs);
+                }
+                /* ahead of the simulation wave (QPre), first what does not need the table — so that it shares the table's long dependent chains' shadow:
+                 * the next tick's key, the arena's escape flag for that tick, this lane's script draw */
+                const int steps_t = mbx.pos.steps[mt]; /* read HERE: after Y the simulation wave posts the next tick's */
+                const unsigned long long tk1 = hh_rng_tick_key(akey, (uint32_t)mbx.pos.episode[mt], (uint32_t)(steps_t + 1));
+                const bool l3 = !c.ext_opp && c.level >= 3; /* configuration: the level-3 script of tick t + 1, on the prediction that tick t removes nobody (QPre.spec) */
+                const int ew = mbx.pos.escw[mt];
+                int esc = ew & 0xff, esc_t = (int)(int8_t)((ew >> 8) & 0xff);
+                const int am = (ew >> 16) & 0xf;
+                bool my_escaping = false, escj[2] = {false, false};
+                double u0 = 0.0, u1 = 0.0, u2 = 0.0;
+                if (l3) {
+                    quad_l3_flags(steps_t + 1, tk1, am, s, esc, esc_t, my_escaping, escj);
+                    /* the three draws, as tick_quad spreads them over the lanes */
+                    const int du = (s | 2) + 1, role = helper ? 2 : (s < 2 ? 1 : 0);
+                    const int site_e = role == 0 ? HH_SITE_ESC_HDG : (role == 1 ? HH_SITE_ESC_SPEED : HH_SITE_ESC_FIRE);
+                    const int site_h = role == 0 ? HH_SITE_HC_SPEED1 : (role == 1 ? HH_SITE_HC_R : HH_SITE_HC_SPEED2);
+                    const bool desc = (s & 1) ? escj[1] : escj[0];
+                    int de = desc ? 1 : 0;
+                    if (DUAL) { const int deh = q_down_i(de); de = helper ? deh : de; }
+                    const double u = hh_rng_u01(tk1, (uint32_t)du, (uint32_t)(de ? site_e : site_h), 0u);
+                    u0 = u; u1 = q_perm_d<HH_QP(0, 1, 0, 1)>(u);
+                    if (DUAL) u2 = q_up_d(u);
+                    else u2 = hh_rng_u01(tk1, (uint32_t)(s + 1), (uint32_t)(my_escaping ? HH_SITE_ESC_FIRE : HH_SITE_HC_SPEED2), 0u);
+                }
                 QTab tb;
-                int steps_t = 0;
                 quad_tables<DUAL, false>(m, pub, s, helper, tb); /* the same expressions on the same operands as the simulation wave's own (reset ticks) */
 #pragma unroll
                 for (int k = 0; k < 3; k++) { mbx.tab.dist[k][tid] = tb.dist[k]; mbx.tab.foc[k][tid] = tb.foc[k]; mbx.tab.focr[k][tid] = tb.focr[k]; }
-                { /* ahead of the simulation wave (QPre): the next tick's key, this lane's script draw in both variants, the script's rounded sine / cosine */
-                    steps_t = mbx.pos.steps[mt]; /* read HERE: after Y the simulation wave posts the next tick's */
-                    const unsigned long long tk1 = hh_rng_tick_key(akey, (uint32_t)mbx.pos.episode[mt], (uint32_t)(steps_t + 1));
-                    const int du = (s | 2) + 1, role = helper ? 2 : (s < 2 ? 1 : 0); /* tick_quad's assignment of the three draws to lanes */
-                    const int site_e = role == 0 ? HH_SITE_ESC_HDG : (role == 1 ? HH_SITE_ESC_SPEED : HH_SITE_ESC_FIRE);
-                    const int site_h = role == 0 ? HH_SITE_HC_SPEED1 : (role == 1 ? HH_SITE_HC_R : HH_SITE_HC_SPEED2);
-                    mbx.tab.uc[tid] = pub.uc; mbx.tab.us[tid] = pub.us;
-                    mbx.tab.tk[tid] = tk1;
-                    double sn, cs;
-                    hh_sincos(hh_pymod360(m.hdg) * (HH_PI / 180.0), &sn, &cs);
-                    const double rs = hh_round3(sn), rc = hh_round3(cs);
-                    mbx.tab.sx[tid] = rs; mbx.tab.sy[tid] = rc;
-                    if (!c.ext_opp && c.level >= 3) { /* configuration: the level-3 script of tick t + 1, on the prediction that tick t removes nobody (QPre.spec) */
-                        const int ew = mbx.pos.escw[mt];
-                        int esc = ew & 0xff, esc_t = (int)(int8_t)((ew >> 8) & 0xff);
-                        const int am = (ew >> 16) & 0xf;
-                        bool my_escaping = false, escj[2] = {false, false};
-                        quad_l3_flags(steps_t + 1, tk1, am, s, esc, esc_t, my_escaping, escj);
-                        /* the three draws, as tick_quad spreads them over the lanes */
-                        const bool desc = (s & 1) ? escj[1] : escj[0];
-                        int de = desc ? 1 : 0;
-                        if (DUAL) { const int deh = q_down_i(de); de = helper ? deh : de; }
-                        const double u = hh_rng_u01(tk1, (uint32_t)du, (uint32_t)(de ? site_e : site_h), 0u);
-                        const double u0 = u, u1 = q_perm_d<HH_QP(0, 1, 0, 1)>(u);
-                        double u2;
-                        if (DUAL) u2 = q_up_d(u);
-                        else u2 = hh_rng_u01(tk1, (uint32_t)(s + 1), (uint32_t)(my_escaping ? HH_SITE_ESC_FIRE : HH_SITE_HC_SPEED2), 0u);
-                        tb.amask = am;
-                        Near2 nb;
-                        quad_nearby(c, tb, s, nb);
-                        QScriptOut so_;
-                        quad_l3_script(c, m.lat, m.lon, m.hdg, m.ac_type, my_escaping, u0, u1, u2, nb, tb, rs, rc, so_);
-                        mbx.tab.sp_hdg[tid] = so_.heading; mbx.tab.sp_spd[tid] = so_.speed;
-                        mbx.tab.sp_w[tid] = (so_.fire & 1) | ((so_.fire_m & 1) << 1) | (((so_.opp + 1) & 7) << 2) | ((esc & 0xff) << 8) | ((esc_t & 0xff) << 16);
-                    }
+                mbx.tab.uc[tid] = pub.uc; mbx.tab.us[tid] = pub.us;
+                mbx.tab.tk[tid] = tk1;
+                mbx.tab.sx[tid] = rs_ahead; mbx.tab.sy[tid] = rc_ahead;
+                if (l3) { /* the script itself, from this wave's own table */
+                    tb.amask = am;
+                    Near2 nb;
+                    quad_nearby(c, tb, s, nb);
+                    QScriptOut so_;
+                    quad_l3_script(c, m.lat, m.lon, m.hdg, m.ac_type, my_escaping, u0, u1, u2, nb, tb, rs_ahead, rc_ahead, so_);
+                    mbx.tab.sp_hdg[tid] = so_.heading; mbx.tab.sp_spd[tid] = so_.speed;
+                    mbx.tab.sp_w[tid] = (so_.fire & 1) | ((so_.fire_m & 1) << 1) | (((so_.opp + 1) & 7) << 2) | ((esc & 0xff) << 8) | ((esc_t & 0xff) << 16);
                 }
                 HH_OPROF(1);
                 __syncthreads(); /* barrier Y: the table is there for the simulation wave; its integers are here */

@@ -360,9 +360,10 @@ extern "C" int hh_kernel_instance(hh_world *w, int32_t which, char *buf, int32_t
     else {
         if (pair && !half && pre != 1) pre = 0;
         const bool noshape = pair && pre == 0 && !w->no_owt && !(c.esc_dist_rew && c.agent_mode == HH_MODE_ESCAPE);
+        /* six template arguments, as a profiler prints the instance: W, PRE, TWO, APW, DUAL, SHAPE */
         if (noshape) snprintf(buf, (size_t)len, "hh_k_world_quad<1, 0, true, %d, %s, false>", half ? 8 : 16, (half && !w->no_dual) ? "true" : "false");
-        else if (half && !w->no_dual) snprintf(buf, (size_t)len, "hh_k_world_quad<1, %d, true, 8, true>", pre);
-        else snprintf(buf, (size_t)len, "hh_k_world_quad<%d, %d, %s, %d, false>", two ? 2 : 1, pre, pair ? "true" : "false", half ? 8 : 16);
+        else if (half && !w->no_dual) snprintf(buf, (size_t)len, "hh_k_world_quad<1, %d, true, 8, true, true>", pre);
+        else snprintf(buf, (size_t)len, "hh_k_world_quad<%d, %d, %s, %d, false, true>", two ? 2 : 1, pre, pair ? "true" : "false", half ? 8 : 16);
     }
     return HH_OK;
 }

@@ -319,9 +319,9 @@ def test_two_wave_form_equals_single_wave(monkeypatch, kw):
         if N <= 8192:   # which general two-wave instance runs: six template arguments = SHAPE false = pair table on the output wave
             shaping = bool(kw.get("esc_dist_rew"))
             half = N <= 4096
-            old = "hh_k_world_quad<1, 0, true, 8, true>" if half else "hh_k_world_quad<1, 0, true, 16, false>"
+            old = "hh_k_world_quad<1, 0, true, 8, true, true>" if half else "hh_k_world_quad<1, 0, true, 16, false, true>"   # W, PRE, TWO, APW, DUAL, SHAPE
             assert worlds[4].kernel_instance() == old
-            assert worlds[3].kernel_instance() == (old if shaping else old[:-1] + ", false>")
+            assert worlds[3].kernel_instance() == (old if shaping else old[:-len("true>")] + "false>")
         obs0 = [w.reset() for w in worlds]
         assert all(torch.equal(obs0[0], o) for o in obs0[1:])
         rng = np.random.default_rng(N)

@@ -77,8 +77,6 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=0, help="rollout / hier --pilot net: split the arenas into this many sub-worlds (disjoint global arena ids, "
                                                                  "bit-identical to one world) stepped on as many HIP streams inside the one graph, so that one sub-world's world "
                                                                  "launches run under another's policy kernel (0 = the workload's default)")
-    ap.add_argument("--no-spec", action="store_true", help="hier --pilot net: one side per policy call (the round-4 order) instead of hh_hl_set_speculation: both sides' pilot rows "
-                                                            "per call, then only the opponents whose observed weapon flags changed (same results)")
     ap.add_argument("--no-extra", action="store_true", help="default workload at 1 GPU: skip the short runs of the other single-GPU configurations "
                                                              "(BASELINE configs[2], configs[3] tape / networks) that fill line['extra']")
     return ap.parse_args()
@@ -633,8 +631,7 @@ def main_hier(args, R=None):
     elif args.pilot == "random":
         pilot = RandomPilot(R.dev, args.seed + R.rank)
     elif args.pilot == "net":
-        bind = os.environ.get("HH_BENCH_NO_BIND", "0") != "1"   # HH_BENCH_NO_BIND=1: binning pass per call (A/B)
-        pilot = NetPilot(w, seed=args.seed, bind=bind, speculate=bind and not getattr(args, "no_spec", False))
+        pilot = NetPilot(w, seed=args.seed, bind=os.environ.get("HH_BENCH_NO_BIND", "0") != "1")   # HH_BENCH_NO_BIND=1: binning pass per call (A/B)
     else:
         pilot = MLPPilot(R.dev, seed=args.seed)
     cmds = commander_tape(args, R, N)
@@ -754,9 +751,8 @@ def main_hier_split(args, R, own, N, K):
     worlds = [x.world for x in sws]
     for w in worlds:
         w.reset()
-    spec = not getattr(args, "no_spec", False)
-    pilots_ = [NetPilot(w, seed=args.seed, speculate=spec) for w in worlds]
-    if not spec and "HH_POLICY_TILE" not in os.environ and n * 3 <= 10240:
+    pilots_ = [NetPilot(w, seed=args.seed) for w in worlds]
+    if "HH_POLICY_TILE" not in os.environ and n * 3 <= 10240:
         for pl in pilots_:   # small calls on concurrent streams stay on the tile forms: wide tiles, the other streams fill what a partial round leaves idle
             pl.bank.set_tile_rows(64)
     cmds = commander_tape(args, R, N)
@@ -821,9 +817,7 @@ def main_hier_split(args, R, own, N, K):
         "sim_ticks_per_s": ticks * R.world / dt, "ticks_per_commander_step": ticks / float(N * steps),
         "config": {"workload": f"{N} arenas/GPU x 3-vs-3 HighLevelEnv commander steps (<= 16 sub-steps each), uniform commander actions, "
                                f"pilots = {PILOT_DESC['net']}, auto-reset (BASELINE configs[3])", "arenas_per_gpu": N,
-                   "parallelism": f"arena-sharded x{R.world}, no data-path collective; {K} sub-worlds on {K} streams inside one HIP graph",
-                   "policy_calls": ("one call per sub-step serves both sides (the opponents' rows ahead of the agents' actions), a second one recomputes the opponents whose "
-                                    "observed weapon flags changed: hh_hl_set_speculation, same results") if spec else "one side per call"},
+                   "parallelism": f"arena-sharded x{R.world}, no data-path collective; {K} sub-worlds on {K} streams inside one HIP graph"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": f"{worlds[0].kernel_instance(0)} (every phase launch of the macro step) + hh_k_policy_h", "algorithmic_bytes": algo_bytes,
                      "note": "2056 B per arena-tick actually run + 424 B per commander step (SURVEY.md 8d)"},

@@ -38,9 +38,6 @@ struct DevCfg {
     int friendly_kill, friendly_punish, esc_dist_rew, hier_action_assess, hier_opp_fight_ratio;
     int auto_reset, ext_opp, D, n_ctrl;
     int sel_side; /* hh_config.opp_side_selector: an opponent's fight row selects "fight_*_opp" (env_base.py:387-390) */
-    int hl_spec;  /* hh_hl_set_speculation: bit 0 = hh_hl_begin / hh_hl_tick emit (and bin) BOTH sides' pilot rows — the opponents' as they would observe if no
-                     agent's weapon flag changes in the coming hh_hl_agents_act —, and hh_hl_agents_act bins only the opponents of arenas where one did;
-                     bit 1 (tests only, HH_SPEC_NO_REDO): never re-bin */
     double glob_frac, rew_scale, ext_lat, ext_lon, inv_ext_lat, inv_ext_lon, lat_hi, lon_hi, inv_diag;
     uint64_t seed, arena_offset;
 };

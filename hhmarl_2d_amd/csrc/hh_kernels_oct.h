@@ -1074,36 +1074,24 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
     /* a bound policy bank (hh_bind_policy): this launch's pilot rows are binned by network here (see hh_k_hier) */
     int pslot = 0;
     HhBinTicket bt{0, 0};
-    /* side 0 agents, 1 opponents, 2 both (speculation), 3 the opponents of arenas flagged `redo` (speculation: hh_hl_agents_act) */
-    bool redo = false;
     auto bin_issue = [&](int side) {
-        const bool mine_ = side == 2 ? true : (side == 3 ? (!agent && redo) : (side == 0 ? agent : !agent));
+        const bool mine_ = side == 0 ? agent : !agent;
         const int sb = (L.exists && ar.hl_run && m.alive && mine_) ? hl_selector(c, m.cmd_act != 0 ? 1 : 2, m.ac_type, agent) : 0;
         pslot = sb ? (int)P.pol_lut[sb] : 0;
         bt = hh_bin_rows_issue(P.pol_counts, pslot);
     };
-    /* Speculation (hh_hl_set_speculation): what an opponent's pilot observes after the agents acted differs from what it would observe before only in the
-     * agents' weapon flags (env_base.py:208-211) — so hh_hl_begin / hh_hl_tick emit BOTH sides' rows, the opponents' with the flags as they stand, one policy
-     * call serves all six units, and hh_hl_agents_act re-lists only the opponents of arenas in which an agent's flag did change (their actions are computed
-     * again from the rows this launch writes): the same actions as the one-side-at-a-time order, half the large policy calls. */
-    const bool spec = (c.hl_spec & 1) != 0;
     if (phase == HH_HL_BEGIN) {
         oct_do_begin(c, tb, L, n, active, H, cmd);
-        obs_side = spec ? 2 : 0;
-        if (P.pol_lut && pilot_obs) bin_issue(obs_side);
+        obs_side = 0;
+        if (P.pol_lut && pilot_obs) bin_issue(0);
     } else if (phase == HH_HL_AGENTS_ACT) {
         int8_t act[4];
         hl_load_act(actions, u, L.exists, act, act_fault, active && ar.hl_run && m.alive && agent);
-        if (!spec && P.pol_lut && pilot_obs) bin_issue(1);
+        if (P.pol_lut && pilot_obs) bin_issue(1);
         const bool running = active && ar.hl_run;
-        const int fl0 = pub.flags;
         act_oct<(W >= 2), true>(c, sh, tid, L, running, m, ar, act, agent, tb, pub, H.evm);
         HH_O_FETCH5(i, tb.fl, pub.flags); /* the opponents observe the agents' weapon flags of this sub-step (env_base.py:208-211) */
         obs_side = 1;
-        if (spec) {
-            redo = oct_arena_bits(__ballot(agent && L.exists && (((pub.flags ^ fl0) & FL_SHOT) != 0)), L) != 0 && !(c.hl_spec & 2);
-            if (P.pol_lut && pilot_obs) bin_issue(3);
-        }
     } else if (phase == HH_HL_TICK) {
         int8_t act[4];
         hl_load_act(actions, u, L.exists, act, act_fault, active && ar.hl_run && m.alive && !agent);
@@ -1115,8 +1103,8 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
             const unsigned long long rn = __ballot(ran && L.p == 0);
             if (rn && tid == 0 && tick_total) atomicAdd(tick_total, (unsigned long long)__popcll(rn));
         }
-        obs_side = spec ? 2 : 0;
-        if (P.pol_lut && pilot_obs) bin_issue(obs_side);
+        obs_side = 0;
+        if (P.pol_lut && pilot_obs) bin_issue(0);
     } else { /* HH_HL_END */
         if (P.pol_lut && grp == 0 && tid <= 8) P.pol_counts[tid * HH_BIN_STRIDE] = 0; /* rows the last tick binned and nobody consumed */
         oct_do_end(P, c, sh, tid, L, n, active, H, tb, pub, HH_HL_END, reward_out, valid_out, done_out, nullptr);
@@ -1128,7 +1116,7 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
         }
     }
     if (obs_side >= 0 && pilot_obs) {
-        const bool mine = obs_side == 2 ? true : (obs_side == 0 ? agent : !agent);
+        const bool mine = obs_side == 0 ? agent : !agent;
         o_wave_sync(); /* the queue's exchange area (same LDS) is free */
         if (c.nA + c.nO < 6) { /* n-vs-m: the rows of the slots without an aircraft */
             for (int k = tid; k < 8 * 6 * 30; k += 64) sh.u.prow[k] = 0.0f;

@@ -111,7 +111,6 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     d.hier_action_assess = cfg->hier_action_assess; d.hier_opp_fight_ratio = cfg->hier_opp_fight_ratio;
     d.auto_reset = cfg->auto_reset; d.ext_opp = cfg->ext_opp_actions;
     d.sel_side = (cfg->env_kind == HH_ENV_HIGHLEVEL && cfg->opp_side_selector) ? 1 : 0;
-    d.hl_spec = 0;
     d.D = cfg->env_kind == HH_ENV_HIGHLEVEL ? HH_OBS_HL : (cfg->agent_mode == HH_MODE_FIGHT ? HH_OBS_FIGHT_AC1 : HH_OBS_ESC_AC1);
     d.n_ctrl = cfg->ext_opp_actions ? A : cfg->n_agents;
     d.glob_frac = cfg->glob_frac; d.rew_scale = cfg->rew_scale;
@@ -366,16 +365,6 @@ extern "C" int hh_kernel_instance(hh_world *w, int32_t which, char *buf, int32_t
         else if (half && !w->no_dual) snprintf(buf, (size_t)len, "hh_k_world_quad<1, %d, true, 8, true, true>", pre);
         else snprintf(buf, (size_t)len, "hh_k_world_quad<%d, %d, %s, %d, false, true>", two ? 2 : 1, pre, pair ? "true" : "false", half ? 8 : 16);
     }
-    return HH_OK;
-}
-
-/* speculation of the opponents' pilot rows (hh_abi.h) */
-extern "C" int hh_hl_set_speculation(hh_world *w, int32_t on) {
-    if (!w) { g_err = "null argument"; return HH_E_ARG; }
-    if (w->cfg.env_kind != HH_ENV_HIGHLEVEL) { g_err = "hh_hl_set_speculation: not a HighLevelEnv world"; return HH_E_ARG; }
-    if (on && w->no_oct) { g_err = "hh_hl_set_speculation: the LDS-exchange phase kernels (HH_NO_OCT=1) emit one side per launch only"; return HH_E_ARG; }
-    const char *e = getenv("HH_SPEC_NO_REDO"); /* tests: prove that the re-listing matters */
-    w->dc.hl_spec = on ? (1 | ((e && atoi(e)) ? 2 : 0)) : 0;
     return HH_OK;
 }
 

@@ -23,12 +23,11 @@ def macro_step(world, commander_actions, pilot, out=None, pilot_buf=None, early_
     """One HighLevelEnv.step for every arena of `world` (env_hier.py:114-140).
     commander_actions: int8 [N, n_agents] on the world's device."""
     nA = world.n_agents
-    spec = bool(getattr(pilot, "speculative", False))   # pilots.NetPilot(speculate=True): both sides' rows per call, then only the ones to recompute
     po, pm = world.hl_begin(commander_actions, pilot_buf)
     for sub in range(N_SUB_STEPS):
         act = pilot(po, pm).contiguous()
         po, pm = world.hl_agents_act(act, pilot_buf)
-        act_o = pilot(po, pm, redo=True) if spec else pilot(po, pm)
+        act_o = pilot(po, pm)
         if act_o.data_ptr() != act.data_ptr():
             act[:, nA:] = act_o[:, nA:]
         po, pm, running = world.hl_tick(act, pilot_buf, count_running=early_exit)

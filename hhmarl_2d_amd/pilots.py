@@ -257,19 +257,16 @@ class PolicyBank:
                                       C.c_void_p(actions.data_ptr()), lp, st))
         return actions
 
-    def act_binned(self, obs, actions, logits=None, live_rows=None):
+    def act_binned(self, obs, actions, logits=None):
         """the forward over row lists a bound world's kernels wrote (World.bind_policy): no binning pass, the kernel clears the
-        row counters behind itself.  live_rows: the caller's estimate of how many rows are listed (picks the kernel form: hh_policy_act_binned_live)"""
+        row counters behind itself"""
         assert obs.dtype == torch.float32 and obs.is_contiguous() and actions.dtype == torch.int8 and actions.is_contiguous()
         stride = obs.shape[-1]
         n_rows = obs.numel() // stride
         assert actions.numel() == n_rows * 4
         st = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
         lp = None if logits is None else C.c_void_p(logits.data_ptr())
-        if live_rows is None:
-            L.check(L.lib().hh_policy_act_binned(self.h, C.c_void_p(obs.data_ptr()), n_rows, stride, C.c_void_p(actions.data_ptr()), lp, st))
-        else:
-            L.check(L.lib().hh_policy_act_binned_live(self.h, C.c_void_p(obs.data_ptr()), n_rows, stride, C.c_void_p(actions.data_ptr()), lp, int(live_rows), st))
+        L.check(L.lib().hh_policy_act_binned(self.h, C.c_void_p(obs.data_ptr()), n_rows, stride, C.c_void_p(actions.data_ptr()), lp, st))
         return actions
 
     @staticmethod
@@ -281,37 +278,23 @@ class NetPilot:
     """HighLevelEnv pilots (env_base.py:349-398): every live unit's lowlevel_state row through the network its selector
     byte names (fight / escape policy of its aircraft type), actions written into one static [N, A, 4] buffer."""
 
-    def __init__(self, world, bank=None, seed=0, bind=True, speculate=False):
-        """speculate (bound banks only): the world emits BOTH sides' pilot rows after hl_begin / hl_tick — the opponents' as they would observe if no agent's
-        weapon flag changes when the agents act —, ONE policy call computes all six units' actions, and the call behind hl_agents_act recomputes only the
-        opponents of arenas where a flag did change (hh_hl_set_speculation): the same actions, half the large policy calls.  macro_step tells the two calls
-        apart through `redo`."""
+    def __init__(self, world, bank=None, seed=0, bind=True):
         self.bank = bank if bank is not None else PolicyBank.random_init(world.device, seed=seed, max_rows=world.N * world.A)
         self.act = torch.zeros((world.N, world.A, 4), dtype=torch.int8, device=world.device)
         # bound: the world's phase kernels write the bank's row lists themselves (hh_bind_policy), every call is the forward only.
         # The pilot must then be called exactly once after every hl_begin / hl_agents_act / hl_tick whose rows are wanted, which is
         # what macro_step does; bind=False keeps the self-contained form (binning pass per call from pilot_mode).
         self.world = world if bind else None
-        self.speculative = bool(speculate)
-        if self.speculative and not bind:
-            raise ValueError("NetPilot(speculate=True) needs the bank bound to the world (the world's kernels list the rows to recompute)")
         if bind:
             world.bind_policy(self.bank)
-        if self.speculative:
-            world.hl_speculate(True)
-        self._rows = world.N * world.A
 
-    def __call__(self, pilot_obs, pilot_mode, redo=False):
+    def __call__(self, pilot_obs, pilot_mode):
         if self.world is not None:
-            if self.speculative:   # both sides' rows (about half of the units are alive inside a running macro step) | the few opponents to recompute
-                return self.bank.act_binned(pilot_obs, self.act, live_rows=max(64, self._rows // 32) if redo else self._rows)
             return self.bank.act_binned(pilot_obs, self.act)
         return self.bank.act(pilot_obs, pilot_mode, self.act)
 
     def close(self):
         if self.world is not None:
-            if self.speculative:
-                self.world.hl_speculate(False)
             self.world.bind_policy(None)
             self.world = None
 

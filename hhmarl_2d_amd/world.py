@@ -173,12 +173,6 @@ class World:
         L.check(L.lib().hh_hl_end(self.h, _p(obs), _p(rew), _p(val), _p(done), self._stream()))
         return obs, rew, val, done
 
-    def hl_speculate(self, on=True):
-        """hh_hl_set_speculation: hl_begin / hl_tick emit (and, with a bound bank, list) BOTH sides' pilot rows — the opponents' as they would observe if no
-        agent's weapon flag changes in the coming hl_agents_act —, and hl_agents_act lists only the opponents of arenas where one did (pilots.NetPilot(speculate=True))"""
-        L.check(L.lib().hh_hl_set_speculation(self.h, 1 if on else 0))
-        self.speculating = bool(on)
-
     def hl_rollout(self, commander_actions, pilot_tape, out=None):
         """one whole commander step per arena in ONE launch: commander_actions int8 [N, n_agents], pilot_tape int8 [16, N, A, 4]"""
         assert commander_actions.dtype == torch.int8 and commander_actions.is_contiguous()

@@ -156,15 +156,6 @@ int hh_hl_agents_act(hh_world *w, const int8_t *actions, float *pilot_obs, uint8
 int hh_hl_tick(hh_world *w, const int8_t *actions, float *pilot_obs, uint8_t *pilot_mode, int32_t *running, void *stream);
 int hh_hl_end(hh_world *w, float *obs, float *reward, uint8_t *reward_valid, uint8_t *done, void *stream);
 
-/* Speculation of the opponents' pilot rows, for callers that evaluate the pilots' networks between the phases.  What an opponent's pilot observes after
- * the agents acted (env_hier.py:126-133 in unit id order) differs from what it would observe before only in the agents' weapon flags
- * (env_base.py:208-211: cannon burst running / missile in flight).  With on != 0, hh_hl_begin and hh_hl_tick write BOTH sides' rows into pilot_obs /
- * pilot_mode (the opponents' with the flags as they stand) and, with a bound bank, list all of them — one policy call then computes the actions of all six
- * units —, and hh_hl_agents_act writes the opponents' rows as before but lists only those of arenas in which an agent's flag did change: the policy call
- * behind it recomputes exactly the actions that would differ.  Same actions and results as the default order (tests/test_gpu_composition.py), half the large
- * policy calls.  Off by default; register-exchange phase kernels only. */
-int hh_hl_set_speculation(hh_world *w, int32_t on);
-
 /* HighLevelEnv.step in ONE launch for callers whose pilot actions exist before the step starts (a recorded / scripted tape,
  * env-only throughput runs): pilot_tape [dev] i8 [16, N, 6, 4] = the actions of sub-step k in slice k (each side's rows are
  * read at its turn).  Same result as hh_hl_begin + 16 x {hh_hl_agents_act, hh_hl_tick} + hh_hl_end with those actions, bit

@@ -97,11 +97,6 @@ int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_st
 struct hh_world;
 int hh_bind_policy(struct hh_world *w, hh_policy *p);
 int hh_policy_act_binned(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, int8_t *actions, float *logits, void *stream);
-/* the same with the caller's estimate of how many of the n_rows rows are listed (the host cannot see the device-side counts): it only picks the kernel
- * form and tile width (weights-through-LDS forms for large calls, activation-tile forms for small ones); < 0 = hh_policy_act_binned's own guess.  For
- * hh_hl_set_speculation callers: ~n_rows after hh_hl_begin / hh_hl_tick, a small number after hh_hl_agents_act. */
-int hh_policy_act_binned_live(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, int8_t *actions, float *logits, int32_t live_rows,
-                              void *stream);
 
 /* ---- The TRAINABLE policies inside a PPO rollout (configs[2]).  What RLlib's sampler does per env step for each of
  * train_hetero.py's two policies (train_hetero.py:206-243): model.forward on the observer's dict (central_critic_observer, 162-181:

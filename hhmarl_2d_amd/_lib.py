@@ -10,6 +10,16 @@ ENV_LOWLEVEL, ENV_HIGHLEVEL = 0, 1
 MODE_FIGHT, MODE_ESCAPE = 0, 1
 OPP_MODE_EPISODE = -1  # hh_step_begin: every arena observes in the mode of its own level-5 draw
 ACF_K, ACI_K, RKF_K, RKI_K, ARI_K, TGT_K = 6, 10, 4, 4, 6, 3
+
+
+def hl_slots(n_agents, n_opps):
+    """unit slots of a HighLevelEnv arena (include/hh_spec.h: HH_HL_SLOTS)"""
+    return 10 if max(n_agents, n_opps) > 3 else 6
+
+
+def tgt_k_of(n_agents, n_opps):
+    """entries of a unit's stored target list in the state views (include/hh_spec.h: HH_TGT_K_OF)"""
+    return 5 if max(n_agents, n_opps) > 3 else TGT_K
 EVAL_KEYS = ("agents_win", "opps_win", "draw", "agent_fight", "agent_escape", "opp_fight", "opp_escape", "agent_steps", "opp_steps",
              "opp1", "opp2", "opp3")  # columns of hh_eval_info (env_base.py:104-106)
 

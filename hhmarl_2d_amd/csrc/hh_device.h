@@ -69,7 +69,7 @@ inline bool hh_cfg_is_hl_default(const DevCfg &c) {
 struct DevPtrs {
     double *lat, *lon, *hdg, *spd, *cmd_hdg, *cmd_spd;   /* [U]  a1/a6 */
     int4 *pack;                                          /* [U]  small ints, 16 B */
-    double *tgt_d;                                       /* [3][U] stored target distances */
+    double *tgt_d;                                       /* [3][U] stored target distances ([5][U] in ten-slot worlds) */
     double *rk_lat, *rk_lon, *rk_hdg, *rk_cmd;           /* [U]  rocket slot s <- launcher slot s */
     int2 *rk_pack;                                       /* [U] */
     int4 *ar_pack;                                       /* [N]  steps, episode, flags, next_seq */
@@ -102,6 +102,13 @@ struct Unit {
     double tgt_d0, tgt_d1, tgt_d2;
     int rk_alive, rk_target, rk_life, rk_seq;
     double rk_lat, rk_lon, rk_hdg, rk_cmd;
+};
+/* ten-slot HighLevelEnv arenas (more than 3 aircraft on a side): entries 4 and 5 of an opponent's stored list of agents (env_hier.py:97).
+ * Only the kernels instantiated for A = 10 hold this type; they hand it to the shared device functions as a Unit & and the three places
+ * that need the extra entries (hl_target_slot<true>, hl_pilot_obs, hl_commander_obs, unit_load / unit_store<true>) cast back */
+struct UnitW : Unit {
+    int tgt3, tgt4;
+    double tgt_d3, tgt_d4;
 };
 
 /* register-resident arena scalars, replicated on every lane of the group */
@@ -178,6 +185,9 @@ __device__ __forceinline__ void trace_append(const DevPtrs &P, int A, int n, int
     cursor += 1;
 }
 
+/* X: the world's arenas have ten unit slots — target-list entries 4 and 5 travel in the free top byte of rk_pack.x (two 4-bit ids) and
+ * in planes 3 and 4 of tgt_d (allocated for such worlds only) */
+template <bool X = false>
 __device__ __forceinline__ void unit_load(const DevPtrs &P, size_t U, size_t u, Unit &m) {
     m.lat = P.lat[u]; m.lon = P.lon[u]; m.hdg = P.hdg[u]; m.spd = P.spd[u];
     m.cmd_hdg = P.cmd_hdg[u]; m.cmd_spd = P.cmd_spd[u];
@@ -191,8 +201,14 @@ __device__ __forceinline__ void unit_load(const DevPtrs &P, size_t U, size_t u, 
     int2 r = P.rk_pack[u];
     m.rk_alive = r.x & 0xff; m.rk_target = (r.x >> 8) & 0xff; m.rk_life = (r.x >> 16) & 0xff; m.rk_seq = r.y;
     m.rk_lat = P.rk_lat[u]; m.rk_lon = P.rk_lon[u]; m.rk_hdg = P.rk_hdg[u]; m.rk_cmd = P.rk_cmd[u];
+    if constexpr (X) {
+        UnitW &x = static_cast<UnitW &>(m);
+        x.tgt3 = (r.x >> 24) & 15; x.tgt4 = (r.x >> 28) & 15;
+        x.tgt_d3 = P.tgt_d[3 * U + u]; x.tgt_d4 = P.tgt_d[4 * U + u];
+    }
 }
 
+template <bool X = false>
 __device__ __forceinline__ void unit_store(const DevPtrs &P, size_t U, size_t u, const Unit &m) {
     P.lat[u] = m.lat; P.lon[u] = m.lon; P.hdg[u] = m.hdg; P.spd[u] = m.spd;
     P.cmd_hdg[u] = m.cmd_hdg; P.cmd_spd[u] = m.cmd_spd;
@@ -205,6 +221,11 @@ __device__ __forceinline__ void unit_store(const DevPtrs &P, size_t U, size_t u,
     P.tgt_d[u] = m.tgt_d0; P.tgt_d[U + u] = m.tgt_d1; P.tgt_d[2 * U + u] = m.tgt_d2;
     int2 r;
     r.x = (m.rk_alive & 0xff) | ((m.rk_target & 0xff) << 8) | ((m.rk_life & 0xff) << 16);
+    if constexpr (X) {
+        const UnitW &x = static_cast<const UnitW &>(m);
+        r.x |= (int)(((unsigned)(x.tgt3 & 15) << 24) | ((unsigned)(x.tgt4 & 15) << 28));
+        P.tgt_d[3 * U + u] = x.tgt_d3; P.tgt_d[4 * U + u] = x.tgt_d4;
+    }
     r.y = m.rk_seq;
     P.rk_pack[u] = r;
     P.rk_lat[u] = m.rk_lat; P.rk_lon[u] = m.rk_lon; P.rk_hdg[u] = m.rk_hdg; P.rk_cmd[u] = m.rk_cmd;

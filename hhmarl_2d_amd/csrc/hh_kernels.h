@@ -73,8 +73,9 @@ struct Shared {
     int flags[B];                   /* bit0 alive, bits1-2 ac_type, bit3 shot flag */
     int aux[B];                     /* per-phase scratch */
     int res[B];                     /* envelope results per requesting lane: bit0 launch ok, bits1-8 cannon hit
-                                       on slot j, bit9 rocket fuse on target, bit10 fuse on "friendly" */
-    int g_alive[GPB], g_nev[GPB], g_ev[GPB][HH_MAX_AIRCRAFT], g_rkdead[GPB];
+                                       on slot j, bit9 rocket fuse on target, bit10 fuse on "friendly" (ten-slot arenas:
+                                       cannon bits 1-10, fuse bits 12 / 13: HH_RES_FUSE_BIT) */
+    int g_alive[GPB], g_nev[GPB], g_ev[GPB][A > 8 ? A : 8], g_rkdead[GPB];
     union alignas(16) {
         struct {
             double lat1[B], lon1[B], hdg1[B]; /* position / heading after this tick's aircraft update */
@@ -90,6 +91,8 @@ struct Shared {
 
 #define FL_ALIVE 1
 #define FL_SHOT 8
+/* first of the two rocket-fuse bits of an envelope result word, by lanes per arena group */
+#define HH_RES_FUSE_BIT(GS) ((GS) > 8 ? 12 : 9)
 
 template <int A, int B>
 __device__ __forceinline__ int sh_alive(const Shared<A, B> &sh, int idx) { return sh.flags[idx] & FL_ALIVE; }
@@ -397,7 +400,7 @@ __device__ __forceinline__ void drain_envelope_queue_t(SH &sh, int tid, int coun
 #pragma unroll 1
     for (int q = tid; q < count; q += B) {
         int code = sh.u.t.q_code[q];
-        int src = code & 0xff, kind = (code >> 8) & 3, j = (code >> 10) & 7;
+        int src = code & 0xff, kind = (code >> 8) & 3, j = (code >> 10) & (GS > 8 ? 15 : 7);
         int ss = src % GS, sb = src - ss;
         double la1, lo1, la2, lo2;
         if (kind <= 1) { la1 = sh.lat0[src]; lo1 = sh.lon0[src]; }
@@ -448,7 +451,7 @@ __device__ __forceinline__ void drain_envelope_queue_t(SH &sh, int tid, int coun
                 const int id_tgt = GS == 8 ? (j < 4 ? j + 1 : opp_id0 + (j - 4)) : j + 1;
                 double u = hh_rng_u01(sh.g_tkey[src / GS], (uint32_t)id_src, HH_SITE_CANNON, (uint32_t)id_tgt);
                 if (u < HH_AC_HIT_PROB(t)) bit = 2 << j;
-            } else bit = kind == 2 ? (1 << 9) : (1 << 10);
+            } else bit = kind == 2 ? (1 << HH_RES_FUSE_BIT(GS)) : (1 << (HH_RES_FUSE_BIT(GS) + 1));
         }
         if (bit) atomicOr(&sh.res[src], bit);
     }
@@ -781,7 +784,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
         m.rk_target = launch_tgt + 1; m.rk_life = 0;
         m.has_missile = 1;
         m.missile_remain = m.missile_remain - 1 > 0 ? m.missile_remain - 1 : 0;
-        evm |= 1u << (24 + s);
+        evm |= HH_EV_BIT(A, 3, s, agent);
         /* the launcher's own update in this tick already steers it (ac1.py:127) */
         m.rk_cmd = rk_ncmd;
     }
@@ -795,7 +798,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     }
     if (want_launch && wait_after >= 0) m.missile_wait = wait_after;
     const int rk_at_start = m.rk_alive; /* rockets in do_tick's snapshot: in flight + launched this step */
-    sh.aux[tid] = launched | ((fired ? (myres >> 1) & 0xff : 0) << 8);
+    sh.aux[tid] = launched | ((fired ? (myres >> 1) & (A > 8 ? 0x3ff : 0xff) : 0) << 8);
     hh_wg_sync<B>();
     {   /* launch order = unit id order (cmano_simulator.py:104-108): seq = running id counter */
         int before = 0, total = 0;
@@ -811,7 +814,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     int rkw = 0; /* bit0 present, bit1 fuse on target, bit2 fuse on "friendly", bit3 end of life, bits4-6 target, bits 8.. seq */
     if (running && rk_at_start) {
         int eol = m.rk_life > HH_ROCKET_MAX_LIFE;
-        rkw = 1 | (((myres >> 9) & 1) << 1) | (((myres >> 10) & 1) << 2) | (eol << 3) | ((m.rk_target - 1) << 4) | (m.rk_seq << 8);
+        rkw = 1 | (((myres >> HH_RES_FUSE_BIT(A)) & 1) << 1) | (((myres >> (HH_RES_FUSE_BIT(A) + 1)) & 1) << 2) | (eol << 3) | ((m.rk_target - 1) << 4) | (m.rk_seq << 8);
     }
     sh.res[tid] = rkw; /* res was consumed into myres above; reuse it for the rocket word */
 
@@ -848,7 +851,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
                 }
                 if (best < 0) break;
                 done_mask |= 1 << best;
-                int tg = (w >> 4) & 7;
+                int tg = (w >> 4) & 15;
                 int fid = best == 1 ? 0 : 1;
                 if (((w >> 1) & 1) && ((alive >> tg) & 1)) {
                     alive &= ~(1 << tg); dead |= 1 << best;
@@ -924,9 +927,9 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     /* event masks for parity checks */
     for (int e = 0; e < nev; e++) {
         int w = sh.g_ev[g][e];
-        evm |= ((w >> 8) & 1) ? (1u << (8 + ((w >> 4) & 15))) : (1u << ((w >> 4) & 15));
+        evm |= HH_EV_BIT(A, (w >> 8) & 1, (w >> 4) & 15, 0);
     }
-    if (oob) evm |= 1u << (16 + s);
+    if (oob) evm |= HH_EV_BIT(A, 2, s, 0);
     ev_mask_out = evm;
     sh.aux[tid] = oob;
     sh.rew[tid] = rews;
@@ -980,6 +983,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
 }
 
 /* index into the stored target list like Python: commander_actions[i]-1, with -1 = last */
+template <bool X = false> /* X: ten-slot arenas, lists of up to five (an opponent's agents) */
 __device__ __forceinline__ int hl_target_slot(const Unit &m, double &dist) {
     /* fields are read into values first: a select between the addresses of struct members would keep the whole Unit in
      * scratch memory instead of registers */
@@ -991,6 +995,13 @@ __device__ __forceinline__ int hl_target_slot(const Unit &m, double &dist) {
     if (k == 0 && n_tgt > 0) { t = t0; d = d0; }
     if (k == 1 && n_tgt > 1) { t = t1; d = d1; }
     if (k == 2 && n_tgt > 2) { t = t2; d = d2; }
+    if constexpr (X) {
+        const UnitW &x = static_cast<const UnitW &>(m);
+        const int t3 = x.tgt3, t4 = x.tgt4;
+        const double d3 = x.tgt_d3, d4 = x.tgt_d4;
+        if (k == 3 && n_tgt > 3) { t = t3; d = d3; }
+        if (k == 4 && n_tgt > 4) { t = t4; d = d4; }
+    }
     dist = d;
     return t; /* 1-based unit id, 0 = none */
 }
@@ -1009,7 +1020,7 @@ __device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int
     bool base_gate = false;
     if (snap) {
         double dd;
-        int t = hl ? hl_target_slot(m, dd) : (m.n_tgt ? m.tgt0 : 0);
+        int t = hl ? hl_target_slot<(A > 8)>(m, dd) : (m.n_tgt ? m.tgt0 : 0);
         if (!hl && agent) { /* env_hetero.py:168-170 */
             valid = 1;
             if (t && sh_alive(sh, base + t - 1)) opp_stat0 = norm180(sh.p_foc[s][base + t - 1]);
@@ -1051,7 +1062,7 @@ __device__ __forceinline__ void act_phase(const DevCfg &c, Shared<A, B> &sh, int
         m.rk_target = launch_tgt + 1; m.rk_life = 0;
         m.has_missile = 1;
         m.missile_remain = m.missile_remain - 1 > 0 ? m.missile_remain - 1 : 0;
-        evm |= 1u << (24 + s);
+        evm |= HH_EV_BIT(A, 3, s, agent);
     }
     if (base_gate) {
         double uu = d_rng(ar, id, HH_SITE_MISSILE_WAIT, 0);

@@ -21,6 +21,7 @@
 #define HH_KERNELS_HIER_H
 
 #include "hh_kernels.h"
+#include <type_traits>
 
 enum { HH_HL_BEGIN = 0, HH_HL_AGENTS_ACT = 1, HH_HL_TICK = 2, HH_HL_END = 3, HH_HL_REFRESH = 4, HH_HL_RESET = 5 };
 
@@ -45,6 +46,13 @@ __device__ __forceinline__ int hl_pilot_obs(const DevCfg &c, const Shared<A, B> 
         int oj = t0 - 1;
         if (cmd_act == 2) { dist = d1; oj = t1 - 1; }
         if (cmd_act >= 3) { dist = d2; oj = t2 - 1; }
+        if constexpr (A > 8) { /* an opponent's list of up to five agents */
+            const UnitW &x = static_cast<const UnitW &>(m);
+            const int t3 = x.tgt3, t4 = x.tgt4;
+            const double d3 = x.tgt_d3, d4 = x.tgt_d4;
+            if (cmd_act == 4) { dist = d3; oj = t3 - 1; }
+            if (cmd_act >= 5) { dist = d4; oj = t4 - 1; }
+        }
         out[n++] = (float)norm180(sh.p_foc[oj][tid]);
         out[n++] = (float)aspect(sh.p_foc[s][base + oj]);
         out[n++] = sh.p_hd[oj][tid];
@@ -71,13 +79,57 @@ __device__ __forceinline__ int hl_pilot_obs(const DevCfg &c, const Shared<A, B> 
     return mode;
 }
 
+/* env_base.py:400-422 _nearby_object, every live unit of the other side (up to five) — the list an opponent of a ten-slot arena keeps
+ * (env_hier.py:97); same distances, same stable order as nearby() */
+struct Near5 {
+    int n, i[5];
+    double d[5];
+};
+template <int A, int B>
+__device__ __forceinline__ void nearby5(const DevCfg &c, const Shared<A, B> &sh, int tid, int base, int s, Near5 &o) {
+    o.n = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) { o.i[k] = 0; o.d[k] = 0.0; }
+    const bool me_agent = s < c.nA;
+    const int lo = me_agent ? c.nA : 0, hi = me_agent ? A : c.nA;
+#pragma unroll
+    for (int j = 0; j < A; j++) {
+        if (j < lo || j >= hi || j == s || !(sh.flags[base + j] & FL_ALIVE)) continue;
+        const double dn = c.inv_diag * sh.p_dist[j][tid];
+        int p = 0; /* stable: behind every entry that is not farther */
+#pragma unroll
+        for (int k = 0; k < 5; k++) p += (k < o.n && o.d[k] <= dn) ? 1 : 0;
+        if (p >= 5) continue;
+#pragma unroll
+        for (int k = 4; k >= 1; k--) if (k > p) { o.i[k] = o.i[k - 1]; o.d[k] = o.d[k - 1]; }
+#pragma unroll
+        for (int k = 0; k < 5; k++) if (k == p) { o.i[k] = j; o.d[k] = dn; }
+        if (o.n < 5) o.n++;
+    }
+}
+
 /* env_hier.py:49-98 state(): commander observation (agents) and the stored sorted target lists (all units) */
 template <int A, int B>
 __device__ __forceinline__ void hl_commander_obs(const DevCfg &c, const Shared<A, B> &sh, int tid, int base, int s, Unit &m, float *out) {
     const bool agent = s < c.nA;
     if (agent) for (int k = 0; k < HH_OBS_HL; k++) out[k] = 0.0f;
     m.n_tgt = 0; m.tgt0 = m.tgt1 = m.tgt2 = 0; m.tgt_d0 = m.tgt_d1 = m.tgt_d2 = 0.0;
+    if constexpr (A > 8) { UnitW &x = static_cast<UnitW &>(m); x.tgt3 = x.tgt4 = 0; x.tgt_d3 = x.tgt_d4 = 0.0; }
     if (!m.alive) return;
+    if constexpr (A > 8) {
+        if (!agent) { /* up to five agents (env_hier.py:97) */
+            Near5 n5;
+            nearby5(c, sh, tid, base, s, n5);
+            m.n_tgt = n5.n;
+            if (n5.n >= 1) { m.tgt0 = n5.i[0] + 1; m.tgt_d0 = n5.d[0]; }
+            if (n5.n >= 2) { m.tgt1 = n5.i[1] + 1; m.tgt_d1 = n5.d[1]; }
+            if (n5.n >= 3) { m.tgt2 = n5.i[2] + 1; m.tgt_d2 = n5.d[2]; }
+            UnitW &x = static_cast<UnitW &>(m);
+            if (n5.n >= 4) { x.tgt3 = n5.i[3] + 1; x.tgt_d3 = n5.d[3]; }
+            if (n5.n >= 5) { x.tgt4 = n5.i[4] + 1; x.tgt_d4 = n5.d[4]; }
+            return;
+        }
+    }
     Near3 nb;
     nearby(c, sh, tid, base, s, false, nb);
     if (agent) {
@@ -159,15 +211,17 @@ __device__ __forceinline__ double hl_action_assess(const DevCfg &c, const Shared
 /* ---- the phases of a commander step as device functions: the phase-by-phase kernel (pilot networks between launches) and
  *      the persistent macro-step kernel (actions from a tape) run the SAME code, so their results are bit-identical ---- */
 
-/* everything a lane carries through a macro step */
-struct HlLane {
-    Unit m;
+/* everything a lane carries through a macro step (X: a lane of a ten-slot arena, hh_device.h UnitW) */
+template <bool X>
+struct HlLaneT {
+    typename std::conditional<X, UnitW, Unit>::type m;
     Arena ar;
     double acc;     /* reward accumulated over the macro step (agents) */
     double ep_ret;  /* episode return (lane s == 0) */
     uint32_t evm;   /* event bits of the current sub-step */
     int tcur;       /* trace cursor of the lane's arena (hh_trace_enable) */
 };
+using HlLane = HlLaneT<false>;
 
 /* consumed: the row is one the reference hands to _take_base_action in this phase (hh_device.h: hh_act_unpack) */
 __device__ __forceinline__ void hl_load_act(const int8_t *__restrict__ actions, size_t row, bool active, int8_t (&act)[4], int &fault, bool consumed) {
@@ -180,7 +234,7 @@ __device__ __forceinline__ void hl_load_act(const int8_t *__restrict__ actions, 
 
 /* HL_BEGIN: env_hier.py:142-190 _action_assess + the opponents' draws */
 template <int A, int B>
-__device__ __forceinline__ void hl_do_begin(const DevCfg &c, Shared<A, B> &sh, int tid, int base, int s, int n, bool active, HlLane &L,
+__device__ __forceinline__ void hl_do_begin(const DevCfg &c, Shared<A, B> &sh, int tid, int base, int s, int n, bool active, HlLaneT<(A > 8)> &L,
                                             const int8_t *__restrict__ cmd) {
     const bool agent = s < c.nA;
     L.ar.hl_s = 0;
@@ -195,7 +249,7 @@ __device__ __forceinline__ void hl_do_begin(const DevCfg &c, Shared<A, B> &sh, i
 
 /* HL_AGENTS_ACT: the agents' _take_base_action (incl. the missile envelope) */
 template <int A, int B, int W>
-__device__ __forceinline__ void hl_do_agents_act(const DevCfg &c, Shared<A, B> &sh, int tid, int base, int s, bool active, HlLane &L,
+__device__ __forceinline__ void hl_do_agents_act(const DevCfg &c, Shared<A, B> &sh, int tid, int base, int s, bool active, HlLaneT<(A > 8)> &L,
                                                  const int8_t (&act)[4]) {
     double pr = 0.0, os0 = 0.0;
     int vl = 0;
@@ -208,7 +262,7 @@ __device__ __forceinline__ void hl_do_agents_act(const DevCfg &c, Shared<A, B> &
  * Returns 1 iff this lane's arena ran the tick. */
 template <int A, int B, int W, bool TAB>
 __device__ __forceinline__ int hl_do_tick(const DevPtrs &P, const DevCfg &c, Shared<A, B> &sh, int tid, int g, int base, int s, int n, bool active,
-                                          HlLane &L, const int8_t (&act)[4]) {
+                                          HlLaneT<(A > 8)> &L, const int8_t (&act)[4]) {
     const bool agent = s < c.nA;
     { double pr = 0.0, os0 = 0.0; int vl = 0; act_phase<A, B, (W >= 2), TAB>(c, sh, tid, s, base, active, L.ar.hl_run != 0, L.m, L.ar, act, !agent, true, pr, os0, vl, L.evm); }
     StepOut so;
@@ -248,7 +302,7 @@ __device__ __forceinline__ int hl_do_tick(const DevPtrs &P, const DevCfg &c, Sha
  * stored target lists (env_hier.py:49-98); the agents' rows are left staged in sh.u.obs for the caller to store */
 template <int A, int B>
 __device__ __forceinline__ void hl_do_end(const DevPtrs &P, const DevCfg &c, Shared<A, B> &sh, int tid, int g, int base, int s, int n, bool active,
-                                          HlLane &L, int phase, float *__restrict__ reward_out, uint8_t *__restrict__ valid_out,
+                                          HlLaneT<(A > 8)> &L, int phase, float *__restrict__ reward_out, uint8_t *__restrict__ valid_out,
                                           uint8_t *__restrict__ done_out, const uint8_t *__restrict__ mask) {
     const bool agent = s < c.nA;
     Unit &m = L.m;
@@ -270,7 +324,7 @@ __device__ __forceinline__ void hl_do_end(const DevPtrs &P, const DevCfg &c, Sha
     }
     if (phase == HH_HL_END) {
         /* eval_info of this commander step (env_base.py:91-107): units that still exist, by assessed commander action */
-        sh.res[tid] = (ending && m.alive) ? (1 | ((m.cmd_act & 3) << 1)) : 0;
+        sh.res[tid] = (ending && m.alive) ? (1 | ((m.cmd_act & 7) << 1)) : 0;
         hh_wg_sync<B>();
         if (active && s == 0) {
             int e[HH_EVAL_K];
@@ -366,15 +420,15 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
     const size_t U = (size_t)c.N * A;
     const size_t u = (size_t)n * A + s;
     const bool agent = s < c.nA;
-    HlLane L;
-    L.m = Unit{};
+    HlLaneT<(A > 8)> L;
+    L.m = {};
     L.ar = Arena{};
     L.acc = 0.0; L.ep_ret = 0.0; L.evm = 0;
     L.tcur = (P.trace != nullptr && active && n < P.trace_K) ? P.trace_pos[n] : 0;
     Unit &m = L.m;
     Arena &ar = L.ar;
     if (active) {
-        unit_load(P, U, u, m);
+        unit_load<(A > 8)>(P, U, u, m);
         arena_load(P, c, n, ar);
         L.acc = P.acc_rew[u];
         if (s == 0) L.ep_ret = P.ep_ret[n];
@@ -499,7 +553,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier(DevPtrs P, DevCfg c, int phase
     }
     HH_HPROF(4); /* pilot rows staged and stored */
     if (active) {
-        unit_store(P, U, u, m);
+        unit_store<(A > 8)>(P, U, u, m);
         P.acc_rew[u] = L.acc;
         if (s == 0) {
             if (P.trace != nullptr && n < P.trace_K) P.trace_pos[n] = L.tcur;
@@ -543,13 +597,13 @@ __global__ __launch_bounds__(B, W) void hh_k_hier_macro(DevPtrs P, DevCfg c_in, 
     const bool active = g < GPB && n < c.N;
     const size_t U = (size_t)c.N * A;
     const size_t u = (size_t)n * A + s;
-    HlLane L;
-    L.m = Unit{};
+    HlLaneT<(A > 8)> L;
+    L.m = {};
     L.ar = Arena{};
     L.acc = 0.0; L.ep_ret = 0.0; L.evm = 0;
     L.tcur = (P.trace != nullptr && active && n < P.trace_K) ? P.trace_pos[n] : 0;
     if (active) {
-        unit_load(P, U, u, L.m);
+        unit_load<(A > 8)>(P, U, u, L.m);
         arena_load(P, c, n, L.ar);
         if (s == 0) L.ep_ret = P.ep_ret[n];
     } else {
@@ -581,7 +635,7 @@ __global__ __launch_bounds__(B, W) void hh_k_hier_macro(DevPtrs P, DevCfg c_in, 
     hl_do_end<A, B>(P, c, sh, tid, g, base, s, n, active, L, HH_HL_END, reward_out, valid_out, done_out, nullptr);
     hl_store_commander_obs<A, B, GPB>(c, sh, tid, HH_HL_END, obs_out, nullptr);
     if (active) {
-        unit_store(P, U, u, L.m);
+        unit_store<(A > 8)>(P, U, u, L.m);
         P.acc_rew[u] = L.acc;
         if (s == 0) {
             if (P.trace != nullptr && n < P.trace_K) P.trace_pos[n] = L.tcur;

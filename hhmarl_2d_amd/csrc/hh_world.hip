@@ -77,9 +77,10 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     if (cfg->reserved0 != 0) { g_err = "hh_config.reserved0 must be 0 (a caller built against an older hh_abi.h, whose struct had no opp_side_selector / reserved0 pair?)"; return HH_E_ARG; }
     if (cfg->env_kind == HH_ENV_HIGHLEVEL) {
         /* evaluation.py's n-vs-m scenarios (README.md:43): any 1..3 agents against 1..3 opponents live in the six unit slots of the
-         * 3-vs-3 kernel — agents in slots 0..n_agents-1, opponents behind them, the remaining slots are never alive */
-        if (cfg->n_agents > 3 || cfg->n_opps > 3) { g_err = "HighLevelEnv: at most 3 aircraft per side"; return HH_E_ARG; }
-        A = 6;
+         * 3-vs-3 kernels — agents in slots 0..n_agents-1, opponents behind them, the remaining slots are never alive; with more than
+         * three on a side (up to five) the arena has ten slots and runs on the LDS-exchange kernels (hh_k_hier<10, ...>) */
+        if (cfg->n_agents > HH_SIDE_MAX || cfg->n_opps > HH_SIDE_MAX) { g_err = "HighLevelEnv: at most 5 aircraft per side"; return HH_E_ARG; }
+        A = HH_HL_SLOTS(cfg->n_agents, cfg->n_opps);
     } else if (A != 4) {
         g_err = "LowLevelEnv is 2-vs-2 (envs/env_hetero.py:24-44)";
         return HH_E_ARG;
@@ -136,7 +137,7 @@ extern "C" int hh_world_create(const hh_config *cfg, int device, hh_world **out)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     size_t o_f[6]; for (int k = 0; k < 6; k++) o_f[k] = take(U * 8);
-    size_t o_pack = take(U * 16), o_tgt = take(3 * U * 8);
+    size_t o_pack = take(U * 16), o_tgt = take((A > 8 ? HH_TGT_K_WIDE : HH_TGT_K) * U * 8);
     size_t o_rk[4]; for (int k = 0; k < 4; k++) o_rk[k] = take(U * 8);
     size_t o_rkp = take(U * 8), o_ar = take(N * 16), o_ep = take(N * 8), o_lr = take(N * 4), o_ll = take(N * 4);
     size_t o_lo = take(N), o_ev = take(N * 4), o_acc = take(U * 8), o_cnt = take(256);
@@ -220,8 +221,14 @@ extern "C" int hh_n_ctrl(const hh_world *w) { return w ? w->dc.n_ctrl : HH_E_ARG
 static int launch_hier(hh_world *w, int phase, const int8_t *cmd, const int8_t *actions, float *pilot_obs, uint8_t *pilot_mode,
                        float *obs, float *reward, uint8_t *valid, uint8_t *done, const uint8_t *mask, hipStream_t st) {
     const DevCfg &c = w->dc;
-    if (w->cfg.env_kind != HH_ENV_HIGHLEVEL || c.A != 6) { g_err = "not a HighLevelEnv (3-vs-3) world"; return HH_E_ARG; }
+    if (w->cfg.env_kind != HH_ENV_HIGHLEVEL || (c.A != 6 && c.A != 10)) { g_err = "not a HighLevelEnv world"; return HH_E_ARG; }
     HH_GUARD(w);
+    if (c.A == 10) { /* more than three aircraft on a side: six ten-lane arenas per wave on the LDS-exchange kernel */
+        hipLaunchKernelGGL((hh_k_hier<10, HH_BLOCK, 1>), dim3((c.N + 5) / 6), dim3(HH_BLOCK), 0, st, w->P, c, phase, cmd, actions, pilot_obs, pilot_mode, obs,
+                           reward, valid, done, w->counter, mask);
+        HIPCHK(hipGetLastError());
+        return HH_OK;
+    }
     if (!w->no_oct && phase <= HH_HL_END) { /* register-exchange form (hh_kernels_oct.h): one arena per 8-lane group */
         const int grid8 = (c.N + 7) / 8;
         if (w->force_w == 2 || (w->force_w == 0 && grid8 > w->n_simd))
@@ -309,7 +316,8 @@ extern "C" int hh_rollout_kernel_name(hh_world *w, char *buf, int32_t len) {
     if (w->cfg.env_kind != HH_ENV_LOWLEVEL) {
         const int grid = (c.N + 9) / 10;
         const bool two = (w->force_w == 2 || (w->force_w == 0 && grid > w->n_simd)) && c.nA == 3 && c.nO == 3;
-        snprintf(buf, (size_t)len, "hh_k_hier<6,64,%d>", two ? 2 : 1);
+        if (c.A == 10) snprintf(buf, (size_t)len, "hh_k_hier<10,64,1>");
+        else snprintf(buf, (size_t)len, "hh_k_hier<6,64,%d>", two ? 2 : 1);
         return HH_OK;
     }
     const int waves = (c.N + 15) / 16;
@@ -334,6 +342,10 @@ extern "C" int hh_kernel_instance(hh_world *w, int32_t which, char *buf, int32_t
     const DevCfg &c = w->dc;
     if (w->cfg.env_kind != HH_ENV_LOWLEVEL) {
         const int grid = (c.N + 9) / 10, grid8 = (c.N + 7) / 8;
+        if (c.A == 10) {
+            snprintf(buf, (size_t)len, which == 0 ? "hh_k_hier<10, 64, 1>" : "hh_k_hier_macro<10, 64, 1, false, 6>");
+            return HH_OK;
+        }
         if (which == 0) {
             const bool two = (w->force_w == 2 || (w->force_w == 0 && grid > w->n_simd)) && c.nA == 3 && c.nO == 3;
             if (!w->no_oct) snprintf(buf, (size_t)len, "hh_k_hier_oct<%d>", (w->force_w == 2 || (w->force_w == 0 && grid8 > w->n_simd)) ? 2 : 1);
@@ -507,7 +519,8 @@ extern "C" int hh_get_state(hh_world *w, hh_state_view *v) {
     HIPCHK(hipDeviceSynchronize());
     const DevCfg &c = w->dc;
     size_t U = (size_t)c.N * c.A, N = (size_t)c.N;
-    std::vector<double> f[6], tg(3 * U), rk[4];
+    const int K = c.A > 8 ? HH_TGT_K_WIDE : HH_TGT_K; /* entries of a stored target list (hh_spec.h: HH_TGT_K_OF) */
+    std::vector<double> f[6], tg((size_t)K * U), rk[4];
     std::vector<int4> pack(U), ar(N);
     std::vector<int2> rkp(U);
     const double *src[6] = {w->P.lat, w->P.lon, w->P.hdg, w->P.spd, w->P.cmd_hdg, w->P.cmd_spd};
@@ -515,7 +528,7 @@ extern "C" int hh_get_state(hh_world *w, hh_state_view *v) {
     for (int k = 0; k < 6; k++) { f[k].resize(U); HIPCHK(hipMemcpy(f[k].data(), src[k], U * 8, hipMemcpyDeviceToHost)); }
     for (int k = 0; k < 4; k++) { rk[k].resize(U); HIPCHK(hipMemcpy(rk[k].data(), rsrc[k], U * 8, hipMemcpyDeviceToHost)); }
     HIPCHK(hipMemcpy(pack.data(), w->P.pack, U * 16, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(tg.data(), w->P.tgt_d, 3 * U * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tg.data(), w->P.tgt_d, (size_t)K * U * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(rkp.data(), w->P.rk_pack, U * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(ar.data(), w->P.ar_pack, N * 16, hipMemcpyDeviceToHost));
     for (size_t u = 0; u < U; u++) {
@@ -526,12 +539,12 @@ extern "C" int hh_get_state(hh_world *w, hh_state_view *v) {
         q[0] = (p.z >> 8) & 0xff; q[1] = p.z & 0xff; q[2] = p.x & 0xffff; q[3] = p.y & 0xff; q[4] = (p.x >> 16) & 0xffff;
         q[5] = (p.y >> 8) & 0xff; q[6] = (p.y >> 16) & 0xff; q[7] = (p.y >> 24) & 0xff; q[8] = (p.z >> 16) & 0xff;
         q[9] = n_tgt ? (p.w & 0xff) : 0;
-        int ids[3] = {p.w & 0xff, (p.w >> 8) & 0xff, (p.w >> 16) & 0xff};
-        for (int k = 0; k < HH_TGT_K; k++) {
-            v->tgt_id[u * HH_TGT_K + k] = k < n_tgt ? ids[k] : 0;
-            v->tgt_d[u * HH_TGT_K + k] = k < n_tgt ? tg[(size_t)k * U + u] : 0.0;
-        }
         int2 r = rkp[u];
+        int ids[HH_TGT_K_WIDE] = {p.w & 0xff, (p.w >> 8) & 0xff, (p.w >> 16) & 0xff, (r.x >> 24) & 15, (r.x >> 28) & 15};
+        for (int k = 0; k < K; k++) {
+            v->tgt_id[u * K + k] = k < n_tgt ? ids[k] : 0;
+            v->tgt_d[u * K + k] = k < n_tgt ? tg[(size_t)k * U + u] : 0.0;
+        }
         int alive = r.x & 0xff;
         for (int k = 0; k < 4; k++) v->rk_f[u * HH_RKF_K + k] = alive ? rk[k][u] : 0.0;
         int32_t *rp = v->rk_i + u * HH_RKI_K;
@@ -555,7 +568,8 @@ extern "C" int hh_set_state(hh_world *w, const hh_state_view *v) {
     HIPCHK(hipDeviceSynchronize());
     const DevCfg &c = w->dc;
     size_t U = (size_t)c.N * c.A, N = (size_t)c.N;
-    std::vector<double> f[6], tg(3 * U), rk[4];
+    const int K = c.A > 8 ? HH_TGT_K_WIDE : HH_TGT_K;
+    std::vector<double> f[6], tg((size_t)K * U), rk[4];
     std::vector<int4> pack(U), ar(N);
     std::vector<int2> rkp(U);
     for (int k = 0; k < 6; k++) f[k].resize(U);
@@ -569,10 +583,10 @@ extern "C" int hh_set_state(hh_world *w, const hh_state_view *v) {
     for (size_t u = 0; u < U; u++) {
         for (int k = 0; k < 6; k++) f[k][u] = v->ac_f[u * HH_ACF_K + k];
         const int32_t *q = v->ac_i + u * HH_ACI_K;
-        int n_tgt = 0, ids[3];
-        for (int k = 0; k < HH_TGT_K; k++) {
-            ids[k] = v->tgt_id[u * HH_TGT_K + k];
-            tg[(size_t)k * U + u] = v->tgt_d[u * HH_TGT_K + k];
+        int n_tgt = 0, ids[HH_TGT_K_WIDE] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < K; k++) {
+            ids[k] = v->tgt_id[u * K + k];
+            tg[(size_t)k * U + u] = v->tgt_d[u * K + k];
             if (ids[k]) n_tgt = k + 1;
         }
         int4 p;
@@ -584,7 +598,7 @@ extern "C" int hh_set_state(hh_world *w, const hh_state_view *v) {
         for (int k = 0; k < 4; k++) rk[k][u] = v->rk_f[u * HH_RKF_K + k];
         const int32_t *rp = v->rk_i + u * HH_RKI_K;
         int2 r;
-        r.x = (rp[0] & 0xff) | ((rp[1] & 0xff) << 8) | ((rp[2] & 0xff) << 16);
+        r.x = (rp[0] & 0xff) | ((rp[1] & 0xff) << 8) | ((rp[2] & 0xff) << 16) | (int)(((unsigned)(ids[3] & 15) << 24) | ((unsigned)(ids[4] & 15) << 28));
         r.y = rp[3];
         rkp[u] = r;
     }
@@ -607,7 +621,7 @@ extern "C" int hh_set_state(hh_world *w, const hh_state_view *v) {
     for (int k = 0; k < 6; k++) HIPCHK(hipMemcpy(dst[k], f[k].data(), U * 8, hipMemcpyHostToDevice));
     for (int k = 0; k < 4; k++) HIPCHK(hipMemcpy(rdst[k], rk[k].data(), U * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(w->P.pack, pack.data(), U * 16, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(w->P.tgt_d, tg.data(), 3 * U * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(w->P.tgt_d, tg.data(), (size_t)K * U * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(w->P.rk_pack, rkp.data(), U * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(w->P.ar_pack, ar.data(), N * 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(w->P.ep_ret, 0, N * 8));
@@ -659,8 +673,14 @@ extern "C" int hh_hl_rollout(hh_world *w, const int8_t *commander_actions, const
                              uint8_t *done, void *stream) {
     if (!w || !commander_actions || !pilot_tape) { g_err = "null argument"; return HH_E_ARG; }
     const DevCfg &c = w->dc;
-    if (w->cfg.env_kind != HH_ENV_HIGHLEVEL || c.A != 6) { g_err = "not a HighLevelEnv (3-vs-3) world"; return HH_E_ARG; }
+    if (w->cfg.env_kind != HH_ENV_HIGHLEVEL || (c.A != 6 && c.A != 10)) { g_err = "not a HighLevelEnv world"; return HH_E_ARG; }
     HH_GUARD(w);
+    if (c.A == 10) {
+        hipLaunchKernelGGL((hh_k_hier_macro<10, HH_BLOCK, 1, false>), dim3((c.N + 5) / 6), dim3(HH_BLOCK), 0, (hipStream_t)stream, w->P, c, commander_actions,
+                           pilot_tape, obs, reward, reward_valid, done, w->counter);
+        HIPCHK(hipGetLastError());
+        return HH_OK;
+    }
     constexpr int B = HH_BLOCK, GPB = B / 6;
     const int grid = (c.N + GPB - 1) / GPB;
     const bool two = w->force_w == 2 || (w->force_w == 0 && grid > w->n_simd);

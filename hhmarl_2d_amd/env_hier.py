@@ -54,12 +54,12 @@ class HighLevelEnv(_Base):
         if self.pilot is None and policy_dir is None:
             raise ValueError("HighLevelEnv flies frozen low-level pilot policies (envs/env_base.py:312-398); pass env_config['policy_dir'] "
                              "= the directory of the exported L*_AC*_{fight,escape}.pt files, or env_config['pilot'] = "
-                             "callable(pilot_obs, pilot_mode) -> int8 actions [N, 6, 4]")
+                             "callable(pilot_obs, pilot_mode) -> int8 actions [N, A, 4] (A = 6 unit slots, 10 with more than three aircraft on a side)")
         cfg = config_from_args(self.args, L.ENV_HIGHLEVEL, self.num_envs, int(env_config.get("seed", 0)), arena_offset=int(env_config.get("arena_offset", 0)))
         self.world = World(cfg, device=int(env_config.get("device", 0)))
         if self.pilot is None:   # _get_policies("HighLevel"), env_base.py:333-343
             from .pilots import NetPilot, PolicyBank
-            bank = PolicyBank.from_reference_dir(self.world.device, policy_dir, "HighLevel", self.args, max_rows=self.num_envs * 6)
+            bank = PolicyBank.from_reference_dir(self.world.device, policy_dir, "HighLevel", self.args, max_rows=self.num_envs * self.world.A)
             self.pilot = NetPilot(self.world, bank=bank)
         self._cmd = torch.zeros((self.num_envs, self.args.num_agents), dtype=torch.int8, device=self.world.device)
         self.commander_actions = None

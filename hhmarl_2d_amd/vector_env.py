@@ -366,7 +366,7 @@ class _GpuHierBackend:
         self.pilot = pilot
         if self.pilot is None:   # _get_policies("HighLevel"), env_base.py:333-343
             from .pilots import NetPilot, PolicyBank
-            bank = PolicyBank.from_reference_dir(w.device, policy_dir, "HighLevel", args, max_rows=w.N * 6)
+            bank = PolicyBank.from_reference_dir(w.device, policy_dir, "HighLevel", args, max_rows=w.N * w.A)
             self.pilot = NetPilot(w, bank=bank)
         self._cmd = torch.zeros((w.N, w.n_agents), dtype=torch.int8, device=w.device)
         self._cmd_pin = torch.zeros((w.N, w.n_agents), dtype=torch.int8).pin_memory()
@@ -439,7 +439,7 @@ class HighLevelVectorEnv(_VectorProtocol):
         self.args = _require_args(env_config, "HighLevelVectorEnv")
         if env_config.get("pilot") is None and env_config.get("policy_dir") is None and env_config.get("_backend") is None:
             raise ValueError("HighLevelEnv flies frozen low-level pilot policies (envs/env_base.py:312-398); pass env_config['policy_dir'] = the directory of the "
-                             "exported L*_AC*_{fight,escape}.pt files, or env_config['pilot'] = callable(pilot_obs, pilot_mode) -> int8 actions [N, 6, 4]")
+                             "exported L*_AC*_{fight,escape}.pt files, or env_config['pilot'] = callable(pilot_obs, pilot_mode) -> int8 actions [N, A, 4]")
         self.num_envs = int(env_config.get("num_envs", 1))
         self._observation_space = spaces.Box(low=np.zeros(OBS_HL), high=np.ones(OBS_HL), dtype=np.float32)   # per agent, as the reference declares it (env_hier.py:34-35)
         self._action_space = spaces.Discrete(N_OPP_HL + 1)

@@ -57,7 +57,9 @@ class World:
         L.check(L.lib().hh_world_create(C.byref(cfg), device, C.byref(self.h)))
         self.N = cfg.n_arenas
         self.n_units = cfg.n_agents + cfg.n_opps
-        self.A = 6 if cfg.env_kind == L.ENV_HIGHLEVEL else self.n_units   # unit slots (HighLevelEnv: always six, unused ones never alive)
+        # unit slots (HighLevelEnv: six, or ten with more than three aircraft on a side; unused ones never alive)
+        self.A = L.hl_slots(cfg.n_agents, cfg.n_opps) if cfg.env_kind == L.ENV_HIGHLEVEL else self.n_units
+        self.tgt_k = L.tgt_k_of(cfg.n_agents, cfg.n_opps) if cfg.env_kind == L.ENV_HIGHLEVEL else L.TGT_K
         self.n_agents = cfg.n_agents
         self.D = L.lib().hh_obs_dim(self.h)
         self.n_ctrl = L.lib().hh_n_ctrl(self.h)
@@ -275,8 +277,8 @@ class World:
         return dict(
             ac_f=np.zeros((n, a, L.ACF_K)), ac_i=np.zeros((n, a, L.ACI_K), dtype=np.int32),
             rk_f=np.zeros((n, a, L.RKF_K)), rk_i=np.zeros((n, a, L.RKI_K), dtype=np.int32),
-            ar_i=np.zeros((n, L.ARI_K), dtype=np.int32), tgt_id=np.zeros((n, a, L.TGT_K), dtype=np.int32),
-            tgt_d=np.zeros((n, a, L.TGT_K)))
+            ar_i=np.zeros((n, L.ARI_K), dtype=np.int32), tgt_id=np.zeros((n, a, self.tgt_k), dtype=np.int32),
+            tgt_d=np.zeros((n, a, self.tgt_k)))
 
     @staticmethod
     def _view(st):

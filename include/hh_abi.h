@@ -14,8 +14,9 @@
  * world.  The world owns only its struct-of-arrays state.
  *
  * Units are addressed 1..A in the reference (agents 1..n_agents, opponents after); arrays here
- * are 0-based slots in the same order.  A HighLevelEnv world always has A = 6 unit slots: with fewer than six aircraft
- * (n-vs-m evaluation scenarios) the slots behind the last opponent are never alive and their rows read as zeros.
+ * are 0-based slots in the same order.  A HighLevelEnv world has A = 6 unit slots, or A = 10 when a side has more than 3 aircraft
+ * (HH_HL_SLOTS of hh_spec.h; up to 5 per side): with fewer aircraft than slots (n-vs-m evaluation scenarios) the slots behind the
+ * last opponent are never alive and their rows read as zeros.
  */
 #ifndef HH_ABI_H
 #define HH_ABI_H
@@ -35,8 +36,8 @@ extern "C" {
 typedef struct hh_config {
     int32_t n_arenas;         /* arenas held by THIS world (this rank's shard) */
     int32_t env_kind;         /* HH_ENV_LOWLEVEL | HH_ENV_HIGHLEVEL */
-    int32_t n_agents;         /* args.num_agents (2 low level; 1..3 high level) */
-    int32_t n_opps;           /* args.num_opps   (2 low level; 1..3 high level: evaluation.py's n-vs-m scenarios) */
+    int32_t n_agents;         /* args.num_agents (2 low level; 1..5 high level) */
+    int32_t n_opps;           /* args.num_opps   (2 low level; 1..5 high level: evaluation.py's n-vs-m scenarios) */
     int32_t level;            /* args.level 1..5 */
     int32_t agent_mode;       /* HH_MODE_FIGHT | HH_MODE_ESCAPE (args.agent_mode) */
     int32_t horizon;          /* args.horizon */
@@ -67,15 +68,17 @@ typedef struct hh_config {
 #define HH_RKF_K 4  /* lat, lon, hdg, cmd_hdg                                     (a10)   */
 #define HH_RKI_K 4  /* alive, target, life, seq                                           */
 #define HH_ARI_K 6  /* steps, alive_agents, alive_opps, escaping, escaping_time, episode  */
-#define HH_TGT_K 3  /* stored sorted target list per unit (high level), ids / norm. distances */
+#define HH_TGT_K 3  /* stored sorted target list per unit (high level), ids / norm. distances; HighLevelEnv worlds with more than 3
+                       aircraft on a side keep HH_TGT_K_WIDE entries (hh_spec.h: HH_TGT_K_OF) and their views are [N, A, 5] */
+#define HH_TGT_K_WIDE 5
 typedef struct hh_state_view {
     double *ac_f;   /* [N, A, HH_ACF_K] */
     int32_t *ac_i;  /* [N, A, HH_ACI_K] */
     double *rk_f;   /* [N, A, HH_RKF_K]  rocket slot s belongs to launcher slot s */
     int32_t *rk_i;  /* [N, A, HH_RKI_K] */
     int32_t *ar_i;  /* [N, HH_ARI_K] */
-    int32_t *tgt_id; /* [N, A, HH_TGT_K]  (0 = none) */
-    double *tgt_d;   /* [N, A, HH_TGT_K] */
+    int32_t *tgt_id; /* [N, A, K]  (0 = none), K = HH_TGT_K_OF(n_agents, n_opps) */
+    double *tgt_d;   /* [N, A, K] */
 } hh_state_view;
 
 #define HH_SEL_OPP_SIDE 64 /* selector bit of an opponent's fight row when hh_config.opp_side_selector is set */
@@ -254,7 +257,7 @@ int hh_set_state(hh_world *w, const hh_state_view *view);
 /* integer event masks of the last step, for bit-exact parity checks ([host]; ordered after the work queued on
  * `stream` and synchronises that stream only):
  * per arena u32: bits 0..7 units killed by cannon, 8..15 killed by rocket, 16..23 out of bounds,
- * 24..31 missile launched this step (by unit slot) */
+ * 24..31 missile launched this step (by unit slot); ten-slot arenas (more than 3 aircraft on a side): hh_spec.h HH_EV_BIT */
 int hh_get_event_masks(hh_world *w, uint32_t *masks, void *stream);
 
 #ifdef __cplusplus

@@ -56,7 +56,18 @@
 #define HH_MODE_FIGHT 0
 #define HH_MODE_ESCAPE 1
 
-#define HH_MAX_AIRCRAFT 8 /* 2v2 -> 4, 3v3 -> 6 */
+#define HH_MAX_AIRCRAFT 10 /* unit slots of an arena: 2v2 -> 4, up to 3 per side -> 6, up to 5 per side (evaluation.py's n-vs-m) -> 10 */
+#define HH_SIDE_MAX 5      /* aircraft per side */
+/* unit slots of a HighLevelEnv arena: agents in slots 0 .. n_agents-1, opponents behind them, the rest never alive */
+#define HH_HL_SLOTS(n_agents, n_opps) (((n_agents) > 3 || (n_opps) > 3) ? 10 : 6)
+/* entries of a unit's stored sorted target list (env_hier.py:52,97: an opponent keeps every live agent) */
+#define HH_TGT_K_OF(n_agents, n_opps) (((n_agents) > 3 || (n_opps) > 3) ? 5 : 3)
+
+/* event-mask bit of a unit slot (hh_get_event_masks): classes 0 killed by cannon, 1 killed by rocket, 2 out of bounds, 3 missile
+ * launched.  Arenas of up to 8 slots: class c in bits 8c .. 8c+7.  Ten-slot arenas: classes 0..2 in bits 10c .. 10c+9, launches as
+ * one bit per SIDE (30: an agent launched, 31: an opponent). */
+#define HH_EV_BIT(slots, cls, slot, is_agent) \
+    ((slots) <= 8 ? (1u << (8 * (cls) + (slot))) : ((cls) < 3 ? (1u << (10 * (cls) + (slot))) : (1u << ((is_agent) ? 30 : 31))))
 
 /* Action words: MultiDiscrete([13, 9, 2, 2]) = relative heading, speed level, fire cannon, fire missile (envs/env_hetero.py:37-43,
  * env_base.py:214-238).  The reference's spaces never emit anything else, and its guards would raise on most of what lies outside

@@ -306,6 +306,12 @@ MINI_HL_SCENARIOS = [
     ("hl_fz_3v3_nofriendly", dict(mode=1, friendly_kill=False, horizon=120, hier_opp_fight_ratio=100, eval_info=True), "pursuit", 2, 12, 555085, 3060),
     ("hl_fz_3v3_random_short", dict(mode=1, horizon=60, glob_frac=0.3, hier_action_assess=False), "random", 3, 12, 555102, 3071),
     ("hl_fz_2v1", dict(mode=1, num_agents=2, num_opps=1, horizon=150, hier_opp_fight_ratio=75, eval_info=True), "pursuit", 2, 12, 555119, 3082),
+    # more than three aircraft on a side (README.md:43 "any n-vs-m"): ten unit slots, target lists of up to five (round 5)
+    ("hl_fz_5v5_share", dict(mode=1, num_agents=5, num_opps=5, horizon=150, glob_frac=0.3, eval_info=True), "pursuit", 2, 14, 555136, 3093),
+    ("hl_fz_4v4_random", dict(mode=1, num_agents=4, num_opps=4, horizon=100, hier_opp_fight_ratio=50, hier_action_assess=False), "random", 2, 12, 555153, 3104),
+    ("hl_fz_5v2_fight", dict(mode=1, num_agents=5, num_opps=2, horizon=150, hier_opp_fight_ratio=100, eval_info=True), "pursuit", 2, 12, 555170, 3115),
+    ("hl_fz_1v4_escape_opps", dict(mode=1, num_agents=1, num_opps=4, horizon=120, hier_opp_fight_ratio=0), "pursuit", 2, 12, 555187, 3126),
+    ("hl_fz_4v5_nofriendly", dict(mode=1, num_agents=4, num_opps=5, horizon=150, friendly_kill=False, hier_opp_fight_ratio=100, eval_info=True), "pursuit", 2, 14, 555204, 3137),
 ]
 
 

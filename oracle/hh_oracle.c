@@ -39,6 +39,7 @@
 #include "hh_spec.h"
 
 #define MAXA HH_MAX_AIRCRAFT
+#define O_TGT_K HH_TGT_K_WIDE /* internal capacity of a stored target list; the views carry w->tgt_k of them */
 #define OBS_MAX 34
 
 typedef struct {
@@ -59,8 +60,8 @@ typedef struct {
     o_ac ac[MAXA];
     o_rk rk[MAXA];
     int steps, episode, escaping, escaping_time, next_seq, done;
-    int tgt_n[MAXA], tgt_id[MAXA][HH_TGT_K]; /* opp_to_attack (low level: first entry only) */
-    double tgt_d[MAXA][HH_TGT_K];
+    int tgt_n[MAXA], tgt_id[MAXA][O_TGT_K]; /* opp_to_attack (low level: first entry only) */
+    double tgt_d[MAXA][O_TGT_K];
     uint64_t akey;
     /* outputs of the last step */
     double reward[MAXA];
@@ -82,6 +83,8 @@ typedef struct {
 typedef struct {
     hh_config cfg;
     int A, D, n_ctrl;
+    int tgt_k;  /* entries of a stored target list in the state views (hh_spec.h: HH_TGT_K_OF) */
+    int slots;  /* unit slots of the device world's arenas (event-mask layout, hh_spec.h: HH_EV_BIT) */
     double ext_lat, ext_lon, inv_ext_lat, inv_ext_lon, lat_hi, lon_hi, inv_diag;
     o_arena *ar;
 } o_world;
@@ -346,7 +349,7 @@ static void fire_missile(const o_world *w, o_arena *a, int id, int opp_id) {
                 r->seq = ++a->next_seq;
                 u->has_missile = 1;
                 u->missile_remain = u->missile_remain - 1 > 0 ? u->missile_remain - 1 : 0;
-                a->ev_mask |= 1u << (24 + id - 1);
+                a->ev_mask |= HH_EV_BIT(w->slots, 3, id - 1, is_agent(w, id));
             }
         }
     }
@@ -405,7 +408,7 @@ static void aircraft_update(const o_world *w, o_arena *a, int id, o_event *ev, i
                     ev[*nev].killer = id;
                     ev[*nev].destroyed = j;
                     (*nev)++;
-                    a->ev_mask |= 1u << (j - 1);
+                    a->ev_mask |= HH_EV_BIT(w->slots, 0, j - 1, 0);
                 }
             }
         }
@@ -436,7 +439,7 @@ static void rocket_update(const o_world *w, o_arena *a, int slot, o_event *ev, i
         r->alive = 0;
         tg->alive = 0;
         ev[*nev].origin_rocket = 1; ev[*nev].killer = source; ev[*nev].destroyed = r->target; (*nev)++;
-        a->ev_mask |= 1u << (8 + r->target - 1);
+        a->ev_mask |= HH_EV_BIT(w->slots, 1, r->target - 1, 0);
         return;
     }
     if (w->cfg.friendly_kill) {
@@ -448,7 +451,7 @@ static void rocket_update(const o_world *w, o_arena *a, int slot, o_event *ev, i
                 r->alive = 0;
                 f->alive = 0;
                 ev[*nev].origin_rocket = 1; ev[*nev].killer = source; ev[*nev].destroyed = fid; (*nev)++;
-                a->ev_mask |= 1u << (8 + fid - 1);
+                a->ev_mask |= HH_EV_BIT(w->slots, 1, fid - 1, 0);
                 return;
             }
         }
@@ -622,7 +625,7 @@ static int combat_rewards(const o_world *w, o_arena *a, int hl, const o_event *e
         if (u->alive && !in_boundary(w, u)) {
             u->alive = 0;
             kill_event = 1;
-            a->ev_mask |= 1u << (16 + i - 1);
+            a->ev_mask |= HH_EV_BIT(w->slots, 2, i - 1, 0);
             if (i <= nA) {
                 rews[i - 1] += (hl ? -2.0 : -5.0) * s;
                 destroyed[i - 1] = 1;
@@ -755,7 +758,7 @@ static void arena_reset(const o_world *w, o_arena *a) {
             }
             memset(&a->rk[id - 1], 0, sizeof(o_rk));
             a->tgt_n[id - 1] = 0;
-            for (int k = 0; k < HH_TGT_K; k++) { a->tgt_id[id - 1][k] = 0; a->tgt_d[id - 1][k] = 0.0; }
+            for (int k = 0; k < O_TGT_K; k++) { a->tgt_id[id - 1][k] = 0; a->tgt_d[id - 1][k] = 0.0; }
         }
     }
     for (int i = 0; i < MAXA; i++) { a->reward[i] = 0.0; a->reward_valid[i] = 0; }
@@ -870,7 +873,7 @@ static void hl_state(const o_world *w, o_arena *a) {
     for (int id = 1; id <= w->A; id++) {
         int ids[MAXA]; double dn[MAXA], dr[MAXA];
         a->tgt_n[id - 1] = 0;
-        for (int k = 0; k < HH_TGT_K; k++) { a->tgt_id[id - 1][k] = 0; a->tgt_d[id - 1][k] = 0.0; }
+        for (int k = 0; k < O_TGT_K; k++) { a->tgt_id[id - 1][k] = 0; a->tgt_d[id - 1][k] = 0.0; }
         if (id <= nA) {
             double st[OBS_MAX];
             int n = 0;
@@ -908,8 +911,8 @@ static void hl_state(const o_world *w, o_arena *a) {
             obs_store(a, id - 1, st, n);
         } else if (a->ac[id - 1].alive) {
             int no = nearby(w, a, id, 0, ids, dn, dr);
-            for (int k = 0; k < no && k < HH_TGT_K; k++) { a->tgt_id[id - 1][k] = ids[k]; a->tgt_d[id - 1][k] = dn[k]; }
-            a->tgt_n[id - 1] = no < HH_TGT_K ? no : HH_TGT_K;
+            for (int k = 0; k < no && k < O_TGT_K; k++) { a->tgt_id[id - 1][k] = ids[k]; a->tgt_d[id - 1][k] = dn[k]; }
+            a->tgt_n[id - 1] = no < O_TGT_K ? no : O_TGT_K;
         }
     }
 }
@@ -925,6 +928,9 @@ API int hho_create(const hh_config *cfg, void **out) {
     o_world *w = (o_world *)calloc(1, sizeof(o_world));
     w->cfg = *cfg;
     w->A = A;
+    if (cfg->env_kind == HH_ENV_HIGHLEVEL && (cfg->n_agents > HH_SIDE_MAX || cfg->n_opps > HH_SIDE_MAX)) { free(w); return HH_E_ARG; }
+    w->tgt_k = cfg->env_kind == HH_ENV_HIGHLEVEL ? HH_TGT_K_OF(cfg->n_agents, cfg->n_opps) : HH_TGT_K;
+    w->slots = cfg->env_kind == HH_ENV_HIGHLEVEL ? HH_HL_SLOTS(cfg->n_agents, cfg->n_opps) : A;
     w->n_ctrl = cfg->ext_opp_actions ? A : cfg->n_agents;
     if (cfg->env_kind == HH_ENV_HIGHLEVEL) w->D = HH_OBS_HL;
     else w->D = cfg->agent_mode == HH_MODE_FIGHT ? HH_OBS_FIGHT_AC1 : HH_OBS_ESC_AC1;
@@ -1135,9 +1141,9 @@ API int hho_get_state(void *h, hh_state_view *v) {
                 g[0] = g[1] = g[2] = g[3] = 0.0;
                 p[0] = p[1] = p[2] = p[3] = 0;
             }
-            for (int k = 0; k < HH_TGT_K; k++) {
-                v->tgt_id[b * HH_TGT_K + k] = k < a->tgt_n[s] ? a->tgt_id[s][k] : 0;
-                v->tgt_d[b * HH_TGT_K + k] = k < a->tgt_n[s] ? a->tgt_d[s][k] : 0.0;
+            for (int k = 0; k < w->tgt_k; k++) {
+                v->tgt_id[b * w->tgt_k + k] = k < a->tgt_n[s] ? a->tgt_id[s][k] : 0;
+                v->tgt_d[b * w->tgt_k + k] = k < a->tgt_n[s] ? a->tgt_d[s][k] : 0.0;
             }
         }
         int32_t *ai = v->ar_i + (size_t)n * HH_ARI_K;
@@ -1167,9 +1173,9 @@ API int hho_set_state(void *h, const hh_state_view *v) {
             r->alive = p[0]; r->target = p[1]; r->life = p[2]; r->seq = p[3];
             if (r->seq > a->next_seq) a->next_seq = r->seq;
             a->tgt_n[s] = 0;
-            for (int k = 0; k < HH_TGT_K; k++) {
-                a->tgt_id[s][k] = v->tgt_id[b * HH_TGT_K + k];
-                a->tgt_d[s][k] = v->tgt_d[b * HH_TGT_K + k];
+            for (int k = 0; k < w->tgt_k; k++) {
+                a->tgt_id[s][k] = v->tgt_id[b * w->tgt_k + k];
+                a->tgt_d[s][k] = v->tgt_d[b * w->tgt_k + k];
                 if (a->tgt_id[s][k]) a->tgt_n[s] = k + 1;
             }
         }

@@ -58,11 +58,16 @@ def make_config(n_arenas=1, env_kind=ENV_LOWLEVEL, level=1, agent_mode=MODE_FIGH
                     int(auto_reset), int(ext_opp_actions), int(opp_side_selector), 0, map_size, glob_frac, rew_scale, seed, arena_offset)
 
 
-def alloc_state(n, a):
+def tgt_k_of(n_agents, n_opps):
+    """entries of a stored target list in the state views (include/hh_spec.h: HH_TGT_K_OF)"""
+    return 5 if max(n_agents, n_opps) > 3 else TGT_K
+
+
+def alloc_state(n, a, k=TGT_K):
     return dict(
         ac_f=np.zeros((n, a, ACF_K)), ac_i=np.zeros((n, a, ACI_K), dtype=np.int32), rk_f=np.zeros((n, a, RKF_K)),
         rk_i=np.zeros((n, a, RKI_K), dtype=np.int32), ar_i=np.zeros((n, ARI_K), dtype=np.int32),
-        tgt_id=np.zeros((n, a, TGT_K), dtype=np.int32), tgt_d=np.zeros((n, a, TGT_K)),
+        tgt_id=np.zeros((n, a, k), dtype=np.int32), tgt_d=np.zeros((n, a, k)),
     )
 
 
@@ -177,7 +182,7 @@ class OracleWorld:
         return obs, rew, val, done
 
     def get_state(self):
-        st = alloc_state(self.N, self.A)
+        st = alloc_state(self.N, self.A, tgt_k_of(self.n_agents, self.A - self.n_agents) if self.cfg.env_kind == ENV_HIGHLEVEL else TGT_K)
         v = state_view(st)
         lib().hho_get_state(self.h, C.byref(v))
         return st

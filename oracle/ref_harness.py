@@ -340,12 +340,13 @@ def dump_state(env, n_units):
             rk_i[s] = (1, r.target.id, (sim.utc_time - r.firing_time).seconds, uid - n_units)
     ar_i = np.array([env.steps, env.alive_agents, env.alive_opps, int(env.hardcoded_opps_escaping),
                      env.opps_escaping_time], dtype=np.int32)
-    tgt_id = np.zeros((n_units, 3), dtype=np.int32)
-    tgt_d = np.zeros((n_units, 3))
+    K = 5 if max(env.args.num_agents, env.args.num_opps) > 3 else 3   # include/hh_spec.h: HH_TGT_K_OF
+    tgt_id = np.zeros((n_units, K), dtype=np.int32)
+    tgt_d = np.zeros((n_units, K))
     for i in range(1, n_units + 1):
         t = env.opp_to_attack.get(i)
         if isinstance(t, list):
-            for k, e in enumerate(t[:3]):
+            for k, e in enumerate(t[:K]):
                 tgt_id[i - 1, k] = e[0]
                 tgt_d[i - 1, k] = e[1]
         elif t:

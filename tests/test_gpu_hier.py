@@ -227,7 +227,7 @@ def test_reference_traces_on_gpu(path):
     from hhmarl_2d_amd.world import World, make_config
     g, meta = load_golden(path)
     w = World(make_config(**cfg_kwargs_from_meta(meta)))
-    nA, ptr, nU = w.n_agents, 0, w.n_units      # nU < 6 for the n-vs-m traces: the world's remaining unit slots are never alive
+    nA, ptr, nU = w.n_agents, 0, w.n_units      # nU < A for the n-vs-m traces: the remaining unit slots are never alive
     for r in range(len(g["kind"])):
         if g["kind"][r] == 0:
             obs = w.reset().cpu().numpy()[0]
@@ -235,7 +235,7 @@ def test_reference_traces_on_gpu(path):
         else:
             po, pm = w.hl_begin(torch.from_numpy(np.ascontiguousarray(g["cmd"][r][None])).cuda())
             for k in range(g["nsub"][r]):
-                a6 = np.zeros((1, 6, 4), dtype=np.int8)
+                a6 = np.zeros((1, w.A, 4), dtype=np.int8)   # six unit slots, ten with more than three aircraft on a side
                 a6[0, :nU] = g["sub_act"][ptr]
                 act = torch.from_numpy(a6).cuda()
                 po1, pm1 = w.hl_agents_act(act)

@@ -503,6 +503,9 @@ HL_NET_SCENARIOS = [
     # evaluation.py's low-level-vs-low-level mode (eval_hl = False): the opponents fly L{eval_level_opp} fight nets (env_base.py:343-346,387-390)
     ("hl_nets_lowlevel_eval", dict(mode=1, eval_hl=False, eval_level_ag=5, eval_level_opp=4, eval_info=True, horizon=200),
      ("L5_AC1_fight.pt", "L5_AC2_fight.pt", "L5_AC1_escape.pt", "L5_AC2_escape.pt", "L4_AC1_fight.pt", "L4_AC2_fight.pt"), 2, 30),
+    # evaluation.py's larger scenarios (README.md:43): five against four on ten unit slots, opponents' target lists of up to five agents (round 5)
+    ("hl_nets_5v4", dict(mode=1, num_agents=5, num_opps=4, eval_info=True, horizon=200),
+     ("L5_AC1_fight.pt", "L5_AC2_fight.pt", "L5_AC1_escape.pt", "L5_AC2_escape.pt"), 2, 24),
 ]
 
 

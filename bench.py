@@ -73,6 +73,9 @@ def parse_args():
                                                         "actor: per tick hh_policy_sample = actor forward + Categorical draw per action component (keyed RNG) + its "
                                                         "log-probability + the centralised value branch on central_critic_observer's rows, then hh_step")
     ap.add_argument("--no-graph", action="store_true", help="hier/rollout: launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--pilot-rows", choices=["variants", "sides"], default="variants",
+                    help="hier --pilot net: 'variants' = one launch + one policy call per sub-step (each opponent's row evaluated in the variants the agents' "
+                         "same-sub-step weapon flags can produce: hh_hl_begin_variants / hh_hl_act_tick); 'sides' = the two-launch, two-call path (A/B; same trajectories)")
     ap.add_argument("--phases", action="store_true", help="hier with --pilot tape: the 34-launch phase path instead of the one-launch macro step")
     ap.add_argument("--streams", type=int, default=0, help="rollout / hier --pilot net: split the arenas into this many sub-worlds (disjoint global arena ids, "
                                                                  "bit-identical to one world) stepped on as many HIP streams inside the one graph, so that one sub-world's world "
@@ -621,7 +624,7 @@ def main_hier(args, R=None):
     K = (args.streams or DEFAULT_STREAMS["hier_net"]) if args.pilot == "net" else 1
     assert N % K == 0, "--streams must divide the arena count"
     n_sub = N // K
-    if K > 1:
+    if K > 1 or args.pilot == "net":   # the networks-in-the-loop workload always runs the sub-world form (K = 1: one sub-world)
         return main_hier_split(args, R, own, N, K)
     sw = ShardedWorld(dict(n_arenas=N, env_kind=1, seed=args.seed, auto_reset=True), rank=R.rank, world_size=R.world, device=R.local_rank)
     w = sw.world
@@ -743,22 +746,27 @@ def main_hier_split(args, R, own, N, K):
     (single-pass, latency-bound) run under another sub-world's policy kernel"""
     torch = R.torch
     from hhmarl_2d_amd.env_hier import macro_step
-    from hhmarl_2d_amd.pilots import NetPilot
+    from hhmarl_2d_amd.pilots import NetPilot, VariantNetPilot
     from hhmarl_2d_amd.sharding import ShardedWorld
     n = N // K
+    variants = args.pilot_rows == "variants"
+    if variants and "HH_POLICY_W" not in os.environ and "HH_POLICY_TILE" not in os.environ and K > 1:
+        # calls of ~10 k listed rows from several streams at once: the streamed form with 128-row tiles is ahead of what the bank's back-to-back heuristic
+        # picks (4.64e6 against 3.92e6 commander-steps/s at K = 4; tools/variants_rates2.sh); read by hh_policy_create
+        os.environ["HH_POLICY_W"] = "3"
     sws = [ShardedWorld(dict(n_arenas=n, env_kind=1, seed=args.seed, auto_reset=True, arena_offset=k * n + R.rank * (N - n)), rank=R.rank, world_size=R.world,
                         device=R.local_rank) for k in range(K)]
     worlds = [x.world for x in sws]
     for w in worlds:
         w.reset()
-    pilots_ = [NetPilot(w, seed=args.seed) for w in worlds]
-    if "HH_POLICY_TILE" not in os.environ and n * 3 <= 10240:
+    pilots_ = [(VariantNetPilot if variants else NetPilot)(w, seed=args.seed) for w in worlds]
+    if "HH_POLICY_TILE" not in os.environ and (n * 3 <= 10240 if not variants else pilots_[0].live <= 10240):
         for pl in pilots_:   # small calls on concurrent streams stay on the tile forms: wide tiles, the other streams fill what a partial round leaves idle
             pl.bank.set_tile_rows(64)
     cmds = commander_tape(args, R, N)
     cmd_static = [cmds[0, k * n:(k + 1) * n].clone() for k in range(K)]
     outs = [w.alloc_outputs() for w in worlds]
-    pbufs = [w.alloc_pilot() for w in worlds]
+    pbufs = [(w.alloc_pilot_variants() if variants else w.alloc_pilot()) for w in worlds]
     streams = [torch.cuda.Stream() for _ in range(K)]
 
     def step():
@@ -817,11 +825,14 @@ def main_hier_split(args, R, own, N, K):
         "sim_ticks_per_s": ticks * R.world / dt, "ticks_per_commander_step": ticks / float(N * steps),
         "config": {"workload": f"{N} arenas/GPU x 3-vs-3 HighLevelEnv commander steps (<= 16 sub-steps each), uniform commander actions, "
                                f"pilots = {PILOT_DESC['net']}, auto-reset (BASELINE configs[3])", "arenas_per_gpu": N,
-                   "parallelism": f"arena-sharded x{R.world}, no data-path collective; {K} sub-worlds on {K} streams inside one HIP graph"},
+                   "parallelism": f"arena-sharded x{R.world}, no data-path collective; {K} sub-worlds on {K} streams inside one HIP graph",
+                   "pilot_rows": ("variants: one launch + one policy call per sub-step (hh_hl_begin_variants / hh_hl_act_tick)" if variants else
+                                  "sides: a launch and a policy call per side and sub-step")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": f"{worlds[0].kernel_instance(0)} (every phase launch of the macro step) + hh_k_policy_h", "algorithmic_bytes": algo_bytes,
+                     "kernel": (f"hh_k_hier_oct_v (one launch per sub-step) + {'hh_k_policy_w16<8>' if os.environ.get('HH_POLICY_W') == '3' else 'hh_k_policy_* by row count'}" if variants else
+                                f"{worlds[0].kernel_instance(0)} (every phase launch of the macro step) + hh_k_policy_h"), "algorithmic_bytes": algo_bytes,
                      "note": "2056 B per arena-tick actually run + 424 B per commander step (SURVEY.md 8d)"},
-        "gpu_ms_per_step": gpu_s / steps * 1e3, "launches_per_step": 66 * K,
+        "gpu_ms_per_step": gpu_s / steps * 1e3, "launches_per_step": (34 if variants else 66) * K,
     }
     for p in pilots_:
         p.close()
@@ -906,7 +917,7 @@ def extra_configs(args, R):
                 "ticks_per_commander_step", "streams", "collect", "agent_steps_per_s")
         out = {k: line[k] for k in keys if k in line}
         out["workload"] = line["config"]["workload"]
-        for k in ("actions", "ticks_per_step", "timed_ticks_per_arena"):
+        for k in ("actions", "ticks_per_step", "timed_ticks_per_arena", "pilot_rows"):
             if k in line["config"]:
                 out[k] = line["config"][k]
         out["roofline"] = line["roofline"]

@@ -65,7 +65,8 @@ EXPORTS = ["hh_world_create", "hh_world_destroy", "hh_last_error", "hh_obs_dim",
            "hh_episode_stats_packed", "hh_hl_tick_count", "hh_rollout_kernel_name", "hh_opp_policy", "hh_eval_info", "hh_arena_status", "hh_hl_rollout", "hh_trace_enable", "hh_trace_read",
            "hh_policy_create", "hh_policy_destroy", "hh_policy_set_net", "hh_policy_set_lut", "hh_policy_set_tile_rows", "hh_policy_act",
            "hh_bind_policy", "hh_policy_act_binned", "hh_kernel_instance", "hh_gae_rllib", "hh_math_eval",
-           "hh_policy_set_critic", "hh_policy_sample", "hh_policy_kernel_name", "hh_action_faults", "hh_action_tape_uniform"]
+           "hh_policy_set_critic", "hh_policy_sample", "hh_policy_kernel_name", "hh_action_faults", "hh_action_tape_uniform",
+           "hh_hl_begin_variants", "hh_hl_act_tick", "hh_policy_act_binned_live"]
 
 _lib = None
 
@@ -120,6 +121,9 @@ def lib():
         L.hh_policy_act.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.hh_bind_policy.argtypes = [vp, vp]
         L.hh_policy_act_binned.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp]
+        L.hh_policy_act_binned_live.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_int32, vp]
+        L.hh_hl_begin_variants.argtypes = [vp, vp, vp, vp, vp]
+        L.hh_hl_act_tick.argtypes = [vp, vp, vp, vp, vp, vp]
         L.hh_policy_set_critic.argtypes = [vp, C.c_int32, C.POINTER(HHCriticWeights)]
         L.hh_policy_sample.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
         L.hh_policy_kernel_name.argtypes = [vp, C.c_int32, C.c_int32, C.c_char_p, C.c_int32]

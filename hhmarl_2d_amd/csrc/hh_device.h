@@ -161,6 +161,34 @@ __device__ __forceinline__ void hh_bin_rows_finish(const HhBinTicket &t, int *__
     if (slot > 0 && base + t.rank < max_rows) lists[(size_t)(slot - 1) * max_rows + base + t.rank] = row;
 }
 
+/* the same for lanes that list up to FOUR rows of one network (variant rows of hh_k_hier_oct_v): vmask bit v = the lane lists a row in round v;
+ * a network's rows of round v follow its rows of the rounds before.  Still one atomic round trip per wave. */
+struct HhBinTicket4 { int base; int rank[4]; };
+__device__ __forceinline__ HhBinTicket4 hh_bin_rows_issue4(int *__restrict__ counts, int slot, int vmask) {
+    const int lane = threadIdx.x & 63;
+    int mine = 0;
+    HhBinTicket4 t{0, {0, 0, 0, 0}};
+#pragma unroll
+    for (int n = 1; n <= 8; n++) {
+        int acc = 0;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const unsigned long long m = __ballot(slot == n && ((vmask >> v) & 1));
+            if (slot == n) t.rank[v] = acc + __popcll(m & ((1ULL << lane) - 1ULL));
+            acc += __popcll(m);
+        }
+        if (lane == n - 1) mine = acc;
+    }
+    if (lane < 8 && mine) t.base = atomicAdd(&counts[lane * HH_BIN_STRIDE], mine);
+    return t;
+}
+__device__ __forceinline__ void hh_bin_rows_finish4(const HhBinTicket4 &t, int *__restrict__ lists, int max_rows, int row0, int slot, int vmask) {
+    const int base = __shfl(t.base, slot > 0 ? slot - 1 : 0);
+#pragma unroll
+    for (int v = 0; v < 4; v++)
+        if (slot > 0 && ((vmask >> v) & 1) && base + t.rank[v] < max_rows) lists[(size_t)(slot - 1) * max_rows + base + t.rank[v]] = row0 + v;
+}
+
 /* The lane's action word -> its four components, sanitised where it is loaded (hh_spec.h: hh_action_sanitize — heading / speed component
  * clamped to their ranges, fire components as booleans); `fault` collects "a component of a CONSUMED word was out of range" for
  * hh_act_fault_commit.  consumed = the lane's unit is alive in a running arena and it is its side's turn: exactly the rows the reference

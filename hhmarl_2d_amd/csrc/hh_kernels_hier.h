@@ -23,7 +23,10 @@
 #include "hh_kernels.h"
 #include <type_traits>
 
-enum { HH_HL_BEGIN = 0, HH_HL_AGENTS_ACT = 1, HH_HL_TICK = 2, HH_HL_END = 3, HH_HL_REFRESH = 4, HH_HL_RESET = 5 };
+enum { HH_HL_BEGIN = 0, HH_HL_AGENTS_ACT = 1, HH_HL_TICK = 2, HH_HL_END = 3, HH_HL_REFRESH = 4, HH_HL_RESET = 5,
+       /* the variant-row form (hh_kernels_oct.h: hh_k_hier_oct_v): one launch and one policy call per sub-step */
+       HH_HL_ACT_TICK = 6, HH_HL_BEGIN_V = 7 };
+/* HH_HL_VROWS (hh_abi.h) = 15 pilot row slots of an arena in the variant-row form: 3 agents + 3 opponents x 4 variants */
 
 /* env_hier.py:100-112 lowlevel_state of the lane's unit -> 30 floats (zero padded) + policy type */
 template <int A, int B>

@@ -976,8 +976,11 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_macro_oct(DevPtrs P, DevCfg c
     hh_act_fault_commit(P, n, L.exists, act_fault);
 }
 
+/* which aircraft's weapon flags (env_base.py:208-211 "shot" entry of opp_ac_values) the lane's pilot row carries: relation of the (up to two)
+ * observed aircraft, -1 = none, and the index of their flag entry in the row (the variant-row form patches exactly those entries) */
+struct OVar { int ra, rb, fa, fb; };
 /* env_hier.py:100-112 lowlevel_state of the lane's unit -> 30 floats (zero padded) + policy type (hl_pilot_obs of hh_kernels_hier.h) */
-__device__ __forceinline__ int oct_pilot_obs(const DevCfg &c, const OTab &t, const OPub &p, const OLane &L, const Unit &m, float *out) {
+__device__ __forceinline__ int oct_pilot_obs(const DevCfg &c, const OTab &t, const OPub &p, const OLane &L, const Unit &m, float *out, OVar *ov = nullptr) {
     for (int k = 0; k < 30; k++) out[k] = 0.0f;
     Near3 fr;
     oct_nearby(c, t, L, true, fr);
@@ -1008,6 +1011,7 @@ __device__ __forceinline__ int oct_pilot_obs(const DevCfg &c, const OTab &t, con
         } else {
             out[n++] = m.burst > 0 ? 1.0f : 0.0f;
         }
+        if (ov) { ov->ra = r; ov->fa = n + 8; ov->rb = -1; ov->fb = 0; }
         n += oct_opp_block(t, 0, r, dist, out + n);
     } else {
         mode = 2;
@@ -1016,6 +1020,7 @@ __device__ __forceinline__ int oct_pilot_obs(const DevCfg &c, const OTab &t, con
         out[n++] = (p.flags & FL_SHOT) ? 1.0f : 0.0f;
         if (n_tgt >= 1) oct_opp_block(t, 1, r0, d0, out + n);
         if (n_tgt >= 2) oct_opp_block(t, 1, r1, d1, out + n + 9);
+        if (ov) { ov->ra = n_tgt >= 1 ? r0 : -1; ov->fa = n + 8; ov->rb = n_tgt >= 2 ? r1 : -1; ov->fb = n + 17; }
         n += 18;
     }
     if (fr.n) oct_friend_block(c, t, fr.i0, out + n);
@@ -1026,12 +1031,18 @@ __device__ __forceinline__ int oct_pilot_obs(const DevCfg &c, const OTab &t, con
  * register table): HL_BEGIN / HL_AGENTS_ACT / HL_TICK / HL_END.  Same results, bit for bit; HL_REFRESH / HL_RESET stay on the
  * generic kernel (the state in HBM is the same). ---- */
 /* one phase for the eight arenas grp * 8 .. grp * 8 + 7, executed by ONE wave (tid = lane): the body of hh_k_hier_oct */
-template <int W>
+/* VAR: the variant-row form (hh_k_hier_oct_v, phases HH_HL_BEGIN_V / HH_HL_ACT_TICK).  The reference lets the opponents' pilots observe the agents' weapon
+ * flags of the SAME sub-step (env_base.py:208-211: units act in id order), which is why the standard path needs a launch and a policy call per side.
+ * An agent's act can only RAISE its flag (arm the cannon, launch a missile), and an opponent's row carries the flag of at most two agents, so the
+ * launch that ends a sub-step emits, next to every opponent's row, the copies with the observed agents' still-zero flags forced to one (up to three
+ * variants, `vrow` slots 3 + 4 j + v); ONE policy call evaluates the agents' rows and all variants, and the next launch lets the agents act, looks at
+ * which flags rose, takes each opponent's action from the matching variant and runs the tick.  Same rows through the same networks: same results. */
+template <int W, bool VAR = false>
 __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c, int phase, int grp, int tid, OctShared &sh, const int8_t *__restrict__ cmd,
                                                const int8_t *__restrict__ actions, float *__restrict__ pilot_obs, uint8_t *__restrict__ pilot_mode,
                                                float *__restrict__ obs_out, float *__restrict__ reward_out, uint8_t *__restrict__ valid_out,
                                                uint8_t *__restrict__ done_out, int *__restrict__ running_count,
-                                               unsigned long long *__restrict__ tick_total) {
+                                               unsigned long long *__restrict__ tick_total, float *vrow = nullptr) {
     OLane L;
     L.g = tid >> 3; L.p = tid & 7; L.q = (tid >> 2) & 1; L.i = tid & 3;
     L.base = tid & ~7;
@@ -1071,6 +1082,7 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
     o_wave_sync();
     int obs_side = -1; /* which side's pilot observations this launch emits */
     int act_fault = 0;  /* a consumed action word was out of range and ran sanitised (hh_act_unpack) */
+    int ran_tick = 0;   /* HL_ACT_TICK: the lane's arena ran the tick in this launch */
     /* a bound policy bank (hh_bind_policy): this launch's pilot rows are binned by network here (see hh_k_hier) */
     int pslot = 0;
     HhBinTicket bt{0, 0};
@@ -1080,7 +1092,41 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
         pslot = sb ? (int)P.pol_lut[sb] : 0;
         bt = hh_bin_rows_issue(P.pol_counts, pslot);
     };
-    if (phase == HH_HL_BEGIN) {
+    if (VAR && phase == HH_HL_BEGIN_V) {
+        oct_do_begin(c, tb, L, n, active, H, cmd);
+        obs_side = 2;
+    } else if (VAR && phase == HH_HL_ACT_TICK) {
+        const size_t row0 = (size_t)n * HH_HL_VROWS;
+        const bool running = active && ar.hl_run;
+        int8_t act[4];
+        hl_load_act(actions, row0 + L.i, L.exists && agent, act, act_fault, running && m.alive && agent);
+        int flb[5]; /* the flags the emitted rows were built from */
+#pragma unroll
+        for (int k = 0; k < 5; k++) flb[k] = tb.fl[k];
+        act_oct<(W >= 2), true>(c, sh, tid, L, running, m, ar, act, agent, tb, pub, H.evm);
+        HH_O_FETCH5(i, tb.fl, pub.flags);
+        int v = 0; /* which of its rows describes what the opponent sees now: bit 0 / 1 = the first / second observed agent raised its flag */
+        {
+            const int cmd_act = m.cmd_act, n_tgt = m.n_tgt, t0 = m.tgt0, t1 = m.tgt1, t2 = m.tgt2;
+            const int r0 = t0 ? o_pos_rel(L, o_slot_pos(c, t0 - 1)) : 2, r1 = t1 ? o_pos_rel(L, o_slot_pos(c, t1 - 1)) : 2;
+            int ra, rb = -1;
+            if (cmd_act != 0) { ra = r0; if (cmd_act == 2) ra = r1; if (cmd_act >= 3) ra = t2 ? o_pos_rel(L, o_slot_pos(c, t2 - 1)) : 2; }
+            else { ra = n_tgt >= 1 ? r0 : -1; rb = n_tgt >= 2 ? r1 : -1; }
+            if (ra >= 0 && ((o_sel5(tb.fl, ra) & ~o_sel5(flb, ra)) & FL_SHOT)) v |= 1;
+            if (rb >= 0 && ((o_sel5(tb.fl, rb) & ~o_sel5(flb, rb)) & FL_SHOT)) v |= 2;
+        }
+        int8_t act2[4];
+        hl_load_act(actions, row0 + 3 + 4 * L.i + v, L.exists && !agent, act2, act_fault, running && m.alive && !agent);
+        act_oct<(W >= 2), true>(c, sh, tid, L, running, m, ar, act2, !agent, tb, pub, H.evm);
+        const int ran = oct_do_tick<(W >= 2), true>(P, c, sh, tid, L, n, active, H, tb, pub);
+        ran_tick = ran;
+        if (L.p == 0 && ran && ar.hl_run && running_count) atomicAdd(running_count, 1);
+        {
+            const unsigned long long rn = __ballot(ran && L.p == 0);
+            if (rn && tid == 0 && tick_total) atomicAdd(tick_total, (unsigned long long)__popcll(rn));
+        }
+        obs_side = 2;
+    } else if (phase == HH_HL_BEGIN) {
         oct_do_begin(c, tb, L, n, active, H, cmd);
         obs_side = 0;
         if (P.pol_lut && pilot_obs) bin_issue(0);
@@ -1115,7 +1161,62 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
             for (int k = tid; k < cnt; k += 64) dst[k] = sh.u.obs[k];
         }
     }
-    if (obs_side >= 0 && pilot_obs) {
+    if (VAR && obs_side == 2 && pilot_obs) {
+        /* both sides' rows of the next sub-step: agents in slots 0..2, opponent j's variant v in slot 3 + 4 j + v */
+        o_wave_sync(); /* the queue's exchange area is free */
+        if (c.nA + c.nO < 6) {
+            for (int k = tid; k < 8 * HH_HL_VROWS * 30; k += 64) vrow[k] = 0.0f;
+            o_wave_sync();
+        }
+        const int slot0 = agent ? L.i : 3 + 4 * L.i;
+        int sel = 0, vmask = 0;
+        if (L.exists) {
+            float *rw = &vrow[(L.g * HH_HL_VROWS + slot0) * 30];
+            OVar ov{-1, -1, 0, 0};
+            int mode = 0;
+            if (ar.hl_run && m.alive) mode = oct_pilot_obs(c, tb, pub, L, m, rw, &ov);
+            else for (int k = 0; k < 30; k++) rw[k] = 0.0f;
+            sel = mode ? hl_selector(c, mode, m.ac_type, agent) : 0;
+            vmask = sel ? 1 : 0;
+            if (!agent) {
+                /* a variant exists where the observed agent can still raise its flag: alive (it acts) and the flag down */
+                const int fa_ = ov.ra >= 0 ? o_sel5(tb.fl, ov.ra) : 0, fb_ = ov.rb >= 0 ? o_sel5(tb.fl, ov.rb) : 0;
+                const bool a0 = sel && ov.ra >= 0 && (fa_ & FL_ALIVE) && !(fa_ & FL_SHOT);
+                const bool a1 = sel && ov.rb >= 0 && (fb_ & FL_ALIVE) && !(fb_ & FL_SHOT);
+                vmask |= (a0 ? 2 : 0) | (a1 ? 4 : 0) | ((a0 && a1) ? 8 : 0);
+                for (int k = 0; k < 30; k++) { /* slots without a variant carry the copy too: deterministic buffers, never listed */
+                    const float x = rw[k];
+                    rw[30 + k] = (a0 && k == ov.fa) ? 1.0f : x;
+                    rw[60 + k] = (a1 && k == ov.fb) ? 1.0f : x;
+                    rw[90 + k] = ((a0 && k == ov.fa) || (a1 && k == ov.fb)) ? 1.0f : x;
+                }
+            }
+            if (pilot_mode) {
+                uint8_t *pmq = pilot_mode + (size_t)n * HH_HL_VROWS + slot0;
+                pmq[0] = (uint8_t)sel;
+                if (!agent) { pmq[1] = (uint8_t)((vmask & 2) ? sel : 0); pmq[2] = (uint8_t)((vmask & 4) ? sel : 0); pmq[3] = (uint8_t)((vmask & 8) ? sel : 0); }
+            }
+        }
+        if (active && pilot_mode && c.nA + c.nO < 6 && L.p == 3) { /* the bytes of the slots without an aircraft */
+            for (int sl = c.nA; sl < 3; sl++) pilot_mode[(size_t)n * HH_HL_VROWS + sl] = 0;
+            for (int sl = c.nO; sl < 3; sl++) for (int q = 0; q < 4; q++) pilot_mode[(size_t)n * HH_HL_VROWS + 3 + 4 * sl + q] = 0;
+        }
+        const int pslot_v = (P.pol_lut && sel) ? (int)P.pol_lut[sel] : 0;
+        HhBinTicket4 bt4{0, {0, 0, 0, 0}};
+        if (P.pol_lut) bt4 = hh_bin_rows_issue4(P.pol_counts, pslot_v, vmask);
+        o_wave_sync();
+        const int arenas = min(8, c.N - grp * 8);
+        const int cnt = arenas * HH_HL_VROWS * 30; /* 450 floats per arena: a multiple of two */
+        float *dst = pilot_obs + (size_t)grp * 8 * HH_HL_VROWS * 30;
+        if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0) {
+            const float4 *src4 = reinterpret_cast<const float4 *>(vrow);
+            float4 *dst4 = reinterpret_cast<float4 *>(dst);
+            for (int k = tid; k < (cnt >> 2); k += 64) dst4[k] = src4[k];
+        } else {
+            for (int k = tid; k < cnt; k += 64) dst[k] = vrow[k];
+        }
+        if (P.pol_lut) hh_bin_rows_finish4(bt4, P.pol_lists, P.pol_max_rows, (int)((size_t)n * HH_HL_VROWS + slot0), pslot_v, vmask);
+    } else if (obs_side >= 0 && pilot_obs) {
         const bool mine = obs_side == 0 ? agent : !agent;
         o_wave_sync(); /* the queue's exchange area (same LDS) is free */
         if (c.nA + c.nO < 6) { /* n-vs-m: the rows of the slots without an aircraft */
@@ -1154,8 +1255,9 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
         arena_store(P, n, ar);
         P.ep_ret[n] = H.ep_ret;
     }
-    if (phase == HH_HL_AGENTS_ACT || phase == HH_HL_TICK) {
-        if (active && L.p == 0 && phase == HH_HL_AGENTS_ACT && ar.hl_run) P.ev_mask[n] = 0;
+    if (phase == HH_HL_AGENTS_ACT || phase == HH_HL_TICK || (VAR && phase == HH_HL_ACT_TICK)) {
+        /* (HL_ACT_TICK: hl_run may have dropped in this very launch, so the arenas that ran the tick clear their mask) */
+        if (active && L.p == 0 && ((phase == HH_HL_AGENTS_ACT && ar.hl_run) || (VAR && phase == HH_HL_ACT_TICK && ran_tick))) P.ev_mask[n] = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the clear is acknowledged before this wave's atomics leave (one wave per arena group) */
         if (L.exists && H.evm) atomicOr(&P.ev_mask[n], H.evm);
         hh_act_fault_commit(P, n, L.exists, act_fault);
@@ -1170,6 +1272,17 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_oct(DevPtrs P, DevCfg c, int 
     __shared__ OctShared sh;
     oct_phase_body<W>(P, c, phase, (int)blockIdx.x, (int)threadIdx.x, sh, cmd, actions, pilot_obs, pilot_mode, obs_out, reward_out, valid_out, done_out,
                       running_count, running_count ? reinterpret_cast<unsigned long long *>(running_count + 2) : nullptr);
+}
+
+/* the variant-row form of the two phases that carry a sub-step (see oct_phase_body): HH_HL_BEGIN_V, then HH_HL_ACT_TICK per sub-step; HH_HL_END is the
+ * standard kernel's.  pilot_obs [N, 15, 30], pilot_mode [N, 15], actions [N, 15, 4]. */
+template <int W>
+__global__ __launch_bounds__(64, W) void hh_k_hier_oct_v(DevPtrs P, DevCfg c, int phase, const int8_t *__restrict__ cmd, const int8_t *__restrict__ actions,
+                                                       float *__restrict__ pilot_obs, uint8_t *__restrict__ pilot_mode, int *__restrict__ running_count) {
+    __shared__ OctShared sh;
+    __shared__ alignas(16) float vrow[8 * HH_HL_VROWS * 30];
+    oct_phase_body<W, true>(P, c, phase, (int)blockIdx.x, (int)threadIdx.x, sh, cmd, actions, pilot_obs, pilot_mode, nullptr, nullptr, nullptr, nullptr,
+                            running_count, running_count ? reinterpret_cast<unsigned long long *>(running_count + 2) : nullptr, vrow);
 }
 
 #endif /* HH_KERNELS_OCT_H */

@@ -754,6 +754,14 @@ extern "C" int hh_policy_act_binned(hh_policy *p, const float *obs, int32_t n_ro
     return hhp_launch_forward(p, obs, n_rows, obs_stride, actions, logits, HHP_CONSUME, (hipStream_t)stream, one_side ? n_rows / 2 : -1);
 }
 
+/* the same with the caller's estimate of the rows that carry a network (the form is chosen by it): the variant-row phases list ~0.3 of their [N, 15] slots */
+extern "C" int hh_policy_act_binned_live(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, int8_t *actions, float *logits, int32_t live_rows, void *stream) {
+    if (!p || !obs || !actions || n_rows <= 0 || obs_stride <= 0) { g_err = "bad argument"; return HH_E_ARG; }
+    if (n_rows > p->max_rows) { g_err = "hh_policy_act_binned_live: n_rows exceeds max_rows of hh_policy_create"; return HH_E_ARG; }
+    if (p->n_nets == 0) { g_err = "hh_policy_act_binned_live: no network loaded"; return HH_E_ARG; }
+    HH_GUARD(p);
+    return hhp_launch_forward(p, obs, n_rows, obs_stride, actions, logits, HHP_CONSUME, (hipStream_t)stream, live_rows);
+}
 
 /* ---- the value branches of the trainable policies + one sampler step (hh_policy_kernel_ppo.h) ---- */
 static const int HHC_DIMS[4][4] = {

@@ -663,6 +663,43 @@ extern "C" int hh_hl_tick(hh_world *w, const int8_t *actions, float *pilot_obs, 
     return HH_OK;
 }
 
+/* the variant-row form: one launch (and one policy call) per sub-step — hh_kernels_oct.h: oct_phase_body<W, true> */
+static int launch_hier_v(hh_world *w, int phase, const int8_t *cmd, const int8_t *actions, float *pilot_obs, uint8_t *pilot_mode, hipStream_t st) {
+    const DevCfg &c = w->dc;
+    if (w->cfg.env_kind != HH_ENV_HIGHLEVEL || c.A != 6) { g_err = "the variant-row phases serve HighLevelEnv worlds of up to 3 aircraft per side"; return HH_E_ARG; }
+    if (!pilot_obs || !pilot_mode) { g_err = "null argument"; return HH_E_ARG; }
+    if (w->P.pol_lut && (long long)w->P.pol_max_rows < (long long)c.N * HH_HL_VROWS) {
+        g_err = "the bound policy bank's max_rows is smaller than n_arenas x 15 (hh_hl_begin_variants / hh_hl_act_tick)"; return HH_E_ARG;
+    }
+    HH_GUARD(w);
+    const int grid8 = (c.N + 7) / 8;
+    if (w->force_w == 2 || (w->force_w == 0 && grid8 > w->n_simd))
+        hipLaunchKernelGGL((hh_k_hier_oct_v<2>), dim3(grid8), dim3(64), 0, st, w->P, c, phase, cmd, actions, pilot_obs, pilot_mode, w->counter);
+    else
+        hipLaunchKernelGGL((hh_k_hier_oct_v<1>), dim3(grid8), dim3(64), 0, st, w->P, c, phase, cmd, actions, pilot_obs, pilot_mode, w->counter);
+    HIPCHK(hipGetLastError());
+    return HH_OK;
+}
+
+extern "C" int hh_hl_begin_variants(hh_world *w, const int8_t *commander_actions, float *pilot_obs, uint8_t *pilot_mode, void *stream) {
+    if (!w || !commander_actions) { g_err = "null argument"; return HH_E_ARG; }
+    return launch_hier_v(w, HH_HL_BEGIN_V, commander_actions, nullptr, pilot_obs, pilot_mode, (hipStream_t)stream);
+}
+
+extern "C" int hh_hl_act_tick(hh_world *w, const int8_t *actions, float *pilot_obs, uint8_t *pilot_mode, int32_t *running, void *stream) {
+    if (!w || !actions) { g_err = "null argument"; return HH_E_ARG; }
+    HH_GUARD(w);
+    hipStream_t st = (hipStream_t)stream;
+    if (running) HIPCHK(hipMemsetAsync(w->counter, 0, 4, st));
+    int rc = launch_hier_v(w, HH_HL_ACT_TICK, nullptr, actions, pilot_obs, pilot_mode, st);
+    if (rc) return rc;
+    if (running) {
+        HIPCHK(hipMemcpyAsync(running, w->counter, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return HH_OK;
+}
+
 extern "C" int hh_hl_end(hh_world *w, float *obs, float *reward, uint8_t *reward_valid, uint8_t *done, void *stream) {
     if (!w) return HH_E_ARG;
     return launch_hier(w, HH_HL_END, nullptr, nullptr, nullptr, nullptr, obs, reward, reward_valid, done, nullptr, (hipStream_t)stream);

@@ -23,6 +23,13 @@ def macro_step(world, commander_actions, pilot, out=None, pilot_buf=None, early_
     """One HighLevelEnv.step for every arena of `world` (env_hier.py:114-140).
     commander_actions: int8 [N, n_agents] on the world's device."""
     nA = world.n_agents
+    if getattr(pilot, "variants", False):   # one launch + one policy call per sub-step (pilots.VariantNetPilot; same trajectories)
+        po, pm = world.hl_begin_variants(commander_actions, pilot_buf)
+        for sub in range(N_SUB_STEPS):
+            po, pm, running = world.hl_act_tick(pilot(po, pm), pilot_buf, count_running=early_exit)
+            if early_exit and running == 0:
+                break
+        return world.hl_end(out)
     po, pm = world.hl_begin(commander_actions, pilot_buf)
     for sub in range(N_SUB_STEPS):
         act = pilot(po, pm).contiguous()

@@ -269,6 +269,17 @@ class PolicyBank:
         L.check(L.lib().hh_policy_act_binned(self.h, C.c_void_p(obs.data_ptr()), n_rows, stride, C.c_void_p(actions.data_ptr()), lp, st))
         return actions
 
+    def act_binned_live(self, obs, actions, live_rows, logits=None):
+        """act_binned with the caller's estimate of the listed rows (the variant-row phases list ~0.3 of their [N, 15] slots): it picks the kernel form"""
+        assert obs.dtype == torch.float32 and obs.is_contiguous() and actions.dtype == torch.int8 and actions.is_contiguous()
+        stride = obs.shape[-1]
+        n_rows = obs.numel() // stride
+        assert actions.numel() == n_rows * 4
+        st = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
+        lp = None if logits is None else C.c_void_p(logits.data_ptr())
+        L.check(L.lib().hh_policy_act_binned_live(self.h, C.c_void_p(obs.data_ptr()), n_rows, stride, C.c_void_p(actions.data_ptr()), lp, int(live_rows), st))
+        return actions
+
     @staticmethod
     def flops_per_row(kind):
         return PN.flops_per_row(kind)
@@ -291,6 +302,32 @@ class NetPilot:
     def __call__(self, pilot_obs, pilot_mode):
         if self.world is not None:
             return self.bank.act_binned(pilot_obs, self.act)
+        return self.bank.act(pilot_obs, pilot_mode, self.act)
+
+    def close(self):
+        if self.world is not None:
+            self.world.bind_policy(None)
+            self.world = None
+
+
+class VariantNetPilot:
+    """NetPilot for the variant-row form (World.hl_begin_variants / hl_act_tick: one launch and one policy call per sub-step): every listed row of
+    the [N, 15, 30] buffer — the agents' rows and each opponent's row in its up-to-four variants — through the network its selector byte names."""
+
+    variants = True
+
+    def __init__(self, world, bank=None, seed=0, bind=True, live_fraction=0.3):
+        rows = world.N * world.V_ROWS
+        self.bank = bank if bank is not None else PolicyBank.random_init(world.device, seed=seed, max_rows=rows)
+        self.act = torch.zeros((world.N, world.V_ROWS, 4), dtype=torch.int8, device=world.device)
+        self.live = max(1, int(rows * live_fraction))
+        self.world = world if bind else None
+        if bind:
+            world.bind_policy(self.bank)
+
+    def __call__(self, pilot_obs, pilot_mode):
+        if self.world is not None:
+            return self.bank.act_binned_live(pilot_obs, self.act, self.live)
         return self.bank.act(pilot_obs, pilot_mode, self.act)
 
     def close(self):

@@ -170,6 +170,29 @@ class World:
                                    self._stream()))
         return po, pm, (running.value if count_running else None)
 
+    # ---- the variant-row form: one launch and one policy call per sub-step (include/hh_abi.h: hh_hl_begin_variants / hh_hl_act_tick)
+    V_ROWS = 15   # row slots per arena: agents 0..2, opponent j's variant v at 3 + 4 j + v
+
+    def alloc_pilot_variants(self):
+        return (torch.zeros((self.N, self.V_ROWS, 30), dtype=torch.float32, device=self.device),
+                torch.zeros((self.N, self.V_ROWS), dtype=torch.uint8, device=self.device))
+
+    def hl_begin_variants(self, commander_actions, pilot=None):
+        """commander_actions int8 [N, n_agents] -> (pilot_obs [N, 15, 30], pilot_mode [N, 15]): BOTH sides' rows of the first sub-step"""
+        assert commander_actions.dtype == torch.int8 and commander_actions.is_contiguous()
+        po, pm = pilot if pilot is not None else self.alloc_pilot_variants()
+        L.check(L.lib().hh_hl_begin_variants(self.h, _p(commander_actions), _p(po), _p(pm), self._stream()))
+        return po, pm
+
+    def hl_act_tick(self, actions, pilot=None, count_running=True):
+        """actions int8 [N, 15, 4] (the policy's output for every listed row) -> agents act, each opponent flies the variant that matches, tick;
+        returns both sides' rows of the next sub-step and the number of arenas still inside their macro step"""
+        assert actions.dtype == torch.int8 and actions.is_contiguous() and actions.numel() == self.N * self.V_ROWS * 4
+        po, pm = pilot if pilot is not None else self.alloc_pilot_variants()
+        running = C.c_int32(0)
+        L.check(L.lib().hh_hl_act_tick(self.h, _p(actions), _p(po), _p(pm), C.byref(running) if count_running else None, self._stream()))
+        return po, pm, (running.value if count_running else None)
+
     def hl_end(self, out=None):
         obs, rew, val, done = out if out is not None else self.alloc_outputs()
         L.check(L.lib().hh_hl_end(self.h, _p(obs), _p(rew), _p(val), _p(done), self._stream()))

@@ -159,6 +159,20 @@ int hh_hl_agents_act(hh_world *w, const int8_t *actions, float *pilot_obs, uint8
 int hh_hl_tick(hh_world *w, const int8_t *actions, float *pilot_obs, uint8_t *pilot_mode, int32_t *running, void *stream);
 int hh_hl_end(hh_world *w, float *obs, float *reward, uint8_t *reward_valid, uint8_t *done, void *stream);
 
+/* The same commander step with ONE launch and ONE policy call per sub-step (worlds of up to 3 aircraft per side):
+ *   hh_hl_begin_variants(commander actions) -> up to 16 x { pilots(all rows) -> hh_hl_act_tick } -> hh_hl_end
+ * The standard path needs a launch per SIDE because the opponents' pilots observe the agents' weapon flags of the same sub-step (env_base.py:208-211,
+ * units act in id order).  An agent's action can only RAISE its flag, and an opponent's row carries the flag of at most two agents, so these calls emit
+ * each opponent's row together with its VARIANTS — the copies with the observed agents' still-zero flags forced to one — and hh_hl_act_tick, after
+ * letting the agents act, takes each opponent's action from the variant that matches what happened.  Same rows through the same networks: the same
+ * trajectories as the standard path, bit for bit.  Row slots per arena: HH_HL_VROWS = 15 = agents 0..2, then opponent j's variant v at 3 + 4 j + v
+ * (v bit 0 / bit 1 = the first / second observed agent's flag forced; v = 0 is the row as the world stands).
+ * pilot_obs [dev] f32 [N, 15, 30], pilot_mode [dev] u8 [N, 15] (0 = slot not in use), actions [dev] i8 [N, 15, 4] (the policy's output for every listed row).
+ * A bound policy bank (hh_bind_policy) needs max_rows >= 15 * N. */
+#define HH_HL_VROWS 15
+int hh_hl_begin_variants(hh_world *w, const int8_t *commander_actions, float *pilot_obs, uint8_t *pilot_mode, void *stream);
+int hh_hl_act_tick(hh_world *w, const int8_t *actions, float *pilot_obs, uint8_t *pilot_mode, int32_t *running, void *stream);
+
 /* HighLevelEnv.step in ONE launch for callers whose pilot actions exist before the step starts (a recorded / scripted tape,
  * env-only throughput runs): pilot_tape [dev] i8 [16, N, 6, 4] = the actions of sub-step k in slice k (each side's rows are
  * read at its turn).  Same result as hh_hl_begin + 16 x {hh_hl_agents_act, hh_hl_tick} + hh_hl_end with those actions, bit
@@ -204,7 +218,7 @@ int hh_action_tape_uniform(uint64_t seed, uint64_t arena_offset, int32_t step0, 
 
 /* The device-side replacement of the reference's raising guards (ac1.py:58-66 set_heading / set_speed; SURVEY.md section 5 "invalid-state
  * flag per arena instead of raising"): out [dev] u8 [N] (nullable) = 1 for every arena in which, since the flags were last cleared, a step
- * (hh_step / hh_rollout / hh_step_begin / hh_step_finish / hh_hl_agents_act / hh_hl_tick / hh_hl_rollout) consumed an action word with a
+ * (hh_step / hh_rollout / hh_step_begin / hh_step_finish / hh_hl_agents_act / hh_hl_tick / hh_hl_act_tick / hh_hl_rollout) consumed an action word with a
  * component outside MultiDiscrete([13,9,2,2]); that step ran on the sanitised word (see hh_step).  clear != 0 zeroes the flags after
  * copying them.  Resets do not clear them.  Ordered on `stream`, no host synchronisation. */
 int hh_action_faults(hh_world *w, uint8_t *out, int32_t clear, void *stream);

@@ -97,6 +97,9 @@ int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_st
 struct hh_world;
 int hh_bind_policy(struct hh_world *w, hh_policy *p);
 int hh_policy_act_binned(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, int8_t *actions, float *logits, void *stream);
+/* the same for the variant-row phases (hh_abi.h: hh_hl_begin_variants / hh_hl_act_tick; n_rows = n_arenas x 15): live_rows = the caller's estimate of
+ * the rows that carry a network (< 0: n_rows), which picks the kernel form */
+int hh_policy_act_binned_live(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_stride, int8_t *actions, float *logits, int32_t live_rows, void *stream);
 
 /* ---- The TRAINABLE policies inside a PPO rollout (configs[2]).  What RLlib's sampler does per env step for each of
  * train_hetero.py's two policies (train_hetero.py:206-243): model.forward on the observer's dict (central_critic_observer, 162-181:

@@ -35,7 +35,7 @@ ALGO_BYTES_3V3_TICK = 2056       # 656 + 656 + pilot obs 720 +
 ALGO_BYTES_3V3_TICK_TAPE = 1336  # the same tick when the pilots' actions come from a tape: nobody builds or reads the 720 B of pilot observations
 ALGO_BYTES_3V3_STATE = 656       # one arena's state record (read once and written once per commander step by the one-launch macro step)
 ALGO_BYTES_3V3_CMD_FIXED = 424   # commander obs 408 + actions 3 + rewards 12 + done 1
-DEFAULT_STREAMS = {"rollout": 1, "hier_net": 4}   # sub-worlds / streams of the policy-in-the-loop workloads (--streams)
+DEFAULT_STREAMS = {"rollout": 1, "hier_net": 4, "hier_net_variants": 2}   # sub-worlds / streams of the policy-in-the-loop workloads (--streams)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F16_PEAK_TFLOPS = 2500.0    # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md; AMD's headline figure includes 2:1 sparsity)
 MFMA_F32_PEAK_TFLOPS = 157.3     # fp32-in MFMA runs at the vector rate
@@ -621,7 +621,7 @@ def main_hier(args, R=None):
     from hhmarl_2d_amd.pilots import MLPPilot, NetPilot, RandomPilot, TapePilot
     from hhmarl_2d_amd.sharding import ShardedWorld
     N = args.arenas or 8192
-    K = (args.streams or DEFAULT_STREAMS["hier_net"]) if args.pilot == "net" else 1
+    K = (args.streams or DEFAULT_STREAMS["hier_net_variants" if args.pilot_rows == "variants" else "hier_net"]) if args.pilot == "net" else 1
     assert N % K == 0, "--streams must divide the arena count"
     n_sub = N // K
     if K > 1 or args.pilot == "net":   # the networks-in-the-loop workload always runs the sub-world form (K = 1: one sub-world)
@@ -785,9 +785,11 @@ def main_hier_split(args, R, own, N, K):
             step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        step()
+    graph = None
+    if not args.no_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
     state = {"k": 0}
 
     def run(m):
@@ -795,7 +797,10 @@ def main_hier_split(args, R, own, N, K):
             k = state["k"]
             for j in range(K):
                 cmd_static[j].copy_(cmds[k % 64, j * n:(j + 1) * n])
-            graph.replay()
+            if graph is not None:
+                graph.replay()
+            else:   # --no-graph: the same launches issued eagerly on the K streams (A/B of the graph's scheduling)
+                step()
             state["k"] = k + 1
 
     t_spin = time.perf_counter()

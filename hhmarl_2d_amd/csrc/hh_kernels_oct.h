@@ -1077,7 +1077,7 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
     oct_publish_vec(m, pub);
     oct_publish_norm(c, m, pub);
     oct_publish_flags(m, pub);
-    if (phase == HH_HL_TICK) oct_positions(m, L, tb); /* the tick builds its table afterwards; before it only a launch test may ask for an entry */
+    if (phase == HH_HL_TICK || (VAR && phase == HH_HL_ACT_TICK)) oct_positions(m, L, tb); /* the tick builds its table afterwards; before it only a launch test may ask for an entry */
     else oct_tables<true>(m, pub, L, tb);
     o_wave_sync();
     int obs_side = -1; /* which side's pilot observations this launch emits */
@@ -1101,9 +1101,8 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
         int8_t act[4];
         hl_load_act(actions, row0 + L.i, L.exists && agent, act, act_fault, running && m.alive && agent);
         int flb[5]; /* the flags the emitted rows were built from */
-#pragma unroll
-        for (int k = 0; k < 5; k++) flb[k] = tb.fl[k];
-        act_oct<(W >= 2), true>(c, sh, tid, L, running, m, ar, act, agent, tb, pub, H.evm);
+        HH_O_FETCH5(i, flb, pub.flags);
+        act_oct<(W >= 2), false>(c, sh, tid, L, running, m, ar, act, agent, tb, pub, H.evm);
         HH_O_FETCH5(i, tb.fl, pub.flags);
         int v = 0; /* which of its rows describes what the opponent sees now: bit 0 / 1 = the first / second observed agent raised its flag */
         {
@@ -1117,7 +1116,7 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
         }
         int8_t act2[4];
         hl_load_act(actions, row0 + 3 + 4 * L.i + v, L.exists && !agent, act2, act_fault, running && m.alive && !agent);
-        act_oct<(W >= 2), true>(c, sh, tid, L, running, m, ar, act2, !agent, tb, pub, H.evm);
+        act_oct<(W >= 2), false>(c, sh, tid, L, running, m, ar, act2, !agent, tb, pub, H.evm);
         const int ran = oct_do_tick<(W >= 2), true>(P, c, sh, tid, L, n, active, H, tb, pub);
         ran_tick = ran;
         if (L.p == 0 && ran && ar.hl_run && running_count) atomicAdd(running_count, 1);

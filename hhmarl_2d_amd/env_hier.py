@@ -65,9 +65,8 @@ class HighLevelEnv(_Base):
         cfg = config_from_args(self.args, L.ENV_HIGHLEVEL, self.num_envs, int(env_config.get("seed", 0)), arena_offset=int(env_config.get("arena_offset", 0)))
         self.world = World(cfg, device=int(env_config.get("device", 0)))
         if self.pilot is None:   # _get_policies("HighLevel"), env_base.py:333-343
-            from .pilots import NetPilot, PolicyBank
-            bank = PolicyBank.from_reference_dir(self.world.device, policy_dir, "HighLevel", self.args, max_rows=self.num_envs * self.world.A)
-            self.pilot = NetPilot(self.world, bank=bank)
+            from .pilots import own_pilot
+            self.pilot = own_pilot(self.world, policy_dir, self.args, env_config.get("pilot_rows", "variants"))
         self._cmd = torch.zeros((self.num_envs, self.args.num_agents), dtype=torch.int8, device=self.world.device)
         self.commander_actions = None
         self.rewards = {}
@@ -101,17 +100,18 @@ class HighLevelEnv(_Base):
 
     def _macro_step_batched(self):
         """large batches: no early exit (some arena is practically always still inside its macro step), and with the library's
-        own NetPilot — launches only, nothing the host has to see in between — the 66 launches of a commander step are captured
+        own NetPilot / VariantNetPilot — launches only, nothing the host has to see in between — the 66 (34) launches of a commander step are captured
         once in a HIP graph and replayed"""
-        from .pilots import NetPilot
-        if not isinstance(self.pilot, NetPilot):
+        from .pilots import NetPilot, VariantNetPilot
+        if not isinstance(self.pilot, (NetPilot, VariantNetPilot)):
             return macro_step(self.world, self._cmd, self.pilot, early_exit=False)
         # the captured graph holds the world's device pointers (trace ring, bound bank's row lists) by value: re-capture whenever
         # World.trace_enable / bind_policy changed them since
         if getattr(self, "_graph", None) is not None and self._graph_gen != getattr(self.world, "ptr_generation", 0):
             self._graph = None
         if getattr(self, "_graph", None) is None:
-            self._g_out, self._g_pilot = self.world.alloc_outputs(), self.world.alloc_pilot()
+            self._g_out = self.world.alloc_outputs()
+            self._g_pilot = self.world.alloc_pilot_variants() if getattr(self.pilot, "variants", False) else self.world.alloc_pilot()
             # the forward kernels' first launch must not happen inside a capture: one call on rows without a network
             self.pilot.bank.act(torch.zeros((64, 30), device=self.world.device), torch.zeros((64,), dtype=torch.uint8, device=self.world.device))
             torch.cuda.synchronize(self.world.device)

@@ -310,6 +310,15 @@ class NetPilot:
             self.world = None
 
 
+def own_pilot(world, policy_dir, args, pilot_rows="variants"):
+    """the pilot the facades fly when they load the reference's exported policies themselves (_get_policies("HighLevel"), env_base.py:333-343):
+    the variant-row form (one launch + one policy call per sub-step) for worlds of up to three aircraft per side, the two-call form otherwise or on request
+    (pilot_rows = "sides"); both fly the same trajectories"""
+    variants = pilot_rows == "variants" and world.A == 6
+    bank = PolicyBank.from_reference_dir(world.device, policy_dir, "HighLevel", args, max_rows=world.N * (world.V_ROWS if variants else world.A))
+    return VariantNetPilot(world, bank=bank) if variants else NetPilot(world, bank=bank)
+
+
 class VariantNetPilot:
     """NetPilot for the variant-row form (World.hl_begin_variants / hl_act_tick: one launch and one policy call per sub-step): every listed row of
     the [N, 15, 30] buffer — the agents' rows and each opponent's row in its up-to-four variants — through the network its selector byte names."""

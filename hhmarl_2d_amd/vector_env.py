@@ -352,10 +352,10 @@ class LowLevelVectorEnv(_VectorProtocol):
 
 
 class _GpuHierBackend:
-    """the batched 3-vs-3 HighLevelEnv world behind HighLevelVectorEnv: one commander step of every sub-environment per step() — the 66 launches of
-    env_hier.macro_step, replayed from ONE HIP graph when the library's own NetPilot flies the units, eager with the early exit for a handful of arenas"""
+    """the batched 3-vs-3 HighLevelEnv world behind HighLevelVectorEnv: one commander step of every sub-environment per step() — the 34 launches of
+    env_hier.macro_step (variant rows; 66 with pilot_rows = "sides"), replayed from ONE HIP graph when the library's own NetPilot flies the units, eager with the early exit for a handful of arenas"""
 
-    def __init__(self, cfg, device, args, policy_dir=None, pilot=None, graph_from=65):
+    def __init__(self, cfg, device, args, policy_dir=None, pilot=None, graph_from=65, pilot_rows="variants"):
         import torch
         from .env_hier import macro_step
         from .world import World
@@ -365,13 +365,13 @@ class _GpuHierBackend:
         self.N, self.n_agents, self.D = w.N, w.n_agents, w.D
         self.pilot = pilot
         if self.pilot is None:   # _get_policies("HighLevel"), env_base.py:333-343
-            from .pilots import NetPilot, PolicyBank
-            bank = PolicyBank.from_reference_dir(w.device, policy_dir, "HighLevel", args, max_rows=w.N * w.A)
-            self.pilot = NetPilot(w, bank=bank)
+            from .pilots import own_pilot
+            self.pilot = own_pilot(w, policy_dir, args, pilot_rows)
         self._cmd = torch.zeros((w.N, w.n_agents), dtype=torch.int8, device=w.device)
         self._cmd_pin = torch.zeros((w.N, w.n_agents), dtype=torch.int8).pin_memory()
         self.act_host = self._cmd_pin.numpy()
-        self._out, self._pbuf = w.alloc_outputs(), w.alloc_pilot()
+        self._out = w.alloc_outputs()
+        self._pbuf = w.alloc_pilot_variants() if getattr(self.pilot, "variants", False) else w.alloc_pilot()
         self._out_pin = [torch.zeros(t.shape, dtype=t.dtype).pin_memory() for t in self._out]
         self._mask = torch.zeros((w.N,), dtype=torch.uint8, device=w.device)
         self._mask_pin = torch.zeros((w.N,), dtype=torch.uint8).pin_memory()
@@ -389,9 +389,9 @@ class _GpuHierBackend:
         return self._robs_pin.numpy()
 
     def _replay(self):
-        from .pilots import NetPilot
+        from .pilots import NetPilot, VariantNetPilot
         torch, w = self.torch, self.world
-        if not isinstance(self.pilot, NetPilot):   # a foreign pilot may read things on the host: no capture
+        if not isinstance(self.pilot, (NetPilot, VariantNetPilot)):   # a foreign pilot may read things on the host: no capture
             return self._macro_step(w, self._cmd, self.pilot, out=self._out, pilot_buf=self._pbuf, early_exit=False)
         gen = getattr(w, "ptr_generation", 0)      # the graph holds device pointers by value (trace ring, bound bank's row lists)
         if self._graph is None or self._graph_gen != gen:
@@ -447,7 +447,8 @@ class HighLevelVectorEnv(_VectorProtocol):
         if backend is None:
             cfg = config_from_args(self.args, L.ENV_HIGHLEVEL, self.num_envs, int(env_config.get("seed", 0)), auto_reset=False,
                                    arena_offset=int(env_config.get("arena_offset", 0)))
-            backend = _GpuHierBackend(cfg, int(env_config.get("device", 0)), self.args, env_config.get("policy_dir"), env_config.get("pilot"))
+            backend = _GpuHierBackend(cfg, int(env_config.get("device", 0)), self.args, env_config.get("policy_dir"), env_config.get("pilot"),
+                                      pilot_rows=env_config.get("pilot_rows", "variants"))
         self._init_protocol(backend, self.num_envs, range(1, self.args.num_agents + 1))
         self._eval = bool(getattr(self.args, "eval_info", False))
         self._last_eval = None

@@ -121,8 +121,9 @@ def test_lowlevel_env_with_policy_dir_reproduces_the_reference_trace(path, fp32,
 
 
 @pytest.mark.parametrize("fp32", FORMS)
+@pytest.mark.parametrize("rows", ["variants", "sides"])
 @pytest.mark.parametrize("path", nets_in_loop_files("high"), ids=lambda p: os.path.basename(p)[4:-4])
-def test_highlevel_env_with_policy_dir_reproduces_the_reference_trace(path, fp32, tmp_path, monkeypatch):
+def test_highlevel_env_with_policy_dir_reproduces_the_reference_trace(path, fp32, rows, tmp_path, monkeypatch):
     """HighLevelEnv(policy_dir): every pilot's action of every sub-step from the HIP policy kernel == the reference's networks';
     commander observations, rewards, done and eval_info follow.  Covers the L5 -> L3 escape fallback (hl_nets_2v3) and
     evaluation.py's eval_hl = False mode, where the opponents fly their own L{eval_level_opp} fight nets (hl_nets_lowlevel_eval)."""
@@ -136,13 +137,49 @@ def test_highlevel_env_with_policy_dir_reproduces_the_reference_trace(path, fp32
     pdir = _write_policy_dir(tmp_path, meta)
     orig = _with_arena_offset(eh, meta["arena"])
     try:
-        env = HighLevelEnv({"args": _args(meta, 1), "seed": meta["seed"], "policy_dir": pdir})
+        env = HighLevelEnv({"args": _args(meta, 1), "seed": meta["seed"], "policy_dir": pdir, "pilot_rows": rows})
     finally:
         eh.config_from_args = orig
     inner = env.pilot
+    variants = bool(getattr(inner, "variants", False))   # (ten-slot worlds fly the two-call form whatever was asked)
     flips, tape = Flips(), {"calls": 0}
     files = meta["file_names"]
     want_files = set()
+
+    def checked_variants(po, pm):
+        """the variant-row form (the facade's default): ONE pilot call per sub-step over [1, 15, 30] — the agents' rows are the recorded ones; each
+        opponent's recorded row (what the reference's pilot saw AFTER the agents acted) is one of its listed variants, and that variant's action is the
+        recorded one"""
+        k = tape["calls"]
+        tape["calls"] += 1
+        assert k < len(g["sub_act"]), "more pilot calls than the reference made sub-steps"
+        pm_h, po_h = pm.cpu().numpy()[0], po.cpu().numpy()[0]
+        assert np.array_equal(pm_h[:nA] & 3, g["sub_mode"][k][:nA]), f"sub-step {k}: agents' policy types"
+        assert np.abs(po_h[:nA] - g["sub_obs"][k][:nA]).max() <= 1e-6, f"sub-step {k}: agents' pilot observations"
+        act = inner(po, pm)
+        got = act.cpu().numpy()[0]
+        for j in range(A):
+            if not g["sub_mode"][k][j]:
+                continue
+            want_files.add(files[g["sub_file"][k][j]])
+            if j < nA:
+                slots = [j]
+            else:   # the variant that matches what the reference's pilot observed
+                base = 3 + 4 * (j - nA)
+                slots = [base + v for v in range(4) if pm_h[base + v] and np.abs(po_h[base + v] - g["sub_obs"][k][j]).max() <= 1e-6]
+                assert slots, f"sub-step {k} unit {j + 1}: the recorded observation is not among the listed variants"
+                assert all((pm_h[q] & 3) == g["sub_mode"][k][j] for q in slots)
+                if a["eval_hl"] is False:
+                    assert all(((pm_h[q] & 64) != 0) == (g["sub_mode"][k][j] == 1) for q in slots), "side bit on the opponents' fight rows"
+                slots = slots[:1]
+            if flips.check(got[slots[0]], g["sub_act"][k][j], g["sub_margin"][k][j], f"sub-step {k} unit {j + 1}"):
+                fix = torch.from_numpy(np.ascontiguousarray(g["sub_act"][k][j])).to(act.device)
+                if j < nA:
+                    act[0, j] = fix
+                else:
+                    act[0, 3 + 4 * (j - nA): 7 + 4 * (j - nA)] = fix
+        return act
+    checked_variants.variants = True
 
     def checked(po, pm):
         k, side = tape["calls"] // 2, tape["calls"] % 2      # sub-step record, 0 = agents' call, 1 = opponents' call
@@ -162,7 +199,7 @@ def test_highlevel_env_with_policy_dir_reproduces_the_reference_trace(path, fp32
                 if flips.check(got[j], g["sub_act"][k][j], g["sub_margin"][k][j], f"sub-step {k} unit {j + 1}"):
                     act[0, j] = torch.from_numpy(np.ascontiguousarray(g["sub_act"][k][j])).to(act.device)
         return act
-    env.pilot = checked
+    env.pilot = checked_variants if variants else checked
     for r in range(len(g["kind"])):
         if g["kind"][r] == 0:
             obs, info = env.reset()
@@ -178,11 +215,11 @@ def test_highlevel_env_with_policy_dir_reproduces_the_reference_trace(path, fp32
             assert np.abs(st["ac_f"][0][:A] - g["ac_f"][r]).max() <= 1e-9, f"row {r}: aircraft floats"
         for i in range(1, nA + 1):
             assert np.abs(obs[i] - g["obs"][r][i - 1]).max() <= 1e-6, f"row {r}: commander observation"
-    assert tape["calls"] == 2 * len(g["sub_act"]), "sub-step count"
+    assert tape["calls"] == (1 if variants else 2) * len(g["sub_act"]), "sub-step count"
     n_dec = int((g["sub_mode"] != 0).sum())
     assert flips.decisions == n_dec and n_dec > 1500
     assert want_files == set(meta["policy_files"]), "every loaded policy file flew at least once"
-    print(f"{os.path.basename(path)} [{'fp32' if fp32 == '1' else 'fp16x3'}]: {n_dec} decisions reproduced, {flips.n} near-tie flips {flips.log}")
+    print(f"{os.path.basename(path)} [{'fp32' if fp32 == '1' else 'fp16x3'}, {'variant rows' if variants else 'two calls per sub-step'}]: {n_dec} decisions reproduced, {flips.n} near-tie flips {flips.log}")
     assert flips.n <= 3
     env.close()
 

@@ -46,30 +46,35 @@ for N in (1, 256, 4096, 16384):
                          "batched_dict_step_us": dt2 * 1e6, "batched_dict_env_steps_per_s": N / dt2})
     print(rec["rates"][-1], flush=True)
 # the same surface for the 3-vs-3 commander environment, the Fight / Esc pilot networks in the loop (one commander step of every sub-environment per send_actions)
-from hhmarl_2d_amd.pilots import NetPilot
+from hhmarl_2d_amd.pilots import NetPilot, VariantNetPilot
 from hhmarl_2d_amd.vector_env import HighLevelVectorEnv
-rec["hier_rates"] = []
-for N in (1, 256, 4096):
-    venv = HighLevelVectorEnv({"args": make_args(1, level=5, horizon=500), "num_envs": N, "seed": 1, "pilot": lambda po, pm: None})
-    venv.b.pilot = NetPilot(venv.b.world, seed=2)
-    per_env = [{e: {k: int(rng.integers(3)) for k in (1, 2, 3)} for e in range(N)} for _ in range(4)]
+for rows, key in (("variants", "hier_rates"), ("sides", "hier_rates_two_calls_per_sub_step")):
+    rec[key] = []
+    for N in (1, 256, 4096):
+        venv = HighLevelVectorEnv({"args": make_args(1, level=5, horizon=500), "num_envs": N, "seed": 1, "pilot": lambda po, pm: None})
+        if rows == "variants":   # what the facade builds itself from a policy_dir: one launch + one policy call per sub-step
+            venv.b.pilot = VariantNetPilot(venv.b.world, seed=2)
+            venv.b._pbuf = venv.b.world.alloc_pilot_variants()
+        else:
+            venv.b.pilot = NetPilot(venv.b.world, seed=2)
+        per_env = [{e: {k: int(rng.integers(3)) for k in (1, 2, 3)} for e in range(N)} for _ in range(4)]
 
-    def ith(k):
-        obs, rew, term, trunc, info, _ = venv.poll()
-        for e in obs:
-            if term[e]["__all__"]:
-                venv.try_reset(e)
-        venv.send_actions(per_env[k % 4])
-    for k in range(4):
-        ith(k)
-    S = 100 if N <= 256 else 20
-    t0 = time.perf_counter()
-    for k in range(S):
-        ith(k)
-    dt = (time.perf_counter() - t0) / S
-    rec["hier_rates"].append({"num_envs": N, "ms_per_iteration": dt * 1e3, "commander_steps_per_s": N / dt})
-    print(rec["hier_rates"][-1], flush=True)
-    venv.stop()
+        def ith(k):
+            obs, rew, term, trunc, info, _ = venv.poll()
+            for e in obs:
+                if term[e]["__all__"]:
+                    venv.try_reset(e)
+            venv.send_actions(per_env[k % 4])
+        for k in range(4):
+            ith(k)
+        S = 100 if N <= 256 else 20
+        t0 = time.perf_counter()
+        for k in range(S):
+            ith(k)
+        dt = (time.perf_counter() - t0) / S
+        rec[key].append({"num_envs": N, "ms_per_iteration": dt * 1e3, "commander_steps_per_s": N / dt})
+        print(rows, rec[key][-1], flush=True)
+        venv.stop()
 v = [r["vector_env_steps_per_s"] for r in rec["rates"]]
 rec["monotone_in_num_envs"] = all(b >= a for a, b in zip(v, v[1:]))
 os.makedirs(os.path.dirname(out_path), exist_ok=True)

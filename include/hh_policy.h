@@ -84,7 +84,8 @@ int hh_policy_act(hh_policy *p, const float *obs, int32_t n_rows, int32_t obs_st
 
 /* The networks inside the env step (env_base.py:349-398 within env_hier.py:114-140 and env_hetero.py:160-172): bind a bank to a world
  * and the kernels that emit policy rows bin them by network themselves — through this bank's LUT into its row lists — while they
- * still hold the selector in a register: hh_hl_begin / hh_hl_agents_act / hh_hl_tick for the HighLevelEnv pilots (rows [N, 6]),
+ * still hold the selector in a register: hh_hl_begin / hh_hl_agents_act / hh_hl_tick for the HighLevelEnv pilots (rows [N, 6]; the variant-row
+ * launches hh_hl_begin_variants / hh_hl_act_tick: rows [N, 15], max_rows >= 15 N),
  * hh_step_begin for the frozen opponents of LowLevelEnv levels 4-5 (rows [N, n_opps]; selector = policy type | aircraft type << 2,
  * + 16 (k - 3) for the policy set k of the arena's level-5 draw, i.e. 5 / 9 at level 4 and 5 / 9, 21 / 25, 38 / 42 at level 5).
  * hh_policy_act_binned then runs the forward over those lists with no binning pass, and the last workgroup to read the row counters

@@ -544,10 +544,13 @@ def test_facades_load_the_reference_policy_files_themselves(tmp_path):
     env.close()
     # HighLevelEnv: L{eval_level_ag} fights + L5 escapes, falling back to the L3 escapes when those were not exported
     hl = HighLevelEnv({"args": make_args(1, eval_level_ag=5), "num_envs": 64, "seed": 2, "policy_dir": str(tmp_path)})
-    assert isinstance(hl.pilot, pilots.NetPilot) and sorted(hl.pilot.bank.kinds.values()) == [PN.FIGHT1, PN.FIGHT2, PN.ESC1, PN.ESC2]
+    assert isinstance(hl.pilot, pilots.VariantNetPilot) and sorted(hl.pilot.bank.kinds.values()) == [PN.FIGHT1, PN.FIGHT2, PN.ESC1, PN.ESC2]   # the facade's default pilot-row form
     hl.reset()
     obs, rew, term, trunc, info = hl.step({1: np.ones(64, dtype=np.int64), 2: np.zeros(64, dtype=np.int64), 3: np.full(64, 2)})
     assert obs[1].shape == (64, 34) and np.isfinite(obs[1]).all()
+    hl.close()
+    hl = HighLevelEnv({"args": make_args(1, eval_level_ag=5), "num_envs": 4, "seed": 2, "policy_dir": str(tmp_path), "pilot_rows": "sides"})
+    assert isinstance(hl.pilot, pilots.NetPilot)
     hl.close()
     with pytest.raises(FileNotFoundError):
         HighLevelEnv({"args": make_args(1, eval_level_ag=4), "num_envs": 4, "policy_dir": str(tmp_path / "missing")})

@@ -100,19 +100,31 @@ def test_vector_env_levels_4_and_5_equal_single_env_facades(level):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["sides", "variants", "4v5"])
 @pytest.mark.parametrize("N,iters", [(16, 40), (70, 25)], ids=["16-eager-early-exit", "70-hip-graph"])
-def test_highlevel_vector_env_equals_single_env_facades(N, iters):
+def test_highlevel_vector_env_equals_single_env_facades(N, iters, form, monkeypatch):
     """HighLevelVectorEnv (one commander step of every sub-environment per send_actions: eager with the early exit for a handful, one replayed HIP graph
     above 64) against N single-arena HighLevelEnv facades with the same random-init pilot networks, through episode ends, masked resets and the eval counters"""
     from test_vector_env import make_hl_args
     from hhmarl_2d_amd import _lib as L
     from hhmarl_2d_amd.env_hier import HighLevelEnv
-    from hhmarl_2d_amd.pilots import NetPilot
+    from hhmarl_2d_amd.pilots import NetPilot, VariantNetPilot
     from hhmarl_2d_amd.vector_env import HighLevelVectorEnv
-    args = make_hl_args(horizon=45, eval_info=True)
+    # form: "sides" = two pilot calls per sub-step on both sides of the comparison; "variants" = the vector env flies the variant-row pilot (what the facade
+    # builds itself from a policy_dir: one launch + one policy call per sub-step) against single environments on the two-call path; "4v5" = ten-slot arenas
+    if form == "variants":   # both pilots on the tile form of one width: a row's logits must not depend on which call evaluates it
+        monkeypatch.setenv("HH_POLICY_W", "0")
+        monkeypatch.setenv("HH_POLICY_TILE", "32")
+    nA, nO = (4, 5) if form == "4v5" else (3, 3)
+    ids = tuple(range(1, nA + 1))
+    args = make_hl_args(horizon=45, eval_info=True, num_agents=nA, num_opps=nO)
     placeholder = lambda po, pm: None
     venv = HighLevelVectorEnv({"args": args, "num_envs": N, "seed": 4, "arena_offset": 700, "pilot": placeholder})
-    venv.b.pilot = NetPilot(venv.b.world, seed=9)
+    if form == "variants":
+        venv.b.pilot = VariantNetPilot(venv.b.world, seed=9)
+        venv.b._pbuf = venv.b.world.alloc_pilot_variants()
+    else:
+        venv.b.pilot = NetPilot(venv.b.world, seed=9)
     singles = []
     for i in range(N):
         s = HighLevelEnv({"args": args, "seed": 4, "arena_offset": 700 + i, "pilot": placeholder})
@@ -121,22 +133,22 @@ def test_highlevel_vector_env_equals_single_env_facades(N, iters):
     obs, rew, term, trunc, info, _ = venv.poll()
     for i, s in enumerate(singles):
         o, _ = s.reset()
-        assert all(np.array_equal(o[k], obs[i][k]) for k in (1, 2, 3)) and obs[i][1].shape == (34,)
+        assert all(np.array_equal(o[k], obs[i][k]) for k in ids) and obs[i][1].shape == (34,)
     rng = np.random.default_rng(6)
     dones = 0
     for it in range(iters):
-        acts = {e: {k: int(rng.integers(3)) for k in (1, 2, 3)} for e in range(N)}
+        acts = {e: {k: int(rng.integers(3)) for k in ids} for e in range(N)}
         venv.send_actions(acts)
         obs, rew, term, trunc, info, _ = venv.poll()
         for i, s in enumerate(singles):
             o, r, t, tr, inf = s.step(acts[i])
-            assert all(np.array_equal(o[k], obs[i][k]) for k in (1, 2, 3)), f"step {it}, sub-environment {i}"
+            assert all(np.array_equal(o[k], obs[i][k]) for k in ids), f"step {it}, sub-environment {i}"
             assert r == rew[i] and t == term[i] and tr == trunc[i] and inf == info[i] and set(inf) == set(L.EVAL_KEYS)
             if t["__all__"]:
                 dones += 1
                 ro, ri = venv.try_reset(i)
                 so, _ = s.reset()
-                assert all(np.array_equal(so[k], ro[i][k]) for k in (1, 2, 3))
+                assert all(np.array_equal(so[k], ro[i][k]) for k in ids)
     assert dones >= N // 4
     venv.stop()
     for s in singles:

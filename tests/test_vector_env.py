@@ -139,8 +139,8 @@ def test_protocol_errors_and_corner_cases(oracle):
 
 
 # ------------------------------------------------------------------------------------------------ HighLevelVectorEnv
-def make_hl_args(horizon=60, eval_info=False):
-    return types.SimpleNamespace(level=5, agent_mode="fight", num_agents=3, num_opps=3, horizon=horizon, friendly_kill=True, friendly_punish=False,
+def make_hl_args(horizon=60, eval_info=False, num_agents=3, num_opps=3):
+    return types.SimpleNamespace(level=5, agent_mode="fight", num_agents=num_agents, num_opps=num_opps, horizon=horizon, friendly_kill=True, friendly_punish=False,
                                  esc_dist_rew=False, map_size=0.5, glob_frac=0.0, rew_scale=1, hier_action_assess=True, hier_opp_fight_ratio=75,
                                  eval_info=eval_info, eval_hl=True)
 

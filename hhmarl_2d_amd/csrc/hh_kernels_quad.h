@@ -1139,38 +1139,6 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
             const unsigned long long akey = hh_rng_arena_key(c.seed, c.arena_offset + (uint64_t)n);
             const bool stat_lane = row && s == 0; /* one lane per arena keeps the episode statistics */
             double ep_ret = stat_lane ? P.ep_ret[n] : 0.0;
-            const bool l3 = !c.ext_opp && c.level >= 3; /* configuration: the level-3 script of tick t + 1, on the prediction that tick t removes nobody (QPre.spec) */
-            const bool lane_arena = g < GPB && n < c.N;
-            /* What the window between X and Y computes for tick t + 1 WITHOUT the table — the tick key, the arena's escape flag, this lane's script draw — is a
-             * function of three integers the simulation wave posts at X (step counter, episode, flag word).  This wave knows at the end of tick t - 1 what they
-             * will almost always be, and it idles there (it waits ~3 400 cycles for X), so it evaluates the function then and only compares at X: equal on every
-             * lane that has an arena = the same inputs = the same values; anything else (a reset, a removal, a finished arena) takes the in-window path. */
-            auto ahead = [&](int steps_in, int ep_in, int ew_in, unsigned long long &tk, int &esc_o, int &esc_t_o, bool &my_o, double &a0, double &a1, double &a2) {
-                tk = hh_rng_tick_key(akey, (uint32_t)ep_in, (uint32_t)(steps_in + 1));
-                esc_o = ew_in & 0xff; esc_t_o = (int)(int8_t)((ew_in >> 8) & 0xff);
-                const int am_ = (ew_in >> 16) & 0xf;
-                my_o = false; a0 = a1 = a2 = 0.0;
-                bool escj[2] = {false, false};
-                if (l3) {
-                    quad_l3_flags(steps_in + 1, tk, am_, s, esc_o, esc_t_o, my_o, escj);
-                    /* the three draws, as tick_quad spreads them over the lanes */
-                    const int du = (s | 2) + 1, role = helper ? 2 : (s < 2 ? 1 : 0);
-                    const int site_e = role == 0 ? HH_SITE_ESC_HDG : (role == 1 ? HH_SITE_ESC_SPEED : HH_SITE_ESC_FIRE);
-                    const int site_h = role == 0 ? HH_SITE_HC_SPEED1 : (role == 1 ? HH_SITE_HC_R : HH_SITE_HC_SPEED2);
-                    const bool desc = (s & 1) ? escj[1] : escj[0];
-                    int de = desc ? 1 : 0;
-                    if (DUAL) { const int deh = q_down_i(de); de = helper ? deh : de; }
-                    const double u = hh_rng_u01(tk, (uint32_t)du, (uint32_t)(de ? site_e : site_h), 0u);
-                    a0 = u; a1 = q_perm_d<HH_QP(0, 1, 0, 1)>(u);
-                    if (DUAL) a2 = q_up_d(u);
-                    else a2 = hh_rng_u01(tk, (uint32_t)(s + 1), (uint32_t)(my_o ? HH_SITE_ESC_FIRE : HH_SITE_HC_SPEED2), 0u);
-                }
-            };
-            bool p_have = false;
-            int p_steps = 0, p_ep = 0, p_ew = 0, p_esc = 0, p_esc_t = 0;
-            unsigned long long p_tk = 0ULL;
-            bool p_my = false;
-            double p_u0 = 0.0, p_u1 = 0.0, p_u2 = 0.0;
             for (int t = 0; t < T; t++) {
                 __syncthreads(); /* barrier X: the moved positions are posted */
                 HH_OPROF(0);
@@ -1198,20 +1166,27 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                 /* ahead of the simulation wave (QPre), first what does not need the table — so that it shares the table's long dependent chains' shadow:
                  * the next tick's key, the arena's escape flag for that tick, this lane's script draw */
                 const int steps_t = mbx.pos.steps[mt]; /* read HERE: after Y the simulation wave posts the next tick's */
-                const int ep_t = mbx.pos.episode[mt];
+                const unsigned long long tk1 = hh_rng_tick_key(akey, (uint32_t)mbx.pos.episode[mt], (uint32_t)(steps_t + 1));
+                const bool l3 = !c.ext_opp && c.level >= 3; /* configuration: the level-3 script of tick t + 1, on the prediction that tick t removes nobody (QPre.spec) */
                 const int ew = mbx.pos.escw[mt];
+                int esc = ew & 0xff, esc_t = (int)(int8_t)((ew >> 8) & 0xff);
                 const int am = (ew >> 16) & 0xf;
-                unsigned long long tk1;
-                int esc, esc_t;
-                bool my_escaping;
-                double u0, u1, u2;
-#ifdef HHQ_NO_AHEAD2 /* A/B builds: always the in-window path */
-                const bool hit = false;
-#else
-                const bool hit = p_have && !q_any(lane_arena && (steps_t != p_steps || ep_t != p_ep || ew != p_ew));
-#endif
-                if (hit) { tk1 = p_tk; esc = p_esc; esc_t = p_esc_t; my_escaping = p_my; u0 = p_u0; u1 = p_u1; u2 = p_u2; }
-                else ahead(steps_t, ep_t, ew, tk1, esc, esc_t, my_escaping, u0, u1, u2);
+                bool my_escaping = false, escj[2] = {false, false};
+                double u0 = 0.0, u1 = 0.0, u2 = 0.0;
+                if (l3) {
+                    quad_l3_flags(steps_t + 1, tk1, am, s, esc, esc_t, my_escaping, escj);
+                    /* the three draws, as tick_quad spreads them over the lanes */
+                    const int du = (s | 2) + 1, role = helper ? 2 : (s < 2 ? 1 : 0);
+                    const int site_e = role == 0 ? HH_SITE_ESC_HDG : (role == 1 ? HH_SITE_ESC_SPEED : HH_SITE_ESC_FIRE);
+                    const int site_h = role == 0 ? HH_SITE_HC_SPEED1 : (role == 1 ? HH_SITE_HC_R : HH_SITE_HC_SPEED2);
+                    const bool desc = (s & 1) ? escj[1] : escj[0];
+                    int de = desc ? 1 : 0;
+                    if (DUAL) { const int deh = q_down_i(de); de = helper ? deh : de; }
+                    const double u = hh_rng_u01(tk1, (uint32_t)du, (uint32_t)(de ? site_e : site_h), 0u);
+                    u0 = u; u1 = q_perm_d<HH_QP(0, 1, 0, 1)>(u);
+                    if (DUAL) u2 = q_up_d(u);
+                    else u2 = hh_rng_u01(tk1, (uint32_t)(s + 1), (uint32_t)(my_escaping ? HH_SITE_ESC_FIRE : HH_SITE_HC_SPEED2), 0u);
+                }
                 QTab tb;
                 quad_tables<DUAL, false>(m, pub, s, helper, tb); /* the same expressions on the same operands as the simulation wave's own (reset ticks) */
 #pragma unroll
@@ -1233,8 +1208,6 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                 HH_OPROF(2);
                 int valid = 0, done = 0;
                 float rew = 0.0f;
-                const int w7n = mbx.slim.w7[mt];  /* (bits 27..30: who is alive after the tick, before a reset = the alive mask the next X will post) */
-                const bool full_t = mbx.slim.full != 0;
                 { /* episode statistics (the simulation wave's own code in the other forms): return summed in agent order, then length and outcome */
                     const int w7s = mbx.slim.w7[tid];
                     const double rv = ((w7s >> 24) & 1) ? mbx.slim.rew[tid] : 0.0;
@@ -1286,11 +1259,6 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                     }
                 }
                 q_wave_sync(); /* the tile is free again */
-                /* the next window's table-free part, on what the next X will almost always post (see `ahead`) */
-                p_have = !full_t;
-                p_steps = steps_t + 1; p_ep = ep_t;
-                p_ew = (esc & 0xff) | ((esc_t & 0xff) << 8) | (((w7n >> 27) & 0xf) << 16);
-                ahead(p_steps, p_ep, p_ew, p_tk, p_esc, p_esc_t, p_my, p_u0, p_u1, p_u2);
                 HH_OPROF(3);
             }
             if (stat_lane) P.ep_ret[n] = ep_ret;

@@ -113,7 +113,8 @@ class HighLevelEnv(_Base):
             self._g_out = self.world.alloc_outputs()
             self._g_pilot = self.world.alloc_pilot_variants() if getattr(self.pilot, "variants", False) else self.world.alloc_pilot()
             # the forward kernels' first launch must not happen inside a capture: one call on rows without a network
-            self.pilot.bank.act(torch.zeros((64, 30), device=self.world.device), torch.zeros((64,), dtype=torch.uint8, device=self.world.device))
+            nw = min(64, self.pilot.bank.max_rows)
+            self.pilot.bank.act(torch.zeros((nw, 30), device=self.world.device), torch.zeros((nw,), dtype=torch.uint8, device=self.world.device))
             torch.cuda.synchronize(self.world.device)
             side = torch.cuda.Stream(device=self.world.device)
             side.wait_stream(torch.cuda.current_stream(self.world.device))
@@ -138,12 +139,14 @@ class HighLevelEnv(_Base):
                 if k <= nA:
                     c[:, k - 1] = np.asarray(v)
             self._cmd.copy_(torch.from_numpy(c))
-            # leaving the sub-step loop early costs a host synchronisation per tick: worth it for a few arenas (RLlib's one env per
-            # worker), pointless for a large batch, where some arena is practically always still inside its macro step
-            if self.num_envs <= 64:
-                obs, rew, val, done = macro_step(self.world, self._cmd, self.pilot, early_exit=True)
-            else:
+            # the library's own pilot: the commander step's launches replayed from ONE HIP graph, all 16 sub-steps (arenas whose macro step is
+            # over idle) — 0.65 against 1.03 ms for a single environment: leaving the loop early costs a host synchronisation per tick, more than the
+            # ~1.5 sub-steps it saves.  A foreign pilot is called eagerly, with the early exit for a handful of arenas (it may be Python per row).
+            from .pilots import NetPilot, VariantNetPilot
+            if isinstance(self.pilot, (NetPilot, VariantNetPilot)):
                 obs, rew, val, done = self._macro_step_batched()
+            else:
+                obs, rew, val, done = macro_step(self.world, self._cmd, self.pilot, early_exit=self.num_envs <= 64)
             rew, val, done = rew.cpu().numpy(), val.cpu().numpy(), done.cpu().numpy()
             if getattr(self.args, "eval_info", False):
                 info = self._eval_info()

@@ -355,7 +355,7 @@ class _GpuHierBackend:
     """the batched 3-vs-3 HighLevelEnv world behind HighLevelVectorEnv: one commander step of every sub-environment per step() — the 34 launches of
     env_hier.macro_step (variant rows; 66 with pilot_rows = "sides"), replayed from ONE HIP graph when the library's own NetPilot flies the units, eager with the early exit for a handful of arenas"""
 
-    def __init__(self, cfg, device, args, policy_dir=None, pilot=None, graph_from=65, pilot_rows="variants"):
+    def __init__(self, cfg, device, args, policy_dir=None, pilot=None, graph_from=1, pilot_rows="variants"):
         import torch
         from .env_hier import macro_step
         from .world import World
@@ -395,7 +395,8 @@ class _GpuHierBackend:
             return self._macro_step(w, self._cmd, self.pilot, out=self._out, pilot_buf=self._pbuf, early_exit=False)
         gen = getattr(w, "ptr_generation", 0)      # the graph holds device pointers by value (trace ring, bound bank's row lists)
         if self._graph is None or self._graph_gen != gen:
-            self.pilot.bank.act(torch.zeros((64, 30), device=w.device), torch.zeros((64,), dtype=torch.uint8, device=w.device))   # first launches outside a capture
+            nw = min(64, self.pilot.bank.max_rows)
+            self.pilot.bank.act(torch.zeros((nw, 30), device=w.device), torch.zeros((nw,), dtype=torch.uint8, device=w.device))   # first launches outside a capture
             torch.cuda.synchronize(w.device)
             side = torch.cuda.Stream(device=w.device)
             side.wait_stream(torch.cuda.current_stream(w.device))
@@ -411,9 +412,11 @@ class _GpuHierBackend:
     def step(self):
         """one commander step (HighLevelEnv.step, env_hier.py:114-140) with the actions in act_host -> (obs, reward, valid, done) host arrays"""
         self._cmd.copy_(self._cmd_pin, non_blocking=True)
-        if self.N < self._graph_from:   # few arenas: leave the sub-step loop as soon as every macro step is over (a host synchronisation per tick)
-            outs = self._macro_step(self.world, self._cmd, self.pilot, out=self._out, pilot_buf=self._pbuf, early_exit=True)
-        else:
+        from .pilots import NetPilot, VariantNetPilot
+        own = isinstance(self.pilot, (NetPilot, VariantNetPilot))
+        if not own or self.N < self._graph_from:   # a foreign pilot (or graph_from raised): eager launches, leaving the sub-step loop early for a handful of arenas
+            outs = self._macro_step(self.world, self._cmd, self.pilot, out=self._out, pilot_buf=self._pbuf, early_exit=self.N < 65)
+        else:   # the library's own pilot: one replayed HIP graph at every size (0.65 against 1.03 ms for a single sub-environment: tools/hl_small_batch_probe.py)
             outs = self._replay()
         for src, dst in zip(outs, self._out_pin):
             dst.copy_(src, non_blocking=True)

@@ -186,27 +186,87 @@ class DryWorld:
 
 
 # ------------------------------------------------------------------------------------------------ baselines / evidence files
-def cpu_baseline(n_arenas, level, seed, budget_s=12.0):
-    """The oracle (plain-C port of the reference path; one OpenMP team, arena-outer / tick-inner) on the host cores.
-    Test infrastructure used only as a reported baseline, never as the measured product."""
+def host_cpu_facts():
+    """What the box offers this process: logical CPUs in the affinity mask, physical cores behind them, the cgroup CPU quota."""
+    aff = sorted(os.sched_getaffinity(0))
+    quota = None
+    for p in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(p) as f:
+                t = f.read().split()
+            if p.endswith("cpu.max"):
+                quota = None if t[0] == "max" else float(t[0]) / float(t[1])
+            else:
+                q = float(t[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    quota = None if q <= 0 else q / float(f.read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    phys = set()
+    for c in aff:
+        try:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            with open(base + "physical_package_id") as f:
+                pk = f.read().strip()
+            with open(base + "core_id") as f:
+                phys.add((pk, f.read().strip()))
+        except OSError:
+            phys.add(("?", str(c)))
+    return {"sched_getaffinity": len(aff), "physical_cores": len(phys), "cgroup_cpu_quota": quota}
+
+
+def cpu_baseline(n_arenas, level, seed, budget_s=14.0):
+    """The oracle (plain-C port of the reference path; one OpenMP team, arena-outer / tick-inner, static blocks of arenas per thread)
+    on the host cores: ONE thread, then every thread OpenMP gives the process, in the same run, with the outputs allocated once
+    outside the timed loops.  `cores` / `threads` are the threads that did the work (counted inside a parallel region), not the
+    affinity mask.  Test infrastructure used only as a reported baseline, never as the measured product."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy as np
     import oracle_lib as O
-    cores = len(os.sched_getaffinity(0))
-    w = O.OracleWorld(O.make_config(n_arenas=n_arenas, level=level, seed=seed, auto_reset=True))
-    w.reset()
-    T = 50
-    act = O.action_tape_uniform(seed, 0, 0, T, n_arenas, w.n_ctrl)   # the first T steps of the same keyed tape the GPU run consumes
-    w.rollout(act[:4])  # warm
-    steps = 0
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        w.rollout(act)
-        steps += T
-    dt = time.perf_counter() - t0
-    out = {"value": n_arenas * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-           "note": "unoptimised scalar C restatement (statement order of the reference, no SIMD): a reported baseline, not a tuned CPU implementation",
-           "sample": f"{n_arenas} arenas x {steps} ticks, same config / seed / keyed action tape (its first {T} steps, cycled), one OpenMP team, arenas outer / ticks inner"}
+    facts = host_cpu_facts()
+    T = 100
+    act = None
+
+    def leg(threads, budget):
+        nonlocal act
+        O.omp_set_threads(threads)
+        team = O.omp_team_size()
+        w = O.OracleWorld(O.make_config(n_arenas=n_arenas, level=level, seed=seed, auto_reset=True))   # arenas first touched by their threads
+        w.reset()
+        if act is None:
+            act = O.action_tape_uniform(seed, 0, 0, T, n_arenas, w.n_ctrl)   # the first T steps of the same keyed tape the GPU run consumes
+        out = w.alloc_rollout_outputs(T)
+        w.rollout(act, out=out)   # untimed: first touch of the output pages by the threads that own them, caches warm
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            w.rollout(act, out=out)
+            steps += T
+            dt = time.perf_counter() - t0
+            if dt >= budget:
+                break
+        return {"threads": team, "value": n_arenas * steps / dt, "ticks": steps, "seconds": dt}
+
+    max_threads = O.omp_max_threads()
+    one = leg(1, budget_s * 0.3)
+    legs = [one]
+    phys = facts["physical_cores"]
+    if 1 < phys < max_threads:
+        legs.append(leg(phys, budget_s * 0.3))   # one thread per physical core (SMT siblings idle)
+    if max_threads > 1:
+        legs.append(leg(max_threads, budget_s * 0.4))
+    O.omp_set_threads(max_threads)
+    best = max(legs, key=lambda r: r["value"])
+    for r in legs:
+        r["efficiency_vs_one_thread"] = r["value"] / (r["threads"] * one["value"])
+    out = {"value": best["value"], "unit": "env-steps/s", "cores": best["threads"], "threads": best["threads"], "kind": "port",
+           "one_thread": one["value"], "per_thread": best["value"] / best["threads"], "scaling_efficiency": best["efficiency_vs_one_thread"],
+           "legs": legs, "host": facts, "omp_max_threads": max_threads,
+           "note": "unoptimised scalar C restatement (statement order of the reference, no SIMD): a reported baseline, not a tuned CPU implementation.  "
+                   "`value` = the fastest leg; `cores` = `threads` = the OpenMP threads that ran it (counted inside a parallel region); `scaling_efficiency` = "
+                   "value / (threads x one_thread) — SMT siblings share a core's FP64 units, so the all-logical-CPUs leg is judged against `host.physical_cores`",
+           "sample": f"{n_arenas} arenas x {best['ticks']} ticks in {best['seconds']:.1f} s (one thread: {one['ticks']} ticks in {one['seconds']:.1f} s), same config / seed / "
+                     f"keyed action tape (its first {T} steps, cycled), outputs pre-allocated and first-touched outside the timed loop, one OpenMP team, "
+                     "arenas outer / ticks inner, schedule(static)"}
     ref = load_json("reference_cpu_rate.json")
     if ref:
         out["reference_python"] = {
@@ -369,9 +429,10 @@ def main_low(args, R=None):
     if R.world > 1 and args.one_gpu_value:
         line["scaling_efficiency"] = value / (R.world * args.one_gpu_value)
         line["one_gpu_value"] = args.one_gpu_value
+    # did the logging collective see every rank?  (rank, first global arena, arenas) of each rank travel over the same backend as the statistics
+    line.update(sw.evidence())
     if R.dry:
         line["dry_run"] = True
-        line["gathered_rows"] = None if sw.last_stats is None else int(sw.last_stats.shape[0])
     else:
         # dominant kernel: average launch duration from HIP events on the launch stream
         durs = [a.elapsed_time(b) * 1e-3 for a, b in evs]
@@ -722,6 +783,9 @@ def main_hier(args, R=None):
         line["roofline"]["schedule"] = {"bytes": sched, "achieved": sched / gpu_s / 1e9, "frac": sched / gpu_s / 1e9 / HBM_PEAK_GBS,
                                         "note": "bytes the one-launch schedule needs (state stays in registers across the sub-steps): the figure the counter traffic should be compared with"}
     line["gpu_ms_per_step"] = gpu_s / steps * 1e3
+    if log_side is not None:
+        sw.log_episode_stats(log_side)
+        line.update(sw.evidence())   # ranks_seen, block order and gathered rows of the logging collective (all ranks call it)
     if tape_launch:   # HBM bytes per commander step of the one-launch kernel, from the committed PMC passes
         tf = "latest_hier_traffic.json" if load_json("latest_hier_traffic.json") else "r03_hier8192_traffic.json"
         tr = launch_traffic(tf, w.kernel_instance(1), N)
@@ -895,16 +959,18 @@ def configs4(args, R):
         R.barrier()
         sw.log_episode_stats(None)
         R.barrier()
-        rows = None if sw.last_stats is None else int(sw.last_stats.shape[0])
         first = None if sw.last_stats is None else [float(sw.last_stats[i * N4, 0]) for i in range(R.world)]   # DryWorld reports the global arena id: ranks in order
-        return {"dry_run": True, "arenas_per_gpu": N4, "n_gpus": R.world, "gathered_rows": rows, "first_global_arena_of_each_block": first}
+        ev = sw.evidence()
+        assert first is None or first == [float(x) for x in ev["first_global_arena_of_each_block"]], (first, ev)   # the statistics blocks sit where the ranks say they are
+        return dict({"dry_run": True, "arenas_per_gpu": N4, "n_gpus": R.world}, **ev)
     a = copy.copy(args)
     a.workload, a.pilot, a.arenas, a.steps, a.warmup, a.spinup, a.phases, a.streams = "hier", "tape", N4, 30, 6, 0.3, False, 0
     try:
         line = main_hier(a, R)
     except Exception as e:   # noqa: BLE001 — reported, never silently dropped
         return {"error": f"{type(e).__name__}: {e}"}
-    keys = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "gpu_ms_per_step", "per_rank_commander_steps_per_s", "sim_ticks_per_s", "ticks_per_commander_step")
+    keys = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "gpu_ms_per_step", "per_rank_commander_steps_per_s", "sim_ticks_per_s", "ticks_per_commander_step",
+            "ranks_seen", "gathered_rows", "first_global_arena_of_each_block", "arenas_of_each_block", "backend")
     out = {k: line[k] for k in keys if k in line}
     out["workload"] = line["config"]["workload"]
     out["parallelism"] = line["config"]["parallelism"]

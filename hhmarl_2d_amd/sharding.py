@@ -26,9 +26,35 @@ def gather_stats(block, world_size, group=None):
     import torch.distributed as dist
     if world_size == 1 and not (dist.is_available() and dist.is_initialized()):
         return block
+    seen = dist.get_world_size(group)
+    if seen != world_size:   # a launcher that started fewer ranks than the shards were cut for: the "global" block would silently lack arenas
+        raise RuntimeError(f"gather_stats: the process group has {seen} ranks but the world was sharded over {world_size}")
     out = torch.empty((world_size * block.shape[0], block.shape[1]), dtype=block.dtype, device=block.device)
     dist.all_gather_into_tensor(out, block, group=group)
+    if out.shape[0] != world_size * block.shape[0]:
+        raise RuntimeError(f"gather_stats: {out.shape[0]} rows gathered, {world_size} blocks of {block.shape[0]} expected")
     return out
+
+
+def gather_evidence(arena_offset, n_arenas, world_size, device, group=None):
+    """What a multi-rank bench line quotes so that "did the collective see N ranks" can be read from the line itself: every rank
+    contributes (rank, first global arena, arenas) through the SAME backend the statistics travel on (RCCL on GPUs, gloo in the CPU
+    tests); the blocks must arrive in rank order and tile the global arena range without gaps."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"ranks_seen": 1, "first_global_arena_of_each_block": [int(arena_offset)], "arenas_of_each_block": [int(n_arenas)], "backend": None}
+    seen = dist.get_world_size(group)
+    mine = torch.tensor([dist.get_rank(group), int(arena_offset), int(n_arenas)], dtype=torch.int64, device=device)
+    out = torch.empty((seen * 3,), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    rows = out.view(seen, 3).cpu().tolist()
+    if seen != world_size or [r[0] for r in rows] != list(range(seen)):
+        raise RuntimeError(f"gather_evidence: {seen} ranks answered {rows}, {world_size} launched")
+    for a, b in zip(rows, rows[1:]):
+        if b[1] != a[1] + a[2]:
+            raise RuntimeError(f"gather_evidence: the ranks' arena ranges do not tile the global range: {rows}")
+    return {"ranks_seen": seen, "first_global_arena_of_each_block": [r[1] for r in rows], "arenas_of_each_block": [r[2] for r in rows],
+            "backend": dist.get_backend(group)}
 
 
 def summarize(all_stats):
@@ -53,6 +79,7 @@ class ShardedWorld:
             self.world = World(make_config(**kw), device=device)
         else:
             self.world = world_factory(kw)
+        self.arena_offset, self.n_arenas = int(kw["arena_offset"]), int(kw["n_arenas"])
         self.last_stats = None
         self._blocks, self._events, self._k = [None, None], [None, None], 0
 
@@ -83,6 +110,16 @@ class ShardedWorld:
         self.last_stats.record_stream(cur)
         self.stats_ready = self._events[k]
         return self.last_stats
+
+    def evidence(self):
+        """ranks_seen / block order / gathered rows of the logging collective, for the bench line (one tiny all-gather on the current stream)"""
+        w = self.world
+        ev = gather_evidence(self.arena_offset, self.n_arenas, self.world_size, getattr(w, "device", torch.device("cpu")))
+        last = self.wait_stats() if hasattr(w, "episode_stats_packed") else self.last_stats
+        ev["gathered_rows"] = None if last is None else int(last.shape[0])
+        if last is not None and ev["gathered_rows"] != sum(ev["arenas_of_each_block"]):
+            raise RuntimeError(f"logging all-gather returned {ev['gathered_rows']} rows for blocks {ev['arenas_of_each_block']}")
+        return ev
 
     def wait_stats(self):
         """last_stats, safe to read from the current stream (orders it after the side-stream all-gather that produces it)"""

@@ -33,6 +33,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 from hhmarl_2d_amd import policy_nets as PN  # noqa: E402
+import policy_ref as PR  # noqa: E402
 
 REF_ROOT = "/root/reference"
 OUT = os.path.join(ROOT, "tests", "golden", "policy_nets.npz")
@@ -205,8 +206,8 @@ def generate_value():
             logits.append(lg[0].numpy())
             value.append(float(vf[0]))
         logits = np.stack(logits).astype(np.float32)
-        logp = PN.multicategorical_logp(logits, given, PN.N_OUT[kind]).numpy().astype(np.float32)
-        drawn, drawn_logp, margin = PN.inverse_cdf_actions(logits, u, PN.N_OUT[kind])
+        logp = PR.multicategorical_logp(logits, given, PN.N_OUT[kind]).numpy().astype(np.float32)
+        drawn, drawn_logp, margin = PR.inverse_cdf_actions(logits, u, PN.N_OUT[kind])
         name = PN.KIND_NAMES[kind].lower()
         out.update({f"obs_own_{name}": own, f"obs_other_{name}": oth, f"crit_act_own_{name}": ca_own, f"crit_act_other_{name}": ca_oth,
                     f"logits_{name}": logits, f"value_{name}": np.asarray(value, dtype=np.float32), f"given_{name}": given, f"logp_given_{name}": logp,

@@ -96,6 +96,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.hho_rng_u01.restype = C.c_double
         _lib.hho_rng_u01.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        _lib.hho_omp_set_threads.restype = None
     return _lib
 
 
@@ -169,13 +170,17 @@ class OracleWorld:
         assert rc == 0, rc
         return obs, rew, val, done
 
-    def rollout(self, actions):
+    def alloc_rollout_outputs(self, T):
+        """the four output arrays of rollout(), uninitialised (np.empty: pages are first touched by the threads that write them)"""
+        return (np.empty((T, self.N, self.n_agents, self.D), dtype=np.float32), np.empty((T, self.N, self.n_agents), dtype=np.float32),
+                np.empty((T, self.N, self.n_agents), dtype=np.uint8), np.empty((T, self.N), dtype=np.uint8))
+
+    def rollout(self, actions, out=None):
+        """T steps of every arena; out = alloc_rollout_outputs(T) re-uses the caller's arrays (every element is written by the call)"""
         T = actions.shape[0]
         actions = np.ascontiguousarray(actions, dtype=np.int8).reshape(T, self.N, self.n_ctrl, 4)
-        obs = np.zeros((T, self.N, self.n_agents, self.D), dtype=np.float32)
-        rew = np.zeros((T, self.N, self.n_agents), dtype=np.float32)
-        val = np.zeros((T, self.N, self.n_agents), dtype=np.uint8)
-        done = np.zeros((T, self.N), dtype=np.uint8)
+        obs, rew, val, done = out if out is not None else self.alloc_rollout_outputs(T)
+        assert obs.shape == (T, self.N, self.n_agents, self.D) and obs.flags.c_contiguous and done.shape == (T, self.N)
         rc = lib().hho_rollout(self.h, T, _ptr(actions, C.c_int8), _ptr(obs, C.c_float), _ptr(rew, C.c_float),
                                _ptr(val, C.c_uint8), _ptr(done, C.c_uint8))
         assert rc == 0, rc
@@ -255,6 +260,20 @@ class OracleWorld:
         oc = np.zeros((self.N,), dtype=np.int8)
         lib().hho_episode_stats(self.h, _ptr(ret, C.c_float), _ptr(ln, C.c_int32), _ptr(oc, C.c_int8))
         return ret, ln, oc
+
+
+def omp_max_threads():
+    """threads an OpenMP team of the oracle library gets (omp_get_max_threads)"""
+    return int(lib().hho_omp_max_threads())
+
+
+def omp_team_size():
+    """threads that really ran a parallel region just now (omp_get_num_threads inside one)"""
+    return int(lib().hho_omp_team_size())
+
+
+def omp_set_threads(n):
+    lib().hho_omp_set_threads(int(n))
 
 
 def action_tape_uniform(seed, arena_offset, step0, T, N, n_units=2):

@@ -49,11 +49,14 @@ def test_gpus_8_dry_run_is_the_scale_table_the_driver_will_fill():
     assert line["n_gpus"] == 8 and line["dry_run"] is True and line["scaling"] == "weak"
     assert len(line["per_rank_env_steps_per_s"]) == 8 and all(v > 0 for v in line["per_rank_env_steps_per_s"])
     assert line["gathered_rows"] == 8 * 8
+    # the keys the REAL N-rank line carries too (bench.py: main_low -> ShardedWorld.evidence): what the collective itself saw
+    assert line["ranks_seen"] == 8 and line["backend"] == "gloo"
+    assert line["first_global_arena_of_each_block"] == [8 * r for r in range(8)] and line["arenas_of_each_block"] == [8] * 8
     assert line["config"]["env_steps_per_step"] == 8 * 500 * 8
     assert abs(line["scaling_efficiency"] - line["value"] / (8 * 1000.0)) < 1e-12 and line["one_gpu_value"] == 1000.0
     c4 = line["extra"]["configs4"]
     assert c4["dry_run"] is True and c4["n_gpus"] == 8 and c4["arenas_per_gpu"] == 8192
-    assert c4["gathered_rows"] == 8 * 8192                                                   # BASELINE configs[4]: 65536 arenas over 8 ranks
+    assert c4["gathered_rows"] == 8 * 8192 and c4["ranks_seen"] == 8                         # BASELINE configs[4]: 65536 arenas over 8 ranks
     assert c4["first_global_arena_of_each_block"] == [float(8192 * r) for r in range(8)]    # blocks in global arena order
     assert "scaling_efficiency" not in _run(["--gpus", "2"])                                 # only when a 1-GPU value was supplied
 

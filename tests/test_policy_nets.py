@@ -11,6 +11,7 @@ import torch
 from helpers import random_actions
 
 from hhmarl_2d_amd import policy_nets as PN
+import policy_ref as PR   # oracle/policy_ref.py: the fp32 PyTorch restatement (test infrastructure)
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "policy_nets.npz")
 LOGIT_TOL = 1e-5
@@ -22,10 +23,10 @@ def test_torch_restatement_matches_reference_classes(kind):
     name = PN.KIND_NAMES[kind].lower()
     sd = PN.random_weights(kind, int(g["seed"]))
     obs = torch.from_numpy(g[f"obs_{name}"])
-    logits = PN.torch_forward(kind, sd, obs)
+    logits = PR.torch_forward(kind, sd, obs)
     assert logits.shape == (obs.shape[0], PN.N_OUT[kind])
     assert np.abs(logits.numpy() - g[f"logits_{name}"]).max() <= LOGIT_TOL
-    assert np.array_equal(PN.decode(logits, PN.N_OUT[kind]).numpy(), g[f"act_{name}"])
+    assert np.array_equal(PR.decode(logits, PN.N_OUT[kind]).numpy(), g[f"act_{name}"])
 
 
 def test_weight_tables_are_consistent():
@@ -100,10 +101,10 @@ def test_hip_kernel_mixed_networks_against_torch_fp32():
         idx = (sel == byte).nonzero().flatten()
         x = torch.zeros((len(idx), D), device="cuda")
         x[:, : PN.OBS_DIM[kind]] = obs[idx, : PN.OBS_DIM[kind]]     # the kernel must ignore columns beyond the net's width
-        ref = PN.torch_forward(kind, PN.random_weights(kind, 3), x.cpu())          # CPU fp32, like the reference
+        ref = PR.torch_forward(kind, PN.random_weights(kind, 3), x.cpu())          # CPU fp32, like the reference
         got = logits[idx, : PN.N_OUT[kind]].cpu()
         assert (got - ref).abs().max() <= LOGIT_TOL, PN.KIND_NAMES[kind]
-        ra = PN.decode(ref, PN.N_OUT[kind])
+        ra = PR.decode(ref, PN.N_OUT[kind])
         # arg-max must agree wherever the reference's winner leads by more than the tolerance
         parts = ref.split(PN.ACTION_SPLIT[: 4 if PN.N_OUT[kind] == 26 else 3], dim=1)
         clear = torch.stack([(p.topk(2, dim=1).values[:, 0] - p.topk(2, dim=1).values[:, 1]) > 1e-4 for p in parts], dim=1).all(dim=1)
@@ -150,12 +151,12 @@ def test_every_form_on_real_observations_of_a_full_world(monkeypatch, form, mode
     torch.cuda.synchronize()
     o = obs.cpu()
     for slot, kind in enumerate(kinds):
-        ref = PN.torch_forward(kind, PN.random_weights(kind, 5), o[:, slot])
+        ref = PR.torch_forward(kind, PN.random_weights(kind, 5), o[:, slot])
         err = (logits[:, slot, : PN.N_OUT[kind]].cpu() - ref).abs()
         assert err.max() <= LOGIT_TOL, f"{PN.KIND_NAMES[kind]}: {float(err.max()):.2e} on {int((err.max(dim=1).values > LOGIT_TOL).sum())} rows"
         parts = ref.split(PN.ACTION_SPLIT[: 4 if PN.N_OUT[kind] == 26 else 3], dim=1)
         clear = torch.stack([(p.topk(2, dim=1).values[:, 0] - p.topk(2, dim=1).values[:, 1]) > 1e-4 for p in parts], dim=1).all(dim=1)
-        assert torch.equal(act[:, slot].cpu()[clear], PN.decode(ref, PN.N_OUT[kind])[clear])
+        assert torch.equal(act[:, slot].cpu()[clear], PR.decode(ref, PN.N_OUT[kind])[clear])
 
 
 @pytest.mark.gpu
@@ -177,10 +178,10 @@ def test_net_pilot_drives_highlevel_env_and_matches_torch():
         if len(idx) == 0:
             continue
         rows = po[idx[:, 0], idx[:, 1]].cpu()
-        ref = PN.torch_forward(kind, PN.random_weights(kind, 9), rows)
+        ref = PR.torch_forward(kind, PN.random_weights(kind, 9), rows)
         parts = ref.split(PN.ACTION_SPLIT[: 4 if PN.N_OUT[kind] == 26 else 3], dim=1)
         clear = torch.stack([(p.topk(2, dim=1).values[:, 0] - p.topk(2, dim=1).values[:, 1]) > 1e-4 for p in parts], dim=1).all(dim=1)
-        assert torch.equal(act[idx[:, 0], idx[:, 1]].cpu()[clear], PN.decode(ref, PN.N_OUT[kind])[clear])
+        assert torch.equal(act[idx[:, 0], idx[:, 1]].cpu()[clear], PR.decode(ref, PN.N_OUT[kind])[clear])
         seen += 1
     assert seen >= 3 and (act[pm == 0] == 0).all()
     from hhmarl_2d_amd.env_hier import macro_step
@@ -216,10 +217,10 @@ def test_opponent_nets_drive_levels_4_5_through_the_facade(level):
                 idx = idx[(opp_obs[idx, slot].abs().sum(dim=1) > 0).cpu().numpy()]   # live opponents of running arenas (others get no action)
                 if len(idx) == 0:
                     continue
-                ref = PN.torch_forward(kind, PN.random_weights(kind, 11), opp_obs[idx, slot].cpu())
+                ref = PR.torch_forward(kind, PN.random_weights(kind, 11), opp_obs[idx, slot].cpu())
                 parts = ref.split(PN.ACTION_SPLIT[: 4 if PN.N_OUT[kind] == 26 else 3], dim=1)
                 clear = torch.stack([(p.topk(2, dim=1).values[:, 0] - p.topk(2, dim=1).values[:, 1]) > 1e-4 for p in parts], dim=1).all(dim=1)
-                assert torch.equal(act[idx, slot].cpu()[clear], PN.decode(ref, PN.N_OUT[kind])[clear])
+                assert torch.equal(act[idx, slot].cpu()[clear], PR.decode(ref, PN.N_OUT[kind])[clear])
                 seen["esc"] += int(kind in (PN.ESC1, PN.ESC2)) * len(idx)
         seen["calls"] += 1
         return act
@@ -490,7 +491,7 @@ def test_bank_from_loaded_modules_acts_like_the_torch_forward():
     bank.act(obs, sel, logits=logits)
     for byte, kind in zip(sels, (PN.FIGHT1, PN.FIGHT2, PN.ESC1, PN.ESC2)):
         idx = (sel == int(byte)).nonzero().flatten()
-        ref = PN.torch_forward(kind, PN.random_weights(kind, 8), obs[idx].cpu())
+        ref = PR.torch_forward(kind, PN.random_weights(kind, 8), obs[idx].cpu())
         assert (logits[idx, : PN.N_OUT[kind]].cpu() - ref).abs().max() <= LOGIT_TOL
 
 
@@ -535,10 +536,10 @@ def test_facades_load_the_reference_policy_files_themselves(tmp_path):
             idx = idx[(opp_obs[idx, slot].abs().sum(dim=1) > 0).cpu().numpy()]
             if len(idx) == 0:
                 continue
-            ref = PN.torch_forward(kind, PN.random_weights(kind, seed), opp_obs[idx, slot].cpu())
+            ref = PR.torch_forward(kind, PN.random_weights(kind, seed), opp_obs[idx, slot].cpu())
             parts = ref.split(PN.ACTION_SPLIT[: 4 if PN.N_OUT[kind] == 26 else 3], dim=1)
             clear = torch.stack([(p.topk(2, dim=1).values[:, 0] - p.topk(2, dim=1).values[:, 1]) > 1e-4 for p in parts], dim=1).all(dim=1)
-            assert torch.equal(got[idx, slot].cpu()[clear], PN.decode(ref, PN.N_OUT[kind])[clear]), (kk, name)
+            assert torch.equal(got[idx, slot].cpu()[clear], PR.decode(ref, PN.N_OUT[kind])[clear]), (kk, name)
             checked += int(clear.sum())
     assert checked > n
     env.close()

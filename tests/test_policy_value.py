@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from hhmarl_2d_amd import policy_nets as PN
+import policy_ref as PR   # oracle/policy_ref.py: the fp32 PyTorch restatement (test infrastructure)
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "policy_value.npz")
 TOL = 1e-5
@@ -32,9 +33,9 @@ def test_torch_value_restatement_matches_reference_classes(kind):
     seed = int(g["seed"])
     sd, csd = PN.random_weights(kind, seed), PN.random_critic_weights(kind, seed)
     t = lambda k: torch.from_numpy(g[f"{k}_{n}"])
-    v = PN.torch_value(kind, sd, csd, t("obs_own"), t("crit_act_own"), t("obs_other"), t("crit_act_other"))
+    v = PR.torch_value(kind, sd, csd, t("obs_own"), t("crit_act_own"), t("obs_other"), t("crit_act_other"))
     assert np.abs(v.numpy() - g[f"value_{n}"]).max() <= TOL
-    assert np.abs(PN.torch_forward(kind, sd, t("obs_own")).numpy() - g[f"logits_{n}"]).max() <= TOL
+    assert np.abs(PR.torch_forward(kind, sd, t("obs_own")).numpy() - g[f"logits_{n}"]).max() <= TOL
     # half of the rows are the sampler's (zero action inputs), half carry scaled actions: both kinds must be present
     z = (g[f"crit_act_own_{n}"] == 0).all(axis=1) & (g[f"crit_act_other_{n}"] == 0).all(axis=1)
     assert 0.3 < z.mean() < 0.7
@@ -44,15 +45,15 @@ def test_torch_value_restatement_matches_reference_classes(kind):
 def test_draw_and_logp_restatements(kind):
     g = np.load(GOLD)
     n = PN.KIND_NAMES[kind].lower()
-    act, logp, margin = PN.inverse_cdf_actions(g[f"logits_{n}"], g[f"u_{n}"], PN.N_OUT[kind])
+    act, logp, margin = PR.inverse_cdf_actions(g[f"logits_{n}"], g[f"u_{n}"], PN.N_OUT[kind])
     assert np.array_equal(act, g[f"drawn_{n}"]) and np.abs(logp - g[f"drawn_logp_{n}"]).max() <= 1e-6
-    lp = PN.multicategorical_logp(g[f"logits_{n}"], g[f"given_{n}"], PN.N_OUT[kind]).numpy()
+    lp = PR.multicategorical_logp(g[f"logits_{n}"], g[f"given_{n}"], PN.N_OUT[kind]).numpy()
     assert np.abs(lp - g[f"logp_given_{n}"]).max() <= 1e-6
     # the float64 inverse-CDF log-probability is the Categorical log_prob of the drawn action
-    assert np.abs(PN.multicategorical_logp(g[f"logits_{n}"], act, PN.N_OUT[kind]).numpy() - logp).max() <= 2e-6
+    assert np.abs(PR.multicategorical_logp(g[f"logits_{n}"], act, PN.N_OUT[kind]).numpy() - logp).max() <= 2e-6
     # a draw follows its distribution: u = 0 takes the first index, u -> 1 the last of every component
-    a0, _, _ = PN.inverse_cdf_actions(g[f"logits_{n}"], np.zeros((64, 4)), PN.N_OUT[kind])
-    a1, _, _ = PN.inverse_cdf_actions(g[f"logits_{n}"], np.full((64, 4), 1.0 - 1e-12), PN.N_OUT[kind])
+    a0, _, _ = PR.inverse_cdf_actions(g[f"logits_{n}"], np.zeros((64, 4)), PN.N_OUT[kind])
+    a1, _, _ = PR.inverse_cdf_actions(g[f"logits_{n}"], np.full((64, 4), 1.0 - 1e-12), PN.N_OUT[kind])
     last = np.array([12, 8, 1, 1 if PN.N_OUT[kind] == 26 else 0])
     assert (a0 == 0).all() and (a1 == last).all()
 
@@ -121,9 +122,9 @@ def test_hip_sample_matches_reference_vectors(monkeypatch, kind, form):
     assert np.abs(logp.cpu().numpy()[:, slot][clear] - g[f"drawn_logp_{n}"][clear]).max() <= TOL
     # greedy: the arg-max and its log-probability; the value does not depend on how the action is chosen
     act_g, logp_g, vf_g = bank.sample(torch.from_numpy(obs).cuda(), None, greedy=True, crit_act=torch.from_numpy(ca).cuda())
-    want = PN.decode(torch.from_numpy(g[f"logits_{n}"]), PN.N_OUT[kind]).numpy()
+    want = PR.decode(torch.from_numpy(g[f"logits_{n}"]), PN.N_OUT[kind]).numpy()
     assert np.array_equal(act_g.cpu().numpy()[:, slot], want)
-    assert np.abs(logp_g.cpu().numpy()[:, slot] - PN.multicategorical_logp(g[f"logits_{n}"], want, PN.N_OUT[kind]).numpy()).max() <= TOL
+    assert np.abs(logp_g.cpu().numpy()[:, slot] - PR.multicategorical_logp(g[f"logits_{n}"], want, PN.N_OUT[kind]).numpy()).max() <= TOL
     assert torch.equal(vf_g, vf)
 
 
@@ -157,17 +158,17 @@ def test_hip_sample_at_rollout_size_with_the_worlds_keyed_draws(monkeypatch, mod
     sub = np.arange(0, N, 37)
     for slot, kind in enumerate(kinds):
         sd, csd = PN.random_weights(kind, 5), PN.random_critic_weights(kind, 5)
-        ref_l = PN.torch_forward(kind, sd, o[:, slot])
-        ref_v = PN.torch_value(kind, sd, csd, o[:, slot], zeros4, o[:, 1 - slot], zeros4)
+        ref_l = PR.torch_forward(kind, sd, o[:, slot])
+        ref_v = PR.torch_value(kind, sd, csd, o[:, slot], zeros4, o[:, 1 - slot], zeros4)
         got_l = logits[:, slot, : PN.N_OUT[kind]].cpu()
         assert (got_l - ref_l).abs().max() <= TOL and (logits[:, slot, PN.N_OUT[kind]:] == 0).all()
         assert (vf[:, slot].cpu() - ref_v).abs().max() <= TOL
         u = np.array([[lib.hho_rng_u01(77, 1000 + int(n), int(st[n, 5]), int(st[n, 0]), slot + 1, 25, c) for c in range(4)] for n in sub])
-        want, want_lp, margin = PN.inverse_cdf_actions(got_l.numpy()[sub].astype(np.float64), u, PN.N_OUT[kind])
+        want, want_lp, margin = PR.inverse_cdf_actions(got_l.numpy()[sub].astype(np.float64), u, PN.N_OUT[kind])
         clear = margin > 1e-6
         assert clear.mean() > 0.99
         assert np.array_equal(act[:, slot].cpu().numpy()[sub][clear], want[clear])
-        lp = PN.multicategorical_logp(got_l, act[:, slot].cpu().numpy(), PN.N_OUT[kind])
+        lp = PR.multicategorical_logp(got_l, act[:, slot].cpu().numpy(), PN.N_OUT[kind])
         assert (logp[:, slot].cpu() - lp).abs().max() <= TOL
         # the draw is a draw: every action value of every component occurs, and the empirical mean log-probability is the (negative) entropy scale
         for c, hi in enumerate((13, 9, 2, 2)[: 4 if PN.N_OUT[kind] == 26 else 3]):
@@ -347,8 +348,8 @@ def test_one_shared_layer_for_both_policies_and_set_net_invalidates_the_value_br
         _, _, vf = bank.sample(obs, sel, greedy=True, logits=logits)
         o = obs.cpu()
         for slot, kind in enumerate((PN.FIGHT1, PN.FIGHT2)):
-            assert (logits[:, slot, : PN.N_OUT[kind]].cpu() - PN.torch_forward(kind, sds[slot], o[:, slot])).abs().max() <= TOL
-            assert (vf[:, slot].cpu() - PN.torch_value(kind, sds[slot], csds[slot], o[:, slot], zeros4, o[:, 1 - slot], zeros4)).abs().max() <= TOL
+            assert (logits[:, slot, : PN.N_OUT[kind]].cpu() - PR.torch_forward(kind, sds[slot], o[:, slot])).abs().max() <= TOL
+            assert (vf[:, slot].cpu() - PR.torch_value(kind, sds[slot], csds[slot], o[:, slot], zeros4, o[:, 1 - slot], zeros4)).abs().max() <= TOL
     csds = [PN.random_critic_weights(k, 3) for k in (PN.FIGHT1, PN.FIGHT2)]
     check(bank, sds, csds)
     # a PPO iteration reloads slot 1's actor only: its value branch would evaluate the OLD shared layer — refused instead

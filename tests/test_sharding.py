@@ -53,6 +53,14 @@ def _worker(rank, world_size, port, n_per_rank, T, out_dir):
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), obs=obs.numpy(), rew=rew.numpy(), done=done.numpy(), stats=stats.numpy())
     s = summarize(stats)
     assert s["episodes"] > 0 and s["agents_win"] + s["opps_win"] + s["draw"] == s["episodes"]
+    # what a multi-rank bench line quotes: the collective itself saw every rank, blocks in rank order tiling the global arena range
+    ev = sw.evidence()
+    assert ev["ranks_seen"] == world_size and ev["gathered_rows"] == n_per_rank * world_size and ev["backend"] == "gloo"
+    assert ev["first_global_arena_of_each_block"] == [r * n_per_rank for r in range(world_size)]
+    # a world sharded for MORE ranks than the job has must not pass for a global block
+    from hhmarl_2d_amd.sharding import gather_stats
+    with pytest.raises(RuntimeError, match="ranks"):
+        gather_stats(stats[:n_per_rank].contiguous(), world_size + 1)
     dist.barrier()
     dist.destroy_process_group()
 

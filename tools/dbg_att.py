@@ -4,7 +4,9 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 os.environ["HH_POLICY_W"] = sys.argv[1] if len(sys.argv) > 1 else "2"
 from hhmarl_2d_amd.world import World, make_config
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 from hhmarl_2d_amd import pilots, policy_nets as PN
+import policy_ref as PR  # noqa: E402  (oracle/policy_ref.py)
 N = 16384
 w = World(make_config(n_arenas=N, level=3, seed=77, arena_offset=1000, auto_reset=True), device=0)
 obs = w.reset()
@@ -28,8 +30,8 @@ for variant in ("plain", "att_out_zero", "att_all_zero", "inp3_small"):
     logits = torch.zeros((N, 32), dtype=torch.float32, device="cuda")
     bank.act(o, sel, logits=logits)
     torch.cuda.synchronize()
-    ref = PN.torch_forward(PN.FIGHT1, sd, o.cpu())
-    ref64 = PN.torch_forward(PN.FIGHT1, sd, o.cpu()).double()
+    ref = PR.torch_forward(PN.FIGHT1, sd, o.cpu())
+    ref64 = PR.torch_forward(PN.FIGHT1, sd, o.cpu()).double()
     err = (logits[:, :26].cpu() - ref).abs()
     r = int(err.max(dim=1).values.argmax())
     print(f"{variant:14s} max err {float(err.max()):.2e}  rows > 5e-6: {int((err.max(dim=1).values > 5e-6).sum())}  worst row {r}: per-column err {err[r].numpy().round(7)[:8]}")
@@ -39,7 +41,7 @@ sd = PN.random_weights(PN.FIGHT1, 5)
 bank = pilots.PolicyBank(torch.device("cuda", 0), N); bank.set_net(0, PN.FIGHT1, sd); bank.set_lut({pilots.SEL_FIGHT1: 0})
 logits = torch.zeros((N, 32), dtype=torch.float32, device="cuda")
 bank.act(o, sel, logits=logits); torch.cuda.synchronize()
-ref = PN.torch_forward(PN.FIGHT1, sd, o.cpu())
+ref = PR.torch_forward(PN.FIGHT1, sd, o.cpu())
 err = (logits[:, :26].cpu() - ref).abs().max(dim=1).values
 bad = err > 5e-6
 oc = o.cpu()

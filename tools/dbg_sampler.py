@@ -3,7 +3,9 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 os.environ["HH_POLICY_W"] = sys.argv[1] if len(sys.argv) > 1 else "2"
 from hhmarl_2d_amd.world import World, make_config
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 from hhmarl_2d_amd import pilots, policy_nets as PN
+import policy_ref as PR  # noqa: E402  (oracle/policy_ref.py)
 N = 16384
 MODE = sys.argv[3] if len(sys.argv) > 3 else "fight"
 from hhmarl_2d_amd import _lib as L
@@ -24,8 +26,8 @@ torch.cuda.synchronize()
 o = obs.cpu()
 for slot, kind in enumerate((PN.FIGHT1, PN.FIGHT2) if MODE == "fight" else (PN.ESC1, PN.ESC2)):
     sd = PN.random_weights(kind, 5)
-    ref = PN.torch_forward(kind, sd, o[:, slot])
-    ref64 = PN.torch_forward(kind, {k: v.astype(np.float64) for k, v in sd.items()}, o[:, slot].double()) if False else None
+    ref = PR.torch_forward(kind, sd, o[:, slot])
+    ref64 = PR.torch_forward(kind, {k: v.astype(np.float64) for k, v in sd.items()}, o[:, slot].double()) if False else None
     err = (logits[:, slot, :PN.N_OUT[kind]].cpu() - ref).abs()
     bad = (err.max(dim=1).values > 5e-6).nonzero().flatten()
     print(PN.KIND_NAMES[kind], "max err", float(err.max()), "rows > 5e-6:", len(bad))

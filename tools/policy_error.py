@@ -6,7 +6,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 from hhmarl_2d_amd import pilots, policy_nets as PN  # noqa: E402
+import policy_ref as PR  # noqa: E402  (oracle/policy_ref.py)
 
 R = 8192
 rng = np.random.default_rng(0)
@@ -27,7 +29,7 @@ for kind, byte in ((PN.FIGHT1, pilots.SEL_FIGHT1), (PN.FIGHT2, pilots.SEL_FIGHT2
         h[2] = F.normalize(h[2] + att)
     s = torch.tanh(F.linear(torch.cat(h, 1), t["shared_layer._model.0.weight"], t["shared_layer._model.0.bias"]))
     ref64 = F.linear(s, t["act_out._model.0.weight"], t["act_out._model.0.bias"])
-    ref32 = PN.torch_forward(kind, PN.random_weights(kind, 3), obs)
+    ref32 = PR.torch_forward(kind, PN.random_weights(kind, 3), obs)
     got = logits[:, : PN.N_OUT[kind]].cpu().double()
     print(f"{PN.KIND_NAMES[kind]:7s} kernel vs f64: max {float((got - ref64).abs().max()):.2e} mean {float((got - ref64).abs().mean()):.2e} | "
           f"torch fp32 (CPU) vs f64: max {float((ref32.double() - ref64).abs().max()):.2e} mean {float((ref32.double() - ref64).abs().mean()):.2e}")

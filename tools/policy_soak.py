@@ -13,7 +13,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 from hhmarl_2d_amd import pilots, policy_nets as PN  # noqa: E402
+import policy_ref as PR  # noqa: E402  (oracle/policy_ref.py)
 from hhmarl_2d_amd.world import World, make_config  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -56,9 +58,9 @@ for mode, kinds, sels in (("fight", (PN.FIGHT1, PN.FIGHT2), (pilots.SEL_FIGHT1, 
     for slot, kind in enumerate(kinds):
         sd = PN.random_weights(kind, SEED)
         x = obs[:, slot].cpu()
-        r64 = PN.torch_forward(kind, sd, x, dtype=torch.float64)
+        r64 = PR.torch_forward(kind, sd, x, dtype=torch.float64)
         ref64.append(r64)
-        ref32.append(float((PN.torch_forward(kind, sd, x).double() - r64).abs().max()))
+        ref32.append(float((PR.torch_forward(kind, sd, x).double() - r64).abs().max()))
     print(f"== {mode}: {R} arena-ticks x 2 agents ({int(live.sum())} rows of live agents); fp32 PyTorch forward vs float64: " + ", ".join(f"{PN.KIND_NAMES[k]} {e:.2e}" for k, e in zip(kinds, ref32)))
     for name, env in FORMS.items():
         setenv(env)
@@ -68,7 +70,7 @@ for mode, kinds, sels in (("fight", (PN.FIGHT1, PN.FIGHT2), (pilots.SEL_FIGHT1, 
         for slot, kind in enumerate(kinds):
             n_out = PN.N_OUT[kind]
             err = (lg[:, slot, :n_out].cpu().double() - ref64[slot]).abs()
-            want = PN.decode(ref64[slot], n_out)
+            want = PR.decode(ref64[slot], n_out)
             top2 = torch.stack([p.topk(2, dim=1).values for p in ref64[slot][:, :n_out].split(PN.ACTION_SPLIT[: 4 if n_out == 26 else 3], dim=1)], dim=0)
             clear = ((top2[..., 0] - top2[..., 1]) > 2 * TOL).all(dim=0)
             agree = bool((act[:, slot][clear] == want[clear]).all())
@@ -90,8 +92,8 @@ for mode, kinds, sels in (("fight", (PN.FIGHT1, PN.FIGHT2), (pilots.SEL_FIGHT1, 
             sd, csd = PN.random_weights(kind, SEED), PN.random_critic_weights(kind, SEED)
             x, x2 = obs[:, slot].cpu(), obs[:, 1 - slot].cpu()
             z = torch.zeros((R, 4))
-            v64 = PN.torch_value(kind, sd, csd, x, z, x2, z, dtype=torch.float64)
-            a64, lp64, margin = PN.inverse_cdf_actions(ref64[slot].numpy(), u[:, slot].cpu().numpy(), n_out)
+            v64 = PR.torch_value(kind, sd, csd, x, z, x2, z, dtype=torch.float64)
+            a64, lp64, margin = PR.inverse_cdf_actions(ref64[slot].numpy(), u[:, slot].cpu().numpy(), n_out)
             clear = margin > TOL
             e_v = float((vf[:, slot].cpu().double() - v64).abs().max())
             e_lp = float(np.abs(logp[:, slot].cpu().numpy().astype(np.float64) - lp64)[clear].max())

@@ -4,7 +4,8 @@ per GPU.  Every rank steps its shard, snapshots its [N, 3] statistics block and 
 (ShardedWorld.log_episode_stats); the gathered block must equal the concatenation of every rank's own
 hh_episode_stats_packed block (exchanged once more with a plain all_gather on the default stream as the check).
 Prints RCCL_CHECK_OK <ranks> <rows> on rank 0.   tests/test_gpu_sharding_rccl.py runs it with one rank on the 1-GPU box;
-`python -m torch.distributed.run --nproc-per-node 8 tools/rccl_check.py` is the 8-GPU form."""
+`python tools/rccl_check.py --launch 8` is the 8-GPU form: it starts the job with NCCL_DEBUG=INFO and also fails when RCCL's own
+log reports fewer ranks than were launched."""
 import os
 import sys
 
@@ -43,11 +44,53 @@ def main():
     assert torch.equal(got[rank * N:(rank + 1) * N], mine)
     finished = int((got[:, 2] != 2).sum())
     assert finished > 0, "no episode finished: the block would be trivially equal"
+    ev = sw.evidence()
+    assert ev["ranks_seen"] == world and ev["gathered_rows"] == world * N and ev["first_global_arena_of_each_block"] == [r * N for r in range(world)], ev
     dist.barrier()
     if rank == 0:
         print(f"RCCL_CHECK_OK {world} {got.shape[0]} finished={finished}", flush=True)
     dist.destroy_process_group()
 
 
+def launch(n):
+    """`python tools/rccl_check.py --launch N`: start the N-rank job itself with NCCL_DEBUG=INFO (one log file per rank) and FAIL unless RCCL's
+    own log says what the script printed: every rank's communicator finished its init with `nranks N`, and N distinct ranks did."""
+    import re
+    import socket
+    import subprocess
+    import tempfile
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    logdir = tempfile.mkdtemp(prefix="rccl_check_")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1", NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT",
+               NCCL_DEBUG_FILE=os.path.join(logdir, "rccl.%h.%p.log"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    sys.stdout.write(p.stdout)
+    sys.stderr.write(p.stderr[-4000:])
+    if p.returncode != 0 or f"RCCL_CHECK_OK {n} " not in p.stdout:
+        sys.exit(f"rccl_check: the {n}-rank job failed (exit {p.returncode})")
+    ranks, nranks = set(), set()
+    for fn in os.listdir(logdir):
+        with open(os.path.join(logdir, fn), errors="replace") as f:
+            for ln in f:
+                m = re.search(r"rank (\d+) nranks (\d+).*Init COMPLETE", ln)
+                if m:
+                    ranks.add(int(m.group(1)))
+                    nranks.add(int(m.group(2)))
+    # the job may create more than one communicator (the default group and device-bound ones); the one that spans the job has nranks == n
+    if n not in nranks or not set(range(n)) <= ranks:
+        sys.exit(f"rccl_check: RCCL's log reports ranks {sorted(ranks)} and communicator sizes {sorted(nranks)}; {n} ranks were launched ({logdir})")
+    print(f"RCCL_LOG_OK ranks={sorted(ranks)} nranks={sorted(nranks)}", flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) >= 3 and sys.argv[1] == "--launch":
+        launch(int(sys.argv[2]))
+    else:
+        main()

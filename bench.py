@@ -693,8 +693,6 @@ def main_hier(args, R=None):
     from hhmarl_2d_amd.sharding import ShardedWorld
     N = args.arenas or 8192
     K = (args.streams or DEFAULT_STREAMS["hier_net_variants" if args.pilot_rows == "variants" else "hier_net"]) if args.pilot == "net" else 1
-    assert N % K == 0, "--streams must divide the arena count"
-    n_sub = N // K
     if K > 1 or args.pilot == "net":   # the networks-in-the-loop workload always runs the sub-world form (K = 1: one sub-world)
         return main_hier_split(args, R, own, N, K)
     sw = ShardedWorld(dict(n_arenas=N, env_kind=1, seed=args.seed, auto_reset=True), rank=R.rank, world_size=R.world, device=R.local_rank)
@@ -822,13 +820,16 @@ def main_hier_split(args, R, own, N, K):
     from hhmarl_2d_amd.env_hier import macro_step
     from hhmarl_2d_amd.pilots import NetPilot, VariantNetPilot
     from hhmarl_2d_amd.sharding import ShardedWorld
-    n = N // K
+    sizes = [N // K + (1 if k < N % K else 0) for k in range(K)]   # K need not divide N: the sub-worlds tile [0, N) with sizes differing by at most one arena
+    offs = [sum(sizes[:k]) for k in range(K)]
+    n = sizes[0]
     variants = args.pilot_rows == "variants"
     if variants and "HH_POLICY_W" not in os.environ and "HH_POLICY_TILE" not in os.environ and K > 1:
         # calls of ~10 k listed rows from several streams at once: the streamed form with 128-row tiles is ahead of what the bank's back-to-back heuristic
         # picks (4.64e6 against 3.92e6 commander-steps/s at K = 4; tools/variants_rates2.sh); read by hh_policy_create
         os.environ["HH_POLICY_W"] = "3"
-    sws = [ShardedWorld(dict(n_arenas=n, env_kind=1, seed=args.seed, auto_reset=True, arena_offset=k * n + R.rank * (N - n)), rank=R.rank, world_size=R.world,
+    # ShardedWorld adds rank * n_arenas to the offset it is given: sub-world k of rank r starts at global arena r N + offs[k]
+    sws = [ShardedWorld(dict(n_arenas=sizes[k], env_kind=1, seed=args.seed, auto_reset=True, arena_offset=offs[k] + R.rank * (N - sizes[k])), rank=R.rank, world_size=R.world,
                         device=R.local_rank) for k in range(K)]
     worlds = [x.world for x in sws]
     for w in worlds:
@@ -838,7 +839,7 @@ def main_hier_split(args, R, own, N, K):
         for pl in pilots_:   # small calls on concurrent streams stay on the tile forms: wide tiles, the other streams fill what a partial round leaves idle
             pl.bank.set_tile_rows(64)
     cmds = commander_tape(args, R, N)
-    cmd_static = [cmds[0, k * n:(k + 1) * n].clone() for k in range(K)]
+    cmd_static = [cmds[0, offs[k]:offs[k] + sizes[k]].clone() for k in range(K)]
     outs = [w.alloc_outputs() for w in worlds]
     pbufs = [(w.alloc_pilot_variants() if variants else w.alloc_pilot()) for w in worlds]
     streams = [torch.cuda.Stream() for _ in range(K)]
@@ -870,7 +871,7 @@ def main_hier_split(args, R, own, N, K):
         for _ in range(m):
             k = state["k"]
             for j in range(K):
-                cmd_static[j].copy_(cmds[k % 64, j * n:(j + 1) * n])
+                cmd_static[j].copy_(cmds[k % 64, offs[j]:offs[j] + sizes[j]])
             if graph is not None:
                 graph.replay()
             else:   # --no-graph: the same launches issued eagerly on the K streams (A/B of the graph's scheduling)

@@ -767,9 +767,11 @@ __device__ __forceinline__ int oct_do_tick(const DevPtrs &P, const DevCfg &c, Oc
     /* env_hier.py:133-135: the surrounding event is looked for only after min_sub_steps (s > 10).  Without FULL the table is
      * built here, on the ticks that read it (wave-uniform: some arena of the wave is that far into its macro step) */
     const bool look = was_running && H.ar.hl_s > 10;
+#ifndef HHO_ABL_NO_EVT /* tuning builds only (tools/build_variant.sh): WRONG RESULTS on purpose — what does the surrounding event's table (sub-steps 11..15) cost? */
     if (__ballot(look)) {
         if (!FULL) oct_tables<false>(H.m, pub, L, tb);
     }
+#endif
     int near_ = 0;
     if (look && L.exists && L.q == 0 && H.m.alive) {
 #pragma unroll
@@ -946,8 +948,10 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_macro_oct(DevPtrs P, DevCfg c
         tab = false;
         if (running) evm_last = H.evm;
     }
+#ifndef HHO_ABL_NO_END_TABLE /* tuning builds only: WRONG RESULTS on purpose — the full pair table in front of the commander observation (what an output wave could take) */
     oct_publish_norm(c, H.m, pub);
     oct_tables<true>(H.m, pub, L, tb);
+#endif
     oct_do_end(P, c, sh, tid, L, n, active, H, tb, pub, HH_HL_END, reward_out, valid_out, done_out, nullptr);
     if (obs_out) { /* the workgroup's agent rows are contiguous in [N, nA, 34] */
         const int arenas = min(8, c.N - (int)blockIdx.x * 8);

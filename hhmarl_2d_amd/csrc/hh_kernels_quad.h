@@ -115,7 +115,15 @@ __device__ __forceinline__ void quad_publish_motion(const DevCfg &c, const Unit 
 struct QPosMail { double lat[64], lon[64], spd[64], hdg[64]; int ac_type[64], steps[64], episode[64], escw[64]; };   /* sim -> out at X; escw: the arena's
                                                                       escape flag | timer << 8 after this tick's script | alive mask at tick start << 16 */
 struct QTabMail { double dist[3][64], foc[3][64], focr[3][64]; double uc[64], us[64], sx[64], sy[64]; unsigned long long tk[64];
-                  double sp_hdg[64], sp_spd[64]; int sp_w[64]; };   /* out -> sim at Y; sp_*: QPre */
+                  double sp_hdg[64], sp_spd[64]; int sp_w[64];      /* out -> sim at Y; sp_*: QPre */
+                  double nr0[64], nfoc[64], nfocr[64]; int nbw[64]; }; /* QTgt / Near2 of the lane, computed by the output wave on the prediction that the tick
+                                                                      * changes no alive mask (QPre.spec): nbw = n | j0 << 2 | k0 << 4 */
+/* What the simulation wave of the OWT forms reads of the post-tick pair table during the next tick is ONE relative slot per lane — the lane's launch target
+ * (env_base.py:227-236: opp_to_attack for an agent, the script's nearest agent for an opponent): its planar distance and focus angle in the launch
+ * stage, its focus on the lane in one reward term (env_hetero.py:169-170 opp_stats).  So that wave carries these three doubles across the tick instead of the
+ * table's nine, and on the four ticks in five that change no alive mask it does not even select them: the output wave, which runs _nearby_object on its
+ * own copy of the table for the speculated script anyway, hands them over with (n, j0, k0) — 12 LDS reads instead of 17 and no quad_nearby behind barrier Y. */
+struct QTgt { double foc, focr, dist; };
 /* The heading unit vector after the turn (a sincos and a square root) is computed by the OUTPUT wave too: the table needs it exactly, the simulation wave
  * needs it inside the tick only for the cannon prefilter (hh_envelope.h: hh_cannon_cone_planar_outside, a one-sided test with a 0.3 deg margin of which the
  * planar-vs-geodesic bound uses 0.26), for which the exact vector of the tick before, rotated by the turn just made (<= 5 deg: cos / sin by their Taylor
@@ -368,7 +376,7 @@ __device__ __forceinline__ void quad_l3_flags(int steps, unsigned long long tkey
 /* what the script decides for one opponent; opp = target slot or -1.  rs / rc: round(sin(hdg), 3), round(cos(hdg), 3) (_correct_angle_sign) */
 struct QScriptOut { double heading, speed; int fire, fire_m, opp; };
 __device__ __forceinline__ void quad_l3_script(const DevCfg &c, double lat, double lon, double hdg, int ac_type, bool my_escaping, double u0, double u1, double u2,
-                                               const Near2 &nb, const QTab &tb, double rs, double rc, QScriptOut &o) {
+                                               const Near2 &nb, const QTab &tb, double focus_k0, double rs, double rc, QScriptOut &o) {
     int opp = -1, fire = 0, fire_m = 0;
     double heading, speed;
     if (my_escaping) { /* env_hetero.py:227-245 _escaping_opp */
@@ -389,7 +397,7 @@ __device__ __forceinline__ void quad_l3_script(const DevCfg &c, double lat, doub
             double val = (x1 - lon) * (ag_lat - lat) - (ag_lon - lon) * (y1 - lat);
             double sign = val < 0.0 ? 1.0 : -1.0;
             double r = hh_rng_uniform(u1, 0.7, 1.3);
-            double focus = q_sel(tb.foc, nb.k0);
+            double focus = focus_k0; /* = q_sel(tb.foc, nb.k0): by value, the OWT simulation wave does not hold the table's focus entries */
             const double turned = hh_pymod360(heading + r * sign * focus);
             heading = ((nb.d0 > 0.008) & (focus > 4.0)) ? turned : heading;
             const double us = u2;
@@ -410,8 +418,9 @@ __device__ __forceinline__ void quad_l3_script(const DevCfg &c, double lat, doub
  * table on return.  Line-by-line counterpart of tick<4, 64>(tmode 0) in hh_kernels.h. */
 template <bool IX, bool DUAL, bool OWT = false>
 __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, int tid, int g, int s, int base, bool active, bool helper, Unit &m,
-                                          Arena &ar, const int8_t *act, QTab &tb, QPub &pub, Near2 &nbc, StepOut &out,
+                                          Arena &ar, const int8_t *act, QTab &tb, QPub &pub, Near2 &nbc, const QTgt &tg, StepOut &out,
                                           uint32_t &ev_mask_out, QPosMail *pos, const QPre &pre HH_PROF_ARGS) {
+    /* OWT: tb.dist / foc / focr are NOT valid in here — the entries of the lane's target travel in `tg` (QTgt above) */
     /* OWT: the post-tick pair table is built by the output wave (QPosMail above).  This function then posts the moved positions and meets the
      * output wave at barrier X after phase B, and returns with tb.lat / lon / amask refreshed but tb.dist / foc / focr and nbc still the PRE-tick
      * ones: the caller takes the new ones from the output wave at barrier Y. */
@@ -551,7 +560,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                 rs = hh_round3(sn); rc = hh_round3(cs);
             }
             QScriptOut so_;
-            quad_l3_script(c, m.lat, m.lon, m.hdg, m.ac_type, my_escaping, u0, u1, u2, nbc, tb, rs, rc, so_);
+            quad_l3_script(c, m.lat, m.lon, m.hdg, m.ac_type, my_escaping, u0, u1, u2, nbc, tb, OWT ? tg.foc : q_sel(tb.foc, nbc.k0), rs, rc, so_);
             m.cmd_hdg = so_.heading;
             m.cmd_spd = so_.speed;
             if (so_.fire) arm_cannon(m);
@@ -702,11 +711,12 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
      * is the geometry of the pair table — its planar focus angle decides all but the ~1 % of launches within half a
      * degree of the cone's edges (hh_envelope.h); only those go through the queue */
     int launch_pre = -1;
-    if (try_launch) {
+    if (q_any(try_launch)) { /* wave-uniform; the stage is straight-line (hh_envelope.h), evaluated on every lane and kept by the launching ones */
         const int kl = (launch_tgt - s) & 3;
         const double t_lat = q_sel(tb.lat, kl), t_lon = q_sel(tb.lon, kl);
         const double cross = pub.uc * (t_lat - lat_old) - pub.us * (t_lon - lon_old);
-        launch_pre = hh_missile_cone_planar(lat_old, lon_old, t_lat, t_lon, q_sel(tb.foc, kl), cross, q_sel(tb.dist, kl));
+        const int lp = hh_missile_cone_planar(lat_old, lon_old, t_lat, t_lon, OWT ? tg.foc : q_sel(tb.foc, kl), cross, OWT ? tg.dist : q_sel(tb.dist, kl));
+        launch_pre = try_launch ? lp : -1;
     }
     int q_total = 0;
     {
@@ -822,9 +832,10 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         ar.next_seq += total;
     }
     int rkw = 0; /* bit0 present, bit1 fuse on target, bit2 fuse on "friendly", bit3 end of life, bits4-6 target, bits 8.. seq */
-    if (running && rk_at_start) {
-        int eol = m.rk_life > HH_ROCKET_MAX_LIFE;
-        rkw = 1 | (((myres >> 9) & 1) << 1) | (((myres >> 10) & 1) << 2) | (eol << 3) | ((m.rk_target - 1) << 4) | (m.rk_seq << 8);
+    {
+        const int eol = m.rk_life > HH_ROCKET_MAX_LIFE;
+        const int w = 1 | (((myres >> 9) & 1) << 1) | (((myres >> 10) & 1) << 2) | (eol << 3) | ((m.rk_target - 1) << 4) | (m.rk_seq << 8);
+        rkw = (running & (rk_at_start != 0)) ? w : 0;
     }
     int res_[A];
     res_[0] = q_bc_i<0>(rkw); res_[1] = q_bc_i<1>(rkw); res_[2] = q_bc_i<2>(rkw); res_[3] = q_bc_i<3>(rkw);
@@ -942,7 +953,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
                             /* the killer acted in this tick (it was alive at tick start), `tb` still holds the pre-tick table here */
                             const int t1 = tgt_at_act ? tgt_at_act - 1 : 0;
                             const bool os_ok = (tgt_at_act != 0) & (((amask0 >> t1) & 1) != 0);
-                            const double opp_stat0 = os_ok ? norm180(q_sel(tb.focr, (t1 - s) & 3)) : 0.0;
+                            const double opp_stat0 = os_ok ? norm180(OWT ? tg.focr : q_sel(tb.focr, (t1 - s) & 3)) : 0.0;
                             double r2 = 0.5 + ((1.0 - 0.5) / (1.0 - 0.0)) * (opp_stat0 - 0.0);
                             rews += (r1 + r2) * sc;
                         }
@@ -1194,12 +1205,17 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                 mbx.tab.uc[tid] = pub.uc; mbx.tab.us[tid] = pub.us;
                 mbx.tab.tk[tid] = tk1;
                 mbx.tab.sx[tid] = rs_ahead; mbx.tab.sy[tid] = rc_ahead;
+                /* _nearby_object on this wave's table with the alive mask the tick started with: what the simulation wave would compute behind Y whenever the
+                 * tick changes no alive mask (QPre.spec), with the entries of the nearest one (QTgt) */
+                tb.amask = am;
+                Near2 nb;
+                quad_nearby(c, tb, s, nb);
+                const double foc_k0 = q_sel(tb.foc, nb.k0);
+                mbx.tab.nr0[tid] = nb.r0; mbx.tab.nfoc[tid] = foc_k0; mbx.tab.nfocr[tid] = q_sel(tb.focr, nb.k0);
+                mbx.tab.nbw[tid] = (nb.n & 3) | ((nb.j0 & 3) << 2) | ((nb.k0 & 3) << 4);
                 if (l3) { /* the script itself, from this wave's own table */
-                    tb.amask = am;
-                    Near2 nb;
-                    quad_nearby(c, tb, s, nb);
                     QScriptOut so_;
-                    quad_l3_script(c, m.lat, m.lon, m.hdg, m.ac_type, my_escaping, u0, u1, u2, nb, tb, rs_ahead, rc_ahead, so_);
+                    quad_l3_script(c, m.lat, m.lon, m.hdg, m.ac_type, my_escaping, u0, u1, u2, nb, tb, foc_k0, rs_ahead, rc_ahead, so_);
                     mbx.tab.sp_hdg[tid] = so_.heading; mbx.tab.sp_spd[tid] = so_.speed;
                     mbx.tab.sp_w[tid] = (so_.fire & 1) | ((so_.fire_m & 1) << 1) | (((so_.opp + 1) & 7) << 2) | ((esc & 0xff) << 8) | ((esc_t & 0xff) << 16);
                 }
@@ -1336,6 +1352,12 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
     quad_publish(c, m, pub);
     quad_tables<DUAL>(m, pub, s, helper, tb);
     quad_nearby(c, tb, s, nbc);
+    QTgt tg;
+    { /* the lane's target entries (OWT).  An agent's opp_to_attack comes with the loaded state and need not be the nearest opponent (hh_set_state): the first
+       * tick reads the entries of THAT slot; every later tick's target is the refreshed one = nbc.j0 */
+        const int ks = (s < 2 && m.n_tgt) ? ((m.tgt0 - 1 - s) & 3) : nbc.k0;
+        tg.foc = q_sel(tb.foc, ks); tg.focr = q_sel(tb.focr, ks); tg.dist = q_sel(tb.dist, ks);
+    }
     /* Action words: vmcnt is one in-order counter for loads AND stores, so waiting for a load also waits for the
      * write acknowledgements of every store issued before it.  The word of tick t+1 is therefore taken (waited
      * for) right after tick t's compute and BEFORE tick t's output stores, when the load is a whole tick old and
@@ -1357,7 +1379,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         QPosMail *posmail = nullptr;
         if constexpr (OWT) posmail = &mbx.pos;
         const int amask_before = tb.amask; /* alive at tick start: QPre.spec holds when the tick leaves it as it is */
-        tick_quad<(W >= 2), DUAL, OWT>(c, sh, tid, g, s, base, active, helper, m, ar, act, tb, pub, nbc, so, evm_last, posmail, pre HH_PROF_PASS);
+        tick_quad<(W >= 2), DUAL, OWT>(c, sh, tid, g, s, base, active, helper, m, ar, act, tb, pub, nbc, tg, so, evm_last, posmail, pre HH_PROF_PASS);
         const int done_now = ar.done;
         if constexpr (TWO && !OWT) { /* post the agents' rows as early as they exist: the LDS stores drain behind the work below */
             if (!helper && s < 2) mail_post(mbx.mail[t & 1], g * 2 + s, tb, pub, m, so, done_now);
@@ -1399,6 +1421,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
             quad_publish(c, m, pub);
             quad_tables<DUAL>(m, pub, s, helper, tb);
             quad_nearby(c, tb, s, nbc);
+            tg.foc = q_sel(tb.foc, nbc.k0); tg.focr = q_sel(tb.focr, nbc.k0); tg.dist = nbc.r0; /* the target refresh below makes j0 everybody's target */
             if constexpr (OWT) { /* the rows of this tick come from THIS table (the first observation of the new episodes) */
                 if (!helper && s < 2) mail_post(mbx.mail[0], g * 2 + s, tb, pub, m, so, done_now);
             } else if constexpr (TWO) { /* the first observation of the new episode replaces the posted rows */
@@ -1420,15 +1443,24 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
             HH_PROF(13);
             pre.ok = !reset_tick;
             pre.spec = !reset_tick && !q_any(active && tb.amask != amask_before);
-            if (!reset_tick) { /* wave-uniform: take the post-tick table the output wave built while this wave ran the envelope phases, and what it computed ahead */
-#pragma unroll
-                for (int k = 0; k < 3; k++) { tb.dist[k] = mbx.tab.dist[k][tid]; tb.foc[k] = mbx.tab.foc[k][tid]; tb.focr[k] = mbx.tab.focr[k][tid]; }
+            if (!reset_tick) { /* wave-uniform: take what the output wave built while this wave ran the envelope phases, and what it computed ahead */
                 pre.tkey = mbx.tab.tk[tid]; pre.sx = mbx.tab.sx[tid]; pre.sy = mbx.tab.sy[tid];
                 pub.uc = mbx.tab.uc[tid]; pub.us = mbx.tab.us[tid]; /* the exact heading vector (the tick carried a rotated one) */
                 pre.sp_hdg = mbx.tab.sp_hdg[tid]; pre.sp_spd = mbx.tab.sp_spd[tid]; pre.sp_w = mbx.tab.sp_w[tid];
-#ifndef HHQ_ABL_NEARBY
-                quad_nearby(c, tb, s, nbc);
-#endif
+                if (pre.spec) { /* wave-uniform: no alive mask of the wave changed — the output wave's _nearby_object and target entries are this tick's (QTgt) */
+                    const int w = mbx.tab.nbw[tid];
+                    const double r0 = mbx.tab.nr0[tid];
+                    tg.foc = mbx.tab.nfoc[tid]; tg.focr = mbx.tab.nfocr[tid]; tg.dist = r0;
+                    nbc.n = w & 3; nbc.j0 = (w >> 2) & 3; nbc.k0 = (w >> 4) & 3;
+                    nbc.r0 = r0; nbc.d0 = c.inv_diag * r0; /* quad_nearby's own product (r0 = 0 without a live opponent) */
+                    nbc.j1 = nbc.k1 = 0; nbc.d1 = nbc.r1 = 0.0; /* the second entry is read by escape-mode rows and the escape shaping only: never on this wave */
+                } else { /* somebody was removed: the table's distances with the new alive mask */
+                    QTab tf = tb;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { tf.dist[k] = mbx.tab.dist[k][tid]; tf.foc[k] = mbx.tab.foc[k][tid]; tf.focr[k] = mbx.tab.focr[k][tid]; }
+                    quad_nearby(c, tf, s, nbc);
+                    tg.foc = q_sel(tf.foc, nbc.k0); tg.focr = q_sel(tf.focr, nbc.k0); tg.dist = nbc.r0;
+                }
             }
             { /* env_hetero.py:99-101: the observation refreshes opp_to_attack (straight-line on every lane, kept by the agents') */
                 Unit mr = m;

@@ -28,14 +28,15 @@
 #define HH_PLANAR_AZI_MARGIN 0.5
 HH_HD int hh_missile_cone_planar(double lat1, double lon1, double lat2, double lon2, double focus_deg, double cross,
                                  double sep_deg) {
-    const int dom = hh_fabs(lat1) <= HH_GEO_EST_MAX_LAT && hh_fabs(lat2) <= HH_GEO_EST_MAX_LAT && hh_fabs(lon1) < 170.0 &&
-                    hh_fabs(lon2) < 170.0 && sep_deg >= HH_PLANAR_MIN_DEG && sep_deg <= HH_GEO_EST_LONG_DEG;
-    if (!dom) return -1;
+    const int dom = (hh_fabs(lat1) <= HH_GEO_EST_MAX_LAT) & (hh_fabs(lat2) <= HH_GEO_EST_MAX_LAT) & (hh_fabs(lon1) < 170.0) &
+                    (hh_fabs(lon2) < 170.0) & (sep_deg >= HH_PLANAR_MIN_DEG) & (sep_deg <= HH_GEO_EST_LONG_DEG);
     /* cross = east(heading) * dlat - north(heading) * dlon > 0: the target is to the left, the bearing is smaller */
     const double beta = cross < 0.0 ? focus_deg : -focus_deg;
-    if (beta >= -1.0 + HH_PLANAR_AZI_MARGIN && beta <= (HH_MISSILE_HALF_DEG * 2.0 + 1.0) - HH_PLANAR_AZI_MARGIN) return 1;
-    if (beta < -1.0 - HH_PLANAR_AZI_MARGIN || beta > (HH_MISSILE_HALF_DEG * 2.0 + 1.0) + HH_PLANAR_AZI_MARGIN) return 0;
-    return -1;
+    /* straight-line (the kernels evaluate it on every lane behind one wave-uniform test): the three answers as selects */
+    const int inside = (beta >= -1.0 + HH_PLANAR_AZI_MARGIN) & (beta <= (HH_MISSILE_HALF_DEG * 2.0 + 1.0) - HH_PLANAR_AZI_MARGIN);
+    const int outside = (beta < -1.0 - HH_PLANAR_AZI_MARGIN) | (beta > (HH_MISSILE_HALF_DEG * 2.0 + 1.0) + HH_PLANAR_AZI_MARGIN);
+    const int r = inside ? 1 : (outside ? 0 : -1);
+    return dom ? r : -1;
 }
 
 /* Cannon cone (ac1.py:106-115,135-141): range < R km and |sdiff(heading, bearing)| <= w (5 / 3.5 deg).  Nine

@@ -14,6 +14,9 @@ level = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 shaping = bool(int(sys.argv[5])) if len(sys.argv) > 5 else bool(mode)
 kw = dict(n_arenas=N, level=level, agent_mode=mode, esc_dist_rew=shaping, seed=20260927, auto_reset=True, ext_opp_actions=level >= 4)
+if os.environ.get("SOAK_KW"):   # extra configuration fields as JSON, e.g. SOAK_KW='{"friendly_punish": true, "glob_frac": 0.3}' (the general, non-preset kernel instances)
+    import json
+    kw.update(json.loads(os.environ["SOAK_KW"]))
 g = World(make_config(**kw))
 o = O.OracleWorld(O.make_config(**kw))
 assert np.array_equal(g.reset().cpu().numpy(), o.reset())
@@ -36,4 +39,4 @@ sg, so = g.get_state(), o.get_state()
 for k in sg:
     if not np.array_equal(sg[k], so[k]):
         print("MISMATCH final state", k); bad += 1
-print(f"{'FAIL' if bad else 'OK'}: {N} arenas x {T} ticks = {N * T / 1e6:.1f} M arena-steps, level {level} mode {mode}, {time.time() - t0:.0f} s")
+print(f"{'FAIL' if bad else 'OK'}: {N} arenas x {T} ticks = {N * T / 1e6:.1f} M arena-steps, level {level} mode {mode} {os.environ.get('SOAK_KW', '')} kernel {g.kernel_instance()}, {time.time() - t0:.0f} s")

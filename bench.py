@@ -453,6 +453,7 @@ def main_low(args, R=None):
         traffic, fp64, issue = counter_evidence(w.kernel_instance(), N, chunk, N * chunk / avg_launch_s, 4)   # 2-vs-2: four aircraft lanes per arena
         line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                             "traffic": traffic, "kernel": kname, "kernel_instance": w.kernel_instance(), "avg_launch_ms": avg_launch_s * 1e3,
+                            "launch_ms_min": min(durs) * 1e3, "launch_ms_max": max(durs) * 1e3, "launches_timed": len(durs),
                             "traffic_source": None if traffic is None else "profiles/latest_traffic.json: builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                                                            "kernel instance at this arena count (tools/prof_pmc.sh), NOT measured by this run",
                             "algorithmic_bytes_per_launch": bytes_per_launch, "issue": issue, "fp64": fp64,
@@ -590,13 +591,12 @@ def main_policy_rollout(args, R=None):
     useful = (bank.flops_per_row(PolicyBank.FIGHT1) + bank.flops_per_row(PolicyBank.FIGHT2)) * n     # one sub-world's rows, fp32-equivalent
     if ppo:
         useful += (PN.critic_flops_per_row(PN.FIGHT1) + PN.critic_flops_per_row(PN.FIGHT2)) * n      # the value branch of every row
-    fp32_form = os.environ.get("HH_POLICY_FP32", "0") == "1"
     pname = bank.kernel_name(2 * n, sampler=ppo)
     line["kernels_ms"] = {pname: pol_ms, w.kernel_instance(): world_ms, "arenas_per_launch": n}
-    issued = useful if fp32_form else 3.0 * useful   # split-fp16: hi*hi + hi*lo + lo*hi = three MFMA passes per product
-    peak = MFMA_F32_PEAK_TFLOPS if fp32_form else MFMA_F16_PEAK_TFLOPS
+    issued = 3.0 * useful   # split-fp16: hi*hi + hi*lo + lo*hi = three MFMA passes per product
+    peak = MFMA_F16_PEAK_TFLOPS
     line["roofline"]["dominant"] = {
-        "kernel": pname + (" (fp32 MFMA)" if fp32_form else " (split-fp16: hi*hi + hi*lo + lo*hi on " + ("v_mfma_f32_16x16x32_f16)" if "w16" in pname else "v_mfma_f32_32x32x16_f16)")), "bound": "mfma", "avg_launch_ms": pol_ms,
+        "kernel": pname + " (split-fp16: hi*hi + hi*lo + lo*hi on " + ("v_mfma_f32_16x16x32_f16)" if "w16" in pname else "v_mfma_f32_32x32x16_f16)"), "bound": "mfma", "avg_launch_ms": pol_ms,
         "achieved": useful / (pol_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": useful / (pol_ms * 1e-3) / 1e12 / peak,
         "frac_note": "USEFUL flops (one fp32-equivalent multiply-add per weight and row) over the dense fp16 MFMA peak; the three emulation passes "
                      "that buy fp32 accuracy are matrix-pipe work, not useful work: `issued_frac` counts them",
@@ -1007,6 +1007,7 @@ def extra_configs(args, R):
 
     extra = {}
     R.torch.cuda.synchronize()
+    t_extra, budget_s = time.perf_counter(), float(os.environ.get("HH_BENCH_EXTRA_BUDGET_S", "120"))   # the riders may not push the line past a few minutes
     for name, flags in (("configs1_saturated", ["--workload", "low", "--arenas", "262144", "--chunk", "125", "--steps", "8", "--warmup", "2", "--no-extra"]),
                         ("configs2", ["--workload", "rollout", "--ppo", "--steps", "300", "--warmup", "30"]),
                         ("configs2_collect", ["--workload", "collect", "--chunk", "64", "--steps", "6", "--warmup", "2"]),
@@ -1015,13 +1016,19 @@ def extra_configs(args, R):
                         ("configs3_networks_in_loop", ["--workload", "hier", "--pilot", "net", "--steps", "12", "--warmup", "3"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--spinup", "0.3", "--seed", str(args.seed), "--no-cpu-baseline"] + flags
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        left = budget_s - (time.perf_counter() - t_extra)
+        if left < 10.0:
+            extra[name] = {"skipped": f"the extra runs' time budget ({budget_s:.0f} s, HH_BENCH_EXTRA_BUDGET_S) was spent; run `python bench.py {' '.join(flags)}`"}
+            continue
+        t_child = time.perf_counter()
         try:
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=env)
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=min(90.0, left), env=env)
             lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
             if p.returncode != 0 or not lines:
                 extra[name] = {"error": f"child exited with {p.returncode}: {(p.stderr or '')[-300:]}"}
             else:
                 extra[name] = brief(json.loads(lines[-1]))
+                extra[name]["child_seconds"] = round(time.perf_counter() - t_child, 1)
         except Exception as e:   # noqa: BLE001 — reported, never silently dropped
             extra[name] = {"error": f"{type(e).__name__}: {e}"}
     return extra

@@ -80,7 +80,7 @@ struct Shared {
         struct {
             double lat1[B], lon1[B], hdg1[B]; /* position / heading after this tick's aircraft update */
             double rk_lat[B], rk_lon[B];      /* rocket position before its move (speculative for a pending launch) */
-            int q_code[B * 8];                /* Inverse work queue: src lane | kind<<8 | slot<<10 */
+            int q_code[B * (A > 6 ? 12 : 8)]; /* Inverse work queue: src lane | kind<<8 | slot<<10; per lane at most 1 launch + (A - 1) cannon + 2 fuse tests */
             int q_count;
         } t;
         /* observation staging tile (after the tick): agents' rows; 3-vs-3: every unit's 30-float pilot row.  Kept as small
@@ -718,13 +718,21 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
     const bool rk_maybe = running && (rk_pre || try_launch);
     const int launch_pre = try_launch ? launch_planar(sh, tid, base, launch_tgt) : -1; /* pair table = pre-tick geometry */
     {
+        /* a lane queues at most 1 launch + (A - 1) cannon candidates + 2 rocket fuses: 8 with six unit slots, 12 with ten (the ten-slot instances with
+         * friendly fire: nine cannon candidates) — one code register per entry, so that the count a lane reserves is the count it writes */
+        constexpr int QCAP = A > 6 ? 12 : 8;
+        static_assert(1 + (A - 1) + 2 <= QCAP, "envelope queue: code registers per lane");
         int nq = 0;
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0, c8 = 0, c9 = 0, c10 = 0, c11 = 0;
 #define HH_PUSH(code)                                                                                       \
     do {                                                                                                    \
         int cd_ = (code);                                                                                   \
         switch (nq) { case 0: c0 = cd_; break; case 1: c1 = cd_; break; case 2: c2 = cd_; break; case 3: c3 = cd_; break; \
-                      case 4: c4 = cd_; break; case 5: c5 = cd_; break; case 6: c6 = cd_; break; default: c7 = cd_; break; } \
+                      case 4: c4 = cd_; break; case 5: c5 = cd_; break; case 6: c6 = cd_; break;           \
+                      default:                                                                              \
+                          if (QCAP == 8) c7 = cd_;                                                          \
+                          else switch (nq) { case 7: c7 = cd_; break; case 8: c8 = cd_; break; case 9: c9 = cd_; break; case 10: c10 = cd_; break; default: c11 = cd_; break; } \
+                          break; }                                                                          \
         nq++;                                                                                               \
     } while (0)
         if (try_launch && launch_pre < 0) HH_PUSH(tid | (0 << 8) | (launch_tgt << 10));
@@ -765,6 +773,12 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
             if (nq > 5) sh.u.t.q_code[at + 5] = c5;
             if (nq > 6) sh.u.t.q_code[at + 6] = c6;
             if (nq > 7) sh.u.t.q_code[at + 7] = c7;
+            if (QCAP > 8) {
+                if (nq > 8) sh.u.t.q_code[at + 8] = c8;
+                if (nq > 9) sh.u.t.q_code[at + 9] = c9;
+                if (nq > 10) sh.u.t.q_code[at + 10] = c10;
+                if (nq > 11) sh.u.t.q_code[at + 11] = c11;
+            }
         }
     }
     hh_wg_sync<B>();

@@ -9,20 +9,17 @@
  *      sequence of length 1, where the softmax is identically 1]
  *     shared layer 500 -> 500 (tanh), act_out 500 -> 26 | 24 logits, arg-max per MultiDiscrete component.
  *
- * This is the one dense contraction on the whole path, so it runs on the matrix cores: fp32-in / fp32-accumulate
- * v_mfma_f32_32x32x2_f32 (an exact, k-ordered fmaf chain: no precision is given up against the reference's fp32
- * torch forward; gfx950 has no tf32-like mode).  One 256-thread workgroup (one wave per SIMD) carries a tile of 32 rows
- * of ONE network through all layers with the activations resident in LDS:
- *     L1   X[32 x 32] . W1[32 x 512]    the three FCs as one zero-padded matrix         (64 MFMAs per wave)
- *     att  Y[32 x 104] . Wov[104 x 128] out_proj . v_proj folded on the host           (52, fight nets only)
- *     L2   Z[32 x 512] . Ws[512 x 512]                                                  (1024)
- *     L3   S[32 x 512] . Wa[512 x 32]   split-K over the four waves, summed in order    (64)
- * Each wave owns 128 of the 512 output columns (4 MFMA tiles); the A operand comes from LDS and the B operand (weights)
- * straight from L2 — both stored k-interleaved, P[k/8][k&1][col][(k/2)&3], so that ONE 16-byte access per lane feeds four
- * consecutive MFMA k-steps (lane l of a 32x32x2 MFMA holds A[l&31][l>>5] / B[l>>5][l&31]) and every wave-wide access is
- * unit-stride.  Rows of different networks are first binned into per-network lists (hh_k_policy_bin); rows without a
- * network get a zero action.  Per-row results do not depend on which tile a row lands in, so the outputs are
- * deterministic although the binning order is not.
+ * This is the one dense contraction on the whole path, so it runs on the matrix cores.  gfx950 has no tf32-like mode and its fp32-in MFMA runs
+ * at the vector rate, so every operand is split into two fp16 halves and a product is accumulated in fp32 as hi hi + lo hi + hi lo
+ * (hh_policy_kernel_h16.h: logits within 1e-6 of a float64 forward, like PyTorch's own fp32 forward).  This header holds what the forms share
+ * — the bank of loaded networks (weights packed on the host), the row binning by network (hh_k_policy_bin), the choice of a form per call —
+ * and the C ABI; the kernels:
+ *     hh_k_policy_h<1|2>     hh_policy_kernel_h16.h   activations in an LDS tile of 32 | 64 rows, weights out of L2              small calls
+ *     hh_k_policy_w16<4|8>   hh_policy_kernel_w16.h   weights streamed through LDS, activations in registers, 64 | 128-row tiles  >= 40 rows x n_CU
+ *     hh_k_policy_ppo, hh_k_policy_w16_ppo            the PPO sampler's step (hh_policy_sample): actor + Categorical draw + value branch
+ * (Round 6 retired the fp32-MFMA forward hh_k_policy of round 2 and the 32-rows-per-wave form hh_k_policy_w of round 4: no row count selected them.)
+ * Rows of different networks are first binned into per-network lists; rows without a network get a zero action.  Per-row results do not depend
+ * on which tile a row lands in, so the outputs are deterministic although the binning order is not.
  */
 #ifndef HH_POLICY_KERNEL_H
 #define HH_POLICY_KERNEL_H
@@ -54,19 +51,6 @@ struct HhpBank {
 
 /* packed index of element (k, col) of a [K x J] operand */
 __host__ __device__ inline size_t hhp_pidx(int k, int col, int J) { return ((size_t)((k >> 3) * 2 + (k & 1)) * J + col) * 4 + ((k >> 1) & 3); }
-/* the same for the 32-row activation tiles in LDS, with the row slot XOR-swizzled by the plane (k/8, k&1): an MFMA epilogue
- * writes one row of 32 consecutive k per instruction — 8 planes x 4 sub-slots — and without the swizzle those land on 4 banks */
-__device__ __forceinline__ int hhp_aidx(int k, int row) {
-    const int plane = (k >> 3) * 2 + (k & 1);
-    return (plane * 32 + (row ^ (plane & 7))) * 4 + ((k >> 1) & 3);
-}
-/* tanh(x) = 1 - 2 / (1 + e^(2x)) from the hardware exp2 and reciprocal: five instructions, |error| < 5e-7 absolute over the whole
- * range including the saturated ends (e^(2x) = inf -> 1, 0 -> -1); the logits tolerate 1e-5 */
-__device__ __forceinline__ float hhp_tanh(float x) {
-    const float e = __expf(2.0f * x);
-    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f); /* raw v_rcp_f32 (1 ulp): __frcp_rn expands to the ten-instruction IEEE division */
-}
-
 /* two at a time: the multiply, the add and the final multiply-add are packed instructions (v_pk_mul / add / fma_f32: one issue slot
  * for both values); the exponential and the reciprocal stay one transcendental each */
 typedef float hh_f2 __attribute__((ext_vector_type(2)));
@@ -155,192 +139,6 @@ __device__ __forceinline__ hh_f32x16 hhp_zero16() {
 /* C/D layout of the 32x32 MFMA: lane holds column (lane & 31), rows (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) */
 __device__ __forceinline__ int hhp_crow(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-/* NT tiles of 32 columns starting at column j0 (+32 per tile) over KB 8-k blocks: A from LDS (packed, 32 rows), B from global
- * (packed, J columns).  Software pipeline: the operands of block kb+1 are REQUESTED before the 4 NT MFMAs of block kb issue and
- * first touched after them (4 NT x 64 cycles later: an L2 round trip fits).  hipcc's scheduler would otherwise sink each load
- * to just before its use and reuse the registers — the scheduling barriers pin the order, the loop stays rolled. */
-template <int NT>
-__device__ __forceinline__ void hhp_gemm(const float4 *__restrict__ a_lds, int kb0, int KB, const float4 *__restrict__ b_glb, int bkb0, int J,
-                                         int j0, int lane, hh_f32x16 (&acc)[NT]) {
-    const int h = lane >> 5, i = lane & 31;
-    const float4 *ap = a_lds + (kb0 * 2 + h) * 32 + (i ^ ((kb0 * 2 + h) & 7)); /* swizzled row slot: see hhp_aidx */
-    const float4 *bp = b_glb + (size_t)(bkb0 * 2 + h) * J + j0 + i;
-    float4 a = *ap;
-    float4 b[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) b[t] = bp[t * 32];
-#pragma nounroll
-    for (int kb = 0; kb < KB; kb++) {
-        ap = a_lds + (((kb0 + kb + 1) * 2 + h) * 32 + (i ^ (((kb0 + kb + 1) * 2 + h) & 7))); /* next 8-k block, its own swizzle */
-        bp += (size_t)2 * J;
-        float4 an = a, bn[NT];
-#pragma unroll
-        for (int t = 0; t < NT; t++) bn[t] = b[t];
-        if (kb + 1 < KB) {        /* wave-uniform */
-            an = *ap;
-#pragma unroll
-            for (int t = 0; t < NT; t++) bn[t] = bp[t * 32];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        a = an;
-#pragma unroll
-        for (int t = 0; t < NT; t++) b[t] = bn[t];
-    }
-}
-
-/* LDS: one 64 KB activation tile (Z, then S in place, then the L3 partials) | X 4 KB | logits 4 KB | row ids, norm partials
- * = 72.6 KB, so TWO workgroups share a CU (two waves per SIMD): one tile's global-latency phases (row lists, observation
- * gather, first weight fetches, output stores) and epilogues hide behind the other tile's MFMA streams */
-#define HHP_LDS_FLOATS (16384 + 1024 + 1024 + 32 + 128)
-#define HHP_LDS_BYTES (HHP_LDS_FLOATS * 4)
-
-__global__ __launch_bounds__(256, 2) void hh_k_policy(HhpBank bank, int n_nets, const float *__restrict__ obs, int obs_stride,
-                                                      int *counts, const int *__restrict__ lists, int max_rows,
-                                                      int8_t *__restrict__ actions, float *__restrict__ logits_out, int consume) {
-    extern __shared__ __align__(16) float lds[];
-    float *Zp = lds;                 /* [64][2][32][4]  activations after L1 (A operand of att and L2), then after L2 (A operand of
-                                        L3: wave w reads only its own columns = planes [32 w, 32 w + 32)), then wave w's L3 partial */
-    float *Xp = lds + 16384;         /* [4][2][32][4]   observation tile */
-    float *Lg = lds + 17408;         /* [32][32]        logits */
-    int *rows = reinterpret_cast<int *>(lds + 18432); /* [32] */
-    float *npart = lds + 18464;      /* [4][32] squared-norm partials */
-
-    /* which (network, tile) is this workgroup's?  (all counters requested at once: one global round trip) */
-    int cn[HH_POLICY_MAX_NETS];
-#pragma unroll
-    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? min(hhp_row_count(counts, n, consume), max_rows) : 0;
-    int net = -1, tile = blockIdx.x, cnt = 0;
-#pragma unroll
-    for (int n = 0; n < HH_POLICY_MAX_NETS; n++) {
-        const int nt = (cn[n] + HHP_ROWS - 1) / HHP_ROWS;
-        if (net < 0) {
-            if (tile < nt) { net = n; cnt = cn[n]; }
-            else tile -= nt;
-        }
-    }
-    if (net < 0) { hhp_consume_counts(counts, consume); return; }
-    const HhpNet N = bank.net[net];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = lane >> 5, ci = lane & 31;
-
-    if (tid < HHP_ROWS) {
-        const int q = tile * HHP_ROWS + tid;
-        rows[tid] = q < cnt ? lists[(size_t)net * max_rows + q] : -1;
-    }
-    __syncthreads();
-    for (int e = tid; e < HHP_ROWS * HHP_XK; e += 256) {
-        const int i = e >> 5, c = e & 31, r = rows[i];
-        Xp[hhp_aidx(c, i)] = (r >= 0 && c < N.obs_dim) ? obs[(size_t)r * obs_stride + c] : 0.0f;
-    }
-    __syncthreads();
-
-    /* ---- L1: the three input FCs as one [32 x 512] matrix, tanh ---- */
-    {
-        hh_f32x16 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = hhp_zero16();
-        hhp_gemm<4>(reinterpret_cast<const float4 *>(Xp), 0, HHP_XK / 8, reinterpret_cast<const float4 *>(N.w1p), 0, HHP_H, wave * 128, lane, acc);
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int j = wave * 128 + t * 32 + ci;
-            const float bj = N.b1[j];
-#pragma unroll
-            for (int r = 0; r < 16; r++) Zp[hhp_aidx(j, hhp_crow(r, lane))] = hhp_tanh(acc[t][r] + bj);
-        }
-    }
-    __syncthreads();
-
-    /* ---- fight nets: x <- normalize(x + Wov x + bov) on the third block (columns 400..499) ---- */
-    if (N.has_att) {
-        hh_f32x16 acc[1];
-        acc[0] = hhp_zero16();
-        hhp_gemm<1>(reinterpret_cast<const float4 *>(Zp), 400 / 8, HHP_ATT_K / 8, reinterpret_cast<const float4 *>(N.wovp), 0, HHP_ATT_J, wave * 32, lane, acc);
-        const int j = wave * 32 + ci; /* column inside the 100-wide block */
-        const float bj = N.bov[j];
-        float y[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float x = j < 100 ? Zp[hhp_aidx(400 + j, hhp_crow(r, lane))] : 0.0f;
-            y[r] = j < 100 ? x + (acc[0][r] + bj) : 0.0f;
-            float s = y[r] * y[r];
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
-            if (ci == 0) npart[wave * 32 + hhp_crow(r, lane)] = s;
-        }
-        __syncthreads(); /* every wave is done reading the block as an operand; partial sums are posted */
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = hhp_crow(r, lane);
-            const float nn = ((npart[row] + npart[32 + row]) + npart[64 + row]) + npart[96 + row];
-            const float den = fmaxf(sqrtf(nn), 1e-12f); /* F.normalize: x / max(||x||_2, eps) */
-            if (j < 100) Zp[hhp_aidx(400 + j, row)] = y[r] / den;
-        }
-        __syncthreads();
-    }
-
-    /* ---- L2: shared layer 500 -> 500, tanh; the result replaces Z in place once every wave has finished reading Z ---- */
-    {
-        hh_f32x16 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = hhp_zero16();
-        hhp_gemm<4>(reinterpret_cast<const float4 *>(Zp), 0, HHP_H / 8, reinterpret_cast<const float4 *>(N.wsp), 0, HHP_H, wave * 128, lane, acc);
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const float bj = N.bs[wave * 128 + t * 32 + ci];
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[t][r] = hhp_tanh(acc[t][r] + bj);
-        }
-        __syncthreads(); /* Z is dead */
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int j = wave * 128 + t * 32 + ci;
-#pragma unroll
-            for (int r = 0; r < 16; r++) Zp[hhp_aidx(j, hhp_crow(r, lane))] = acc[t][r];
-        }
-    }
-    __syncthreads();
-
-    /* ---- L3: logits, split-K: wave w contracts its own columns [128 w, 128 w + 128) of S, then parks its partial in the
-     *      first 4 KB of that same region (its operand reads are complete by then; nobody else touches the region) ---- */
-    {
-        hh_f32x16 acc[1];
-        acc[0] = hhp_zero16();
-        hhp_gemm<1>(reinterpret_cast<const float4 *>(Zp), wave * 16, 16, reinterpret_cast<const float4 *>(N.wap), wave * 16, HHP_OUT, 0, lane, acc);
-#pragma unroll
-        for (int r = 0; r < 16; r++) Zp[wave * 4096 + hhp_crow(r, lane) * 32 + ci] = acc[0][r];
-    }
-    __syncthreads();
-    for (int e = tid; e < HHP_ROWS * HHP_OUT; e += 256) {
-        const int i = e >> 5, c = e & 31;
-        const float v = (((Zp[e] + Zp[4096 + e]) + Zp[8192 + e]) + Zp[12288 + e]) + N.ba[c];
-        Lg[e] = v;
-        if (logits_out && rows[i] >= 0) logits_out[(size_t)rows[i] * HH_POLICY_LOGITS + c] = c < N.n_out ? v : 0.0f;
-    }
-    __syncthreads();
-    /* ---- greedy decode (env_base.py:373-382): first maximum of each MultiDiscrete component ---- */
-    if (tid < HHP_ROWS && rows[tid] >= 0) {
-        const float *lg = Lg + tid * 32;
-        int a[4] = {0, 0, 0, 0};
-        const int seg0[5] = {0, 13, 22, 24, 26};
-        const int ncomp = N.n_out == 26 ? 4 : 3;
-        for (int k = 0; k < ncomp; k++) {
-            int best = seg0[k];
-            for (int c = seg0[k] + 1; c < seg0[k + 1]; c++) if (lg[c] > lg[best]) best = c;
-            a[k] = best - seg0[k];
-        }
-        reinterpret_cast<int *>(actions)[rows[tid]] = (a[0] & 0xff) | ((a[1] & 0xff) << 8) | ((a[2] & 0xff) << 16) | ((a[3] & 0xff) << 24);
-    }
-    hhp_consume_counts(counts, consume);
-}
-
 #include "hh_policy_kernel_h16.h"
 #include "hh_policy_kernel_ppo.h"
 #include "hh_policy_kernel_w.h"
@@ -353,7 +151,6 @@ struct hh_policy {
     HhpBank bank;
     HhpBankH bankh;
     int binned_rows;          /* n_rows of the call that built the current row lists (0: none) */
-    int fp32;                 /* HH_POLICY_FP32=1: the fp32-MFMA kernel (A/B runs; default is the split-fp16 kernel) */
     int tile_rows;            /* HH_POLICY_TILE=32 / 64: that tile instance of the split-fp16 kernel (A/B runs); 0 = unset: chosen per call by the row count */
     int n_cu;
     int persist;              /* HH_POLICY_PERSIST=0: 64-row tiles one workgroup per tile instead of a grid-stride walk (A/B runs) */
@@ -365,11 +162,9 @@ struct hh_policy {
     uint8_t *lut;             /* [256] dev */
     int *counts, *lists;      /* counters (HHP_COUNTS_INTS), [MAX_NETS][max_rows] dev */
     hh_world *bound;          /* hh_bind_policy: the world whose kernels write the lists (one world per bank), or nullptr */
-    HhpBankW bankw;           /* the weights-through-LDS form (hh_policy_kernel_w.h): one linear fragment stream per network */
-    unsigned char *wblob[HH_POLICY_MAX_NETS];
-    HhpBankX bankx;           /* the same for hh_k_policy_w16 (16 rows per wave: other fragment shape) */
+    HhpBankX bankx;           /* the weights-through-LDS forms (hh_policy_kernel_w16.h): one linear stream of 1 KB fragments per network */
     unsigned char *xblob[HH_POLICY_MAX_NETS];
-    int wform;                /* HH_POLICY_W: 3 / 2 = always hh_k_policy_w16<8> / <4>, 1 = always hh_k_policy_w, 0 = the tile forms only, unset (-1) = by row count (hhp_choose_form) */
+    int wform;                /* HH_POLICY_W: 3 / 2 = always hh_k_policy_w16<8> / <4>, 0 = the tile forms only, unset (-1) = by row count (hhp_choose_form) */
     HhpCritBank cbank;        /* hh_policy_set_critic: the value branches of the trainable policies (hh_policy_sample) */
     char *cblob[HH_POLICY_MAX_NETS]; /* one allocation per loaded value branch */
     HhpCritBankX cbankx;      /* the same as fragment streams for hh_k_policy_w16_ppo */
@@ -405,18 +200,16 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     p->device = device; p->max_rows = max_rows; p->n_nets = 0; p->binned_rows = 0; p->bound = nullptr;
     memset(&p->bank, 0, sizeof(p->bank));
     memset(&p->bankh, 0, sizeof(p->bankh));
-    { const char *e = getenv("HH_POLICY_FP32"); p->fp32 = e ? atoi(e) : 0; }
     { const char *e = getenv("HH_POLICY_TILE"); p->tile_rows = e ? atoi(e) : 0; } /* 32 / 64: that instance; unset: by row count (hhp_rows_suit_wide_tiles) */
     { const char *e = getenv("HH_POLICY_PERSIST"); p->persist = e ? atoi(e) : 1; }
     { hipDeviceProp_t prop; p->n_cu = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256; }
     for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { p->blob[i] = nullptr; p->blobh[i] = nullptr; }
     p->slab = nullptr;
     memset(&p->cbank, 0, sizeof(p->cbank));
-    memset(&p->bankw, 0, sizeof(p->bankw));
     memset(&p->bankx, 0, sizeof(p->bankx));
     memset(&p->cbankx, 0, sizeof(p->cbankx));
     for (int i = 0; i < HH_POLICY_MAX_NETS; i++) p->cxblob[i] = nullptr;
-    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { p->cblob[i] = nullptr; p->wblob[i] = nullptr; p->xblob[i] = nullptr; }
+    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { p->cblob[i] = nullptr; p->xblob[i] = nullptr; }
     { const char *e = getenv("HH_POLICY_W"); p->wform = e ? atoi(e) : -1; }
     p->lut = nullptr; p->counts = nullptr; p->lists = nullptr;
     hipError_t e = hipMalloc(&p->lut, 256);
@@ -425,11 +218,9 @@ extern "C" int hh_policy_create(int device, int32_t max_rows, hh_policy **out) {
     if (e == hipSuccess) e = hipMemset(p->counts, 0, HHP_COUNTS_INTS * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&p->lists, (size_t)HH_POLICY_MAX_NETS * max_rows * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&p->slab, HHP_SLOT_BYTES * HH_POLICY_MAX_NETS);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy), hipFuncAttributeMaxDynamicSharedMemorySize, HHP_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_h<1>), hipFuncAttributeMaxDynamicSharedMemorySize, HHPH_LDS_BYTES(1));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_h<2>), hipFuncAttributeMaxDynamicSharedMemorySize, HHPH_LDS_BYTES(2));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_ppo), hipFuncAttributeMaxDynamicSharedMemorySize, HHPP_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_w<4>), hipFuncAttributeMaxDynamicSharedMemorySize, HHW_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_w16<4>), hipFuncAttributeMaxDynamicSharedMemorySize, HHX_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_w16<8>), hipFuncAttributeMaxDynamicSharedMemorySize, HHX_LDS_BYTES_NB(4));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(hh_k_policy_w16_ppo), hipFuncAttributeMaxDynamicSharedMemorySize, HHXC_LDS_BYTES);
@@ -451,7 +242,7 @@ extern "C" int hh_policy_destroy(hh_policy *p) {
     hhp_unbind(p); /* a world still bound to this bank goes back to emitting selector bytes only */
     DeviceGuard guard_(p->device);
     (void)hipFree(p->slab);
-    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { if (p->cblob[i]) (void)hipFree(p->cblob[i]); if (p->wblob[i]) (void)hipFree(p->wblob[i]); if (p->xblob[i]) (void)hipFree(p->xblob[i]); if (p->cxblob[i]) (void)hipFree(p->cxblob[i]); }
+    for (int i = 0; i < HH_POLICY_MAX_NETS; i++) { if (p->cblob[i]) (void)hipFree(p->cblob[i]); if (p->xblob[i]) (void)hipFree(p->xblob[i]); if (p->cxblob[i]) (void)hipFree(p->cxblob[i]); }
     (void)hipFree(p->lut); (void)hipFree(p->counts); (void)hipFree(p->lists);
     delete p;
     return HH_OK;
@@ -525,40 +316,12 @@ static int hhp_set_net(hh_policy *p, int32_t slot, const hh_net_weights *w) {
         for (int k = 0; k < 500; k++) { B[o_wa + hhp_pidx(k, j, HHP_OUT)] = w->out_w[(size_t)j * 500 + k]; hhp_split_put_t(Hh, Hl, h_wa, k, j, HHP_OUT, w->out_w[(size_t)j * 500 + k]); }
         B[o_ba + j] = w->out_b[j];
     }
-    { /* the same four matrices as ONE linear stream of 1 KB fragments in consumption order (hh_policy_kernel_w.h) */
-        std::vector<uint16_t> S((size_t)HHW_STREAM_PIECES * (HHW_PIECE / 2), 0);
+    { /* the same four matrices as ONE linear stream of 1 KB fragments in consumption order (hh_policy_kernel_w16.h) */
         auto w1 = [&](int k, int col) { return k < HHP_XK ? B[o_w1 + hhp_pidx(k, col, HHP_H)] : 0.0f; };
         auto wov = [&](int k, int col) { return (att && k < 100 && col < 100) ? B[o_wov + hhp_pidx(k, col, HHP_ATT_J)] : 0.0f; };
         auto wsf = [&](int k, int col) { return (k < 500 && col < 500) ? w->shared_w[(size_t)col * 500 + k] : 0.0f; };
         auto waf = [&](int k, int col) { return (k < 500 && col < n_out) ? w->out_w[(size_t)col * 500 + k] : 0.0f; };
-        for (int T = 0; T < 16; T++)
-            for (int kb = 0; kb < 2; kb++)
-                for (int wq = 0; wq < 16; wq++)
-                    for (int c = 0; c < 32; c++) hhw_put(S, (size_t)(T * 2 + kb) * 2, 16 * kb + wq, 32 * T + c, true, w1(16 * kb + wq, 32 * T + c));
-        for (int j = 0; j < 4; j++)
-            for (int kb = 0; kb < 7; kb++)
-                for (int wq = 0; wq < 16; wq++)
-                    for (int c = 0; c < 32; c++) hhw_put(S, (size_t)HHW_L1_PIECES + (size_t)(j * 7 + kb) * 2, 16 * kb + wq, 32 * j + c, false, wov(16 * kb + wq, 32 * j + c));
-        const size_t l2_0 = (size_t)HHW_L1_PIECES + HHW_ATT_PIECES;
-        for (int pp = 0; pp < 8; pp++) {
-            for (int hf = 0; hf < 2; hf++)
-                for (int kk = 0; kk < 16; kk++)
-                    for (int t = 0; t < 2; t++)
-                        for (int wq = 0; wq < 16; wq++)
-                            for (int c = 0; c < 32; c++)
-                                hhw_put(S, l2_0 + hhw_chunk_piece(pp, hf) + (size_t)kk * 4 + t * 2, 16 * (16 * hf + kk) + wq, 32 * (2 * pp + t) + c, false,
-                                        wsf(16 * (16 * hf + kk) + wq, 32 * (2 * pp + t) + c));
-            const size_t l3 = l2_0 + (pp < 7 ? hhw_chunk_piece(pp + 1, 0) : hhw_chunk_piece(7, 1)) + HHW_L2_PIECES; /* behind the chunk in whose shadow pair pp's epilogue runs */
-            for (int t = 0; t < 2; t++)
-                for (int b2 = 0; b2 < 2; b2++)
-                    for (int wq = 0; wq < 16; wq++)
-                        for (int c = 0; c < 32; c++)
-                            hhw_put(S, l3 + (size_t)(t * 2 + b2) * 2, 16 * ((2 * pp + t) * 2 + b2) + wq, c, false, waf(16 * ((2 * pp + t) * 2 + b2) + wq, c));
-        }
-        if (!p->wblob[slot]) HIPCHK(hipMalloc(&p->wblob[slot], (size_t)HHW_STREAM_PIECES * HHW_PIECE));
-        HIPCHK(hipMemcpy(p->wblob[slot], S.data(), (size_t)HHW_STREAM_PIECES * HHW_PIECE, hipMemcpyHostToDevice));
-        p->bankw.net[slot].stream = p->wblob[slot];
-        /* ... and in the fragment shape of hh_k_policy_w16 (16 columns x 32 k per piece; chunk order of hh_policy_kernel_w16.h) */
+        /* the fragment shape of hh_k_policy_w16 (16 columns x 32 k per piece; chunk order of hh_policy_kernel_w16.h) */
         std::vector<uint16_t> X((size_t)HHX_STREAM_PIECES * (HHW_PIECE / 2), 0);
         for (int T = 0; T < 32; T++)
             for (int k = 0; k < 32; k++)
@@ -635,7 +398,7 @@ static inline bool hhp_rows_suit_wide_tiles(int n_rows, int n_cu) {
 /* Which form for how many rows (tools/policy_bench.py, Fight1 + Fight2 rows, us per call back to back on one MI355X):
  *      rows            4096   8192  12288  16384  20480  24576  32768  49152  65536
  *      hh_k_policy_h   23.7   28.0   43.5   41.9   62.8   67.4   78.9  114.0  144.9     (LDS activation tile: 32 / 64 rows per workgroup)
- *      hh_k_policy_w   46.7   47.5   48.4   50.7   53.6   57.2   63.4  108.8  120.6     (weights through LDS, 128 rows per workgroup, one wave per SIMD)
+ *      hh_k_policy_w   46.7   47.5   48.4   50.7   53.6   57.2   63.4  108.8  120.6     (32 rows per wave, one wave per SIMD: retired in round 6, never ahead)
  *      hh_k_policy_w16 30.8   32.6   34.4   38.7   51.9   55.8   64.1   93.0  117.4     (weights through LDS, 64 rows per workgroup, two workgroups per CU)
  * A weights-through-LDS tile takes ~31 us however few CUs have one; the tile forms are faster while the rows fit one round of 32-row tiles
  * (two per CU) with room to spare.  So: from 10 k rows that carry a network upwards hh_k_policy_w16, below the tile forms. */
@@ -646,15 +409,13 @@ static inline bool hhp_rows_suit_w8(int n_rows, int n_cu) {
     const int tiles = (n_rows + 127) / 128, rem = tiles % n_cu;
     return tiles >= n_cu && (rem == 0 || rem * 4 > n_cu * 3);
 }
-enum { HHP_FORM_H32, HHP_FORM_H64, HHP_FORM_FP32, HHP_FORM_W, HHP_FORM_W16, HHP_FORM_W16X8 };
+enum { HHP_FORM_H32, HHP_FORM_H64, HHP_FORM_W16, HHP_FORM_W16X8 };
 /* the form of a forward over heur_rows rows that carry a network: HH_POLICY_W (3 / 2 / 1 = always hh_k_policy_w16<8> / <4> / hh_k_policy_w, 0 = the tile forms only,
- * unset = by row count), then HH_POLICY_FP32, then the tile width (hh_policy_set_tile_rows / HH_POLICY_TILE, 0 = by row count) */
+ * unset = by row count), then the tile width (hh_policy_set_tile_rows / HH_POLICY_TILE, 0 = by row count) */
 static int hhp_choose_form(const hh_policy *p, int heur_rows) {
     if (p->wform == 3) return HHP_FORM_W16X8;
     if (p->wform == 2) return HHP_FORM_W16;
-    if (p->wform == 1) return HHP_FORM_W;
-    if (p->wform < 0 && !p->fp32 && p->tile_rows == 0 && hhp_rows_suit_w(heur_rows, p->n_cu)) return hhp_rows_suit_w8(heur_rows, p->n_cu) ? HHP_FORM_W16X8 : HHP_FORM_W16;
-    if (p->fp32) return HHP_FORM_FP32;
+    if (p->wform < 0 && p->tile_rows == 0 && hhp_rows_suit_w(heur_rows, p->n_cu)) return hhp_rows_suit_w8(heur_rows, p->n_cu) ? HHP_FORM_W16X8 : HHP_FORM_W16;
     if (p->tile_rows == 64 || (p->tile_rows == 0 && hhp_rows_suit_wide_tiles(heur_rows, p->n_cu))) return HHP_FORM_H64;
     return HHP_FORM_H32;
 }
@@ -671,12 +432,6 @@ static int hhp_launch_forward(hh_policy *p, const float *obs, int32_t n_rows, in
     } else if (form == HHP_FORM_W16X8) { /* the same with eight waves per workgroup: 128-row tiles, half the weight stream per row */
         hipLaunchKernelGGL(hh_k_policy_w16<8>, dim3((n_rows + 127) / 128 + p->n_nets), dim3(512), HHX_LDS_BYTES_NB(4), st, p->bank, p->bankx, p->n_nets, obs, obs_stride, p->counts,
                            p->lists, p->max_rows, actions, logits, consume);
-    } else if (form == HHP_FORM_W) { /* weights through LDS, activations in registers, 32 rows per wave: 128-row tiles, one workgroup per CU (A/B form) */
-        hipLaunchKernelGGL(hh_k_policy_w<4>, dim3((n_rows + 127) / 128 + p->n_nets), dim3(256), HHW_LDS_BYTES, st, p->bank, p->bankw, p->n_nets, obs, obs_stride,
-                           p->counts, p->lists, p->max_rows, actions, logits, consume);
-    } else if (form == HHP_FORM_FP32) {
-        hipLaunchKernelGGL(hh_k_policy, dim3(grid), dim3(256), HHP_LDS_BYTES, st, p->bank, p->n_nets, obs, obs_stride, p->counts, p->lists, p->max_rows,
-                           actions, logits, consume);
     } else if (form == HHP_FORM_H64) { /* persistent: one workgroup per CU walks the tiles grid-stride */
         const int tiles = (n_rows + 63) / 64 + p->n_nets;
         hipLaunchKernelGGL(hh_k_policy_h<2>, dim3(p->persist && tiles > p->n_cu ? p->n_cu : tiles), dim3(512), HHPH_LDS_BYTES(2), st, p->bank, p->bankh, p->n_nets,
@@ -694,15 +449,13 @@ static const char *hhp_form_name(const hh_policy *p, int n_rows, int live_rows) 
     switch (hhp_choose_form(p, live_rows >= 0 ? live_rows : n_rows)) {
     case HHP_FORM_W16X8: return "hh_k_policy_w16<8>";
     case HHP_FORM_W16: return "hh_k_policy_w16<4>";
-    case HHP_FORM_W: return "hh_k_policy_w<4>";
-    case HHP_FORM_FP32: return "hh_k_policy";
     case HHP_FORM_H64: return "hh_k_policy_h<2>";
     default: return "hh_k_policy_h<1>";
     }
 }
 /* hh_policy_sample: the weights-through-LDS form for large calls (HH_POLICY_W = 2 always, 0 / 1 never), the tile form otherwise */
 static bool hhp_sampler_is_w16(const hh_policy *p, int n_rows) {
-    return p->wform == 2 || p->wform == 3 || (p->wform < 0 && !p->fp32 && p->tile_rows == 0 && hhp_rows_suit_w(n_rows, p->n_cu));
+    return p->wform == 2 || p->wform == 3 || (p->wform < 0 && p->tile_rows == 0 && hhp_rows_suit_w(n_rows, p->n_cu));
 }
 extern "C" int hh_policy_kernel_name(hh_policy *p, int32_t n_rows, int32_t sampler, char *buf, int32_t len) {
     if (!p || !buf || len <= 0 || n_rows <= 0) { g_err = "bad argument"; return HH_E_ARG; }
@@ -941,14 +694,14 @@ extern "C" int hh_policy_sample(hh_policy *p, const float *obs, int32_t n_rows, 
 }
 
 /* tuning probe: workgroups of a forward kernel form that the runtime reports co-resident per CU (which: 0 hh_k_policy_h<1>, 1 hh_k_policy_h<2>,
- * 2 hh_k_policy_w<4>, 3 hh_k_policy_w16, 4 hh_k_policy_ppo) */
+ * 2 retired, 3 hh_k_policy_w16, 4 hh_k_policy_ppo) */
 extern "C" int hh_policy_occupancy(int32_t which, int32_t *blocks_per_cu) {
     if (!blocks_per_cu) return HH_E_ARG;
     int n = 0;
     hipError_t e = hipErrorInvalidValue;
     if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(hh_k_policy_h<1>), 256, HHPH_LDS_BYTES(1));
     else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(hh_k_policy_h<2>), 512, HHPH_LDS_BYTES(2));
-    else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(hh_k_policy_w<4>), 256, HHW_LDS_BYTES);
+    else if (which == 2) { g_err = "hh_policy_occupancy: form 2 (hh_k_policy_w) was retired in round 6"; return HH_E_ARG; }
     else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(hh_k_policy_w16<4>), 256, HHX_LDS_BYTES);
     else if (which == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(hh_k_policy_ppo), 256, HHPP_LDS_BYTES);
     if (e != hipSuccess) { g_err = std::string("hh_policy_occupancy: ") + hipGetErrorString(e); return HH_E_HIP; }

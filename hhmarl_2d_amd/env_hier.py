@@ -105,9 +105,11 @@ class HighLevelEnv(_Base):
         from .pilots import NetPilot, VariantNetPilot
         if not isinstance(self.pilot, (NetPilot, VariantNetPilot)):
             return macro_step(self.world, self._cmd, self.pilot, early_exit=False)
-        # the captured graph holds the world's device pointers (trace ring, bound bank's row lists) by value: re-capture whenever
-        # World.trace_enable / bind_policy changed them since
-        if getattr(self, "_graph", None) is not None and self._graph_gen != getattr(self.world, "ptr_generation", 0):
+        # the captured graph holds the world's device pointers (trace ring, bound bank's row lists) and the bank's (weight blobs, selector table, the
+        # kernel instance its tile width picks) by value: re-capture whenever World.trace_enable / bind_policy or PolicyBank.set_net / set_critic /
+        # set_lut / set_tile_rows / close changed them since — the bank may be the caller's own and shared with other worlds
+        gen = (getattr(self.world, "ptr_generation", 0), id(self.pilot.bank), getattr(self.pilot.bank, "generation", 0))
+        if getattr(self, "_graph", None) is not None and self._graph_gen != gen:
             self._graph = None
         if getattr(self, "_graph", None) is None:
             self._g_out = self.world.alloc_outputs()
@@ -124,7 +126,7 @@ class HighLevelEnv(_Base):
                     macro_step(self.world, self._cmd, self.pilot, out=self._g_out, pilot_buf=self._g_pilot, early_exit=False)
             torch.cuda.current_stream(self.world.device).wait_stream(side)
             self._graph = graph
-            self._graph_gen = getattr(self.world, "ptr_generation", 0)
+            self._graph_gen = gen
         self._graph.replay()
         return self._g_out
 

@@ -45,11 +45,13 @@ class PolicyBank:
         L.check(L.lib().hh_policy_create(self.device.index or 0, self.max_rows, C.byref(self.h)))
         self.kinds = {}
         self._lut = np.zeros(256, dtype=np.uint8)
+        self.generation = 0   # bumped by every call that (re)allocates or rewrites what a captured HIP graph holds by value: weight blobs, the selector table
 
     def close(self):
         if getattr(self, "h", None):
             L.lib().hh_policy_destroy(self.h)
             self.h = None
+            self.generation += 1
 
     def __del__(self):
         try:
@@ -74,6 +76,7 @@ class PolicyBank:
         w.out_w, w.out_b = p("act_out._model.0.weight"), p("act_out._model.0.bias")
         L.check(L.lib().hh_policy_set_net(self.h, int(slot), C.byref(w)))
         self.kinds[int(slot)] = kind
+        self.generation += 1
 
     def set_critic(self, slot, kind, sd, csd):
         """the value branch of the network in `slot` (hh_policy_set_critic): sd = its actor tensors (for the shared layer), csd = the value
@@ -95,6 +98,7 @@ class PolicyBank:
         w.shared_w, w.shared_b = p("sw"), p("sb")
         w.val_w, w.val_b = p("val_out._model.0.weight"), p("val_out._model.0.bias")
         L.check(L.lib().hh_policy_set_critic(self.h, int(slot), C.byref(w)))
+        self.generation += 1
 
     def sample(self, obs, sel, world=None, uniforms=None, crit_act=None, greedy=False, actions=None, logp=None, vf=None, logits=None,
                want_vf=True):
@@ -159,6 +163,7 @@ class PolicyBank:
     def set_tile_rows(self, rows):
         """rows per workgroup tile of the forward kernel: 0 = by row count (default), 32 or 64 (hh_policy_set_tile_rows)"""
         L.check(L.lib().hh_policy_set_tile_rows(self.h, int(rows)))
+        self.generation += 1   # another kernel instance: a captured graph would keep launching the old one
 
     def set_lut(self, mapping):
         """mapping: selector byte -> network slot (everything else: no action)"""
@@ -167,6 +172,7 @@ class PolicyBank:
             lut[int(sel)] = int(slot) + 1
         L.check(L.lib().hh_policy_set_lut(self.h, lut.ctypes.data_as(C.c_void_p)))
         self._lut = lut
+        self.generation += 1
 
     @classmethod
     def random_init(cls, device, seed=0, max_rows=1 << 20):
@@ -313,7 +319,8 @@ class NetPilot:
 def own_pilot(world, policy_dir, args, pilot_rows="variants"):
     """the pilot the facades fly when they load the reference's exported policies themselves (_get_policies("HighLevel"), env_base.py:333-343):
     the variant-row form (one launch + one policy call per sub-step) for worlds of up to three aircraft per side, the two-call form otherwise or on request
-    (pilot_rows = "sides"); both fly the same trajectories"""
+    (pilot_rows = "sides"); both fly the same trajectories bit for bit when the policy kernel runs the same forward form in both (the two paths issue calls of
+    different sizes, which hhp_choose_form may hand to different forms — tile / weights-through-LDS, last-bit differences in the logits: HH_POLICY_W pins one)"""
     variants = pilot_rows == "variants" and world.A == 6
     bank = PolicyBank.from_reference_dir(world.device, policy_dir, "HighLevel", args, max_rows=world.N * (world.V_ROWS if variants else world.A))
     return VariantNetPilot(world, bank=bank) if variants else NetPilot(world, bank=bank)

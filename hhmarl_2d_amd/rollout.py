@@ -135,8 +135,10 @@ class PPORollout:
             raise ValueError("levels 4-5 fly frozen opponent policies (envs/env_base.py:312-398): pass opponents = pilots.OpponentNets(world, skip_first=False)")
         if getattr(opponents, "_skip", 0):
             # OpponentNets(skip_first=True) serves a facade whose reset() already ran one step_begin: its one-shot path re-bins rows that
-            # hh_step_begin listed, and captured into the collect's graph it would do so on every replay (every row evaluated twice)
-            opponents._skip = 0
+            # hh_step_begin listed, and captured into the collect's graph it would do so on every replay (every row evaluated twice).  The
+            # object may be shared with such a facade, so it is refused rather than silently changed
+            raise ValueError("PPORollout needs opponents = pilots.OpponentNets(world, skip_first=False): this one still holds the one-shot skip of a "
+                             "facade-style binding (skip_first=True)")
         self.opponents = opponents
         self.w, self.bank, self.T, self.gamma, self.lam = world, bank, int(T), float(gamma), float(lam)
         N, D, dev = world.N, world.D, world.device

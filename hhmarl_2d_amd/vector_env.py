@@ -343,7 +343,7 @@ class LowLevelVectorEnv(_VectorProtocol):
         n = len(dicts)
         a1 = np.concatenate([d[1] for d in dicts])   # agent 1: MultiDiscrete([13, 9, 2, 2]); agent 2 (type 2, no missile): ([13, 9, 2])
         a2 = np.concatenate([d[2] for d in dicts])
-        if a1.size != 4 * n or a2.size != 3 * n or len(dicts[0]) != 2:
+        if a1.size != 4 * n or a2.size != 3 * n or not all(len(d) == 2 for d in dicts):   # a dict with other agent ids: the per-row path decides what it means
             return False
         a[:, 0, :] = a1.reshape(n, 4)
         a[:, 1, :3] = a2.reshape(n, 3)
@@ -393,7 +393,8 @@ class _GpuHierBackend:
         torch, w = self.torch, self.world
         if not isinstance(self.pilot, (NetPilot, VariantNetPilot)):   # a foreign pilot may read things on the host: no capture
             return self._macro_step(w, self._cmd, self.pilot, out=self._out, pilot_buf=self._pbuf, early_exit=False)
-        gen = getattr(w, "ptr_generation", 0)      # the graph holds device pointers by value (trace ring, bound bank's row lists)
+        # the graph holds device pointers by value: the world's (trace ring, bound bank's row lists) and the bank's (weight blobs, selector table)
+        gen = (getattr(w, "ptr_generation", 0), id(self.pilot.bank), getattr(self.pilot.bank, "generation", 0))
         if self._graph is None or self._graph_gen != gen:
             nw = min(64, self.pilot.bank.max_rows)
             self.pilot.bank.act(torch.zeros((nw, 30), device=w.device), torch.zeros((nw,), dtype=torch.uint8, device=w.device))   # first launches outside a capture
@@ -464,15 +465,21 @@ class HighLevelVectorEnv(_VectorProtocol):
 
     def _put_action(self, a, e, k, v):
         if k <= len(self._ids):
-            a[e, k - 1] = int(v)
+            v = int(v)
+            if not 0 <= v <= 2:   # Discrete(3): an int8 cast would wrap 256 -> 0 silently
+                raise ValueError(f"commander action {v} of agent {k} in sub-environment {e} is outside Discrete(3)")
+            a[e, k - 1] = v
 
     def _pack_all(self, a, dicts):
         n, ids = len(dicts), self._ids
-        if len(dicts[0]) != len(ids):
+        if not all(len(d) == len(ids) for d in dicts):   # a dict with other agent ids: the per-row path decides what it means
             return False
+        cols = [np.fromiter((d[i] for d in dicts), dtype=np.int64, count=n) for i in ids]   # Discrete(3) per agent id
+        if any(c.min() < 0 or c.max() > 2 for c in cols):
+            return False   # the per-row path names the offender
         a[:] = 0
-        for i in ids:   # Discrete(3) per agent id
-            a[:, i - 1] = np.fromiter((d[i] for d in dicts), dtype=np.int64, count=n)
+        for i, c in zip(ids, cols):
+            a[:, i - 1] = c
         return True
 
     def send_actions(self, action_dict):

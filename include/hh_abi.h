@@ -165,7 +165,9 @@ int hh_hl_end(hh_world *w, float *obs, float *reward, uint8_t *reward_valid, uin
  * units act in id order).  An agent's action can only RAISE its flag, and an opponent's row carries the flag of at most two agents, so these calls emit
  * each opponent's row together with its VARIANTS — the copies with the observed agents' still-zero flags forced to one — and hh_hl_act_tick, after
  * letting the agents act, takes each opponent's action from the variant that matches what happened.  Same rows through the same networks: the same
- * trajectories as the standard path, bit for bit.  Row slots per arena: HH_HL_VROWS = 15 = agents 0..2, then opponent j's variant v at 3 + 4 j + v
+ * trajectories as the standard path, bit for bit — WHEN both run the same forward form of the policy kernel (a row's logits do not depend on its
+ * tile, but the tile forms and the weights-through-LDS forms differ in the last bits, and the two paths' call sizes can fall on different sides of
+ * the form threshold: a near-tie arg-max could then differ; pin the form with HH_POLICY_W / hh_policy_set_tile_rows for a bit-for-bit A/B).  Row slots per arena: HH_HL_VROWS = 15 = agents 0..2, then opponent j's variant v at 3 + 4 j + v
  * (v bit 0 / bit 1 = the first / second observed agent's flag forced; v = 0 is the row as the world stands).
  * pilot_obs [dev] f32 [N, 15, 30], pilot_mode [dev] u8 [N, 15] (0 = slot not in use), actions [dev] i8 [N, 15, 4] (the policy's output for every listed row).
  * A bound policy bank (hh_bind_policy) needs max_rows >= 15 * N. */

@@ -62,12 +62,12 @@ int hh_policy_set_lut(hh_policy *p, const uint8_t *lut);
  * Calls with more than 40 x (number of CUs) rows that carry a network (10240 on an MI355X) run another form when the width is 0: the weights
  * streamed through LDS once per 64 rows, the activations resident in registers (hh_policy_kernel_w16.h: hh_k_policy_w16<4>; when 128-row tiles come in
  * whole rounds of one per CU its eight-wave instance hh_k_policy_w16<8>: one pass over the weights per 128 rows.  HH_POLICY_W=0 keeps the tile forms,
- * 2 / 3 force the <4> / <8> instance, 1 the 128-row predecessor hh_policy_kernel_w.h).  Its logits differ from the tile forms' in the last bits (the
+ * 2 / 3 force the <4> / <8> instance).  Its logits differ from the tile forms' in the last bits (the
  * output layer is summed in one k-ordered accumulator): same 1e-5 bound; <4> and <8> compute every row with the same operation order. */
 int hh_policy_set_tile_rows(hh_policy *p, int32_t rows);
 
 /* name of the forward kernel instance a call of n_rows rows launches on this bank, as a profiler prints it ("hh_k_policy_h<1>",
- * "hh_k_policy_h<2>", "hh_k_policy_w<4>", "hh_k_policy_w16<4>", "hh_k_policy_w16<8>", "hh_k_policy"; sampler != 0: hh_policy_sample's
+ * "hh_k_policy_h<2>", "hh_k_policy_w16<4>", "hh_k_policy_w16<8>"; sampler != 0: hh_policy_sample's
  * "hh_k_policy_ppo" / "hh_k_policy_w16_ppo"): bench.py quotes counter
  * evidence only for the instance it actually ran */
 int hh_policy_kernel_name(hh_policy *p, int32_t n_rows, int32_t sampler, char *buf, int32_t len);

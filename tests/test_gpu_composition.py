@@ -5,7 +5,7 @@ tests/golden/env_*_nets.npz were recorded (oracle/gen_env_golden.py: record_nets
 Fight1/Fight2/Esc1/Esc2.forward -> get_torch_action -> _take_base_action (env_base.py:312-398, env_hetero.py:160-172,
 env_hier.py:114-140).  Here the drop-in facades get a policy directory with the same (synthetic, seeded) weights under the
 reference's file names and must reproduce every opponent / pilot ACTION, then state / observation / reward / done — with the
-HIP policy kernel (split-fp16 default and the fp32 MFMA form) inside the loop.
+HIP policy kernel (the tile form hh_k_policy_h and the weights-through-LDS form hh_k_policy_w16) inside the loop.
 
 Near-ties are NOT skipped: every decision's top-2 logit margin was recorded; an arg-max that differs from the reference's is
 an error unless that margin is <= 1e-5 (north_star's float tolerance on the logits), in which case it is counted, reported
@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 MARGIN_TOL = 1e-5    # a flipped arg-max is tolerated only below this top-2 logit gap
 LOGIT_TOL = 1e-5     # HIP kernel vs the reference's own fp32 forward
-FORMS = [pytest.param("0", id="split-fp16"), pytest.param("1", id="fp32-mfma")]
+FORMS = [pytest.param("0", id="tile-form"), pytest.param("2", id="weights-through-lds")]   # HH_POLICY_W, read at hh_policy_create
 
 
 def _write_policy_dir(tmp_path, meta):
@@ -67,13 +67,13 @@ class Flips:
         return True
 
 
-@pytest.mark.parametrize("fp32", FORMS)
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("path", nets_in_loop_files("low"), ids=lambda p: os.path.basename(p)[4:-4])
-def test_lowlevel_env_with_policy_dir_reproduces_the_reference_trace(path, fp32, tmp_path, monkeypatch):
+def test_lowlevel_env_with_policy_dir_reproduces_the_reference_trace(path, form, tmp_path, monkeypatch):
     """LowLevelEnv(level 4 / 5, policy_dir): opponents' actions from the HIP policy kernel == the reference's own networks'"""
     from hhmarl_2d_amd import env_hetero
     from hhmarl_2d_amd.env_hetero import LowLevelEnv
-    monkeypatch.setenv("HH_POLICY_FP32", fp32)
+    monkeypatch.setenv("HH_POLICY_W", form)
     g, meta = load_golden(path)
     pdir = _write_policy_dir(tmp_path, meta)
     orig = _with_arena_offset(env_hetero, meta["arena"])
@@ -115,21 +115,21 @@ def test_lowlevel_env_with_policy_dir_reproduces_the_reference_trace(path, fp32,
             assert np.abs(obs[i] - g["obs"][r][i - 1, : dims[i]]).max() <= 1e-6, f"row {r}: observation"
     n_dec = int(np.isfinite(g["opp_margin"]).sum())
     assert flips.decisions == n_dec and n_dec > 300
-    print(f"{os.path.basename(path)} [{'fp32' if fp32 == '1' else 'fp16x3'}]: {n_dec} decisions reproduced, {flips.n} near-tie flips {flips.log}")
+    print(f"{os.path.basename(path)} [{'hh_k_policy_w16' if form == '2' else 'hh_k_policy_h'}]: {n_dec} decisions reproduced, {flips.n} near-tie flips {flips.log}")
     assert flips.n <= 2
     env.close()
 
 
-@pytest.mark.parametrize("fp32", FORMS)
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("rows", ["variants", "sides"])
 @pytest.mark.parametrize("path", nets_in_loop_files("high"), ids=lambda p: os.path.basename(p)[4:-4])
-def test_highlevel_env_with_policy_dir_reproduces_the_reference_trace(path, fp32, rows, tmp_path, monkeypatch):
+def test_highlevel_env_with_policy_dir_reproduces_the_reference_trace(path, form, rows, tmp_path, monkeypatch):
     """HighLevelEnv(policy_dir): every pilot's action of every sub-step from the HIP policy kernel == the reference's networks';
     commander observations, rewards, done and eval_info follow.  Covers the L5 -> L3 escape fallback (hl_nets_2v3) and
     evaluation.py's eval_hl = False mode, where the opponents fly their own L{eval_level_opp} fight nets (hl_nets_lowlevel_eval)."""
     import hhmarl_2d_amd.env_hier as eh
     from hhmarl_2d_amd.env_hier import HighLevelEnv
-    monkeypatch.setenv("HH_POLICY_FP32", fp32)
+    monkeypatch.setenv("HH_POLICY_W", form)
     g, meta = load_golden(path)
     infos = json.loads(str(g["infos"]))
     a = meta["args"]
@@ -219,18 +219,18 @@ def test_highlevel_env_with_policy_dir_reproduces_the_reference_trace(path, fp32
     n_dec = int((g["sub_mode"] != 0).sum())
     assert flips.decisions == n_dec and n_dec > 1500
     assert want_files == set(meta["policy_files"]), "every loaded policy file flew at least once"
-    print(f"{os.path.basename(path)} [{'fp32' if fp32 == '1' else 'fp16x3'}, {'variant rows' if variants else 'two calls per sub-step'}]: {n_dec} decisions reproduced, {flips.n} near-tie flips {flips.log}")
+    print(f"{os.path.basename(path)} [{'hh_k_policy_w16' if form == '2' else 'hh_k_policy_h'}, {'variant rows' if variants else 'two calls per sub-step'}]: {n_dec} decisions reproduced, {flips.n} near-tie flips {flips.log}")
     assert flips.n <= 3
     env.close()
 
 
-@pytest.mark.parametrize("fp32", FORMS)
-def test_policy_kernel_logits_equal_the_reference_networks_on_recorded_observations(fp32, monkeypatch):
+@pytest.mark.parametrize("form", FORMS)
+def test_policy_kernel_logits_equal_the_reference_networks_on_recorded_observations(form, monkeypatch):
     """every (observation row, logits) pair the reference's networks produced INSIDE the recorded environments, through the HIP
     kernel in one batch per trace: logits <= 1e-5, arg-max equal wherever the top-2 margin exceeds 1e-5 — no row is skipped"""
     from hhmarl_2d_amd import policy_nets as PN
     from hhmarl_2d_amd.pilots import PolicyBank
-    monkeypatch.setenv("HH_POLICY_FP32", fp32)
+    monkeypatch.setenv("HH_POLICY_W", form)
     total = worst = 0
     for kind_ in ("low", "high"):
         for path in nets_in_loop_files(kind_):

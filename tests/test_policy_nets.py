@@ -45,14 +45,13 @@ def _bank(seed, max_rows=1 << 16):
     return PolicyBank.random_init(torch.device("cuda", 0), seed=seed, max_rows=max_rows)
 
 
-FORMS = {"split-fp16": {}, "fp32-mfma": {"HH_POLICY_FP32": "1"}, "split-fp16-64-row-tiles": {"HH_POLICY_TILE": "64"},
-         "weights-through-lds": {"HH_POLICY_W": "1"}, "weights-through-lds-16-rows": {"HH_POLICY_W": "2"},
-         "weights-through-lds-16-rows-8-waves": {"HH_POLICY_W": "3"}}
+FORMS = {"split-fp16": {}, "split-fp16-64-row-tiles": {"HH_POLICY_TILE": "64"},
+         "weights-through-lds-16-rows": {"HH_POLICY_W": "2"}, "weights-through-lds-16-rows-8-waves": {"HH_POLICY_W": "3"}}
 
 
 def _form(monkeypatch, form):
     """the kernel form a bank created from now on runs (read at hh_policy_create)"""
-    for k in ("HH_POLICY_FP32", "HH_POLICY_TILE", "HH_POLICY_W"):
+    for k in ("HH_POLICY_TILE", "HH_POLICY_W"):
         monkeypatch.delenv(k, raising=False)
     for k, v in FORMS[form].items():
         monkeypatch.setenv(k, v)
@@ -338,8 +337,8 @@ def test_tile_instances_of_the_kernel_agree_bit_for_bit(monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("force_w,nA,nO,N,form", [("0", 3, 3, 1003, "split-fp16"), ("2", 3, 3, 517, "split-fp16"), ("0", 2, 3, 300, "split-fp16"),
-                                                  ("0", 3, 3, 700, "fp32-mfma"), ("0", 3, 3, 900, "split-fp16-64-row-tiles")],
-                         ids=["3v3", "3v3-W2", "2v3", "3v3-fp32-mfma", "3v3-64-row-tiles"])
+                                                  ("0", 3, 3, 700, "weights-through-lds-16-rows"), ("0", 3, 3, 900, "split-fp16-64-row-tiles")],
+                         ids=["3v3", "3v3-W2", "2v3", "3v3-weights-through-lds", "3v3-64-row-tiles"])
 def test_rows_binned_by_the_world_kernels_give_the_same_macro_steps(monkeypatch, force_w, nA, nO, N, form):
     """hh_bind_policy: the phase kernels write the bank's row lists themselves and hh_policy_act_binned runs the forward only
     (the last workgroup clears the counters; hh_hl_end drops what the last tick binned).  Same worlds, same weights: every macro

@@ -1,4 +1,4 @@
-"""logit error of the policy kernels (split-fp16 default, fp32 MFMA with HH_POLICY_FP32=1) against a float64 PyTorch forward"""
+"""logit error of the policy kernels (split-fp16; HH_POLICY_W / HH_POLICY_TILE pick the form) against a float64 PyTorch forward"""
 import os
 import sys
 

@@ -1,6 +1,6 @@
 """Every form of the policy kernels on the rows REAL worlds produce (not uniform noise: tests/test_policy_nets.py's world-observation test exists because
 noise hid a 2e-5 defect), at scale: agents' observations of 2-vs-2 level-3 worlds in fight and in escape mode collected over many ticks, then
-  * hh_policy_act in every form (tile 32 / 64, fp32 MFMA, hh_k_policy_w, hh_k_policy_w16<4>, <8>): logits against the float64 PyTorch forward (the same
+  * hh_policy_act in every form (tile 32 / 64, hh_k_policy_w16<4>, <8>): logits against the float64 PyTorch forward (the same
     statements as the reference's forward(), policy_nets.torch_forward) with the fp32 PyTorch forward's own distance from it beside them; greedy actions against
     the float64 arg-max wherever its top two logits are more than 2e-5 apart;
   * hh_policy_sample in both forms (hh_k_policy_ppo, hh_k_policy_w16_ppo): value and logp against float64, the drawn action against the float64 inverse CDF
@@ -22,14 +22,14 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 TOL, SEED = 1e-5, 3
 dev = torch.device("cuda", 0)
-FORMS = {"tile 32": {"HH_POLICY_W": "0", "HH_POLICY_TILE": "32"}, "tile 64": {"HH_POLICY_W": "0", "HH_POLICY_TILE": "64"}, "fp32 MFMA": {"HH_POLICY_W": "0", "HH_POLICY_FP32": "1"},
-         "hh_k_policy_w": {"HH_POLICY_W": "1"}, "hh_k_policy_w16<4>": {"HH_POLICY_W": "2"}, "hh_k_policy_w16<8>": {"HH_POLICY_W": "3"}}
+FORMS = {"tile 32": {"HH_POLICY_W": "0", "HH_POLICY_TILE": "32"}, "tile 64": {"HH_POLICY_W": "0", "HH_POLICY_TILE": "64"},
+         "hh_k_policy_w16<4>": {"HH_POLICY_W": "2"}, "hh_k_policy_w16<8>": {"HH_POLICY_W": "3"}}
 SAMPLERS = {"hh_k_policy_ppo": {"HH_POLICY_W": "0"}, "hh_k_policy_w16_ppo": {"HH_POLICY_W": "2"}}
 bad = 0
 
 
 def setenv(d):
-    for k in ("HH_POLICY_W", "HH_POLICY_TILE", "HH_POLICY_FP32"):
+    for k in ("HH_POLICY_W", "HH_POLICY_TILE"):
         os.environ.pop(k, None)
     os.environ.update(d)
 

@@ -27,6 +27,18 @@
 #include "hh_rng.h"
 #include "hh_spec.h"
 
+/* Block placement hints.  At one wave per SIMD a SKIPPED region costs a taken branch when its body sits in line (s_cbranch_execz over the body: ~55 cycles,
+ * tools/ubench/issue.hip); with the body marked cold, hipcc's block placement moves it behind the loop and the usual path falls through a not-taken
+ * s_cbranch_execnz.  HH_RARE / HH_USUAL say which way a test goes on most wave-ticks (any lane of the wave counts); layout only, same results.
+ * -DHH_NO_RARE builds the unhinted layout for the A/B. */
+#ifdef HH_NO_RARE
+#define HH_RARE(x) (x)
+#define HH_USUAL(x) (x)
+#else
+#define HH_RARE(x) __builtin_expect(!!(x), 0)
+#define HH_USUAL(x) __builtin_expect(!!(x), 1)
+#endif
+
 /* threads per workgroup: one 64-lane wave = 16 arenas (2-vs-2) / 10 arenas (3-vs-3).  Single-wave groups
  * measured 15-20 % faster than 256-thread groups: the per-tick barriers then never wait for another wave. */
 #ifndef HH_BLOCK
@@ -342,7 +354,7 @@ __device__ __noinline__ void d_geo_direct_general(double lat1, double lon1, doub
 }
 __device__ __forceinline__ void d_geo_move(double lat1, double lon1, double azi1, double s12, double &lat2, double &lon2) {
     double a, b;
-    if (s12 <= HH_GEO_SHORT_MAX_M && hh_fabs(lat1) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon1) < 170.0 && hh_fabs(azi1) <= 360.0)
+    if (HH_USUAL(s12 <= HH_GEO_SHORT_MAX_M && hh_fabs(lat1) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon1) < 170.0 && hh_fabs(azi1) <= 360.0))
         hh_geo_direct_short(lat1, lon1, azi1, s12, &a, &b);
     else
         d_geo_direct_general(lat1, lon1, azi1, s12, &a, &b);
@@ -356,7 +368,7 @@ __device__ __forceinline__ void d_geo_move2(double lat_a, double lon_a, double a
                                             double lat_b, double lon_b, double azi_b, double s_b, double &lat2_b, double &lon2_b) {
     bool ok_a = s_a <= HH_GEO_SHORT_MAX_M && hh_fabs(lat_a) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon_a) < 170.0 && hh_fabs(azi_a) <= 360.0;
     bool ok_b = s_b <= HH_GEO_SHORT_MAX_M && hh_fabs(lat_b) <= HH_GEO_SHORT_MAX_LAT && hh_fabs(lon_b) < 170.0 && hh_fabs(azi_b) <= 360.0;
-    if (ok_a && ok_b) {
+    if (HH_USUAL(ok_a && ok_b)) {
         double a0, a1, b0, b1;
         hh_geo_direct_short(lat_a, lon_a, azi_a, s_a, &a0, &a1);
         hh_geo_direct_short(lat_b, lon_b, azi_b, s_b, &b0, &b1);

@@ -391,7 +391,7 @@ __device__ __forceinline__ double oct_action_assess(const DevCfg &c, const OTab 
     do {                                                                                                              \
         const bool c_ = (cond);                                                                                       \
         const unsigned long long bm_ = __ballot(c_);                                                                  \
-        if (bm_) {                                                                                                    \
+        if (HH_RARE(bm_ != 0ULL)) {                                                                                   \
             if (c_) sh.u.t.q_code[q_total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm_, 0u))] = (code_); \
             q_total += __popcll(bm_);                                                                                 \
         }                                                                                                             \
@@ -437,7 +437,7 @@ __device__ __forceinline__ void act_oct(const DevCfg &c, OctShared &sh, int tid,
     }
     int q_total = 0, myres = 0;
     HH_O_PUSH(try_launch && launch_pre < 0, tid | (0 << 8) | (launch_pos << 10));
-    if (q_total) { /* wave-uniform */
+    if (HH_RARE(q_total != 0)) { /* wave-uniform */
         sh.lat0[tid] = m.lat; sh.lon0[tid] = m.lon; sh.hdg[tid] = m.hdg;
         sh.flags[tid] = pub.flags;
         sh.res[tid] = 0;
@@ -525,7 +525,7 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
     {
         const bool mv_a = snap && m.spd > 0.0;
         const bool any_rk = __ballot(rk_spec) != 0ULL;
-        if (any_rk) {
+        if (HH_USUAL(any_rk)) {
             double r_hdg = m.rk_hdg;
             const double r_cmd = m.rk_cmd;
             {
@@ -571,7 +571,7 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
             pjs[r] = pj;
             any_push |= push[r];
         }
-        if (o_any(any_push != 0)) {
+        if (HH_RARE(o_any(any_push != 0))) {
 #pragma unroll
             for (int r = 0; r < 5; r++) HH_O_PUSH(push[r] != 0, tid | (1 << 8) | (pjs[r] << 10));
         }
@@ -588,7 +588,7 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
     }
     /* ---------------- phase I: dense pass over the queue ---------------- */
     int myres = 0;
-    if (q_total) { /* wave-uniform */
+    if (HH_RARE(q_total != 0)) { /* wave-uniform */
         sh.lat0[tid] = lat_old; sh.lon0[tid] = lon_old; sh.hdg[tid] = hdg_old;
         sh.flags[tid] = pub.flags;
         sh.u.t.lat1[tid] = m.lat; sh.u.t.lon1[tid] = m.lon; sh.u.t.hdg1[tid] = m.hdg;
@@ -611,7 +611,7 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
     /* ---------------- phases C + D: id-ordered resolution, computed identically by the lanes of the arena ---------------- */
     int alive = amask0, nev = 0, dead = 0;
     unsigned long long evpack = 0; /* 7 bits per event: killer position | victim position << 3 | by rocket << 6 */
-    if (__ballot(aux != 0 || (rkw & 0xe) != 0)) { /* wave-uniform: some arena of the wave has something to resolve */
+    if (HH_RARE(__ballot(aux != 0 || (rkw & 0xe) != 0) != 0ULL)) { /* wave-uniform: some arena of the wave has something to resolve */
         int aux_[8], res_[8];
         aux_[0] = o_bc_i<0>(aux); aux_[1] = o_bc_i<1>(aux); aux_[2] = o_bc_i<2>(aux);
         aux_[4] = o_bc_i<4>(aux); aux_[5] = o_bc_i<5>(aux); aux_[6] = o_bc_i<6>(aux);
@@ -687,7 +687,7 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
     const int oobm = oct_arena_bits(__ballot(oob != 0), L);
     double rews = 0.0;
     int destroyed = 0;
-    if (o_any((nev > 0) | (oob != 0))) { /* kills and removals are rare */
+    if (HH_RARE(o_any((nev > 0) | (oob != 0)))) { /* kills and removals are rare */
     if (running && L.exists && agent) {
         const double sc = c.rew_scale;
         if (oob) { rews += -2.0 * sc; destroyed = 1; }
@@ -858,7 +858,7 @@ __device__ __forceinline__ void oct_do_end(const DevPtrs &P, const DevCfg &c, Oc
     }
     const bool need_reset = phase == HH_HL_END ? (active && ar.done && c.auto_reset)
                                                : (phase == HH_HL_RESET && active && (mask == nullptr || mask[n]));
-    if (__ballot(need_reset)) { /* wave-uniform */
+    if (HH_RARE(__ballot(need_reset) != 0ULL)) { /* wave-uniform */
         if (need_reset) {
             reset_arena_scalars(ar);
             if (L.exists) {

@@ -294,6 +294,11 @@ __device__ __forceinline__ void quad_lowlevel_obs(const DevCfg &c, const QTab &t
         return;
     }
     m.n_tgt = 1; m.tgt0 = nb.j0 + 1; m.tgt_d0 = nb.d0;
+    /* zero padding: D is the AC1 row of the mode (26 fight / 30 escape) and an AC2 row is two / one entries shorter, so the padding is the row's last two
+     * entries at most — zeroed HERE, unconditionally, and overwritten by the longer rows (a lane's LDS stores land in program order), instead of a
+     * `for (; n < D; n++)` loop behind the row: a run-time trip count is an exec-mask loop with a taken branch per entry */
+    out[D - 2] = 0.0f;
+    out[D - 1] = 0.0f;
     int n = 0;
     out[n++] = p.nlat;
     out[n++] = p.nlon;
@@ -333,7 +338,6 @@ __device__ __forceinline__ void quad_lowlevel_obs(const DevCfg &c, const QTab &t
     } else {
         for (int k = 0; k < 5; k++) out[n++] = 0.0f;
     }
-    for (; n < D; n++) out[n] = 0.0f;
 }
 
 /* "does any lane of the wave want this?" as a scalar the compiler cannot fold back into the lanes' own test: a rare body then sits
@@ -359,7 +363,7 @@ __device__ __forceinline__ void quad_l3_flags(int steps, unsigned long long tkey
 #pragma unroll
     for (int j = 2; j < 4; j++) {
         const bool aj = ((amask0 >> j) & 1) != 0;
-        if (any_draw) { /* wave-uniform */
+        if (HH_RARE(any_draw)) { /* wave-uniform */
             if (aj & draw_tick & (esc == 0)) {
                 esc = hh_rng_randint(hh_rng_u01(tkey, (uint32_t)(j + 1), HH_SITE_L3_ESC_COIN, 0u), 0, 1);
                 if (esc) esc_t = (int)hh_rng_uniform(hh_rng_u01(tkey, (uint32_t)(j + 1), HH_SITE_L3_ESC_TIME, 0u), 20.0, 30.0);
@@ -434,7 +438,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     out.valid = 0;
     out.kill_event = 0;
     uint32_t evm = 0;
-    if (OWT && pre.ok) { /* wave-uniform: the key of this tick was computed by the output wave during the last one */
+    if (OWT && HH_USUAL(pre.ok)) { /* wave-uniform: the key of this tick was computed by the output wave during the last one */
         if (running) { ar.steps += 1; ar.tkey = pre.tkey; }
     } else if (running) { ar.steps += 1; arena_rekey(ar); }
     const bool snap = running && m.alive;
@@ -509,7 +513,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     /* env_hetero.py:138-158 level 3: the arena-level escape flag, consumed once per live opponent in id order */
     bool my_escaping = false;
     bool escj[2] = {false, false}; /* the flag as opponent slot 2 / 3 consumes it (every lane of the arena computes both) */
-    if (!spec) {
+    if (HH_RARE(!spec)) {
     if (running && !c.ext_opp && c.level >= 3) {
         int esc = ar.escaping, esc_t = ar.escaping_time;
         quad_l3_flags(ar.steps, ar.tkey, amask0, s, esc, esc_t, my_escaping, escj);
@@ -630,11 +634,11 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         const bool mv_a = snap && m.spd > 0.0;
         const bool any_rk = __ballot(rk_spec) != 0ULL;
         double r_lat = 5.0, r_lon = 7.0, r_hdg = 0.0;
-        if (any_rk) {
+        if (HH_USUAL(any_rk)) {
             r_lat = rk_pre ? m.rk_lat : lat_old; r_lon = rk_pre ? m.rk_lon : lon_old;
             r_hdg = rk_pre ? m.rk_hdg : hdg_old;
             rk_ncmd = m.rk_cmd;
-            if (q_any(!rk_pre & rk_spec)) /* a launch in this tick: rare */
+            if (HH_RARE(q_any(!rk_pre & rk_spec))) /* a launch in this tick: rare */
                 if (!rk_pre) rk_ncmd = hh_clip(hdg_old * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
             {
                 const double delta = d_signed_heading_diff(r_hdg, rk_ncmd);
@@ -648,7 +652,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
             /* ONE chain per lane: the main lane moves the aircraft, its helper the rocket (d_geo_move2's two interleaved chains give
              * the same bits as d_geo_move of each argument set) */
             double x_lat = m.lat, x_lon = m.lon, x_hdg = m.hdg, x_s = mv_a ? m.spd * HH_KNOTS_TO_MS * 1.0 : 0.0;
-            if (any_rk) {
+            if (HH_USUAL(any_rk)) {
                 const double h_lat = q_down_d(rk_spec ? r_lat : 5.0), h_lon = q_down_d(rk_spec ? r_lon : 7.0);
                 const double h_hdg = q_down_d(r_hdg), h_s = q_down_d(rk_speed0 * HH_KNOTS_TO_MS * 1.0);
                 x_lat = helper ? h_lat : x_lat; x_lon = helper ? h_lon : x_lon; x_hdg = helper ? h_hdg : x_hdg; x_s = helper ? h_s : x_s;
@@ -660,8 +664,8 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
             d_geo_move(x_lat, x_lon, x_hdg, x_s, o_lat, o_lon);
 #endif
             if (mv_a) { m.lat = o_lat; m.lon = o_lon; }
-            if (any_rk) { rk_nlat = q_up_d(o_lat); rk_nlon = q_up_d(o_lon); }
-        } else if (any_rk) {
+            if (HH_USUAL(any_rk)) { rk_nlat = q_up_d(o_lat); rk_nlon = q_up_d(o_lon); }
+        } else if (HH_USUAL(any_rk)) {
             const double r_spd = rk_speed0;
             double a_lat, a_lon;
             d_geo_move2(m.lat, m.lon, m.hdg, mv_a ? m.spd * HH_KNOTS_TO_MS * 1.0 : 0.0, a_lat, a_lon,
@@ -755,7 +759,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
             code[5] = tid | (3 << 8) | (fid << 10);
         }
         /* one wave-uniform test for the whole group (87 % of the wave-ticks queue nothing), then slots by ballot prefix */
-        if (__ballot(push[0] | push[1] | push[2] | push[3] | push[4] | push[5])) {
+        if (HH_RARE(__ballot(push[0] | push[1] | push[2] | push[3] | push[4] | push[5]) != 0ULL)) {
 #pragma unroll
             for (int e = 0; e < 6; e++) {
                 const unsigned long long bm = __ballot(push[e]);
@@ -776,7 +780,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     HH_PROF(2);
     /* ---------------- phase I: dense pass over the queue ---------------- */
     int myres = 0;
-    if (q_total) { /* wave-uniform */
+    if (HH_RARE(q_total != 0)) { /* wave-uniform */
         /* what the dense pass reads about the requesting and the target aircraft */
         sh.lat0[tid] = lat_old; sh.lon0[tid] = lon_old; sh.hdg[tid] = hdg_old;
         sh.flags[tid] = pub.flags;
@@ -847,7 +851,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         /* aircraft phase: shooter i (alive at tick start, even if killed earlier in this tick) hits the still-alive
          * targets in id order (ac1.py:106-115).  Most ticks nobody in the WAVE has a hit to apply. */
         const bool any_hit = ((aux_[0] | aux_[1] | aux_[2] | aux_[3]) >> 8) != 0;
-        if (q_any(any_hit)) if (any_hit) {
+        if (HH_RARE(q_any(any_hit))) if (any_hit) {
 #pragma unroll
             for (int i = 0; i < A; i++) {
                 const int ci = aux_[i] >> 8;
@@ -868,7 +872,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         for (int j = 0; j < A; j++) {
             if ((res_[j] & 1) && (res_[j] & 0xe)) { nact++; w1 = res_[j]; b1 = j; }
         }
-        if (q_any(nact > 0)) {
+        if (HH_RARE(q_any(nact > 0))) {
         if (nact == 1) {
             const int tg = (w1 >> 4) & 7;
             const int fid = b1 == 1 ? 0 : 1;
@@ -936,7 +940,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     double rews = 0.0;
     int destroyed = 0;
     /* kills and removals are rare: rewards and event masks behind one wave-uniform test (nothing below does anything without one) */
-    if (q_any((nev > 0) | (oob != 0))) {
+    if (HH_RARE(q_any((nev > 0) | (oob != 0)))) {
     if (running && agent) {
         const double sc = c.rew_scale;
         if (oob) { rews += -5.0 * sc; destroyed = 1; }
@@ -1231,7 +1235,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                     const bool ran = ((w7s >> 26) & 1) != 0, dn = ((w7s >> 25) & 1) != 0;
                     const double e2 = (ep_ret + rv) + r1;
                     ep_ret = ran ? e2 : ep_ret;
-                    if (stat_lane && ran && dn) { /* an episode ended */
+                    if (HH_RARE(stat_lane && ran && dn)) { /* an episode ended */
                         const int am = (w7s >> 27) & 0xf, steps = steps_t;
                         const int ag = __popc(am & 3), op = __popc(am & 12);
                         P.last_ret[n] = (float)ep_ret;
@@ -1240,7 +1244,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                     }
                     if (dn && c.auto_reset) ep_ret = 0.0; /* the arena starts a new episode (K3 of the simulation wave) */
                 }
-                if (mbx.slim.full) { /* a reset in this tick (wave-uniform): the rows come from the simulation wave's own table of the new episodes */
+                if (HH_RARE(mbx.slim.full)) { /* a reset in this tick (wave-uniform): the rows come from the simulation wave's own table of the new episodes */
                     if (row) mail_take(mbx.mail[0], g * 2 + s, tb, pub, m, valid, done, rew);
                 } else {
                     pub.flags = mbx.slim.flags[tid];
@@ -1401,7 +1405,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                 const double e2 = (ep_ret + r0) + r1;
                 ep_ret = was_running ? e2 : ep_ret;
                 const bool fin = was_running & (ar.done != 0) & (s == 0);
-                if (q_any(fin)) if (fin) { /* an episode ended: rare */
+                if (HH_RARE(q_any(fin))) if (fin) { /* an episode ended: rare */
                     const int ag = __popc(tb.amask & 3), op = __popc(tb.amask & 12);
                     P.last_ret[n] = (float)ep_ret;
                     P.last_len[n] = ar.steps;
@@ -1412,7 +1416,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         if (!TWO && active && s == 0 && done_out) done_out[(size_t)t * c.N + n] = (uint8_t)ar.done;
         const bool need_reset = active && ar.done && c.auto_reset;
         const bool reset_tick = q_any(need_reset);
-        if (reset_tick) { /* K3, wave-uniform */
+        if (HH_RARE(reset_tick)) { /* K3, wave-uniform */
             if (need_reset) {
                 reset_arena_scalars(ar);
                 reset_unit<A>(c, s, m, ar);
@@ -1443,11 +1447,11 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
             HH_PROF(13);
             pre.ok = !reset_tick;
             pre.spec = !reset_tick && !q_any(active && tb.amask != amask_before);
-            if (!reset_tick) { /* wave-uniform: take what the output wave built while this wave ran the envelope phases, and what it computed ahead */
+            if (HH_USUAL(!reset_tick)) { /* wave-uniform: take what the output wave built while this wave ran the envelope phases, and what it computed ahead */
                 pre.tkey = mbx.tab.tk[tid]; pre.sx = mbx.tab.sx[tid]; pre.sy = mbx.tab.sy[tid];
                 pub.uc = mbx.tab.uc[tid]; pub.us = mbx.tab.us[tid]; /* the exact heading vector (the tick carried a rotated one) */
                 pre.sp_hdg = mbx.tab.sp_hdg[tid]; pre.sp_spd = mbx.tab.sp_spd[tid]; pre.sp_w = mbx.tab.sp_w[tid];
-                if (pre.spec) { /* wave-uniform: no alive mask of the wave changed — the output wave's _nearby_object and target entries are this tick's (QTgt) */
+                if (HH_USUAL(pre.spec)) { /* wave-uniform: no alive mask of the wave changed — the output wave's _nearby_object and target entries are this tick's (QTgt) */
                     const int w = mbx.tab.nbw[tid];
                     const double r0 = mbx.tab.nr0[tid];
                     tg.foc = mbx.tab.nfoc[tid]; tg.focr = mbx.tab.nfocr[tid]; tg.dist = r0;

@@ -407,7 +407,7 @@ __device__ __forceinline__ void act_oct(const DevCfg &c, OctShared &sh, int tid,
     const bool snap = L.exists && running && m.alive && acts;
     int want_launch = 0, launch_pos = 0;
     bool base_gate = false;
-    if (snap) {
+    if (HH_USUAL(snap)) {
         double dd;
         const int t = hl_target_slot(m, dd);
         double nh = hh_pymod360(m.hdg + (double)(((int)act[0] - 6) * 15));
@@ -491,7 +491,7 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
     const double lat_old = m.lat, lon_old = m.lon, hdg_old = m.hdg;
     bool fired = false;
     const int rk_pre = m.rk_alive;
-    if (snap) {
+    if (HH_USUAL(snap)) {
         const int t = m.ac_type;
         {
             const double delta = d_signed_heading_diff(m.hdg, m.cmd_hdg);
@@ -517,7 +517,7 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
     }
     { /* ac1.py:117-128 */
         const bool steer = snap & (m.has_missile != 0) & (m.rk_alive != 0);
-        if (o_any(steer)) if (steer) m.rk_cmd = hh_clip(m.rk_hdg * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
+        if (HH_USUAL(steer)) m.rk_cmd = hh_clip(m.rk_hdg * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
         m.has_missile = (snap & (m.has_missile != 0) & (m.rk_alive == 0)) ? 0 : m.has_missile;
     }
     const bool rk_spec = running && L.exists && rk_pre && m.rk_life <= HH_ROCKET_MAX_LIFE;
@@ -603,7 +603,7 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
     const int rk_at_start = m.rk_alive;
     const int aux = fired ? (myres >> 1) & 0xff : 0; /* cannon hits by target lane position */
     int rkw = 0; /* bit0 present, bit1 fuse on target, bit2 fuse on "friendly", bit3 end of life, bits4-6 target position, bits 8.. seq */
-    if (running && L.exists && rk_at_start) {
+    if (HH_USUAL(running && L.exists && rk_at_start)) {
         const int eol = m.rk_life > HH_ROCKET_MAX_LIFE;
         rkw = 1 | (((myres >> 9) & 1) << 1) | (((myres >> 10) & 1) << 2) | (eol << 3) | (o_slot_pos(c, m.rk_target - 1) << 4) | (m.rk_seq << 8);
     }
@@ -666,7 +666,7 @@ __device__ __forceinline__ void tick_oct(const DevCfg &c, OctShared &sh, int tid
             }
         }
     }
-    if (o_any(running & L.exists & (rk_at_start != 0))) if (running && L.exists && rk_at_start) {
+    if (HH_USUAL(running && L.exists && rk_at_start)) { /* (usually some rocket of the wave is in flight: no any-lane test in front) */
         if ((dead >> L.p) & 1) {
             m.rk_alive = 0; m.rk_target = 0; m.rk_life = 0; m.rk_seq = 0;
             m.rk_lat = m.rk_lon = m.rk_hdg = m.rk_cmd = 0.0;
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_macro_oct(DevPtrs P, DevCfg c
         if (running) H.evm = 0;
         /* both sides' _take_base_action in one pass: a side's action reads nothing the other side's action writes (positions do not
          * move, the missile_wait draws are keyed by unit), and launches are numbered in unit id order either way */
-        if (tab) act_oct<(W >= 2), true>(c, sh, tid, L, running, H.m, H.ar, act, true, tb, pub, H.evm);
+        if (HH_RARE(tab)) act_oct<(W >= 2), true>(c, sh, tid, L, running, H.m, H.ar, act, true, tb, pub, H.evm); /* the first sub-step only */
         else act_oct<(W >= 2), false>(c, sh, tid, L, running, H.m, H.ar, act, true, tb, pub, H.evm);
         ticks += oct_do_tick<(W >= 2), false>(P, c, sh, tid, L, n, active, H, tb, pub);
         tab = false;

@@ -458,7 +458,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
      * unconditionally (named locals first, so that the front end emits a select and not a branch), nested tests are merged into one
      * region, and rare bodies sit behind ONE wave-uniform ballot test.  Same expressions, same bits. */
     {
-        if (snap & (agent | (c.ext_opp != 0))) {
+        if (HH_USUAL(snap & (agent | (c.ext_opp != 0)))) {
             int t = m.n_tgt ? m.tgt0 : 0;
             if (!agent) { /* env_base.py:349-398 _policy_actions -> lowlevel_state(opp_mode, i): refresh target */
                 const Near2 nb = nbc;
@@ -478,7 +478,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
             double mx = HH_AC_MAX_SPEED(m.ac_type);
             m.cmd_spd = 100.0 + ((mx - 100.0) / 8.0) * (double)act[1];
 #endif
-            if (act[2] && m.cannon_remain > 0) {
+            if (HH_USUAL(act[2] && m.cannon_remain > 0)) {
                 arm_cannon(m);
                 if (agent && c.agent_mode == HH_MODE_ESCAPE && m.cannon_remain < 90) out.reward -= 0.1;
             }
@@ -514,7 +514,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     bool my_escaping = false;
     bool escj[2] = {false, false}; /* the flag as opponent slot 2 / 3 consumes it (every lane of the arena computes both) */
     if (HH_RARE(!spec)) {
-    if (running && !c.ext_opp && c.level >= 3) {
+    if (HH_USUAL(running && !c.ext_opp && c.level >= 3)) {
         int esc = ar.escaping, esc_t = ar.escaping_time;
         quad_l3_flags(ar.steps, ar.tkey, amask0, s, esc, esc_t, my_escaping, escj);
         ar.escaping = esc;
@@ -553,9 +553,9 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
 #ifdef HHQ_ABL_SCRIPT
     if (false) {
 #else
-    if (running && !c.ext_opp && c.level >= 3) {
+    if (HH_USUAL(running && !c.ext_opp && c.level >= 3)) {
 #endif
-        if (snap && !agent) {
+        if (HH_USUAL(snap && !agent)) {
             double rs, rc;
             if (OWT && pre.ok) { rs = pre.sx; rc = pre.sy; } /* wave-uniform */
             else {
@@ -574,10 +574,10 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         }
     }
     } else { /* spec: apply what the output wave decided (same functions, same operands) */
-        if (running) {
+        if (HH_USUAL(running)) {
             ar.escaping = (pre.sp_w >> 8) & 0xff;
             ar.escaping_time = (int)(int8_t)((pre.sp_w >> 16) & 0xff);
-            if (snap && !agent) {
+            if (HH_USUAL(snap && !agent)) {
                 const int opp = ((pre.sp_w >> 2) & 7) - 1;
                 m.cmd_hdg = pre.sp_hdg;
                 m.cmd_spd = pre.sp_spd;
@@ -597,7 +597,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
     const int has_missile_pre = m.has_missile;
     const bool try_launch = want_launch && !m.has_missile && m.missile_remain > 0; /* ac1.py:73 */
     double turn_deg = 0.0;
-    if (snap) {
+    if (HH_USUAL(snap)) {
         int t = m.ac_type;
         {
             const double delta = d_signed_heading_diff(m.hdg, m.cmd_hdg);
@@ -616,14 +616,14 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
             const double ns = hh_fabs(delta) <= max_delta ? m.cmd_spd : stepped;
             m.spd = m.spd != m.cmd_spd ? ns : m.spd;
         }
-        if (m.burst > 0) {
+        if (HH_USUAL(m.burst > 0)) {
             fired = true;
             m.burst = m.burst - 1 > 0 ? m.burst - 1 : 0;
             m.cannon_remain = m.cannon_remain - 1 > 0 ? m.cannon_remain - 1 : 0;
         }
         { /* ac1.py:117-128, rocket launched in an earlier step */
             const bool steer = (m.has_missile != 0) & (m.rk_alive != 0);
-            if (q_any(steer)) if (steer) m.rk_cmd = hh_clip(m.rk_hdg * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
+            if (HH_USUAL(steer)) m.rk_cmd = hh_clip(m.rk_hdg * hh_rng_uniform(d_rng(ar, id, HH_SITE_ROCKET_NOISE, 0), 0.95, 1.05), 0.0, 359.0);
             m.has_missile = ((m.has_missile != 0) & (m.rk_alive == 0)) ? 0 : m.has_missile;
         }
     }
@@ -917,7 +917,7 @@ __device__ __forceinline__ void tick_quad(const DevCfg &c, Shared<4, 64> &sh, in
         }
         }
     }
-    if (q_any(running & (rk_at_start != 0))) if (running && rk_at_start) {
+    if (HH_USUAL(running && rk_at_start)) { /* (usually some rocket of the wave is in flight: no any-lane test in front) */
         if ((dead >> s) & 1) {
             m.rk_alive = 0; m.rk_target = 0; m.rk_life = 0; m.rk_seq = 0;
             m.rk_lat = m.rk_lon = m.rk_hdg = m.rk_cmd = 0.0;
@@ -1258,7 +1258,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                     done = (w7 >> 25) & 1;
                     rew = (float)mbx.slim.rew[tid];
                 }
-                if (row) {
+                if (HH_USUAL(row)) {
                     quad_lowlevel_obs(c, tb, pub, s, c.agent_mode, m, &mbx.tile[(g * 2 + s) * D], D);
                     const size_t o = ((size_t)t * c.N + n) * 2 + s;
                     if (reward_out) reward_out[o] = rew;
@@ -1391,7 +1391,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         asm volatile("" : "+v"(act_next)); /* take the word of tick t+1 HERE (see above) ... */
         act_cur = act_next;
         act_next = *reinterpret_cast<const int *>(act_ptr + (size_t)min(t + 2, T - 1) * act_stride); /* ... and request t+2 */
-        if (!TWO && active && s < 2) {
+        if (!TWO && HH_USUAL(active && s < 2)) {
             size_t o = ((size_t)t * c.N + n) * 2 + s;
             if (reward_out) reward_out[o] = (float)so.reward;
             if (valid_out) valid_out[o] = (uint8_t)so.valid;
@@ -1487,7 +1487,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
             continue;
         }
         /* K2: observation rows staged in LDS, then written with unit-stride 16-byte stores */
-        if (active && s < 2) quad_lowlevel_obs(c, tb, pub, s, c.agent_mode, m, &sh.u.obs[(g * 2 + s) * D], D);
+        if (HH_USUAL(active && s < 2)) quad_lowlevel_obs(c, tb, pub, s, c.agent_mode, m, &sh.u.obs[(g * 2 + s) * D], D);
         q_wave_sync();
         if (obs_out) {
             const int rows = min(GPB, c.N - (int)blockIdx.x * GPB);

@@ -440,7 +440,7 @@ __device__ __forceinline__ void drain_envelope_queue_t(SH &sh, int tid, int coun
             }
         }
 #ifndef HH_ABL_NO_EXACT
-        if (verdict < 0) verdict = INLINE_EXACT ? d_envelope_exact_body(kind, t, la1, lo1, la2, lo2, hdg_src)
+        if (HH_RARE(verdict < 0)) verdict = INLINE_EXACT ? d_envelope_exact_body(kind, t, la1, lo1, la2, lo2, hdg_src)
                                                 : d_envelope_exact(kind, t, la1, lo1, la2, lo2, hdg_src);
 #endif
         int bit = 0;
@@ -675,7 +675,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
 #else
         const bool any_rk = __ballot(rk_spec) != 0ULL;
 #endif
-        if (any_rk) {
+        if (HH_USUAL(any_rk)) {
             const double speed_table[11] = HH_ROCKET_SPEED_TABLE;
             double r_lat = rk_pre ? m.rk_lat : lat_old, r_lon = rk_pre ? m.rk_lon : lon_old;
             double r_hdg = rk_pre ? m.rk_hdg : hdg_old;
@@ -763,7 +763,7 @@ __device__ __forceinline__ void tick(const DevCfg &c, Shared<A, B> &sh, int tid,
             }
         }
 #undef HH_PUSH
-        if (nq) {
+        if (HH_RARE(nq != 0)) {
             int at = atomicAdd(&sh.u.t.q_count, nq);
             sh.u.t.q_code[at] = c0;
             if (nq > 1) sh.u.t.q_code[at + 1] = c1;

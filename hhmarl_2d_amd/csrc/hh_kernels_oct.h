@@ -1167,7 +1167,7 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
     if (VAR && obs_side == 2 && pilot_obs) {
         /* both sides' rows of the next sub-step: agents in slots 0..2, opponent j's variant v in slot 3 + 4 j + v */
         o_wave_sync(); /* the queue's exchange area is free */
-        if (c.nA + c.nO < 6) {
+        if (HH_RARE(c.nA + c.nO < 6)) {
             for (int k = tid; k < 8 * HH_HL_VROWS * 30; k += 64) vrow[k] = 0.0f;
             o_wave_sync();
         }
@@ -1200,7 +1200,7 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
                 if (!agent) { pmq[1] = (uint8_t)((vmask & 2) ? sel : 0); pmq[2] = (uint8_t)((vmask & 4) ? sel : 0); pmq[3] = (uint8_t)((vmask & 8) ? sel : 0); }
             }
         }
-        if (active && pilot_mode && c.nA + c.nO < 6 && L.p == 3) { /* the bytes of the slots without an aircraft */
+        if (HH_RARE(active && pilot_mode && c.nA + c.nO < 6 && L.p == 3)) { /* the bytes of the slots without an aircraft */
             for (int sl = c.nA; sl < 3; sl++) pilot_mode[(size_t)n * HH_HL_VROWS + sl] = 0;
             for (int sl = c.nO; sl < 3; sl++) for (int q = 0; q < 4; q++) pilot_mode[(size_t)n * HH_HL_VROWS + 3 + 4 * sl + q] = 0;
         }
@@ -1211,7 +1211,7 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
         const int arenas = min(8, c.N - grp * 8);
         const int cnt = arenas * HH_HL_VROWS * 30; /* 450 floats per arena: a multiple of two */
         float *dst = pilot_obs + (size_t)grp * 8 * HH_HL_VROWS * 30;
-        if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0) {
+        if (HH_USUAL((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0)) {
             const float4 *src4 = reinterpret_cast<const float4 *>(vrow);
             float4 *dst4 = reinterpret_cast<float4 *>(dst);
             for (int k = tid; k < (cnt >> 2); k += 64) dst4[k] = src4[k];
@@ -1222,7 +1222,7 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
     } else if (obs_side >= 0 && pilot_obs) {
         const bool mine = obs_side == 0 ? agent : !agent;
         o_wave_sync(); /* the queue's exchange area (same LDS) is free */
-        if (c.nA + c.nO < 6) { /* n-vs-m: the rows of the slots without an aircraft */
+        if (HH_RARE(c.nA + c.nO < 6)) { /* n-vs-m: the rows of the slots without an aircraft */
             for (int k = tid; k < 8 * 6 * 30; k += 64) sh.u.prow[k] = 0.0f;
             o_wave_sync();
         }
@@ -1233,14 +1233,14 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
             else for (int k = 0; k < 30; k++) row[k] = 0.0f;
             if (pilot_mode) pilot_mode[u] = (uint8_t)(mode ? hl_selector(c, mode, m.ac_type, agent) : 0);
         }
-        if (active && pilot_mode && c.nA + c.nO < 6 && L.p == 3) { /* the bytes of the slots without an aircraft */
+        if (HH_RARE(active && pilot_mode && c.nA + c.nO < 6 && L.p == 3)) { /* the bytes of the slots without an aircraft */
             for (int sl = c.nA + c.nO; sl < 6; sl++) pilot_mode[(size_t)n * 6 + sl] = 0;
         }
         o_wave_sync();
         const int arenas = min(8, c.N - grp * 8);
         const int cnt = arenas * 6 * 30;
         float *dst = pilot_obs + (size_t)grp * 8 * 6 * 30;
-        if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0) {
+        if (HH_USUAL((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0)) {
             const float4 *src4 = reinterpret_cast<const float4 *>(sh.u.prow);
             float4 *dst4 = reinterpret_cast<float4 *>(dst);
             for (int k = tid; k < (cnt >> 2); k += 64) dst4[k] = src4[k];

@@ -1076,6 +1076,29 @@ __device__ __forceinline__ void mail_take(const ObsMail &mb, int r, QTab &t, QPu
     rew = mb.rew[r];
 }
 
+/* a workgroup's observation rows of one tick, staged in LDS (`tile`: GPB arenas x 2 agents x D floats, contiguous) -> [T, N, 2, D] with unit-stride 16-byte
+ * stores.  The usual workgroup is full and its rows 16-byte aligned: the copy then has a compile-time trip count wherever D is one (the preset
+ * instances) — three or four predicated stores instead of a run-time loop with a taken branch per round. */
+template <int GPB>
+__device__ __forceinline__ void quad_store_rows(float *__restrict__ obs_out, const float *tile, int t, int N, int D, int tid) {
+    const int rows = min(GPB, N - (int)blockIdx.x * GPB);
+    float *dst = obs_out + ((size_t)t * N + (size_t)blockIdx.x * GPB) * 2 * D;
+    const int full = GPB * 2 * D;
+    if (HH_USUAL(rows == GPB && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (full & 3) == 0)) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(tile);
+        float4 *dst4 = reinterpret_cast<float4 *>(dst);
+        const int cnt4 = full >> 2;
+#pragma unroll
+        for (int k0 = 0; k0 < cnt4; k0 += 64) {
+            const int k = k0 + tid;
+            if (k < cnt4) dst4[k] = src4[k];
+        }
+    } else {
+        const int cnt = rows * 2 * D;
+        for (int k = tid; k < cnt; k += 64) dst[k] = tile[k];
+    }
+}
+
 template <bool TWO> struct QuadMailbox { /* LDS of the two-wave form only */
     ObsMail mail[2];
     alignas(16) float tile[16 * 2 * HH_OBS_ESC_AC1];
@@ -1266,18 +1289,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                     if (s == 0 && done_out) done_out[(size_t)t * c.N + n] = (uint8_t)done;
                 }
                 q_wave_sync();
-                if (obs_out) {
-                    const int rows = min(GPB, c.N - (int)blockIdx.x * GPB);
-                    const int cnt = rows * 2 * D;
-                    float *dst = obs_out + ((size_t)t * c.N + (size_t)blockIdx.x * GPB) * 2 * D;
-                    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0) {
-                        const float4 *src4 = reinterpret_cast<const float4 *>(mbx.tile);
-                        float4 *dst4 = reinterpret_cast<float4 *>(dst);
-                        for (int k = tid; k < (cnt >> 2); k += 64) dst4[k] = src4[k];
-                    } else {
-                        for (int k = tid; k < cnt; k += 64) dst[k] = mbx.tile[k];
-                    }
-                }
+                if (obs_out) quad_store_rows<GPB>(obs_out, mbx.tile, t, c.N, D, tid);
                 q_wave_sync(); /* the tile is free again */
                 HH_OPROF(3);
             }
@@ -1307,18 +1319,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
                     if (s == 0 && done_out) done_out[(size_t)t * c.N + n] = (uint8_t)done;
                 }
                 q_wave_sync();
-                if (obs_out) {
-                    const int rows = min(GPB, c.N - (int)blockIdx.x * GPB);
-                    const int cnt = rows * 2 * D;
-                    float *dst = obs_out + ((size_t)t * c.N + (size_t)blockIdx.x * GPB) * 2 * D;
-                    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0) {
-                        const float4 *src4 = reinterpret_cast<const float4 *>(mbx.tile);
-                        float4 *dst4 = reinterpret_cast<float4 *>(dst);
-                        for (int k = tid; k < (cnt >> 2); k += 64) dst4[k] = src4[k];
-                    } else {
-                        for (int k = tid; k < cnt; k += 64) dst[k] = mbx.tile[k];
-                    }
-                }
+                if (obs_out) quad_store_rows<GPB>(obs_out, mbx.tile, t, c.N, D, tid);
                 q_wave_sync(); /* the tile is free again */
             }
             return;
@@ -1489,18 +1490,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, W) __attribute__((amdgpu_waves_per_
         /* K2: observation rows staged in LDS, then written with unit-stride 16-byte stores */
         if (HH_USUAL(active && s < 2)) quad_lowlevel_obs(c, tb, pub, s, c.agent_mode, m, &sh.u.obs[(g * 2 + s) * D], D);
         q_wave_sync();
-        if (obs_out) {
-            const int rows = min(GPB, c.N - (int)blockIdx.x * GPB);
-            const int cnt = rows * 2 * D;
-            float *dst = obs_out + ((size_t)t * c.N + (size_t)blockIdx.x * GPB) * 2 * D;
-            if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (cnt & 3) == 0) {
-                const float4 *src4 = reinterpret_cast<const float4 *>(sh.u.obs);
-                float4 *dst4 = reinterpret_cast<float4 *>(dst);
-                for (int k = tid; k < (cnt >> 2); k += B) dst4[k] = src4[k];
-            } else {
-                for (int k = tid; k < cnt; k += B) dst[k] = sh.u.obs[k];
-            }
-        }
+        if (obs_out) quad_store_rows<GPB>(obs_out, sh.u.obs, t, c.N, D, tid);
         q_wave_sync();
         HH_PROF(10);
     }

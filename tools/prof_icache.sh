@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/icache; rm -rf $OUT; mkdir -p $OUT
 run() { # tag lib args...
   tag=$1; lib=$2; shift; shift
-  HH_WORLD_LIB=$lib rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU -d $OUT/$tag -o p -- python $R/bench.py --no-cpu-baseline --no-extra --spinup 0.3 "$@" > $OUT/$tag.log 2>&1
+  HH_WORLD_LIB=${lib:+$R/$lib} rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU -d $OUT/$tag -o p -- python $R/bench.py --no-cpu-baseline --no-extra --spinup 0.3 "$@" > $OUT/$tag.log 2>&1
   python - $OUT/$tag/p_results.db $tag <<'PY'
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
@@ -20,10 +20,12 @@ for k, d in best.items():
 PY
   find $OUT/$tag -name "*.db" -delete
 }
-for lib in hhmarl_2d_amd/lib/abl_norare.so ""; do
-  n=$( [ -z "$lib" ] && echo hinted || echo norare )
+for lib in ${LIBS_IC:-product}; do
+  [ "$lib" = "product" ] && lib=""
+  n=$( [ -z "$lib" ] && echo product || basename $lib .so )
   run q4096_$n   "$lib" --arenas 4096 --chunk 500 --steps 6 --warmup 2
   run q262144_$n "$lib" --arenas 262144 --chunk 125 --steps 6 --warmup 2
   run h8192_$n   "$lib" --workload hier --arenas 8192 --steps 30 --warmup 5
   run h65536_$n  "$lib" --workload hier --arenas 65536 --steps 12 --warmup 3
+  run nets_$n    "$lib" --workload hier --pilot net --arenas 8192 --steps 8 --warmup 2
 done 2>&1 | tee $OUT/summary.txt

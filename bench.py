@@ -35,7 +35,7 @@ ALGO_BYTES_3V3_TICK = 2056       # 656 + 656 + pilot obs 720 +
 ALGO_BYTES_3V3_TICK_TAPE = 1336  # the same tick when the pilots' actions come from a tape: nobody builds or reads the 720 B of pilot observations
 ALGO_BYTES_3V3_STATE = 656       # one arena's state record (read once and written once per commander step by the one-launch macro step)
 ALGO_BYTES_3V3_CMD_FIXED = 424   # commander obs 408 + actions 3 + rewards 12 + done 1
-DEFAULT_STREAMS = {"rollout": 1, "hier_net": 4, "hier_net_variants": 2}   # sub-worlds / streams of the policy-in-the-loop workloads (--streams)
+DEFAULT_STREAMS = {"rollout": 1, "hier_net": 4, "hier_net_variants": 4}   # sub-worlds / streams of the policy-in-the-loop workloads (--streams)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F16_PEAK_TFLOPS = 2500.0    # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md; AMD's headline figure includes 2:1 sparsity)
 MFMA_F32_PEAK_TFLOPS = 157.3     # fp32-in MFMA runs at the vector rate
@@ -73,6 +73,8 @@ def parse_args():
                                                         "actor: per tick hh_policy_sample = actor forward + Categorical draw per action component (keyed RNG) + its "
                                                         "log-probability + the centralised value branch on central_critic_observer's rows, then hh_step")
     ap.add_argument("--no-graph", action="store_true", help="hier/rollout: launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--joined", action="store_true", help="hier --pilot net: ONE HIP graph whose sub-world branches join at the end of every commander step "
+                                                          "(default: one graph per sub-world, each replayed on its own stream)")
     ap.add_argument("--pilot-rows", choices=["variants", "sides"], default="variants",
                     help="hier --pilot net: 'variants' = one launch + one policy call per sub-step (each opponent's row evaluated in the variants the agents' "
                          "same-sub-step weapon flags can produce: hh_hl_begin_variants / hh_hl_act_tick); 'sides' = the two-launch, two-call path (A/B; same trajectories)")
@@ -812,6 +814,29 @@ def main_hier(args, R=None):
     R.close()
 
 
+def make_streams(torch, K, allow_default=True):
+    """K streams on K different hardware queues.  The runtime drives FOUR hardware queues (more, GPU_MAX_HW_QUEUES, do not run side by side: tools/queue_probe.py);
+    the default stream owns one of them and every other stream shares the remaining three, so four dependent chains only run side by side when one of them is
+    issued on the default stream (tools/timeline.py: with four side streams, sub-world 3 starts when one of the others has finished its commander step).
+    torch.cuda.Stream() also hands out its pool low / high priority in turn — consecutive pool streams land on two queues — and a stream that ever carried work
+    (a warm-up side stream) keeps its queue: the streams are created directly, one after the other.  HH_BENCH_STREAMS = side (no default stream) | pool: A/B."""
+    mode = os.environ.get("HH_BENCH_STREAMS", "default0")
+    if mode == "pool":
+        return [torch.cuda.Stream() for _ in range(K)]
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    out = []
+    if mode == "default0" and K > 3 and allow_default:
+        out.append(torch.cuda.default_stream())
+    for _ in range(K - len(out)):
+        h = ctypes.c_void_p()
+        rc = hip.hipStreamCreateWithFlags(ctypes.byref(h), ctypes.c_uint(1))   # hipStreamNonBlocking
+        if rc != 0:
+            raise RuntimeError(f"hipStreamCreateWithFlags: {rc}")
+        out.append(torch.cuda.ExternalStream(h.value))
+    return out
+
+
 def main_hier_split(args, R, own, N, K):
     """configs[3] with the pilot networks in the loop, the arenas split into K sub-worlds (disjoint global arena ids: the same arenas
     as one world of N) whose 66-launch commander steps run on K streams inside ONE HIP graph: a sub-world's world-phase launches
@@ -842,7 +867,8 @@ def main_hier_split(args, R, own, N, K):
     cmd_static = [cmds[0, offs[k]:offs[k] + sizes[k]].clone() for k in range(K)]
     outs = [w.alloc_outputs() for w in worlds]
     pbufs = [(w.alloc_pilot_variants() if variants else w.alloc_pilot()) for w in worlds]
-    streams = [torch.cuda.Stream() for _ in range(K)]
+    pipelined = not args.no_graph and not args.joined
+    streams = make_streams(torch, K, allow_default=pipelined)   # (a joined graph is captured: nothing may be issued on the default stream meanwhile)
 
     def step():
         cur = torch.cuda.current_stream()
@@ -853,30 +879,51 @@ def main_hier_split(args, R, own, N, K):
         for k in range(K):
             cur.wait_stream(streams[k])
 
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(2):
-            step()
-    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(2):   # (no side stream here: every stream that ever carried work keeps one of the four hardware queues, and K of them are needed below)
+        step()
     torch.cuda.synchronize()
-    graph = None
-    if not args.no_graph:
+    # One graph per sub-world, replayed on the sub-world's own stream (default), or ONE graph whose K branches join at the end of every commander step
+    # (--joined).  hipGraphLaunch enqueues a graph's kernel nodes branch after branch at ~3 us of host time each: branch k of the joined graph starts
+    # k x 100 us after branch 0 and the step ends with the last branch alone on the chip (tools/timeline.py).  Separate graphs let every sub-world go on
+    # with its next commander step as soon as its own last launch is through — the arenas are independent environments, nothing orders sub-world 0's step
+    # n + 1 after sub-world 3's step n — and the host only has to keep K queues fed (34 launches per sub-world and step).  The timed region still covers
+    # exactly `steps` commander steps of every arena, bracketed by a device synchronisation on both sides.
+    graph, graphs = None, []
+    if pipelined:
+        for k in range(K):
+            gk = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gk, stream=(streams[k] if streams[k].cuda_stream != 0 else torch.cuda.Stream())):
+                macro_step(worlds[k], cmd_static[k], pilots_[k], out=outs[k], pilot_buf=pbufs[k])
+            graphs.append(gk)
+    elif not args.no_graph:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             step()
     state = {"k": 0}
 
     def run(m):
+        cur = torch.cuda.current_stream()
+        if pipelined:
+            for j in range(K):
+                streams[j].wait_stream(cur)
         for _ in range(m):
             k = state["k"]
-            for j in range(K):
-                cmd_static[j].copy_(cmds[k % 64, offs[j]:offs[j] + sizes[j]])
-            if graph is not None:
-                graph.replay()
-            else:   # --no-graph: the same launches issued eagerly on the K streams (A/B of the graph's scheduling)
-                step()
+            if pipelined:
+                for j in range(K):
+                    with torch.cuda.stream(streams[j]):
+                        cmd_static[j].copy_(cmds[k % 64, offs[j]:offs[j] + sizes[j]])
+                        graphs[j].replay()
+            else:
+                for j in range(K):
+                    cmd_static[j].copy_(cmds[k % 64, offs[j]:offs[j] + sizes[j]])
+                if graph is not None:
+                    graph.replay()
+                else:   # --no-graph: the same launches issued eagerly on the K streams (A/B of the graph's scheduling)
+                    step()
             state["k"] = k + 1
+        if pipelined:
+            for j in range(K):
+                cur.wait_stream(streams[j])
 
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < args.spinup:
@@ -905,7 +952,7 @@ def main_hier_split(args, R, own, N, K):
         "sim_ticks_per_s": ticks * R.world / dt, "ticks_per_commander_step": ticks / float(N * steps),
         "config": {"workload": f"{N} arenas/GPU x 3-vs-3 HighLevelEnv commander steps (<= 16 sub-steps each), uniform commander actions, "
                                f"pilots = {PILOT_DESC['net']}, auto-reset (BASELINE configs[3])", "arenas_per_gpu": N,
-                   "parallelism": f"arena-sharded x{R.world}, no data-path collective; {K} sub-worlds on {K} streams inside one HIP graph",
+                   "parallelism": f"arena-sharded x{R.world}, no data-path collective; {K} sub-worlds on {K} streams, " + ("one HIP graph per sub-world (no join between commander steps)" if pipelined else "inside one HIP graph (joined at every commander step)"),
                    "pilot_rows": ("variants: one launch + one policy call per sub-step (hh_hl_begin_variants / hh_hl_act_tick)" if variants else
                                   "sides: a launch and a policy call per side and sub-step")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -106,6 +106,34 @@ struct DevPtrs {
 };
 
 
+/* tuning builds only (-DHH_TIMELINE): every workgroup of the commander step's two kernels leaves (tag, CU, start, end) in s_memrealtime ticks (100 MHz) —
+ * the true placement of concurrent streams, which a profiler's serialised trace does not show (tools/timeline.py) */
+#ifdef HH_TIMELINE
+#define HH_TL_CAP (1 << 20)
+__device__ unsigned long long hh_tl[4 + 4 * (size_t)HH_TL_CAP];
+struct HhTl { unsigned long long t0; };
+__device__ __forceinline__ void hh_tl_begin(HhTl &t) { t.t0 = __builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ void hh_tl_end(const HhTl &t, unsigned tag, unsigned aux) {
+    if ((threadIdx.x & 63) != 0) return;
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned long long at = atomicAdd(&hh_tl[0], 1ULL);
+    if (at < HH_TL_CAP) {
+        unsigned long long *e = &hh_tl[4 + 4 * at];
+        e[0] = (unsigned long long)tag | ((unsigned long long)(threadIdx.x >> 6) << 8) | ((unsigned long long)aux << 32);
+        e[1] = (unsigned long long)hw | ((unsigned long long)(xcc & 0xf) << 32);
+        e[2] = t.t0;
+        e[3] = t1;
+    }
+}
+#else
+struct HhTl {};
+__device__ __forceinline__ void hh_tl_begin(HhTl &) {}
+__device__ __forceinline__ void hh_tl_end(const HhTl &, unsigned, unsigned) {}
+#endif
+
 /* register-resident state of one aircraft slot (+ its rocket slot) */
 struct Unit {
     double lat, lon, hdg, spd, cmd_hdg, cmd_spd;

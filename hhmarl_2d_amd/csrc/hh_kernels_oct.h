@@ -1041,12 +1041,16 @@ __device__ __forceinline__ int oct_pilot_obs(const DevCfg &c, const OTab &t, con
  * launch that ends a sub-step emits, next to every opponent's row, the copies with the observed agents' still-zero flags forced to one (up to three
  * variants, `vrow` slots 3 + 4 j + v); ONE policy call evaluates the agents' rows and all variants, and the next launch lets the agents act, looks at
  * which flags rose, takes each opponent's action from the matching variant and runs the tick.  Same rows through the same networks: same results. */
-template <int W, bool VAR = false>
-__device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c, int phase, int grp, int tid, OctShared &sh, const int8_t *__restrict__ cmd,
+#ifndef HHV_IX
+#define HHV_IX(W) false /* the variant-row kernels call the exact envelope test out of line at either occupancy (tuning builds: -DHHV_IX(W)=... ) */
+#endif
+template <int W, bool VAR = false, int PHASE = -1> /* PHASE >= 0: the phase is known at compile time (the variant-row kernels: one instance per phase, each holding only its own path) */
+__device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c, int phase_rt, int grp, int tid, OctShared &sh, const int8_t *__restrict__ cmd,
                                                const int8_t *__restrict__ actions, float *__restrict__ pilot_obs, uint8_t *__restrict__ pilot_mode,
                                                float *__restrict__ obs_out, float *__restrict__ reward_out, uint8_t *__restrict__ valid_out,
                                                uint8_t *__restrict__ done_out, int *__restrict__ running_count,
                                                unsigned long long *__restrict__ tick_total, float *vrow = nullptr) {
+    const int phase = PHASE >= 0 ? PHASE : phase_rt;
     OLane L;
     L.g = tid >> 3; L.p = tid & 7; L.q = (tid >> 2) & 1; L.i = tid & 3;
     L.base = tid & ~7;
@@ -1106,7 +1110,7 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
         hl_load_act(actions, row0 + L.i, L.exists && agent, act, act_fault, running && m.alive && agent);
         int flb[5]; /* the flags the emitted rows were built from */
         HH_O_FETCH5(i, flb, pub.flags);
-        act_oct<(W >= 2), false>(c, sh, tid, L, running, m, ar, act, agent, tb, pub, H.evm);
+        act_oct<HHV_IX(W), false>(c, sh, tid, L, running, m, ar, act, agent, tb, pub, H.evm);
         HH_O_FETCH5(i, tb.fl, pub.flags);
         int v = 0; /* which of its rows describes what the opponent sees now: bit 0 / 1 = the first / second observed agent raised its flag */
         {
@@ -1120,8 +1124,8 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
         }
         int8_t act2[4];
         hl_load_act(actions, row0 + 3 + 4 * L.i + v, L.exists && !agent, act2, act_fault, running && m.alive && !agent);
-        act_oct<(W >= 2), false>(c, sh, tid, L, running, m, ar, act2, !agent, tb, pub, H.evm);
-        const int ran = oct_do_tick<(W >= 2), true>(P, c, sh, tid, L, n, active, H, tb, pub);
+        act_oct<HHV_IX(W), false>(c, sh, tid, L, running, m, ar, act2, !agent, tb, pub, H.evm);
+        const int ran = oct_do_tick<HHV_IX(W), true>(P, c, sh, tid, L, n, active, H, tb, pub);
         ran_tick = ran;
         if (L.p == 0 && ran && ar.hl_run && running_count) atomicAdd(running_count, 1);
         {
@@ -1279,13 +1283,34 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_oct(DevPtrs P, DevCfg c, int 
 
 /* the variant-row form of the two phases that carry a sub-step (see oct_phase_body): HH_HL_BEGIN_V, then HH_HL_ACT_TICK per sub-step; HH_HL_END is the
  * standard kernel's.  pilot_obs [N, 15, 30], pilot_mode [N, 15], actions [N, 15, 4]. */
-template <int W>
-__global__ __launch_bounds__(64, W) void hh_k_hier_oct_v(DevPtrs P, DevCfg c, int phase, const int8_t *__restrict__ cmd, const int8_t *__restrict__ actions,
+/* WPB independent waves per workgroup (no barrier between them: each has its own LDS slice and its own eight arenas).  One wave per workgroup lets the
+ * dispatcher scatter a launch's waves over every CU of the chip, two or three to a CU — and a policy tile of the other sub-world's stream, which needs a
+ * whole CU (eight waves x 256 registers, 141 KB of LDS), then finds none free until the launch is through (tools/timeline.py).  Eight waves x 16.6 KB fill a CU
+ * the way a policy tile does: a launch of 512 waves touches 64 CUs and leaves the other 192 whole. */
+#ifndef HHV_WPB
+#define HHV_WPB 8
+#endif
+template <int W, int PHASE, int WPB>
+__global__ __launch_bounds__(64 * WPB) void hh_k_hier_oct_v(DevPtrs P, DevCfg c, const int8_t *__restrict__ cmd, const int8_t *__restrict__ actions,
                                                        float *__restrict__ pilot_obs, uint8_t *__restrict__ pilot_mode, int *__restrict__ running_count) {
-    __shared__ OctShared sh;
-    __shared__ alignas(16) float vrow[8 * HH_HL_VROWS * 30];
-    oct_phase_body<W, true>(P, c, phase, (int)blockIdx.x, (int)threadIdx.x, sh, cmd, actions, pilot_obs, pilot_mode, nullptr, nullptr, nullptr, nullptr,
+    /* the variant rows are staged where the envelope queue's exchange area lies (free once the tick is through: oct_phase_body waits before it writes them) */
+    union VS {
+        OctShared sh;
+        struct { unsigned char head[offsetof(OctShared, u)]; alignas(16) float vrow[8 * HH_HL_VROWS * 30]; } v;
+    };
+    static_assert(offsetof(OctShared, u) % 16 == 0, "16-byte row stores");
+    __shared__ VS vs_all[WPB];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int grp = (int)blockIdx.x * WPB + wave;
+    if (grp * 8 >= c.N) return;
+    VS &vs = vs_all[wave];
+    OctShared &sh = vs.sh;
+    float *vrow = vs.v.vrow;
+    HhTl tl;
+    hh_tl_begin(tl);
+    oct_phase_body<W, true, PHASE>(P, c, PHASE, grp, (int)threadIdx.x & 63, sh, cmd, actions, pilot_obs, pilot_mode, nullptr, nullptr, nullptr, nullptr,
                             running_count, running_count ? reinterpret_cast<unsigned long long *>(running_count + 2) : nullptr, vrow);
+    hh_tl_end(tl, 1, (unsigned)c.arena_offset);
 }
 
 #endif /* HH_KERNELS_OCT_H */

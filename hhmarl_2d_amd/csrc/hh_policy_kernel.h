@@ -426,11 +426,17 @@ static int hhp_launch_forward(hh_policy *p, const float *obs, int32_t n_rows, in
     /* the form is chosen by the rows that CARRY a network: a bound HighLevelEnv world lists one side's units per call, half of its
      * [N, 6] row buffer at most (a full-buffer count picked 64-row tiles for 1.5 rounds of work: 78 against 67 us at 8192 arenas) */
     const int form = hhp_choose_form(p, live_rows >= 0 ? live_rows : n_rows);
+    /* the streamed forms walk their tiles grid-stride: a grid for 1.5 x the rows the caller expects to carry a network (all of them if it gave no estimate).  Measured
+     * on the commander step with the networks in the loop, four sub-worlds, estimate 0.30 of the slots against 0.32 listed: 110 % -> 5.35e6 (some workgroups take a
+     * second tile: twice the call's latency), 125 % -> 5.90e6, 150 % -> 6.23e6, every slot -> 6.01e6 commander-steps/s */
+    static const int grid_pct = getenv("HH_POLICY_GRID_PCT") ? atoi(getenv("HH_POLICY_GRID_PCT")) : 150; /* tuning: grid as a percentage of the estimate (0 = every row slot) */
+    const long long exp_rows = (live_rows >= 0 && grid_pct > 0) ? ((long long)live_rows * grid_pct + 99) / 100 : (long long)n_rows;
+    const int cover = (int)(exp_rows < (long long)n_rows ? exp_rows : (long long)n_rows);
     if (form == HHP_FORM_W16) { /* weights through LDS, activations in registers, 16 rows per wave: 64-row tiles, two workgroups per CU */
-        hipLaunchKernelGGL(hh_k_policy_w16<4>, dim3((n_rows + 63) / 64 + p->n_nets), dim3(256), HHX_LDS_BYTES, st, p->bank, p->bankx, p->n_nets, obs, obs_stride, p->counts,
+        hipLaunchKernelGGL(hh_k_policy_w16<4>, dim3((cover + 63) / 64 + p->n_nets), dim3(256), HHX_LDS_BYTES, st, p->bank, p->bankx, p->n_nets, obs, obs_stride, p->counts,
                            p->lists, p->max_rows, actions, logits, consume);
     } else if (form == HHP_FORM_W16X8) { /* the same with eight waves per workgroup: 128-row tiles, half the weight stream per row */
-        hipLaunchKernelGGL(hh_k_policy_w16<8>, dim3((n_rows + 127) / 128 + p->n_nets), dim3(512), HHX_LDS_BYTES_NB(4), st, p->bank, p->bankx, p->n_nets, obs, obs_stride, p->counts,
+        hipLaunchKernelGGL(hh_k_policy_w16<8>, dim3((cover + 127) / 128 + p->n_nets), dim3(512), HHX_LDS_BYTES_NB(4), st, p->bank, p->bankx, p->n_nets, obs, obs_stride, p->counts,
                            p->lists, p->max_rows, actions, logits, consume);
     } else if (form == HHP_FORM_H64) { /* persistent: one workgroup per CU walks the tiles grid-stride */
         const int tiles = (n_rows + 63) / 64 + p->n_nets;
@@ -720,6 +726,21 @@ extern "C" int hh_policy_prof_read_ppo(unsigned long long *out32) { /* the 2 x 1
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(hhp_prof), 32 * 8, 16 * 8));
     return HH_OK;
+}
+#endif
+
+#ifdef HH_TIMELINE
+/* tuning builds: the workgroup timeline (hh_device.h: hh_tl).  out = [n][4] words; returns the number of entries written, clears the buffer's counter */
+extern "C" long long hh_debug_timeline(unsigned long long *out, long long cap) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    unsigned long long n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(hh_tl), 8) != hipSuccess) return -1;
+    if (n > HH_TL_CAP) n = HH_TL_CAP;
+    if ((long long)n > cap) n = (unsigned long long)cap;
+    if (out && n && hipMemcpyFromSymbol(out, HIP_SYMBOL(hh_tl), n * 32, 32) != hipSuccess) return -1;
+    const unsigned long long z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hh_tl), &z, 8) != hipSuccess) return -1;
+    return (long long)n;
 }
 #endif
 

@@ -278,7 +278,9 @@ __device__ __forceinline__ void hhx_forward_tile(const HhpNet &N, const unsigned
     /* the stream in PROCESSING order: chunks 0, 1 = first layer, then (fight nets) 2, 3 = attention block, then the shared layer's 32; chunk j sits in
      * ring buffer j % NB and is requested while chunk j - D is worked on (the first D up front) */
     const int att_skip = has_att ? 0 : HHX_ATT_PIECES / HHX_CHUNK;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid)); /* the callers walk their tiles in a loop: what derives from the thread index is recomputed per tile, not held in registers across the tile before */
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ci = lane & 15, g = lane >> 4;
 
     auto request = [&](int j, int first, int n) { /* pieces first .. first + n - 1 of this wave's NPW of chunk j */
@@ -692,9 +694,21 @@ __global__ __launch_bounds__(64 * WV, 2) void hh_k_policy_w16(HhpBank bank, HhpB
 #pragma unroll
     for (int n = 0; n < HH_POLICY_MAX_NETS; n++) cn[n] = n < n_nets ? min(hhp_row_count(counts, n, consume), max_rows) : 0;
     int net, tile, cnt;
-    if (hhp_locate<16 * WV>(cn, (int)blockIdx.x, net, tile, cnt))
+    HhTl tl;
+    hh_tl_begin(tl);
+    /* grid-stride over the tiles: the host sizes the grid by the rows it EXPECTS to carry a network (hhp_launch_forward), not by the row buffer — a workgroup that
+     * finds no tile still needs a whole CU (eight waves x 256 registers, 141 KB of LDS) to find that out, and a call whose grid covers every row slot of the buffer
+     * (three times the rows a HighLevelEnv sub-step lists) ends only when all of them have had one: behind the other sub-worlds' tiles (tools/timeline.py).  A call
+     * with more rows than expected is still complete: some workgroups take a second tile. */
+    bool work = false;
+#pragma nounroll
+    for (int gt = (int)blockIdx.x; hhp_locate<16 * WV>(cn, gt, net, tile, cnt); gt += (int)gridDim.x) {
+        if (work) __syncthreads(); /* the tile before is through with the logits / row ids that share the LDS */
+        work = true;
         hhx_forward_tile<false, WV>(bank.net[net], bankx.stream[net], obs, obs_stride, lists + (size_t)net * max_rows, tile, cnt, actions, logits_out, ldsb);
+    }
     hhp_consume_counts(counts, consume);
+    if (threadIdx.x == 0) hh_tl_end(tl, work ? 2 : 3, (unsigned)(size_t)counts);
 }
 
 /* hh_policy_sample in this form: workgroup 2 t = actor tile t with the sampler's tail, workgroup 2 t + 1 = the value branch of the same 64 rows */

@@ -673,10 +673,10 @@ static int launch_hier_v(hh_world *w, int phase, const int8_t *cmd, const int8_t
     }
     HH_GUARD(w);
     const int grid8 = (c.N + 7) / 8;
-    if (w->force_w == 2 || (w->force_w == 0 && grid8 > w->n_simd))
-        hipLaunchKernelGGL((hh_k_hier_oct_v<2>), dim3(grid8), dim3(64), 0, st, w->P, c, phase, cmd, actions, pilot_obs, pilot_mode, w->counter);
-    else
-        hipLaunchKernelGGL((hh_k_hier_oct_v<1>), dim3(grid8), dim3(64), 0, st, w->P, c, phase, cmd, actions, pilot_obs, pilot_mode, w->counter);
+    /* one instance per phase, at most 256 registers and 16.6 KB of LDS a wave: eight waves fill a CU like a policy tile (hh_kernels_oct.h) */
+    const int wgs = (grid8 + HHV_WPB - 1) / HHV_WPB;
+    if (phase == HH_HL_BEGIN_V) hipLaunchKernelGGL((hh_k_hier_oct_v<2, HH_HL_BEGIN_V, HHV_WPB>), dim3(wgs), dim3(64 * HHV_WPB), 0, st, w->P, c, cmd, actions, pilot_obs, pilot_mode, w->counter);
+    else hipLaunchKernelGGL((hh_k_hier_oct_v<2, HH_HL_ACT_TICK, HHV_WPB>), dim3(wgs), dim3(64 * HHV_WPB), 0, st, w->P, c, cmd, actions, pilot_obs, pilot_mode, w->counter);
     HIPCHK(hipGetLastError());
     return HH_OK;
 }

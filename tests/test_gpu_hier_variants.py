@@ -110,3 +110,33 @@ def test_variant_rows_unbound_and_refusals(monkeypatch):
     wide = World(make_config(n_arenas=4, env_kind=1, n_agents=4, n_opps=4)); wide.reset()
     with pytest.raises(Exception):
         wide.hl_begin_variants(torch.zeros((4, 4), dtype=torch.int8, device=wide.device), (torch.zeros((4, 15, 30), device=wide.device), torch.zeros((4, 15), dtype=torch.uint8, device=wide.device)))
+
+
+@pytest.mark.parametrize("form", ["3", "2"], ids=["w16x8", "w16x4"])
+def test_streamed_policy_forms_walk_their_tiles_when_the_row_estimate_is_low(form, monkeypatch):
+    """hh_policy_act_binned_live sizes the grid of hh_k_policy_w16 by the caller's ESTIMATE of the listed rows (hhp_launch_forward): the workgroups walk the
+    tiles grid-stride, so a call with many more rows than estimated returns the same actions and logits as a call whose grid covers every row slot."""
+    import torch
+    from hhmarl_2d_amd.pilots import PolicyBank, VariantNetPilot
+    from hhmarl_2d_amd.world import World, make_config
+    monkeypatch.setenv("HH_POLICY_W", form)
+    rng = np.random.default_rng(2)
+    got = []
+    for est in (None, 1, 700):   # a grid for every slot; a grid of a handful of workgroups for the same ~6 000 listed rows; one that is short by a few tiles
+        w = World(make_config(n_arenas=600, env_kind=1, seed=3, auto_reset=True))
+        w.reset()
+        p = VariantNetPilot(w, PolicyBank.random_init(w.device, seed=5, max_rows=w.N * 15))
+        cmd = torch.from_numpy(np.random.default_rng(2).integers(0, 3, (w.N, 3)).astype(np.int8)).cuda()
+        rows = w.N * 15
+        po, pm = w.hl_begin_variants(cmd)
+        assert int((pm != 0).sum()) > 5000
+        act = torch.full((w.N, 15, 4), 77, dtype=torch.int8, device=po.device)
+        logits = torch.zeros((rows, 32), dtype=torch.float32, device=po.device)
+        p.bank.act_binned_live(po, act, rows if est is None else est, logits=logits)
+        torch.cuda.synchronize()
+        m = (pm != 0)
+        got.append((pm.clone(), act[m].clone(), logits.view(w.N, 15, 32)[m].clone()))
+        p.close()
+        w.close()
+    for pm, a, l in got[1:]:
+        assert torch.equal(pm, got[0][0]) and torch.equal(a, got[0][1]) and torch.equal(l, got[0][2])

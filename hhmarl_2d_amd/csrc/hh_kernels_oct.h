@@ -924,7 +924,9 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_macro_oct(DevPtrs P, DevCfg c
     oct_publish_norm(c, H.m, pub);
     oct_publish_flags(H.m, pub);
     oct_tables<true>(H.m, pub, L, tb);
+#ifndef HHO_ABL_NO_BEGIN
     oct_do_begin(c, tb, L, n, active, H, cmd);
+#endif
     int ticks = 0;
     uint32_t evm_last = 0;
     int act_fault = 0; /* a consumed action word was out of range and ran sanitised (hh_act_unpack) */
@@ -934,6 +936,19 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_macro_oct(DevPtrs P, DevCfg c
     bool tab = true; /* the table in registers describes the current positions (wave-uniform) */
     for (int sub = 0; sub < 16; sub++) {
         if (!__any(H.ar.hl_run)) break; /* nobody in this wave is inside a macro step any more */
+        /* two waves per SIMD (256 registers): what derives from the lane index is recomputed per sub-step instead of living in registers across the loop —
+         * 236 -> 206 spilled registers, +3 % at 65536 arenas; at one wave per SIMD the recomputation costs more than the AGPR copies it saves (-1.5 % at 8192) */
+        int tid_l = threadIdx.x;
+        if constexpr (W >= 2) asm volatile("" : "+v"(tid_l));
+        OLane L;
+        L.g = tid_l >> 3; L.p = tid_l & 7; L.q = (tid_l >> 2) & 1; L.i = tid_l & 3;
+        L.base = tid_l & ~7;
+        const int n = blockIdx.x * 8 + L.g;
+        const bool active = n < c.N;
+        L.exists = active && L.i < (L.q ? c.nO : c.nA);
+        L.s = L.q ? c.nA + L.i : L.i;
+        const size_t u = (size_t)n * 6 + L.s;
+        const int tid = tid_l;
         const int w = act_next;
         if (L.exists && sub + 1 < 16) act_next = *reinterpret_cast<const int *>(tape + ((size_t)(sub + 1) * U + u) * 4);
         int8_t act[4];
@@ -942,8 +957,11 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_macro_oct(DevPtrs P, DevCfg c
         if (running) H.evm = 0;
         /* both sides' _take_base_action in one pass: a side's action reads nothing the other side's action writes (positions do not
          * move, the missile_wait draws are keyed by unit), and launches are numbered in unit id order either way */
+#ifndef HHO_ABL_NO_ACT0
         if (HH_RARE(tab)) act_oct<(W >= 2), true>(c, sh, tid, L, running, H.m, H.ar, act, true, tb, pub, H.evm); /* the first sub-step only */
-        else act_oct<(W >= 2), false>(c, sh, tid, L, running, H.m, H.ar, act, true, tb, pub, H.evm);
+        else
+#endif
+        act_oct<(W >= 2), false>(c, sh, tid, L, running, H.m, H.ar, act, true, tb, pub, H.evm);
         ticks += oct_do_tick<(W >= 2), false>(P, c, sh, tid, L, n, active, H, tb, pub);
         tab = false;
         if (running) evm_last = H.evm;
@@ -952,7 +970,9 @@ __global__ __launch_bounds__(64, W) void hh_k_hier_macro_oct(DevPtrs P, DevCfg c
     oct_publish_norm(c, H.m, pub);
     oct_tables<true>(H.m, pub, L, tb);
 #endif
+#ifndef HHO_ABL_NO_END
     oct_do_end(P, c, sh, tid, L, n, active, H, tb, pub, HH_HL_END, reward_out, valid_out, done_out, nullptr);
+#endif
     if (obs_out) { /* the workgroup's agent rows are contiguous in [N, nA, 34] */
         const int arenas = min(8, c.N - (int)blockIdx.x * 8);
         const int cnt = arenas * c.nA * HH_OBS_HL;

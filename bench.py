@@ -959,7 +959,7 @@ def main_hier_split(args, R, own, N, K):
                      "kernel": (f"hh_k_hier_oct_v (one launch per sub-step) + {'hh_k_policy_w16<8>' if os.environ.get('HH_POLICY_W') == '3' else 'hh_k_policy_* by row count'}" if variants else
                                 f"{worlds[0].kernel_instance(0)} (every phase launch of the macro step) + hh_k_policy_h"), "algorithmic_bytes": algo_bytes,
                      "note": "2056 B per arena-tick actually run + 424 B per commander step (SURVEY.md 8d)"},
-        "gpu_ms_per_step": gpu_s / steps * 1e3, "launches_per_step": (34 if variants else 66) * K,
+        "gpu_ms_per_step": gpu_s / steps * 1e3, "launches_per_step": (34 if variants else 66) * K, "launches_per_sub_world_step": 34 if variants else 66,
     }
     for p in pilots_:
         p.close()
@@ -1042,7 +1042,7 @@ def extra_configs(args, R):
     each measured by its own `--workload` run of this script in a CHILD process (shorter than a stand-alone run): whatever happens
     there — an exception, a crash — costs the headline nothing but an `error` entry."""
     def brief(line):
-        keys = ("metric", "value", "unit", "steps", "ms_per_step", "gpu_ms_per_step", "dtype", "kernels_ms", "launches_per_step", "sim_ticks_per_s",
+        keys = ("metric", "value", "unit", "steps", "ms_per_step", "gpu_ms_per_step", "dtype", "kernels_ms", "launches_per_step", "launches_per_sub_world_step", "sim_ticks_per_s",
                 "ticks_per_commander_step", "streams", "collect", "agent_steps_per_s")
         out = {k: line[k] for k in keys if k in line}
         out["workload"] = line["config"]["workload"]
@@ -1060,7 +1060,7 @@ def extra_configs(args, R):
                         ("configs2_collect", ["--workload", "collect", "--chunk", "64", "--steps", "6", "--warmup", "2"]),
                         ("configs2_greedy_inference", ["--workload", "rollout", "--steps", "300", "--warmup", "30"]),
                         ("configs3", ["--workload", "hier", "--pilot", "tape", "--steps", "40", "--warmup", "8"]),
-                        ("configs3_networks_in_loop", ["--workload", "hier", "--pilot", "net", "--steps", "12", "--warmup", "3"])):
+                        ("configs3_networks_in_loop", ["--workload", "hier", "--pilot", "net", "--steps", "40", "--warmup", "5"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--spinup", "0.3", "--seed", str(args.seed), "--no-cpu-baseline"] + flags
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
         left = budget_s - (time.perf_counter() - t_extra)

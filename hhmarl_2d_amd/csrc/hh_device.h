@@ -111,8 +111,14 @@ struct DevPtrs {
 #ifdef HH_TIMELINE
 #define HH_TL_CAP (1 << 20)
 __device__ unsigned long long hh_tl[4 + 4 * (size_t)HH_TL_CAP];
-struct HhTl { unsigned long long t0; };
-__device__ __forceinline__ void hh_tl_begin(HhTl &t) { t.t0 = __builtin_amdgcn_s_memrealtime(); }
+struct HhTl { unsigned long long t0, marks; };
+__device__ __forceinline__ void hh_tl_begin(HhTl &t) { t.t0 = __builtin_amdgcn_s_memrealtime(); t.marks = 0; }
+/* up to four marks inside the workgroup: 20 ns units since the start, 11 bits each */
+__device__ __forceinline__ void hh_tl_mark(HhTl &t, int k) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); /* what the phase asked for has arrived: the mark is the phase's end, not its issue */
+    const unsigned long long d = __builtin_amdgcn_s_memrealtime() - t.t0;
+    t.marks |= ((d >> 1) > 2047 ? 2047ULL : (d >> 1)) << (11 * k);
+}
 __device__ __forceinline__ void hh_tl_end(const HhTl &t, unsigned tag, unsigned aux) {
     if ((threadIdx.x & 63) != 0) return;
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
@@ -125,12 +131,13 @@ __device__ __forceinline__ void hh_tl_end(const HhTl &t, unsigned tag, unsigned 
         e[0] = (unsigned long long)tag | ((unsigned long long)(threadIdx.x >> 6) << 8) | ((unsigned long long)aux << 32);
         e[1] = (unsigned long long)hw | ((unsigned long long)(xcc & 0xf) << 32);
         e[2] = t.t0;
-        e[3] = t1;
+        e[3] = ((t1 - t.t0) & 0xfffffULL) | (t.marks << 20); /* duration (20 bits of 10 ns) | the marks */
     }
 }
 #else
 struct HhTl {};
 __device__ __forceinline__ void hh_tl_begin(HhTl &) {}
+__device__ __forceinline__ void hh_tl_mark(HhTl &, int) {}
 __device__ __forceinline__ void hh_tl_end(const HhTl &, unsigned, unsigned) {}
 #endif
 

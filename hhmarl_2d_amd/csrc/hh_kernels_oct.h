@@ -1069,7 +1069,7 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
                                                const int8_t *__restrict__ actions, float *__restrict__ pilot_obs, uint8_t *__restrict__ pilot_mode,
                                                float *__restrict__ obs_out, float *__restrict__ reward_out, uint8_t *__restrict__ valid_out,
                                                uint8_t *__restrict__ done_out, int *__restrict__ running_count,
-                                               unsigned long long *__restrict__ tick_total, float *vrow = nullptr) {
+                                               unsigned long long *__restrict__ tick_total, float *vrow = nullptr, HhTl *tl = nullptr) {
     const int phase = PHASE >= 0 ? PHASE : phase_rt;
     OLane L;
     L.g = tid >> 3; L.p = tid & 7; L.q = (tid >> 2) & 1; L.i = tid & 3;
@@ -1108,6 +1108,9 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
     if (phase == HH_HL_TICK || (VAR && phase == HH_HL_ACT_TICK)) oct_positions(m, L, tb); /* the tick builds its table afterwards; before it only a launch test may ask for an entry */
     else oct_tables<true>(m, pub, L, tb);
     o_wave_sync();
+#ifdef HH_TIMELINE
+    if (tl) hh_tl_mark(*tl, 0); /* state loaded, published, positions / table built */
+#endif
     int obs_side = -1; /* which side's pilot observations this launch emits */
     int act_fault = 0;  /* a consumed action word was out of range and ran sanitised (hh_act_unpack) */
     int ran_tick = 0;   /* HL_ACT_TICK: the lane's arena ran the tick in this launch */
@@ -1145,7 +1148,13 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
         int8_t act2[4];
         hl_load_act(actions, row0 + 3 + 4 * L.i + v, L.exists && !agent, act2, act_fault, running && m.alive && !agent);
         act_oct<HHV_IX(W), false>(c, sh, tid, L, running, m, ar, act2, !agent, tb, pub, H.evm);
+#ifdef HH_TIMELINE
+        if (tl) hh_tl_mark(*tl, 1); /* both sides acted */
+#endif
         const int ran = oct_do_tick<HHV_IX(W), true>(P, c, sh, tid, L, n, active, H, tb, pub);
+#ifdef HH_TIMELINE
+        if (tl) hh_tl_mark(*tl, 2); /* tick, rewards, events */
+#endif
         ran_tick = ran;
         if (L.p == 0 && ran && ar.hl_run && running_count) atomicAdd(running_count, 1);
         {
@@ -1243,6 +1252,9 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
             for (int k = tid; k < cnt; k += 64) dst[k] = vrow[k];
         }
         if (P.pol_lut) hh_bin_rows_finish4(bt4, P.pol_lists, P.pol_max_rows, (int)((size_t)n * HH_HL_VROWS + slot0), pslot_v, vmask);
+#ifdef HH_TIMELINE
+        if (tl) hh_tl_mark(*tl, 3); /* rows built, stored, listed */
+#endif
     } else if (obs_side >= 0 && pilot_obs) {
         const bool mine = obs_side == 0 ? agent : !agent;
         o_wave_sync(); /* the queue's exchange area (same LDS) is free */
@@ -1291,13 +1303,15 @@ __device__ __forceinline__ void oct_phase_body(const DevPtrs &P, const DevCfg &c
     }
 }
 
-template <int W>
-__global__ __launch_bounds__(64, W) void hh_k_hier_oct(DevPtrs P, DevCfg c, int phase, const int8_t *__restrict__ cmd, const int8_t *__restrict__ actions,
+/* one instance per phase (PHASE a compile-time constant: each holds its own path only — the form with the phase as a run-time argument carried every path's
+ * registers: 337 at one wave per SIMD, 124 spilled at two) */
+template <int W, int PHASE>
+__global__ __launch_bounds__(64, W) void hh_k_hier_oct(DevPtrs P, DevCfg c, const int8_t *__restrict__ cmd, const int8_t *__restrict__ actions,
                                                      float *__restrict__ pilot_obs, uint8_t *__restrict__ pilot_mode, float *__restrict__ obs_out,
                                                      float *__restrict__ reward_out, uint8_t *__restrict__ valid_out, uint8_t *__restrict__ done_out,
                                                      int *__restrict__ running_count) {
     __shared__ OctShared sh;
-    oct_phase_body<W>(P, c, phase, (int)blockIdx.x, (int)threadIdx.x, sh, cmd, actions, pilot_obs, pilot_mode, obs_out, reward_out, valid_out, done_out,
+    oct_phase_body<W, false, PHASE>(P, c, PHASE, (int)blockIdx.x, (int)threadIdx.x, sh, cmd, actions, pilot_obs, pilot_mode, obs_out, reward_out, valid_out, done_out,
                       running_count, running_count ? reinterpret_cast<unsigned long long *>(running_count + 2) : nullptr);
 }
 
@@ -1329,7 +1343,7 @@ __global__ __launch_bounds__(64 * WPB) void hh_k_hier_oct_v(DevPtrs P, DevCfg c,
     HhTl tl;
     hh_tl_begin(tl);
     oct_phase_body<W, true, PHASE>(P, c, PHASE, grp, (int)threadIdx.x & 63, sh, cmd, actions, pilot_obs, pilot_mode, nullptr, nullptr, nullptr, nullptr,
-                            running_count, running_count ? reinterpret_cast<unsigned long long *>(running_count + 2) : nullptr, vrow);
+                            running_count, running_count ? reinterpret_cast<unsigned long long *>(running_count + 2) : nullptr, vrow, &tl);
     hh_tl_end(tl, 1, (unsigned)c.arena_offset);
 }
 

@@ -231,10 +231,17 @@ static int launch_hier(hh_world *w, int phase, const int8_t *cmd, const int8_t *
     }
     if (!w->no_oct && phase <= HH_HL_END) { /* register-exchange form (hh_kernels_oct.h): one arena per 8-lane group */
         const int grid8 = (c.N + 7) / 8;
-        if (w->force_w == 2 || (w->force_w == 0 && grid8 > w->n_simd))
-            hipLaunchKernelGGL((hh_k_hier_oct<2>), dim3(grid8), dim3(64), 0, st, w->P, c, phase, cmd, actions, pilot_obs, pilot_mode, obs, reward, valid, done, w->counter);
-        else
-            hipLaunchKernelGGL((hh_k_hier_oct<1>), dim3(grid8), dim3(64), 0, st, w->P, c, phase, cmd, actions, pilot_obs, pilot_mode, obs, reward, valid, done, w->counter);
+        const bool two8 = w->force_w == 2 || (w->force_w == 0 && grid8 > w->n_simd);
+#define HH_LAUNCH_OCT(W_, PH_) hipLaunchKernelGGL((hh_k_hier_oct<W_, PH_>), dim3(grid8), dim3(64), 0, st, w->P, c, cmd, actions, pilot_obs, pilot_mode, obs, reward, valid, done, w->counter)
+#define HH_LAUNCH_OCT_W(PH_) do { if (two8) HH_LAUNCH_OCT(2, PH_); else HH_LAUNCH_OCT(1, PH_); } while (0)
+        switch (phase) {
+        case HH_HL_BEGIN: HH_LAUNCH_OCT_W(HH_HL_BEGIN); break;
+        case HH_HL_AGENTS_ACT: HH_LAUNCH_OCT_W(HH_HL_AGENTS_ACT); break;
+        case HH_HL_TICK: HH_LAUNCH_OCT_W(HH_HL_TICK); break;
+        default: HH_LAUNCH_OCT_W(HH_HL_END); break;
+        }
+#undef HH_LAUNCH_OCT_W
+#undef HH_LAUNCH_OCT
         HIPCHK(hipGetLastError());
         return HH_OK;
     }
@@ -348,7 +355,7 @@ extern "C" int hh_kernel_instance(hh_world *w, int32_t which, char *buf, int32_t
         }
         if (which == 0) {
             const bool two = (w->force_w == 2 || (w->force_w == 0 && grid > w->n_simd)) && c.nA == 3 && c.nO == 3;
-            if (!w->no_oct) snprintf(buf, (size_t)len, "hh_k_hier_oct<%d>", (w->force_w == 2 || (w->force_w == 0 && grid8 > w->n_simd)) ? 2 : 1);
+            if (!w->no_oct) snprintf(buf, (size_t)len, "hh_k_hier_oct<%d, phase>", (w->force_w == 2 || (w->force_w == 0 && grid8 > w->n_simd)) ? 2 : 1);
             else snprintf(buf, (size_t)len, "hh_k_hier<6, 64, %d>", two ? 2 : 1);
             return HH_OK;
         }

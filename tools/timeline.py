@@ -97,7 +97,8 @@ hw = (buf[:, 1] & 0xffffffff).astype(np.int64)
 xcc = (buf[:, 1] >> 32).astype(np.int64)
 cu = xcc * 4096 + ((hw >> 8) & 0xf) + 16 * ((hw >> 12) & 1) + 32 * ((hw >> 13) & 7)   # (xcc, se, sh, cu): unique per CU
 t0 = buf[:, 2].astype(np.int64)
-t1 = buf[:, 3].astype(np.int64)
+t1 = t0 + (buf[:, 3] & 0xfffff).astype(np.int64)
+marks = np.stack([((buf[:, 3] >> (20 + 11 * k)) & 0x7ff).astype(np.int64) * 0.02 for k in range(4)], axis=1)   # us since the workgroup's start
 base = t0.min()
 t0 = (t0 - base) / 100.0   # us
 t1 = (t1 - base) / 100.0
@@ -166,6 +167,12 @@ print(f"mean over the step: CUs with a policy tile {p_cus.mean():.1f}, CUs with 
 print("time-us  P-CUs  W-CUs  W-waves  idle   (every 10 us, first 400 us)")
 for t in range(0, min(T, 400), 10):
     print(f"{t:6d} {p_cus[t]:6d} {w_cus[t]:6d} {w_waves[t]:7d} {idle[t]:6d}")
+wm = np.where((tag == 1) & (marks[:, 2] > 0))[0]   # act-tick waves (the begin launch sets no mark 1 / 2)
+if len(wm):
+    d = t1[wm] - t0[wm]
+    md = np.median(marks[wm], axis=0)
+    print(f"phase waves (act-tick launches, n={len(wm)}), median us since the wave's start: state loaded + positions {md[0]:.2f} | both sides acted {md[1]:.2f} | tick done {md[2]:.2f} | "
+          f"rows built, stored, listed {md[3]:.2f} | end (state stored) {np.median(d):.2f}")
 pl = [x for x in launches if x[1] == 2 and x[0] == 0]
 if len(pl) > 4:
     starts = np.array([t0[x[2]].min() for x in pl])

@@ -530,7 +530,25 @@ def main_policy_rollout(args, R=None):
             cur.wait_stream(streams[k])
 
     graph = None
-    if not args.no_graph:
+    pipelined = K > 1 and not args.no_graph and not args.joined   # one graph per sub-world on its own stream, no join between ticks (main_hier_split)
+    if pipelined:
+        streams = make_streams(torch, K)
+        for _ in range(3):
+            tick()
+        torch.cuda.synchronize()
+        graphs = []
+        for k in range(K):
+            gk = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gk, stream=(streams[k] if streams[k].cuda_stream != 0 else torch.cuda.Stream())):
+                policy(k)
+                sws[k].world.step(acts[k], out=outs[k])
+            graphs.append(gk)
+
+        def run():
+            for k in range(K):
+                with torch.cuda.stream(streams[k]):
+                    graphs[k].replay()
+    elif not args.no_graph:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -540,8 +558,9 @@ def main_policy_rollout(args, R=None):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             tick()
-    run = graph.replay if graph is not None else tick
-    log_side = torch.cuda.Stream()
+    if not pipelined:
+        run = graph.replay if graph is not None else tick
+    log_side = torch.cuda.Stream() if not pipelined else None
 
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < args.spinup:
@@ -553,10 +572,16 @@ def main_policy_rollout(args, R=None):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
+    if pipelined:
+        for k in range(K):
+            streams[k].wait_stream(torch.cuda.current_stream())
     for k in range(args.steps):
         run()
-        if k % 256 == 255:
+        if k % 256 == 255 and log_side is not None:
             sw.log_episode_stats(log_side)
+    if pipelined:
+        for k in range(K):
+            torch.cuda.current_stream().wait_stream(streams[k])
     e1.record()
     R.barrier()
     dt = R.max_over_ranks(time.perf_counter() - t0)

@@ -35,7 +35,7 @@ ALGO_BYTES_3V3_TICK = 2056       # 656 + 656 + pilot obs 720 +
 ALGO_BYTES_3V3_TICK_TAPE = 1336  # the same tick when the pilots' actions come from a tape: nobody builds or reads the 720 B of pilot observations
 ALGO_BYTES_3V3_STATE = 656       # one arena's state record (read once and written once per commander step by the one-launch macro step)
 ALGO_BYTES_3V3_CMD_FIXED = 424   # commander obs 408 + actions 3 + rewards 12 + done 1
-DEFAULT_STREAMS = {"rollout": 1, "hier_net": 4, "hier_net_variants": 4}   # sub-worlds / streams of the policy-in-the-loop workloads (--streams)
+DEFAULT_STREAMS = {"rollout": 2, "hier_net": 4, "hier_net_variants": 4}   # sub-worlds / streams of the policy-in-the-loop workloads (--streams)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F16_PEAK_TFLOPS = 2500.0    # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md; AMD's headline figure includes 2:1 sparsity)
 MFMA_F32_PEAK_TFLOPS = 157.3     # fp32-in MFMA runs at the vector rate
@@ -486,6 +486,10 @@ def main_policy_rollout(args, R=None):
     K = args.streams or DEFAULT_STREAMS["rollout"]
     assert N % K == 0, "--streams must divide the arena count"
     n = N // K
+    if K > 1 and "HH_FORCE_W" not in os.environ and not args.joined and not args.no_graph:
+        # sub-worlds side by side: the single-wave world kernel at 256 registers (two waves per SIMD) and the 64-row policy tiles (half a CU) can share CUs, which the
+        # two-wave world kernel (313 registers a wave) and 128-row tiles cannot: 16384 arenas, K = 2: 2.21e8 against 1.96e8 env-steps/s (read at hh_world_create)
+        os.environ["HH_FORCE_W"] = "2"
     # sub-world k of rank r holds the global arenas [r N + k n, r N + (k + 1) n): the same arenas as one world of N (keyed RNG by global id)
     sws = [ShardedWorld(dict(n_arenas=n, level=args.level, seed=args.seed, auto_reset=True, arena_offset=k * n + R.rank * (N - n)), rank=R.rank,
                         world_size=R.world, device=R.local_rank) for k in range(K)]
@@ -599,7 +603,7 @@ def main_policy_rollout(args, R=None):
                                (f"{N} arenas/GPU x 2-vs-2 fight L{args.level}, actions from random-init Fight1/Fight2 actors (reference "
                                 f"architecture, fp32, fused HIP kernel, greedy decode) evaluated every tick on the same GPU, auto-reset "
                                 f"(BASELINE configs[2] with a frozen / evaluation policy: no draw, no logp, no value)"),
-                   "arenas_per_gpu": N, "ticks_per_step": 1, "parallelism": f"arena-sharded x{R.world}, no data-path collective"},
+                   "arenas_per_gpu": N, "ticks_per_step": 1, "parallelism": f"arena-sharded x{R.world}, no data-path collective" + (f"; {K} sub-worlds, one HIP graph per sub-world on its own stream" if pipelined else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": f"{w.kernel_name()} (T = 1 per launch) + hh_k_policy, " + ("one HIP graph per tick" if graph is not None else "eager"),
                      "policy_flops_per_s": bank.flops_per_row(PolicyBank.FIGHT1) * N * 2 * args.steps / gpu_s},

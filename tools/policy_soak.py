@@ -83,7 +83,7 @@ for mode, kinds, sels in (("fight", (PN.FIGHT1, PN.FIGHT2), (pilots.SEL_FIGHT1, 
     u = torch.rand((R, 2, 4), dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
     for name, env in SAMPLERS.items():
         setenv(env)
-        bank = pilots.PolicyBank.trainable_init(dev, mode=mode, seed=SEED, max_rows=2 * R)
+        bank = pilots.PolicyBank.trainable_init(dev, mode=mode, seed=SEED, max_rows=2 * R, tie_shared=False)   # one shared layer per slot: the references below are built from random_weights(kind) as they are
         lg = torch.zeros((R, 2, 32), device=dev)
         act, logp, vf = bank.sample(obs, sel, uniforms=u, logits=lg)
         torch.cuda.synchronize()

@@ -140,3 +140,69 @@ def test_streamed_policy_forms_walk_their_tiles_when_the_row_estimate_is_low(for
         w.close()
     for pm, a, l in got[1:]:
         assert torch.equal(pm, got[0][0]) and torch.equal(a, got[0][1]) and torch.equal(l, got[0][2])
+
+
+def test_sub_worlds_replayed_from_their_own_graphs_equal_one_world(monkeypatch):
+    """The form bench.py measures the commander step with the networks in: the arenas split into four sub-worlds (disjoint global arena ids), each captured in
+    its own HIP graph and replayed on its own stream with no join between commander steps.  Every commander step's outputs and the final state equal those of
+    ONE world of all the arenas stepped eagerly on the default stream."""
+    import torch
+    import bench
+    from hhmarl_2d_amd.env_hier import macro_step
+    from hhmarl_2d_amd.pilots import PolicyBank, VariantNetPilot
+    from hhmarl_2d_amd.world import World, make_config
+    monkeypatch.setenv("HH_POLICY_W", "3")   # one forward form on both sides (a row's logits do not depend on the tile it rides in, only on the form)
+    N, K, STEPS = 512, 4, 6
+    n = N // K
+    kw = dict(env_kind=1, seed=17, auto_reset=True)
+    one = World(make_config(n_arenas=N, arena_offset=4000, **kw))
+    subs = [World(make_config(n_arenas=n, arena_offset=4000 + k * n, **kw)) for k in range(K)]
+    obs0 = one.reset()
+    for k, w in enumerate(subs):
+        assert torch.equal(w.reset(), obs0[k * n:(k + 1) * n])
+    p_one = VariantNetPilot(one, PolicyBank.random_init(one.device, seed=5, max_rows=N * 15))
+    p_sub = [VariantNetPilot(w, PolicyBank.random_init(w.device, seed=5, max_rows=n * 15)) for w in subs]
+    rng = np.random.default_rng(3)
+    cmds = torch.from_numpy(rng.integers(0, 3, (STEPS, N, 3)).astype(np.int8)).cuda()
+    # one world, eager
+    want = []
+    for s in range(STEPS):
+        want.append([x.clone() for x in macro_step(one, cmds[s].contiguous(), p_one)])
+    torch.cuda.synchronize()
+    # four sub-worlds, one graph each, pipelined: a step's outputs are copied aside on the sub-world's own stream
+    streams = bench.make_streams(torch, K)
+    cmd_static = [cmds[0, k * n:(k + 1) * n].clone() for k in range(K)]
+    outs = [w.alloc_outputs() for w in subs]
+    pbufs = [w.alloc_pilot_variants() for w in subs]
+    graphs = []
+    for k in range(K):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=(streams[k] if streams[k].cuda_stream != 0 else torch.cuda.Stream())):
+            macro_step(subs[k], cmd_static[k], p_sub[k], out=outs[k], pilot_buf=pbufs[k])
+        graphs.append(g)
+    got = [[None] * K for _ in range(STEPS)]
+    cur = torch.cuda.current_stream()
+    for k in range(K):
+        streams[k].wait_stream(cur)
+    for s in range(STEPS):
+        for k in range(K):
+            with torch.cuda.stream(streams[k]):
+                cmd_static[k].copy_(cmds[s, k * n:(k + 1) * n])
+                graphs[k].replay()
+                got[s][k] = [x.clone() for x in outs[k]]
+    for k in range(K):
+        cur.wait_stream(streams[k])
+    torch.cuda.synchronize()
+    for s in range(STEPS):
+        for i, name in enumerate(("obs", "reward", "valid", "done")):
+            g_ = torch.cat([got[s][k][i] for k in range(K)], dim=0)
+            assert torch.equal(g_, want[s][i]), f"commander step {s}: {name} of the four sub-worlds differs from the one world's"
+    so = one.get_state()
+    for k, w in enumerate(subs):
+        sk = w.get_state()
+        for key in so:
+            assert np.array_equal(sk[key], so[key][k * n:(k + 1) * n]), f"final state {key} of sub-world {k}"
+    for p in p_sub + [p_one]:
+        p.close()
+    for w in subs + [one]:
+        w.close()

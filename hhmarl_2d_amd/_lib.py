@@ -78,6 +78,8 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). The MI355X world has no CPU fallback.")
+        import torch  # noqa: F401  — BEFORE the library: torch ships its own HIP runtime; a process that loads libhh_world.so (linked against the system's) first and
+        #                  imports torch afterwards ends up with two, and hh_world_create then reports "no HIP device"
         L = C.CDLL(LIB_PATH)
         L.hh_last_error.restype = C.c_char_p
         vp = C.c_void_p

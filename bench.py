@@ -1089,7 +1089,7 @@ def extra_configs(args, R):
                         ("configs2_collect", ["--workload", "collect", "--chunk", "64", "--steps", "6", "--warmup", "2"]),
                         ("configs2_greedy_inference", ["--workload", "rollout", "--steps", "300", "--warmup", "30"]),
                         ("configs3", ["--workload", "hier", "--pilot", "tape", "--steps", "40", "--warmup", "8"]),
-                        ("configs3_networks_in_loop", ["--workload", "hier", "--pilot", "net", "--steps", "40", "--warmup", "5", "--spinup", "0.6"])):
+                        ("configs3_networks_in_loop", ["--workload", "hier", "--pilot", "net", "--steps", "40", "--warmup", "5"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--spinup", "0.3", "--seed", str(args.seed), "--no-cpu-baseline"] + flags
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
         left = budget_s - (time.perf_counter() - t_extra)
